@@ -1,0 +1,327 @@
+/*
+ * bsx.h — C ABI of the MI355X-native witness engine for Blobstream X `header_range`.
+ *
+ * This is the drop-in boundary for the ONE hot path of succinctlabs/blobstreamx
+ * (circuits/header_range.rs + circuits/data_commitment.rs + circuits/builder.rs +
+ * the host side of the hint, circuits/input.rs).  Every entry point names the reference
+ * interface it replaces (file:line under /root/reference).  Plain pointers and sizes only;
+ * no C++/torch types cross this line.  All multi-byte integers are host-endian (little)
+ * except where the reference is big-endian (EVM-packed u64, the data-root tuple height).
+ *
+ * Two tiers:
+ *   bsx_*      host-pointer tier: synchronous, copies in/out — what a Rust `AsyncHint` /
+ *              builder shim binds.
+ *   bsx_dev_*  device-pointer tier: every pointer marked `d_` is HIP device memory, the call
+ *              only enqueues kernels on `stream` (a hipStream_t passed as void*) and returns.
+ *              The host tier is implemented on top of it.
+ *
+ * Ownership: the caller allocates every buffer; the library never frees caller memory and
+ * never keeps a caller pointer after return.  Errors: every function returns a bsx_status;
+ * nothing aborts (the reference panics: circuits/input.rs:93,100,104,154,173).  A
+ * thread-local message is available from bsx_last_error().  The library has NO CPU
+ * compute fallback: without a HIP device bsx_init fails with BSX_ERR_NO_DEVICE.
+ */
+#ifndef BSX_H
+#define BSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSX_VERSION 0x00010000
+
+/* ------------------------------------------------------------------ constants (circuits/consts.rs) */
+#define BSX_HASH_SIZE 32                 /* consts.rs:1  HASH_SIZE */
+#define BSX_PROTOBUF_HASH_SIZE 34        /* consts.rs:4  PROTOBUF_HASH_SIZE_BYTES */
+#define BSX_PROTOBUF_BLOCK_ID_SIZE 72    /* consts.rs:7  PROTOBUF_BLOCK_ID_SIZE_BYTES */
+#define BSX_HEADER_PROOF_DEPTH 4         /* consts.rs:10 HEADER_PROOF_DEPTH */
+#define BSX_ENC_DATA_ROOT_TUPLE_SIZE 64  /* consts.rs:18 ENC_DATA_ROOT_TUPLE_SIZE_BYTES */
+#define BSX_BLOCK_HEIGHT_INDEX 2         /* consts.rs:21 */
+#define BSX_LAST_BLOCK_ID_INDEX 4        /* consts.rs:22 */
+#define BSX_DATA_HASH_INDEX 6            /* consts.rs:23 */
+#define BSX_HEADER_FIELDS 14             /* tendermint 0.33.2 Header::hash: 14 Merkle leaves */
+#define BSX_MAX_BATCH 256                /* largest BATCH_SIZE one workgroup folds (bins use 32/64) */
+#define BSX_VALIDATOR_MSG_MAX 124        /* tendermintx VALIDATOR_MESSAGE_BYTES_LENGTH_MAX [UPSTREAM] */
+#define BSX_VALIDATOR_LEAF_MAX 48        /* SimpleValidator protobuf: 0a 22 0a 20 pk32 10 varint(<=10) */
+
+/* ------------------------------------------------------------------ status codes */
+typedef enum bsx_status {
+    BSX_OK = 0,
+    BSX_ERR_NO_DEVICE = 1,       /* no HIP device / HIP runtime error at init: there is no CPU fallback */
+    BSX_ERR_HIP = 2,             /* a HIP call failed (message has the hipError string) */
+    BSX_ERR_BAD_ARG = 3,         /* null pointer, zero/invalid size, batch not a power of two, ... */
+    BSX_ERR_RANGE_TOO_LONG = 4,  /* input.rs:154 / builder.rs:292-297 (A7) */
+    BSX_ERR_BAD_HEADER = 5,      /* a packed header violates the field-size rules below */
+    BSX_ERR_ASSERT = 6,          /* a circuit assertion A1..A10 is false; see the returned masks */
+    BSX_ERR_BAD_SIGNATURE = 7,   /* a `signed` validator's Ed25519 signature does not verify */
+    BSX_ERR_VOTING_POWER = 8,    /* 2/3 or 1/3 threshold not met */
+    BSX_ERR_UNSUPPORTED = 9
+} bsx_status;
+
+/* Assertion bits (the circuit `assert_is_equal` sites in circuits/builder.rs). */
+#define BSX_A1_END_GTE_START   (1u << 0)  /* builder.rs:113-114 */
+#define BSX_A2_NB_BLOCKS_U32   (1u << 1)  /* builder.rs:128     */
+#define BSX_A3_PREV_HEADER     (1u << 2)  /* builder.rs:205-207 */
+#define BSX_A4_DATA_HASH_PROOF (1u << 3)  /* builder.rs:210-212 */
+#define BSX_A5_END_HEADER      (1u << 4)  /* builder.rs:216-219 */
+#define BSX_A6_BATCH_END       (1u << 5)  /* builder.rs:229-232 */
+#define BSX_A7_RANGE           (1u << 6)  /* builder.rs:292-297 */
+#define BSX_A8_REDUCE_LINK     (1u << 7)  /* builder.rs:350-355 */
+#define BSX_A9_FINAL           (1u << 8)  /* builder.rs:401-406 */
+#define BSX_A10_NEXT_HEADER    (1u << 9)  /* builder.rs:434     */
+
+/* ------------------------------------------------------------------ data layouts */
+
+/* One Tendermint header as its 14 protobuf-encoded Merkle leaves (tendermint 0.33.2
+ * Header::hash, used at circuits/input.rs:250-261 and through get_inclusion_proof at
+ * input.rs:175-179,188-195).  Fixed 512-byte record, every field 4-byte aligned so a wave
+ * can stage records with 16-byte coalesced loads.  len[i] is the encoded length of field i
+ * (0 = empty field, hashed as the empty leaf 0x00).  Capacity rules (violations ->
+ * BSX_ERR_BAD_HEADER): every field except 4 is <= 55 bytes (one SHA-256 block with the
+ * 0x00 leaf prefix); field 4 (last_block_id) is <= 76. */
+typedef struct bsx_header {
+    uint8_t len[BSX_HEADER_FIELDS];
+    uint8_t _pad[2];
+    uint8_t version[24];        /* 0: Consensus{block,app}            08 .. 10 ..          */
+    uint8_t chain_id[52];       /* 1: StringValue                     0a len ..            */
+    uint8_t height[12];         /* 2: Int64Value                      08 varint            */
+    uint8_t time[20];           /* 3: Timestamp                       08 secs 10 nanos     */
+    uint8_t last_block_id[76];  /* 4: BlockID (72 B when parts.total < 128; consts.rs:7)   */
+    uint8_t hash[8][36];        /* 5..12: last_commit, data, validators, next_validators,
+                                          consensus, app, last_results, evidence: 0a 20 h32 */
+    uint8_t proposer[24];       /* 13: BytesValue                     0a 14 addr20         */
+} bsx_header;                   /* sizeof == 512 */
+
+/* InclusionProof<HEADER_PROOF_DEPTH, PROTOBUF_HASH_SIZE_BYTES> as the hint emits it
+ * (circuits/input.rs:203-217; MerkleInclusionProofVariable{proof, leaf}, vars.rs:17-20).
+ * Packed, no padding: the byte image is exactly the variable's serialization. */
+typedef struct bsx_data_hash_proof {
+    uint8_t aunts[BSX_HEADER_PROOF_DEPTH][BSX_HASH_SIZE];
+    uint8_t leaf[BSX_PROTOBUF_HASH_SIZE];
+} bsx_data_hash_proof;          /* sizeof == 162 */
+
+/* InclusionProof<HEADER_PROOF_DEPTH, PROTOBUF_BLOCK_ID_SIZE_BYTES> (input.rs:208-217; vars.rs:21-25). */
+typedef struct bsx_last_block_id_proof {
+    uint8_t aunts[BSX_HEADER_PROOF_DEPTH][BSX_HASH_SIZE];
+    uint8_t leaf[BSX_PROTOBUF_BLOCK_ID_SIZE];
+} bsx_last_block_id_proof;      /* sizeof == 200 */
+
+/* DataCommitmentSharedCtx (circuits/builder.rs:12-18). */
+typedef struct bsx_shared_ctx {
+    uint64_t start_block;
+    uint64_t end_block;
+    uint8_t start_header_hash[BSX_HASH_SIZE];
+    uint8_t end_header_hash[BSX_HASH_SIZE];
+} bsx_shared_ctx;               /* sizeof == 80 */
+
+/* MapReduceSubchainVariable (circuits/vars.rs:28-36) padded to 128 bytes: the unit that
+ * the map stage hands to the reduce stage and that the multi-GPU all-gather moves. */
+typedef struct bsx_subchain {
+    uint64_t start_block;
+    uint64_t end_block;
+    uint8_t start_header[BSX_HASH_SIZE];
+    uint8_t end_header[BSX_HASH_SIZE];
+    uint8_t data_merkle_root[BSX_HASH_SIZE];
+    uint32_t is_enabled;        /* 0/1 */
+    uint32_t assert_fail;       /* OR of BSX_A* bits that FAILED while producing this record */
+    uint32_t first_bad_slot;    /* lowest slot (map) / node (reduce) index that failed, or 0xffffffff */
+    uint32_t _pad;
+} bsx_subchain;                 /* sizeof == 128 */
+
+/* One validator of one commit, as tendermintx's SkipOffchainInputs / StepOffchainInputs hand
+ * it to the circuit [UPSTREAM tendermintx v1.0.0; reference call sites
+ * circuits/header_range.rs:42-48,67 and circuits/next_header.rs:32-36,55]. 256 bytes. */
+typedef struct bsx_validator {
+    uint8_t pubkey[32];
+    uint8_t signature[64];
+    uint8_t message[BSX_VALIDATOR_MSG_MAX];  /* CanonicalVote sign-bytes, zero padded */
+    uint32_t message_len;
+    uint64_t voting_power;
+    uint8_t enabled;              /* slot holds a validator (index < validator-set size) */
+    uint8_t is_signed;            /* block_id_flag == Commit and a signature is present */
+    uint8_t present_on_trusted;   /* skip only: this validator is also in the trusted set */
+    uint8_t _pad[21];
+} bsx_validator;                  /* sizeof == 256 */
+
+/* Result of verifying one commit (skip/step inner loop). */
+typedef struct bsx_commit_result {
+    uint8_t validators_hash[BSX_HASH_SIZE]; /* Merkle root over the enabled validators' leaves */
+    uint64_t total_power;                   /* sum over enabled */
+    uint64_t signed_power;                  /* sum over enabled & signed & signature valid */
+    uint64_t trusted_signed_power;          /* sum over enabled & signed & present_on_trusted */
+    uint32_t n_enabled;
+    uint32_t n_signed;
+    uint32_t n_bad_signature;               /* signed validators whose signature failed */
+    uint32_t first_bad_signature;           /* index or 0xffffffff */
+    uint32_t n_bad_message;                 /* signed validators whose message lacks the header hash */
+    uint32_t two_thirds_ok;                 /* 3*signed_power > 2*total_power */
+    uint32_t _pad[4];
+} bsx_commit_result;                        /* sizeof == 96 */
+
+typedef struct bsx_ctx bsx_ctx;             /* one per HIP device; calls on distinct contexts are thread-safe */
+
+/* ------------------------------------------------------------------ lifecycle */
+uint32_t bsx_version(void);
+/* device = HIP ordinal.  Fails with BSX_ERR_NO_DEVICE when no GPU is visible (no CPU fallback). */
+int bsx_init(int device, bsx_ctx** out);
+void bsx_shutdown(bsx_ctx* ctx);
+const char* bsx_last_error(void);
+const char* bsx_status_str(int status);
+/* Number of HIP devices visible, or 0.  Never fails. */
+int bsx_device_count(void);
+
+/* ------------------------------------------------------------------ witness layout queries
+ * The witness of one map job is three dense sections: `bytes` (every byte
+ * becomes 8 Goldilocks elements, MSB first — plonky2x ByteVariable), `words` (u32 limbs / U32,
+ * one element each; U64Variable = lo limb then hi limb) and `bools` (one element each).
+ * Expanded size in u64 elements = 8*bytes + words + bools. */
+typedef struct bsx_witness_layout {
+    uint32_t batch_size;
+    uint32_t n_bytes;   /* compact byte section length  */
+    uint32_t n_words;   /* compact u32 section length (count of u32) */
+    uint32_t n_bools;   /* compact bool section length (count of u8) */
+    uint32_t compact_stride;   /* bytes between consecutive jobs' compact witnesses (16-aligned) */
+    uint32_t off_words;        /* byte offset of the u32 section inside one compact witness */
+    uint32_t off_bools;        /* byte offset of the bool section */
+    uint32_t _pad;
+    uint64_t n_elements;       /* expanded u64 count per job */
+} bsx_witness_layout;
+int bsx_map_witness_layout(uint32_t batch_size, bsx_witness_layout* out);
+int bsx_reduce_witness_layout(bsx_witness_layout* out);   /* one reduce node */
+
+/* ------------------------------------------------------------------ host tier */
+
+/* encode_data_root_tuple — circuits/builder.rs:23-27,82-103.  out = 0x00*24 ‖ height BE ‖ data_hash. */
+int bsx_encode_data_root_tuple(bsx_ctx* ctx, const uint8_t data_hash[32], uint64_t height, uint8_t out[64]);
+
+/* get_data_commitment<MAX_LEAVES> — circuits/builder.rs:33-38,105-148.  data_hashes: max_leaves×32.
+ * Fails with BSX_ERR_ASSERT (A1/A2) like the circuit. max_leaves must be a power of two <= BSX_MAX_BATCH. */
+int bsx_get_data_commitment(bsx_ctx* ctx, const uint8_t* data_hashes, uint32_t max_leaves,
+                            uint64_t start_block, uint64_t end_block, uint8_t out_root[32]);
+
+/* Header hashes + the two inclusion proofs per header — tendermint Header::hash and tendermintx
+ * InputDataFetcher::get_inclusion_proof as used at circuits/input.rs:175-179,188-195,250-261.
+ * Any out pointer may be NULL. */
+int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n,
+                      uint8_t* out_hashes /* n×32 */,
+                      bsx_data_hash_proof* out_dh /* n */, bsx_last_block_id_proof* out_lb /* n */);
+
+/* DataCommitmentInputFetcher::get_data_commitment_inputs<MAX_LEAVES> — circuits/input.rs:57-60,149-271,
+ * i.e. the body of `DataCommitmentOffchainInputs<MAX_LEAVES>::hint` (circuits/data_commitment.rs:18-45)
+ * with the RPC replaced by the caller's header array: headers[i] is the header at height
+ * first_height+i and must cover [start_block, min(end_block, latest_block-2)].
+ * Outputs mirror DataCommitmentInputs (input.rs:29-37); out_dh/out_lb hold max_leaves entries. */
+int bsx_data_commitment_inputs(bsx_ctx* ctx, const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
+                               uint64_t latest_block, uint64_t start_block, uint64_t end_block, uint32_t max_leaves,
+                               uint8_t out_start_header[32], uint8_t out_end_header[32],
+                               bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb,
+                               uint8_t out_expected_data_commitment[32]);
+
+/* prove_subchain<BATCH_SIZE> — circuits/builder.rs:45-52,150-271.  One map job.
+ * Returns BSX_ERR_ASSERT when a circuit assertion fails (record->assert_fail says which).
+ * witness (optional): expanded Goldilocks witness, bsx_map_witness_layout(batch).n_elements u64. */
+int bsx_prove_subchain(bsx_ctx* ctx, uint32_t batch_size,
+                       const uint8_t start_header[32], const uint8_t end_header[32],
+                       const bsx_data_hash_proof* dh, const bsx_last_block_id_proof* lb,
+                       uint64_t batch_start_block, uint64_t batch_end_block,
+                       uint64_t global_end_block, const uint8_t global_end_header_hash[32],
+                       bsx_subchain* out_record, uint64_t* witness);
+
+/* The reduce closure of prove_data_commitment — circuits/builder.rs:337-395 — applied as the
+ * binary tree plonky2x mapreduce builds: n (power of two) records -> 1. */
+int bsx_reduce(bsx_ctx* ctx, const bsx_subchain* records, uint32_t n, bsx_subchain* out);
+
+/* prove_data_commitment<C, NB_MAP_JOBS, BATCH_SIZE> — circuits/builder.rs:58-67,273-409 — with the
+ * hint (data_commitment.rs:22-44 -> input.rs:149-271) served from `headers` (height first_height+i).
+ * records (optional): nb_map_jobs map outputs.  witness (optional): nb_map_jobs map-job witnesses,
+ * then nb_map_jobs-1 reduce-node witnesses (level order, leaves' parents first). */
+int bsx_prove_data_commitment(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size,
+                              const bsx_shared_ctx* range,
+                              const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
+                              uint8_t out_data_commitment[32], bsx_subchain* out_result,
+                              bsx_subchain* records, uint64_t* witness);
+
+/* prove_next_header_data_commitment — circuits/builder.rs:73-78,411-443. `header` is the header at
+ * prev_block_number. */
+int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_number, const uint8_t prev_header_hash[32],
+                                          uint64_t next_block_number, const bsx_header* header, uint64_t latest_block,
+                                          uint8_t out_data_commitment[32]);
+
+/* Commit verification: the per-validator hot loop inside builder.skip / builder.step
+ * (circuits/header_range.rs:42-48, circuits/next_header.rs:32-36; body [UPSTREAM] tendermintx
+ * v1.0.0; host twin is_valid_skip at circuits/fetcher.rs:76-80).  n_commits commits of
+ * v_max validator slots each.  header_hashes: n_commits×32, the hash every signed message must
+ * carry (offset 16, or 25 when a round field is present).  out_sig_ok: n_commits×v_max bytes
+ * (1 = signed and valid).  Does not fail on bad signatures: the result says so. */
+int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n_commits, uint32_t v_max,
+                       const uint8_t* header_hashes, bsx_commit_result* out_results, uint8_t* out_sig_ok);
+
+/* CombinedSkipCircuit::define — circuits/header_range.rs:32-59: input48 = u64 BE trusted_block ‖
+ * bytes32 trusted_header_hash ‖ u64 BE target_block (header_range.rs:33-35); output64 =
+ * target_header_hash ‖ data_commitment (header_range.rs:57-58).  The target header is
+ * headers[target-first_height]; its commit is target_validators (v_max slots); the trusted set is
+ * trusted_validators (pubkey, voting_power, enabled used).  Checks skip conditions
+ * [UPSTREAM tendermintx skip]: trusted < target <= trusted + nb_map_jobs*batch_size, signatures,
+ * validators_hash of both sets against the headers' field 7, 2/3 of target power signed, more
+ * than 1/3 of trusted power signed. */
+int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48],
+                     const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
+                     const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
+                     uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness);
+
+/* ------------------------------------------------------------------ device tier (async; d_* = device memory) */
+
+/* P5: one lane per header. d_hashes n×32; d_dh_aunts / d_lb_aunts n×128 (4 aunts, leaf-adjacent first). */
+int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n,
+                          uint8_t* d_hashes, uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint32_t* d_status);
+
+/* The hint for many map jobs at once (input.rs:149-271): job j of range r covers
+ * [S_r + j*B, S_r + (j+1)*B).  d_ranges: n_ranges bsx_shared_ctx.  Headers of range r start at
+ * d_headers[r*headers_per_range] = height S_r.  Writes the DataCommitmentProofVariable part of each
+ * job's compact witness (d_compact, stride layout.compact_stride). */
+int bsx_dev_assemble_inputs(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
+                            const bsx_shared_ctx* d_ranges, const uint64_t* d_latest_block,
+                            const bsx_header* d_headers, uint64_t headers_per_range,
+                            const uint8_t* d_hashes, const uint8_t* d_dh_aunts, const uint8_t* d_lb_aunts,
+                            uint8_t* d_compact);
+
+/* prove_subchain for n_ranges*nb_map_jobs map jobs (builder.rs:150-271 incl. get_data_commitment
+ * :105-148).  job_first/job_count select the slice of map jobs of every range this device owns
+ * (multi-GPU sharding); compact witnesses and records are indexed [range][job - job_first]. */
+int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
+                           uint32_t job_first, uint32_t job_count,
+                           const bsx_shared_ctx* d_ranges, uint8_t* d_compact, bsx_subchain* d_records);
+
+/* Binary reduce (builder.rs:337-395) of `n` consecutive records per range -> 1, n a power of two.
+ * d_reduce_compact (optional) receives n-1 reduce-node compact witnesses per range. */
+int bsx_dev_reduce(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t n,
+                   const bsx_subchain* d_records, bsx_subchain* d_out, uint8_t* d_reduce_compact);
+
+/* Final assertions of prove_data_commitment (builder.rs:292-297,400-406) + the 64-byte public
+ * output (header_range.rs:57-58).  d_status: n_ranges u32 (OR of failed BSX_A* bits). */
+int bsx_dev_finalize(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
+                     const bsx_shared_ctx* d_ranges, const bsx_subchain* d_results,
+                     uint8_t* d_output64, uint32_t* d_status);
+
+/* P10: compact -> Goldilocks.  n_jobs compact witnesses (layout) -> n_jobs*layout.n_elements u64. */
+int bsx_dev_expand_witness(bsx_ctx* ctx, void* stream, const bsx_witness_layout* layout, uint32_t n_jobs,
+                           const uint8_t* d_compact, uint64_t* d_witness);
+
+/* P6: h = SHA512(R ‖ A ‖ M) mod L per validator slot. d_h: n×32 (LE scalar), d_digest (optional) n×64. */
+int bsx_dev_sha512_challenge(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n,
+                             uint8_t* d_h, uint8_t* d_digest);
+/* P7: [s]B == R + [h]A per validator slot. d_ok: n bytes (1 valid, 0 invalid or not signed/enabled). */
+int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
+                           uint64_t n, uint8_t* d_ok);
+/* P8+P9: validator-set hash, voting-power tallies and message checks; one workgroup per commit. */
+int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits,
+                         uint32_t v_max, const uint8_t* d_header_hashes, const uint8_t* d_ok,
+                         bsx_commit_result* d_results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSX_H */

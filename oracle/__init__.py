@@ -1,0 +1,265 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (blobstreamx_amd) never does.  See oracle/orc.h for the pinning status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from blobstreamx_amd import types as T
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_DIR, f) for f in os.listdir(_DIR) if f.endswith((".c", ".h"))]
+    srcs += [os.path.join(_DIR, "..", "include", f) for f in ("bsx.h", "bsx_layout.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.run(["make", "-C", _DIR, "-B", "liboracle.so"], check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_sha256_has_shani.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None  # data_as keeps `a` alive
+
+
+def _b(x, n=None):
+    a = np.frombuffer(bytes(x), dtype=np.uint8).copy()
+    assert n is None or a.size == n, (a.size, n)
+    return a
+
+
+def sha256(msg):
+    out = np.zeros(32, np.uint8)
+    m = _b(msg) if len(msg) else np.zeros(1, np.uint8)
+    lib().orc_sha256(_p(m), C.c_size_t(len(msg)), _p(out))
+    return out.tobytes()
+
+
+def sha256_force_portable(on):
+    lib().orc_sha256_force_portable(C.c_int(int(on)))
+
+
+def has_shani():
+    return bool(lib().orc_sha256_has_shani())
+
+
+def sha512(msg):
+    out = np.zeros(64, np.uint8)
+    m = _b(msg) if len(msg) else np.zeros(1, np.uint8)
+    lib().orc_sha512(_p(m), C.c_size_t(len(msg)), _p(out))
+    return out.tobytes()
+
+
+def sc_reduce64(x):
+    out = np.zeros(32, np.uint8)
+    lib().orc_sc_reduce64(_p(_b(x, 64)), _p(out))
+    return out.tobytes()
+
+
+def ed25519_verify(pk, msg, sig):
+    m = _b(msg) if len(msg) else np.zeros(1, np.uint8)
+    return bool(lib().orc_ed25519_verify(_p(_b(pk, 32)), _p(m), C.c_size_t(len(msg)), _p(_b(sig, 64))))
+
+
+def ed25519_verify_h(pk, sig, h):
+    return bool(lib().orc_ed25519_verify_h(_p(_b(pk, 32)), _p(_b(sig, 64)), _p(_b(h, 32))))
+
+
+def leaf_hash(x):
+    out = np.zeros(32, np.uint8)
+    lib().orc_leaf_hash(_p(_b(x) if len(x) else np.zeros(1, np.uint8)), C.c_size_t(len(x)), _p(out))
+    return out.tobytes()
+
+
+def inner_hash(l, r):
+    out = np.zeros(32, np.uint8)
+    lib().orc_inner_hash(_p(_b(l, 32)), _p(_b(r, 32)), _p(out))
+    return out.tobytes()
+
+
+def header_hashes(headers):
+    """headers: ndarray[HEADER] -> (hashes[n,32], dh[n] DH_PROOF, lb[n] LB_PROOF)"""
+    headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
+    n = headers.size
+    hashes = np.zeros((n, 32), np.uint8)
+    dh = np.zeros(n, T.DH_PROOF)
+    lb = np.zeros(n, T.LB_PROOF)
+    for i in range(n):
+        rc = lib().orc_header_hash(C.c_void_p(headers.ctypes.data + 512 * i), C.c_void_p(hashes.ctypes.data + 32 * i),
+                                   C.c_void_p(dh.ctypes.data + 162 * i), C.c_void_p(lb.ctypes.data + 200 * i))
+        if rc:
+            raise ValueError(f"orc_header_hash: {T.STATUS_NAMES[rc]} at header {i}")
+    return hashes, dh, lb
+
+
+def header_hash_only(headers):
+    headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
+    hashes = np.zeros((headers.size, 32), np.uint8)
+    for i in range(headers.size):
+        rc = lib().orc_header_hash(C.c_void_p(headers.ctypes.data + 512 * i), C.c_void_p(hashes.ctypes.data + 32 * i),
+                                   None, None)
+        if rc:
+            raise ValueError(f"orc_header_hash: {T.STATUS_NAMES[rc]} at header {i}")
+    return hashes
+
+
+def encode_data_root_tuple(data_hash, height):
+    out = np.zeros(64, np.uint8)
+    lib().orc_encode_data_root_tuple(_p(_b(data_hash, 32)), C.c_uint64(height), _p(out))
+    return out.tobytes()
+
+
+def get_data_commitment(data_hashes, start_block, end_block):
+    dhs = np.ascontiguousarray(data_hashes, np.uint8).reshape(-1, 32)
+    out = np.zeros(32, np.uint8)
+    af = C.c_uint32(0)
+    rc = lib().orc_get_data_commitment(_p(dhs), C.c_uint32(dhs.shape[0]), C.c_uint64(start_block), C.c_uint64(end_block),
+                                       _p(out), C.byref(af))
+    return rc, out.tobytes(), af.value
+
+
+def data_commitment_inputs(headers, first_height, latest_block, start_block, end_block, max_leaves):
+    headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
+    sh, eh, exp = np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(32, np.uint8)
+    dh = np.zeros(max_leaves, T.DH_PROOF)
+    lb = np.zeros(max_leaves, T.LB_PROOF)
+    rc = lib().orc_data_commitment_inputs(_p(headers), C.c_uint64(first_height), C.c_uint64(headers.size),
+                                          C.c_uint64(latest_block), C.c_uint64(start_block), C.c_uint64(end_block),
+                                          C.c_uint32(max_leaves), _p(sh), _p(eh), _p(dh), _p(lb), _p(exp))
+    return rc, dict(start_header=sh.tobytes(), end_header=eh.tobytes(), data_hash_proofs=dh, last_block_id_proofs=lb,
+                    expected_data_commitment=exp.tobytes())
+
+
+def prove_subchain(batch_size, start_header, end_header, dh, lb, batch_start, batch_end, global_end, global_end_hash,
+                   ctx=None, want_witness=False):
+    lay = T.map_layout(batch_size)
+    rec = np.zeros(1, T.SUBCHAIN)
+    dh = np.ascontiguousarray(dh, T.DH_PROOF)
+    lb = np.ascontiguousarray(lb, T.LB_PROOF)
+    compact = np.zeros(int(lay["compact_stride"]), np.uint8) if want_witness else None
+    rc = lib().orc_prove_subchain(C.c_uint32(batch_size), _p(ctx) if ctx is not None else None, _p(_b(start_header, 32)),
+                                  _p(_b(end_header, 32)), _p(dh), _p(lb), C.c_uint64(batch_start), C.c_uint64(batch_end),
+                                  C.c_uint64(global_end), _p(_b(global_end_hash, 32)), _p(rec), _p(compact))
+    return rc, rec[0], compact
+
+
+def reduce(records):
+    records = np.ascontiguousarray(records, T.SUBCHAIN)
+    out = np.zeros(1, T.SUBCHAIN)
+    n = records.size
+    lay = T.reduce_layout()
+    compact = np.zeros(max(n - 1, 1) * int(lay["compact_stride"]), np.uint8)
+    rc = lib().orc_reduce(_p(records), C.c_uint32(n), _p(out), _p(compact))
+    return rc, out[0], compact
+
+
+def make_ctx(start_block, start_header_hash, end_block, end_header_hash):
+    ctx = np.zeros(1, T.SHARED_CTX)
+    ctx["start_block"], ctx["end_block"] = start_block, end_block
+    ctx["start_header_hash"][0] = np.frombuffer(bytes(start_header_hash), np.uint8)
+    ctx["end_header_hash"][0] = np.frombuffer(bytes(end_header_hash), np.uint8)
+    return ctx
+
+
+def prove_data_commitment(nb_map_jobs, batch_size, ctx, headers, first_height, latest_block, want_witness=False):
+    headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
+    ml, rl = T.map_layout(batch_size), T.reduce_layout()
+    out = np.zeros(32, np.uint8)
+    result = np.zeros(1, T.SUBCHAIN)
+    records = np.zeros(nb_map_jobs, T.SUBCHAIN)
+    csz = nb_map_jobs * int(ml["compact_stride"]) + (nb_map_jobs - 1) * int(rl["compact_stride"])
+    compact = np.zeros(max(csz, 1), np.uint8) if want_witness else None
+    st = C.c_uint32(0)
+    rc = lib().orc_prove_data_commitment(C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(ctx), _p(headers),
+                                         C.c_uint64(first_height), C.c_uint64(headers.size), C.c_uint64(latest_block),
+                                         _p(out), _p(result), _p(records), _p(compact), C.byref(st))
+    return rc, dict(data_commitment=out.tobytes(), result=result[0], records=records, compact=compact, status=st.value)
+
+
+def prove_next_header_data_commitment(prev_block, prev_header_hash, next_block, header, latest_block):
+    header = np.ascontiguousarray(header, dtype=T.HEADER).reshape(-1)
+    out = np.zeros(32, np.uint8)
+    rc = lib().orc_prove_next_header_data_commitment(C.c_uint64(prev_block), _p(_b(prev_header_hash, 32)),
+                                                     C.c_uint64(next_block), _p(header), C.c_uint64(latest_block), _p(out))
+    return rc, out.tobytes()
+
+
+def expand_witness(layout, n_jobs, compact):
+    layout = np.ascontiguousarray(layout, T.WITNESS_LAYOUT).reshape(1)
+    out = np.zeros(n_jobs * int(layout["n_elements"][0]), np.uint64)
+    lib().orc_expand_witness(_p(layout), C.c_uint32(n_jobs), _p(compact), _p(out))
+    return out
+
+
+def expand_range_witness(nb_map_jobs, batch_size, compact):
+    """compact = jobs then reduce nodes (orc_prove_data_commitment) -> expanded u64 (same order)"""
+    ml, rl = T.map_layout(batch_size), T.reduce_layout()
+    a = expand_witness(ml, nb_map_jobs, compact)
+    off = nb_map_jobs * int(ml["compact_stride"])
+    b = expand_witness(rl, nb_map_jobs - 1, compact[off:]) if nb_map_jobs > 1 else np.zeros(0, np.uint64)
+    return np.concatenate([a, b])
+
+
+def sha512_challenge(validators):
+    validators = np.ascontiguousarray(validators, T.VALIDATOR).reshape(-1)
+    h = np.zeros((validators.size, 32), np.uint8)
+    dig = np.zeros((validators.size, 64), np.uint8)
+    for i in range(validators.size):
+        lib().orc_sha512_challenge(C.c_void_p(validators.ctypes.data + 256 * i), C.c_void_p(h.ctypes.data + 32 * i),
+                                   C.c_void_p(dig.ctypes.data + 64 * i))
+    return h, dig
+
+
+def verify_commit(validators, header_hash):
+    validators = np.ascontiguousarray(validators, T.VALIDATOR).reshape(-1)
+    res = np.zeros(1, T.COMMIT_RESULT)
+    ok = np.zeros(validators.size, np.uint8)
+    lib().orc_verify_commit(_p(validators), C.c_uint32(validators.size), _p(_b(header_hash, 32)), _p(res), _p(ok))
+    return res[0], ok
+
+
+def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest_block, target_validators,
+                 trusted_validators, want_witness=False):
+    headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
+    tv = np.ascontiguousarray(target_validators, T.VALIDATOR).reshape(-1)
+    rv = np.ascontiguousarray(trusted_validators, T.VALIDATOR).reshape(-1)
+    assert tv.size == rv.size
+    ml, rl = T.map_layout(batch_size), T.reduce_layout()
+    csz = nb_map_jobs * int(ml["compact_stride"]) + (nb_map_jobs - 1) * int(rl["compact_stride"])
+    compact = np.zeros(max(csz, 1), np.uint8) if want_witness else None
+    out = np.zeros(64, np.uint8)
+    res = np.zeros(1, T.COMMIT_RESULT)
+    rc = lib().orc_header_range(C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(_b(input48, 48)), _p(headers),
+                                C.c_uint64(first_height), C.c_uint64(headers.size), C.c_uint64(latest_block), _p(tv), _p(rv),
+                                C.c_uint32(tv.size), _p(out), _p(res), _p(compact))
+    return rc, out.tobytes(), res[0], compact
+
+
+def bench_header_range(nb_map_jobs, batch_size, ranges, headers, headers_per_range, latest, target, trusted, v_max,
+                       with_witness, n_threads):
+    ranges = np.ascontiguousarray(ranges, T.SHARED_CTX).reshape(-1)
+    n = ranges.size
+    out64 = np.zeros((n, 64), np.uint8)
+    cs = C.c_uint64(0)
+    latest = np.ascontiguousarray(latest, np.uint64)
+    rc = lib().orc_bench_header_range(C.c_uint32(n), C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(ranges),
+                                      _p(headers), C.c_uint64(headers_per_range), _p(latest), _p(target), _p(trusted),
+                                      C.c_uint32(v_max), C.c_int(int(with_witness)), C.c_int(n_threads), _p(out64),
+                                      C.byref(cs))
+    return rc, out64, cs.value

@@ -1,0 +1,253 @@
+/* oracle/commit.c — CPU ORACLE (test infrastructure only; see orc.h).
+ * Commit verification = the per-validator hot loop inside builder.skip / builder.step
+ * (circuits/header_range.rs:42-48, circuits/next_header.rs:32-36).  The circuit body is
+ * [UPSTREAM] tendermintx v1.0.0 (not in /root/reference); restated from the public Tendermint
+ * light-client rules the reference's host twin applies (is_valid_skip, circuits/fetcher.rs:76-80)
+ * and SURVEY Appendix A/B byte formats, all confirmed on the fixture commits:
+ *   leaf_i   = 0a 22 0a 20 pk32 [10 varint(power)]            (SimpleValidator)
+ *   valhash  = masked power-of-two Merkle tree over leaves, enabled = vals[i].enabled
+ *              (== RFC 6962 root over the enabled prefix)
+ *   h_i      = SHA512(R ‖ A ‖ M) mod L;  ok_i = [s]B == R + [h]A
+ *   msg_ok_i = M carries the header hash at offset 16 (25 when a round field 0x19 is present)
+ *   2/3 rule : 3 * signed_power > 2 * total_power
+ *   1/3 rule : 3 * (trusted power of trusted validators that validly signed) > trusted total
+ * PARITY UNPINNED beyond the V=2 fixture commits. */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "orc.h"
+
+void orc_sha512_challenge(const bsx_validator* v, uint8_t h[32], uint8_t digest[64]) {
+    uint8_t buf[64 + BSX_VALIDATOR_MSG_MAX], dig[64];
+    uint32_t len = v->message_len > BSX_VALIDATOR_MSG_MAX ? BSX_VALIDATOR_MSG_MAX : v->message_len;
+    memcpy(buf, v->signature, 32);
+    memcpy(buf + 32, v->pubkey, 32);
+    memcpy(buf + 64, v->message, len);
+    orc_sha512(buf, 64 + len, dig);
+    orc_sc_reduce64(dig, h);
+    if (digest) memcpy(digest, dig, 64);
+}
+
+int orc_validator_leaf(const uint8_t pk[32], uint64_t power, uint8_t out[BSX_VALIDATOR_LEAF_MAX]) {
+    int n = 0;
+    out[n++] = 0x0a; out[n++] = 0x22; out[n++] = 0x0a; out[n++] = 0x20;
+    memcpy(out + n, pk, 32);
+    n += 32;
+    if (power) {
+        out[n++] = 0x10;
+        while (power >= 0x80) { out[n++] = (uint8_t)(power | 0x80); power >>= 7; }
+        out[n++] = (uint8_t)power;
+    }
+    return n;
+}
+
+static uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p *= 2; return p; }
+
+static void validators_hash(const bsx_validator* vals, uint32_t v_max, uint8_t out[32]) {
+    uint32_t P = next_pow2(v_max);
+    uint8_t(*nodes)[32] = calloc(P, 32);
+    uint8_t* en = calloc(P, 1);
+    for (uint32_t i = 0; i < v_max; i++) {
+        uint8_t leaf[BSX_VALIDATOR_LEAF_MAX];
+        int n = orc_validator_leaf(vals[i].pubkey, vals[i].voting_power, leaf);
+        orc_leaf_hash(leaf, (size_t)n, nodes[i]);
+        en[i] = vals[i].enabled != 0;
+    }
+    for (uint32_t i = v_max; i < P; i++) { /* padding slots: leaf of an all-zero validator, disabled */
+        uint8_t leaf[BSX_VALIDATOR_LEAF_MAX], zero[32] = {0};
+        int n = orc_validator_leaf(zero, 0, leaf);
+        orc_leaf_hash(leaf, (size_t)n, nodes[i]);
+    }
+    for (uint32_t n = P; n > 1; n /= 2)
+        for (uint32_t i = 0; i < n; i += 2) {
+            uint8_t inner[32];
+            orc_inner_hash(nodes[i], nodes[i + 1], inner);
+            if (en[i] && en[i + 1]) memcpy(nodes[i / 2], inner, 32);
+            else memcpy(nodes[i / 2], nodes[i], 32);
+            en[i / 2] = en[i] || en[i + 1];
+        }
+    memcpy(out, nodes[0], 32);
+    free(nodes);
+    free(en);
+}
+
+void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t header_hash[32], bsx_commit_result* out,
+                       uint8_t* sig_ok) {
+    memset(out, 0, sizeof *out);
+    out->first_bad_signature = 0xffffffffu;
+    for (uint32_t i = 0; i < v_max; i++) {
+        const bsx_validator* v = &vals[i];
+        uint8_t ok = 0;
+        if (v->enabled) {
+            out->n_enabled++;
+            out->total_power += v->voting_power;
+            if (v->is_signed) {
+                out->n_signed++;
+                uint8_t h[32];
+                orc_sha512_challenge(v, h, NULL);
+                int sig = orc_ed25519_verify_h(v->pubkey, v->signature, h);
+                uint32_t off = (v->message_len > 12 && v->message[12] == 0x19) ? 25 : 16;
+                int msg = v->message_len <= BSX_VALIDATOR_MSG_MAX && v->message_len >= off + 32 &&
+                          memcmp(v->message + off, header_hash, 32) == 0;
+                if (!sig) {
+                    out->n_bad_signature++;
+                    if (out->first_bad_signature == 0xffffffffu) out->first_bad_signature = i;
+                }
+                if (!msg) out->n_bad_message++;
+                if (sig && msg) {
+                    out->signed_power += v->voting_power;
+                    if (v->present_on_trusted) out->trusted_signed_power += v->voting_power;
+                }
+                ok = (uint8_t)(sig != 0);
+            }
+        }
+        if (sig_ok) sig_ok[i] = ok;
+    }
+    validators_hash(vals, v_max, out->validators_hash);
+    /* 3*signed > 2*total, in 128-bit to avoid overflow */
+    out->two_thirds_ok = (unsigned __int128)out->signed_power * 3 > (unsigned __int128)out->total_power * 2;
+}
+
+static int varint_height_field(uint64_t h, uint8_t out[12]) {
+    int n = 0;
+    out[n++] = 0x08;
+    while (h >= 0x80) { out[n++] = (uint8_t)(h | 0x80); h >>= 7; }
+    out[n++] = (uint8_t)h;
+    return n;
+}
+
+/* circuits/header_range.rs:32-59 */
+int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height,
+                     uint64_t n_headers, uint64_t latest_block, const bsx_validator* target_validators,
+                     const bsx_validator* trusted_validators, uint32_t v_max, uint8_t output64[64],
+                     bsx_commit_result* out_commit, uint8_t* compact) {
+    uint64_t trusted_block = 0, target_block = 0;
+    for (int i = 0; i < 8; i++) trusted_block = trusted_block << 8 | input48[i];      /* :33 evm_read U64 = big endian */
+    const uint8_t* trusted_header_hash = input48 + 8;                                /* :34 */
+    for (int i = 0; i < 8; i++) target_block = target_block << 8 | input48[40 + i];  /* :35 */
+    if (!(target_block > trusted_block) || target_block - trusted_block > (uint64_t)J * B) return BSX_ERR_RANGE_TOO_LONG;
+    if (trusted_block < first_height || target_block - first_height >= n_headers) return BSX_ERR_BAD_ARG;
+    const bsx_header* th = &headers[target_block - first_height];
+    const bsx_header* tr = &headers[trusted_block - first_height];
+    /* builder.skip (:42-48) [UPSTREAM]: target header hash, commit, validator sets */
+    uint8_t target_hash[32], trusted_hash[32];
+    int rc;
+    if ((rc = orc_header_hash(th, target_hash, NULL, NULL))) return rc;
+    if ((rc = orc_header_hash(tr, trusted_hash, NULL, NULL))) return rc;
+    if (memcmp(trusted_hash, trusted_header_hash, 32) != 0) return BSX_ERR_ASSERT;
+    uint8_t hf[12];
+    int hn = varint_height_field(target_block, hf);
+    if (th->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(th->height, hf, (size_t)hn) != 0) return BSX_ERR_ASSERT;
+    bsx_commit_result cr, trc;
+    uint8_t* ok = malloc(v_max);
+    orc_verify_commit(target_validators, v_max, target_hash, &cr, ok);
+    if (out_commit) *out_commit = cr;
+    int status = BSX_OK;
+    if (cr.n_bad_signature || cr.n_bad_message) status = BSX_ERR_BAD_SIGNATURE;
+    /* validators_hash (field 7 = hash[2]) of both headers */
+    if (!status && (th->len[7] != 34 || memcmp(th->hash[2] + 2, cr.validators_hash, 32) != 0)) status = BSX_ERR_ASSERT;
+    validators_hash(trusted_validators, v_max, trc.validators_hash);
+    if (!status && (tr->len[7] != 34 || memcmp(tr->hash[2] + 2, trc.validators_hash, 32) != 0)) status = BSX_ERR_ASSERT;
+    if (!status && !cr.two_thirds_ok) status = BSX_ERR_VOTING_POWER;
+    /* > 1/3 of the trusted power signed the target (fetcher.rs:76-80 is_valid_skip) */
+    unsigned __int128 trusted_total = 0, overlap = 0;
+    for (uint32_t i = 0; i < v_max; i++) {
+        if (!trusted_validators[i].enabled) continue;
+        trusted_total += trusted_validators[i].voting_power;
+        for (uint32_t k = 0; k < v_max; k++)
+            if (target_validators[k].enabled && target_validators[k].is_signed && ok[k] &&
+                memcmp(target_validators[k].pubkey, trusted_validators[i].pubkey, 32) == 0) {
+                overlap += trusted_validators[i].voting_power;
+                break;
+            }
+    }
+    free(ok);
+    if (!status && !(overlap * 3 > trusted_total)) status = BSX_ERR_VOTING_POWER;
+    if (out_commit) out_commit->trusted_signed_power = (uint64_t)overlap;
+    /* prove_data_commitment (:50-55) */
+    bsx_shared_ctx range;
+    range.start_block = trusted_block;
+    range.end_block = target_block;
+    memcpy(range.start_header_hash, trusted_header_hash, 32);
+    memcpy(range.end_header_hash, target_hash, 32);
+    uint8_t commitment[32];
+    uint32_t st = 0;
+    rc = orc_prove_data_commitment(J, B, &range, headers, first_height, n_headers, latest_block, commitment, NULL, NULL,
+                                   compact, &st);
+    if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
+    memcpy(output64, target_hash, 32);      /* :57 */
+    memcpy(output64 + 32, commitment, 32);  /* :58 */
+    if (status) return status;
+    return rc;
+}
+
+/* ------------------------------------------------------------------ cpu_baseline driver */
+typedef struct {
+    uint32_t n_ranges, J, B, v_max;
+    const bsx_shared_ctx* ranges;
+    const bsx_header* headers;
+    uint64_t headers_per_range;
+    const uint64_t* latest;
+    const bsx_validator *target, *trusted;
+    int with_witness, n_threads, tid;
+    uint8_t* out64;
+    uint64_t checksum;
+    int rc;
+} job_t;
+
+static void* worker(void* arg) {
+    job_t* jb = arg;
+    bsx_witness_layout L = bsx_map_layout(jb->B), R = bsx_reduce_layout();
+    size_t csz = (size_t)jb->J * L.compact_stride + (size_t)(jb->J - 1) * R.compact_stride;
+    uint8_t* compact = jb->with_witness ? malloc(csz) : NULL;
+    uint64_t* wit = jb->with_witness ? malloc(((size_t)jb->J * L.n_elements + (size_t)(jb->J - 1) * R.n_elements) * 8) : NULL;
+    uint64_t cs = 0;
+    for (uint32_t r = (uint32_t)jb->tid; r < jb->n_ranges; r += (uint32_t)jb->n_threads) {
+        uint8_t in48[48];
+        const bsx_shared_ctx* rg = &jb->ranges[r];
+        for (int i = 0; i < 8; i++) in48[i] = (uint8_t)(rg->start_block >> (56 - 8 * i));
+        memcpy(in48 + 8, rg->start_header_hash, 32);
+        for (int i = 0; i < 8; i++) in48[40 + i] = (uint8_t)(rg->end_block >> (56 - 8 * i));
+        int rc = orc_header_range(jb->J, jb->B, in48, jb->headers + (size_t)r * jb->headers_per_range, rg->start_block,
+                                  jb->headers_per_range, jb->latest[r], jb->target + (size_t)r * jb->v_max,
+                                  jb->trusted + (size_t)r * jb->v_max, jb->v_max, jb->out64 + 64 * (size_t)r, NULL, compact);
+        if (rc) jb->rc = rc;
+        if (compact) {
+            orc_expand_witness(&L, jb->J, compact, wit);
+            orc_expand_witness(&R, jb->J - 1, compact + (size_t)jb->J * L.compact_stride, wit + (size_t)jb->J * L.n_elements);
+            size_t n = (size_t)jb->J * L.n_elements + (size_t)(jb->J - 1) * R.n_elements;
+            for (size_t i = 0; i < n; i += 4099) cs += wit[i] * (i + 1);
+        }
+        for (int i = 0; i < 8; i++) cs += ((const uint64_t*)(const void*)(jb->out64 + 64 * (size_t)r))[i];
+    }
+    jb->checksum = cs;
+    free(compact);
+    free(wit);
+    return NULL;
+}
+
+int orc_bench_header_range(uint32_t n_ranges, uint32_t J, uint32_t B, const bsx_shared_ctx* ranges,
+                           const bsx_header* headers, uint64_t headers_per_range, const uint64_t* latest_block,
+                           const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
+                           int with_witness, int n_threads, uint8_t* out64, uint64_t* checksum) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    job_t jobs[256];
+    pthread_t th[256];
+    for (int t = 0; t < n_threads; t++) {
+        job_t j = {n_ranges, J, B, v_max, ranges, headers, headers_per_range, latest_block, target_validators,
+                   trusted_validators, with_witness, n_threads, t, out64, 0, 0};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, worker, &jobs[t]);
+    }
+    int rc = 0;
+    uint64_t cs = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        cs += jobs[t].checksum;
+        if (jobs[t].rc) rc = jobs[t].rc;
+    }
+    if (checksum) *checksum = cs;
+    return rc;
+}

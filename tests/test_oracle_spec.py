@@ -1,0 +1,131 @@
+"""CPU suite: spec-level known answers + differential tests that pin the oracle's primitives where the
+reference's fixtures cannot (SURVEY.md §8c "parity unpinned" list): FIPS 180-4 via hashlib, RFC 8032 §7.1,
+and cross-implementation agreement oracle (5x51-bit C) / synth (16x16-bit C signer)."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from blobstreamx_amd import types as T
+
+RFC8032 = [
+    ("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60",
+     "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a", "",
+     "e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e065224901555fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b"),
+    ("4ccd089b28ff96da9db6c346ec114e0f5b8a319f35aba624da8cf6ed4fb8a6fb",
+     "3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c", "72",
+     "92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00"),
+    ("c5aa8df43f9f837bedb7442f31dcb7b166d38535076f094b85ce3a2e0b4458f7",
+     "fc51cd8e6218a1a38da47ed00230f0580816ed13ba3303ac5deb911548908025", "af82",
+     "6291d657deec24024827e69c3abe01a30ce548a284743a445e3680d7db5ac3ac18ff9b538d16f290ae67f760984dc6594a7c15e9716ed28dc027beceea1ec40a"),
+]
+L = 2 ** 252 + 27742317777372353535851937790883648493
+
+
+@pytest.mark.parametrize("portable", [False, True])
+def test_sha_differential(portable):
+    rnd = random.Random(7)
+    oracle.sha256_force_portable(portable)
+    try:
+        for n in list(range(0, 260)) + [511, 512, 1000, 4097]:
+            m = bytes(rnd.getrandbits(8) for _ in range(n))
+            assert oracle.sha256(m) == hashlib.sha256(m).digest()
+            assert oracle.sha512(m) == hashlib.sha512(m).digest()
+    finally:
+        oracle.sha256_force_portable(False)
+
+
+def test_synth_hashes():
+    rnd = random.Random(9)
+    for n in list(range(0, 140)) + [255, 256, 300]:
+        m = bytes(rnd.getrandbits(8) for _ in range(n))
+        assert synth.sha256(m) == hashlib.sha256(m).digest()
+        assert synth.sha512(m) == hashlib.sha512(m).digest()
+
+
+def test_rfc8032_vectors():
+    for sk, pk, m, sig in RFC8032:
+        sk, pk, m, sig = map(bytes.fromhex, (sk, pk, m, sig))
+        assert oracle.ed25519_verify(pk, m, sig)
+        assert synth.ed25519_keypair(sk) == pk
+        assert synth.ed25519_sign(sk, m) == sig
+        bad = bytearray(sig)
+        bad[5] ^= 1
+        assert not oracle.ed25519_verify(pk, m, bytes(bad))
+        assert not oracle.ed25519_verify(pk, m + b"x", sig)
+        # s + L is the same scalar mod L but non-canonical: must be rejected (s < L rule)
+        s = int.from_bytes(sig[32:], "little") + L
+        if s < 2 ** 256:
+            assert not oracle.ed25519_verify(pk, m, sig[:32] + s.to_bytes(32, "little"))
+
+
+def test_ed25519_rejects_bad_encodings():
+    sk, pk, m, sig = map(bytes.fromhex, RFC8032[2])
+    # non-canonical y (y >= p) in A and in R
+    assert not oracle.ed25519_verify((2 ** 255 - 1).to_bytes(32, "little"), m, sig)
+    assert not oracle.ed25519_verify(pk, m, (2 ** 255 - 19 + 1).to_bytes(32, "little") + sig[32:])
+    # y = 2 is not on the curve
+    assert not oracle.ed25519_verify((2).to_bytes(32, "little"), m, sig)
+    # x = 0 with sign bit set (y = 1 | 1<<255)
+    assert not oracle.ed25519_verify((1 | 1 << 255).to_bytes(32, "little"), m, sig)
+
+
+def test_sc_reduce_differential():
+    rnd = random.Random(11)
+    for x in [0, 1, L - 1, L, L + 1, 2 ** 512 - 1, 2 ** 252, 2 ** 256 - 1] + [rnd.getrandbits(512) for _ in range(200)]:
+        assert int.from_bytes(oracle.sc_reduce64(x.to_bytes(64, "little")), "little") == x % L
+
+
+def test_synth_signatures_verify_under_oracle():
+    rnd = random.Random(13)
+    for _ in range(20):
+        seed = bytes(rnd.getrandbits(8) for _ in range(32))
+        msg = bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(0, 125)))
+        pk, sig = synth.ed25519_keypair(seed), synth.ed25519_sign(seed, msg)
+        assert oracle.ed25519_verify(pk, msg, sig)
+        if msg:
+            assert not oracle.ed25519_verify(pk, msg[:-1] + bytes([msg[-1] ^ 1]), sig)
+
+
+def test_merkle_against_hashlib():
+    def root(items):
+        if not items:
+            return hashlib.sha256(b"").digest()
+        if len(items) == 1:
+            return hashlib.sha256(b"\x00" + items[0]).digest()
+        k = 1
+        while k * 2 < len(items):
+            k *= 2
+        return hashlib.sha256(b"\x01" + root(items[:k]) + root(items[k:])).digest()
+
+    rnd = random.Random(17)
+    # masked power-of-two tree (compute_root_from_leaves [UPSTREAM]) == RFC 6962 root over the enabled prefix
+    for B in (1, 2, 4, 8, 16, 64):
+        dhs = np.frombuffer(bytes(rnd.getrandbits(8) for _ in range(32 * B)), np.uint8).reshape(B, 32)
+        for n in sorted({0, 1, B // 2, B - 1, B} & set(range(0, B + 1))):
+            rc, got, af = oracle.get_data_commitment(dhs, 500, 500 + n)
+            assert rc == T.OK
+            tuples = [b"\x00" * 24 + (500 + i).to_bytes(8, "big") + dhs[i].tobytes() for i in range(n)]
+            want = root(tuples) if n else hashlib.sha256(b"\x00" + b"\x00" * 24 + (500).to_bytes(8, "big") + dhs[0].tobytes()).digest()
+            assert got == want, (B, n)
+    rc, _, af = oracle.get_data_commitment(dhs, 10, 9)
+    assert rc == T.ERR_ASSERT and af & T.A1_END_GTE_START
+
+
+def test_synthetic_chain_is_consistent():
+    w = synth.Workload(99, 2, 4, 8, v=5, v_max=8)
+    hs, dh, lb = oracle.header_hashes(w.headers[1])
+    assert (hs == w.hashes[1]).all()
+    for i in range(1, w.hpr):
+        assert bytes(lb[i]["leaf"][2:34]) == hs[i - 1].tobytes()
+    res, ok = oracle.verify_commit(w.validators[1], w.hashes[1, w.n_blocks])
+    assert res["n_enabled"] == 5 and res["n_signed"] == 5 and res["n_bad_signature"] == 0 and res["n_bad_message"] == 0
+    assert bytes(res["validators_hash"]) == w.valset.hash.tobytes()
+    assert w.headers[1][3]["hash"][2][2:34].tobytes() == w.valset.hash.tobytes()
+    rc, out, cres, _ = oracle.header_range(4, 8, w.input48(1), w.headers[1], int(w.first_height[1]), int(w.latest[1]),
+                                           w.validators[1], w.trusted[1])
+    assert rc == T.OK and out[:32] == w.hashes[1, 32].tobytes()
+    assert cres["two_thirds_ok"] == 1 and cres["trusted_signed_power"] == cres["total_power"]
