@@ -1,0 +1,100 @@
+"""ctypes loader for the product library blobstreamx_amd/lib/libbsx.so (C ABI: include/bsx.h).
+
+The library is HIP-only: `context()` raises BsxError(ERR_NO_DEVICE) when no GPU is visible — there is no CPU
+fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+from . import types as T
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "lib", "libbsx.so")
+_lib = None
+_lock = threading.Lock()
+_ctx = {}
+
+# every symbol include/bsx.h declares (checked by tests/test_abi.py without touching a GPU)
+SYMBOLS = [
+    "bsx_version", "bsx_init", "bsx_shutdown", "bsx_last_error", "bsx_status_str", "bsx_device_count",
+    "bsx_map_witness_layout", "bsx_reduce_witness_layout",
+    "bsx_encode_data_root_tuple", "bsx_get_data_commitment", "bsx_header_hashes", "bsx_data_commitment_inputs",
+    "bsx_prove_subchain", "bsx_reduce", "bsx_prove_data_commitment", "bsx_prove_next_header_data_commitment",
+    "bsx_verify_commits", "bsx_header_range",
+    "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_finalize",
+    "bsx_dev_expand_witness", "bsx_dev_fill_end_hash", "bsx_dev_sha512_challenge", "bsx_dev_ed25519_verify",
+    "bsx_dev_commit_tally", "bsx_dev_skip_check",
+]
+
+
+class BsxError(RuntimeError):
+    def __init__(self, status, message):
+        self.status = status
+        name = T.STATUS_NAMES[status] if 0 <= status < len(T.STATUS_NAMES) else str(status)
+        super().__init__(f"{name}: {message}")
+
+
+def build(force=False):
+    """Compile libbsx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(_DIR, "csrc")
+    cmd = ["make", "-C", src, "-j4"] + (["-B"] if force else [])
+    subprocess.run(cmd, check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_SO):
+                raise BsxError(T.ERR_NO_DEVICE, f"{_SO} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+            L = C.CDLL(_SO)
+            L.bsx_version.restype = C.c_uint32
+            L.bsx_last_error.restype = C.c_char_p
+            L.bsx_status_str.restype = C.c_char_p
+            for s in SYMBOLS:
+                getattr(L, s)   # AttributeError here = header/library drift
+            _lib = L
+    return _lib
+
+
+def check(rc, allow=()):
+    if rc != T.OK and rc not in allow:
+        raise BsxError(rc, lib().bsx_last_error().decode(errors="replace"))
+    return rc
+
+
+def last_error():
+    return lib().bsx_last_error().decode(errors="replace")
+
+
+def context(device=0):
+    """One bsx_ctx per device, created on first use.  Raises when no GPU is present."""
+    with _lock:
+        c = _ctx.get(device)
+    if c is not None:
+        return c
+    L = lib()
+    h = C.c_void_p()
+    rc = L.bsx_init(C.c_int(device), C.byref(h))
+    if rc != T.OK:
+        raise BsxError(rc, L.bsx_last_error().decode(errors="replace"))
+    with _lock:
+        _ctx[device] = h
+    return h
+
+
+def p(a):
+    """numpy array -> void* (keeps the array alive through the returned object)."""
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def dp(t):
+    """torch device tensor / int address -> void*"""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())

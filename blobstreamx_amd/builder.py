@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's builder / hint / circuit interface for the header_range path.
+
+Same names, argument meaning and failure behaviour as the reference (panics / failed circuit assertions become
+BsxError with the matching bsx_status), every call going through the C ABI of libbsx.so (include/bsx.h) — so the
+parity tests read like the reference's own tests:
+
+  DataCommitmentBuilder            trait DataCommitmentBuilder            circuits/builder.rs:20-79
+    .encode_data_root_tuple        builder.rs:23-27,82-103
+    .get_data_commitment           builder.rs:33-38,105-148
+    .prove_subchain                builder.rs:45-52,150-271
+    .prove_data_commitment         builder.rs:58-67,273-409
+    .prove_next_header_data_commitment  builder.rs:73-78,411-443
+  InputDataFetcher                 trait DataCommitmentInputFetcher       circuits/input.rs:39-61
+    .get_data_commitment_inputs    input.rs:57-60,149-271  (= DataCommitmentOffchainInputs::hint, data_commitment.rs:18-45)
+  CombinedSkipCircuit.prove        CombinedSkipCircuit::define            circuits/header_range.rs:32-59
+  verify_commits                   inner loop of builder.skip/step        header_range.rs:42-48, next_header.rs:32-36
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import types as T
+
+
+def _b(x, n):
+    a = np.frombuffer(bytes(x), dtype=np.uint8).copy()
+    if a.size != n:
+        raise ValueError(f"expected {n} bytes, got {a.size}")
+    return a
+
+
+class InputDataFetcher:
+    """The header source the hint reads (the reference's RPC / fixture fetcher, circuits/input.rs:66): a
+    contiguous array of packed headers starting at `first_height`, and the chain head `latest_block`."""
+
+    def __init__(self, headers, first_height, latest_block, device=0):
+        self.headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
+        self.first_height = int(first_height)
+        self.latest_block = int(latest_block)
+        self.device = device
+
+    def get_latest_block_number(self):            # input.rs:112-117
+        return self.latest_block
+
+    def header_hashes(self):
+        n = self.headers.size
+        hashes = np.zeros((n, 32), np.uint8)
+        dh = np.zeros(n, T.DH_PROOF)
+        lb = np.zeros(n, T.LB_PROOF)
+        L = _lib.lib()
+        _lib.check(L.bsx_header_hashes(_lib.context(self.device), _lib.p(self.headers), C.c_uint64(n), _lib.p(hashes), None, None))
+        return hashes
+
+    def get_inclusion_proofs(self):
+        """hashes + (data_hash, last_block_id) inclusion proofs of every header (input.rs:175-179,188-195)."""
+        n = self.headers.size
+        hashes = np.zeros((n, 32), np.uint8)
+        dh = np.zeros(n, T.DH_PROOF)
+        lb = np.zeros(n, T.LB_PROOF)
+        _lib.check(_lib.lib().bsx_header_hashes(_lib.context(self.device), _lib.p(self.headers), C.c_uint64(n), _lib.p(hashes),
+                                                _lib.p(dh), _lib.p(lb)))
+        return hashes, dh, lb
+
+    def get_data_commitment_inputs(self, start_block_number, end_block_number, max_leaves):
+        """circuits/input.rs:149-271 -> dict mirroring DataCommitmentInputs (input.rs:29-37)."""
+        sh, eh, exp = np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(32, np.uint8)
+        dh = np.zeros(max_leaves, T.DH_PROOF)
+        lb = np.zeros(max_leaves, T.LB_PROOF)
+        _lib.check(_lib.lib().bsx_data_commitment_inputs(
+            _lib.context(self.device), _lib.p(self.headers), C.c_uint64(self.first_height), C.c_uint64(self.headers.size),
+            C.c_uint64(self.latest_block), C.c_uint64(start_block_number), C.c_uint64(end_block_number), C.c_uint32(max_leaves),
+            _lib.p(sh), _lib.p(eh), _lib.p(dh), _lib.p(lb), _lib.p(exp)))
+        return dict(start_header_hash=sh.tobytes(), end_header_hash=eh.tobytes(), data_hash_proofs=dh,
+                    last_block_id_proofs=lb, expected_data_commitment=exp.tobytes())
+
+
+class DataCommitmentBuilder:
+    def __init__(self, device=0):
+        self.device = device
+
+    @property
+    def _ctx(self):
+        return _lib.context(self.device)
+
+    def encode_data_root_tuple(self, data_hash, height):
+        out = np.zeros(64, np.uint8)
+        _lib.check(_lib.lib().bsx_encode_data_root_tuple(self._ctx, _lib.p(_b(data_hash, 32)), C.c_uint64(height), _lib.p(out)))
+        return out.tobytes()
+
+    def get_data_commitment(self, data_hashes, start_block, end_block):
+        dhs = np.ascontiguousarray(data_hashes, np.uint8).reshape(-1, 32)
+        out = np.zeros(32, np.uint8)
+        _lib.check(_lib.lib().bsx_get_data_commitment(self._ctx, _lib.p(dhs), C.c_uint32(dhs.shape[0]), C.c_uint64(start_block),
+                                                      C.c_uint64(end_block), _lib.p(out)))
+        return out.tobytes()
+
+    def prove_subchain(self, data_comm_proof, batch_start_block, batch_end_block, global_end_block, global_end_header_hash,
+                       want_witness=False, raise_on_assert=True):
+        """data_comm_proof: dict with start_header / end_header (or *_hash) + data_hash_proofs + last_block_id_proofs
+        (DataCommitmentProofVariable, circuits/vars.rs:13-26).  Returns (record, witness | None)."""
+        dh = np.ascontiguousarray(data_comm_proof["data_hash_proofs"], T.DH_PROOF)
+        lb = np.ascontiguousarray(data_comm_proof["last_block_id_proofs"], T.LB_PROOF)
+        B = dh.size
+        sh = data_comm_proof.get("start_header", data_comm_proof.get("start_header_hash"))
+        eh = data_comm_proof.get("end_header", data_comm_proof.get("end_header_hash"))
+        rec = np.zeros(1, T.SUBCHAIN)
+        wit = None
+        if want_witness:
+            lay = T.map_layout(B)
+            wit = np.zeros(int(lay["n_elements"]), np.uint64)
+        rc = _lib.lib().bsx_prove_subchain(self._ctx, C.c_uint32(B), _lib.p(_b(sh, 32)), _lib.p(_b(eh, 32)), _lib.p(dh), _lib.p(lb),
+                                           C.c_uint64(batch_start_block), C.c_uint64(batch_end_block), C.c_uint64(global_end_block),
+                                           _lib.p(_b(global_end_header_hash, 32)), _lib.p(rec), _lib.p(wit))
+        _lib.check(rc, allow=() if raise_on_assert else (T.ERR_ASSERT,))
+        return rec[0], wit
+
+    def reduce(self, records):
+        records = np.ascontiguousarray(records, T.SUBCHAIN)
+        out = np.zeros(1, T.SUBCHAIN)
+        _lib.check(_lib.lib().bsx_reduce(self._ctx, _lib.p(records), C.c_uint32(records.size), _lib.p(out)))
+        return out[0]
+
+    def prove_data_commitment(self, fetcher, nb_map_jobs, batch_size, start_block, start_header_hash, end_block, end_header_hash,
+                              want_witness=False, raise_on_assert=True):
+        """prove_data_commitment::<C, NB_MAP_JOBS, BATCH_SIZE> with the hint served by `fetcher`.
+        Returns dict(data_commitment, result, records, witness, rc)."""
+        ctx = np.zeros(1, T.SHARED_CTX)
+        ctx["start_block"], ctx["end_block"] = start_block, end_block
+        ctx["start_header_hash"][0] = _b(start_header_hash, 32)
+        ctx["end_header_hash"][0] = _b(end_header_hash, 32)
+        out = np.zeros(32, np.uint8)
+        result = np.zeros(1, T.SUBCHAIN)
+        records = np.zeros(nb_map_jobs, T.SUBCHAIN)
+        wit = None
+        if want_witness:
+            ml, rl = T.map_layout(batch_size), T.reduce_layout()
+            wit = np.zeros(nb_map_jobs * int(ml["n_elements"]) + (nb_map_jobs - 1) * int(rl["n_elements"]), np.uint64)
+        rc = _lib.lib().bsx_prove_data_commitment(
+            self._ctx, C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _lib.p(ctx), _lib.p(fetcher.headers),
+            C.c_uint64(fetcher.first_height), C.c_uint64(fetcher.headers.size), C.c_uint64(fetcher.latest_block), _lib.p(out),
+            _lib.p(result), _lib.p(records), _lib.p(wit))
+        _lib.check(rc, allow=() if raise_on_assert else (T.ERR_ASSERT,))
+        return dict(data_commitment=out.tobytes(), result=result[0], records=records, witness=wit, rc=rc)
+
+    def prove_next_header_data_commitment(self, fetcher, prev_block_number, prev_header_hash, next_block_number):
+        header = fetcher.headers[prev_block_number - fetcher.first_height:prev_block_number - fetcher.first_height + 1]
+        out = np.zeros(32, np.uint8)
+        _lib.check(_lib.lib().bsx_prove_next_header_data_commitment(
+            self._ctx, C.c_uint64(prev_block_number), _lib.p(_b(prev_header_hash, 32)), C.c_uint64(next_block_number),
+            _lib.p(np.ascontiguousarray(header)), C.c_uint64(fetcher.latest_block), _lib.p(out)))
+        return out.tobytes()
+
+
+def verify_commits(validators, header_hashes, device=0):
+    """validators: ndarray[n_commits, v_max] of VALIDATOR; header_hashes: [n_commits, 32] -> (results, sig_ok)."""
+    v = np.ascontiguousarray(validators, T.VALIDATOR)
+    if v.ndim == 1:
+        v = v.reshape(1, -1)
+    n, vmax = v.shape
+    hh = np.ascontiguousarray(header_hashes, np.uint8).reshape(n, 32)
+    res = np.zeros(n, T.COMMIT_RESULT)
+    ok = np.zeros((n, vmax), np.uint8)
+    _lib.check(_lib.lib().bsx_verify_commits(_lib.context(device), _lib.p(v), C.c_uint32(n), C.c_uint32(vmax), _lib.p(hh),
+                                             _lib.p(res), _lib.p(ok)))
+    return res, ok
+
+
+class CombinedSkipCircuit:
+    """CombinedSkipCircuit<MAX_VALIDATOR_SET_SIZE, CHAIN_ID_SIZE, C, NB_MAP_JOBS, BATCH_SIZE>
+    (circuits/header_range.rs:13-59; instantiated 100/32/32 and 100/32/64 by bin/header_range_{1024,2048}.rs:6-17)."""
+
+    def __init__(self, max_validator_set_size, nb_map_jobs, batch_size, skip_max=None, device=0):
+        self.V, self.J, self.B = max_validator_set_size, nb_map_jobs, batch_size
+        skip_max = skip_max if skip_max is not None else nb_map_jobs * batch_size
+        # header_range.rs:37-40 (build-time assert)
+        assert nb_map_jobs * batch_size <= skip_max, "NB_MAP_JOBS * BATCH_SIZE must be <= than SKIP_MAX"
+        self.device = device
+
+    def prove(self, input48, fetcher, target_validators, trusted_validators, want_witness=False):
+        """48-byte EVM-packed input -> 64-byte output (target_header_hash ‖ data_commitment)."""
+        tv = np.ascontiguousarray(target_validators, T.VALIDATOR).reshape(-1)
+        rv = np.ascontiguousarray(trusted_validators, T.VALIDATOR).reshape(-1)
+        if tv.size != self.V or rv.size != self.V:
+            raise ValueError(f"validator arrays must have MAX_VALIDATOR_SET_SIZE = {self.V} slots")
+        out = np.zeros(64, np.uint8)
+        res = np.zeros(1, T.COMMIT_RESULT)
+        wit = None
+        if want_witness:
+            ml, rl = T.map_layout(self.B), T.reduce_layout()
+            wit = np.zeros(self.J * int(ml["n_elements"]) + (self.J - 1) * int(rl["n_elements"]), np.uint64)
+        _lib.check(_lib.lib().bsx_header_range(
+            _lib.context(self.device), C.c_uint32(self.J), C.c_uint32(self.B), _lib.p(_b(input48, 48)), _lib.p(fetcher.headers),
+            C.c_uint64(fetcher.first_height), C.c_uint64(fetcher.headers.size), C.c_uint64(fetcher.latest_block), _lib.p(tv),
+            _lib.p(rv), C.c_uint32(self.V), _lib.p(out), _lib.p(res), _lib.p(wit)))
+        return out.tobytes(), res[0], wit

@@ -1,0 +1,682 @@
+// api.hip — host side of libbsx.so: the C ABI declared in include/bsx.h.
+//
+// Mirrors the reference's builder/hint interface for the header_range path (same names, argument meaning and
+// failure conditions — circuits/builder.rs:20-79, circuits/data_commitment.rs:18-45, circuits/input.rs:39-61,
+// circuits/header_range.rs:32-59) with return codes instead of panics.  All arithmetic runs in the HIP kernels; the
+// host code only validates arguments, moves caller bytes into the documented device layouts and turns device
+// status words into bsx_status codes.  There is NO CPU compute path: without a GPU bsx_init fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bsx.h"
+#include "../../include/bsx_layout.h"
+
+extern "C" {
+hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*);
+hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
+                                const uint64_t*, const bsx_header*, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
+                                uint8_t*, uint32_t*);
+hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*);
+hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, bsx_subchain*, uint8_t*);
+hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_subchain*, const uint8_t*,
+                         uint8_t*, uint32_t*);
+hipError_t bsxk_expand_witness(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, uint64_t*);
+hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, uint8_t*, uint8_t*);
+hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
+hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
+hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
+                           const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
+                           uint32_t*, uint8_t*);
+hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
+hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
+hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t);
+int bsxk_tally_vmax(void);
+}
+
+static_assert(sizeof(bsx_header) == 512, "bsx_header");
+static_assert(sizeof(bsx_data_hash_proof) == 162 && sizeof(bsx_last_block_id_proof) == 200, "proofs");
+static_assert(sizeof(bsx_shared_ctx) == 80 && sizeof(bsx_subchain) == 128, "records");
+static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "commit");
+static_assert(sizeof(bsx_witness_layout) == 40, "layout");
+
+struct bsx_ctx {
+    int device;
+    hipStream_t stream;
+};
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(BSX_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define RET(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != BSX_OK) return rc_; \
+    } while (0)
+
+bool pow2(uint32_t x) { return x && !(x & (x - 1)); }
+
+// device buffer with the lifetime of one host-tier call
+struct DBuf {
+    void* p = nullptr;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return fail(BSX_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+        return BSX_OK;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+hipStream_t S(bsx_ctx* c, void* s) { return s ? static_cast<hipStream_t>(s) : c->stream; }
+
+int use(bsx_ctx* ctx) {
+    if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");
+    HIPCHK(hipSetDevice(ctx->device));
+    return BSX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+uint32_t bsx_version(void) { return BSX_VERSION; }
+
+int bsx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bsx_init(int device, bsx_ctx** out) {
+    if (!out) return fail(BSX_ERR_BAD_ARG, "bsx_init: null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(BSX_ERR_NO_DEVICE, "no HIP device visible (%s); libbsx has no CPU fallback", e == hipSuccess ? "count == 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(BSX_ERR_BAD_ARG, "device %d out of range (0..%d)", device, n - 1);
+    if (hipSetDevice(device) != hipSuccess) return fail(BSX_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    bsx_ctx* c = new bsx_ctx{device, nullptr};
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(BSX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return BSX_OK;
+}
+
+void bsx_shutdown(bsx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* bsx_last_error(void) { return g_err.c_str(); }
+
+const char* bsx_status_str(int s) {
+    static const char* N[] = {"BSX_OK", "BSX_ERR_NO_DEVICE", "BSX_ERR_HIP", "BSX_ERR_BAD_ARG", "BSX_ERR_RANGE_TOO_LONG",
+                              "BSX_ERR_BAD_HEADER", "BSX_ERR_ASSERT", "BSX_ERR_BAD_SIGNATURE", "BSX_ERR_VOTING_POWER", "BSX_ERR_UNSUPPORTED"};
+    return (s >= 0 && s < 10) ? N[s] : "BSX_ERR_?";
+}
+
+int bsx_map_witness_layout(uint32_t batch_size, bsx_witness_layout* out) {
+    if (!out || !pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "batch_size must be a power of two <= %d", BSX_MAX_BATCH);
+    *out = bsx_map_layout(batch_size);
+    return BSX_OK;
+}
+int bsx_reduce_witness_layout(bsx_witness_layout* out) {
+    if (!out) return fail(BSX_ERR_BAD_ARG, "null out");
+    *out = bsx_reduce_layout();
+    return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ device tier
+#define DEV_ENTER() RET(use(ctx))
+
+int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n, uint8_t* d_hashes,
+                          uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint32_t* d_status) {
+    DEV_ENTER();
+    if (n && !d_headers) return fail(BSX_ERR_BAD_ARG, "null headers");
+    HIPCHK(bsxk_header_merkle(S(ctx, stream), d_headers, n, d_hashes, d_dh_aunts, d_lb_aunts, d_status));
+    return BSX_OK;
+}
+
+int bsx_dev_assemble_inputs(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
+                            uint32_t job_first, uint32_t job_count, uint32_t span, const bsx_shared_ctx* d_ranges,
+                            const uint64_t* d_latest, const bsx_header* d_headers, uint64_t headers_per_range,
+                            const uint8_t* d_hashes, const uint8_t* d_dh_aunts, const uint8_t* d_lb_aunts, uint8_t* d_compact,
+                            uint32_t* d_status) {
+    DEV_ENTER();
+    if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "batch_size must be a power of two <= %d", BSX_MAX_BATCH);
+    if (span > batch_size) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start = %u > MAX_LEAVES = %u (input.rs:154)", span, batch_size);
+    if (job_first + job_count > nb_map_jobs) return fail(BSX_ERR_BAD_ARG, "job slice [%u,%u) exceeds nb_map_jobs %u", job_first, job_first + job_count, nb_map_jobs);
+    if (!d_ranges || !d_latest || !d_headers || !d_hashes || !d_dh_aunts || !d_lb_aunts || !d_compact) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_assemble_inputs(S(ctx, stream), n_ranges, nb_map_jobs, batch_size, job_first, job_count, span, d_ranges, d_latest,
+                                d_headers, headers_per_range, d_hashes, d_dh_aunts, d_lb_aunts, d_compact, d_status));
+    return BSX_OK;
+}
+
+int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t batch_size, uint32_t job_count,
+                           const bsx_shared_ctx* d_ranges, uint8_t* d_compact, bsx_subchain* d_records) {
+    DEV_ENTER();
+    if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "batch_size must be a power of two <= %d", BSX_MAX_BATCH);
+    if (!d_ranges || !d_compact || !d_records) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_prove_subchain(S(ctx, stream), n_ranges, batch_size, job_count, d_ranges, d_compact, d_records));
+    return BSX_OK;
+}
+
+int bsx_dev_reduce(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t n, const bsx_subchain* d_records, bsx_subchain* d_out,
+                   uint8_t* d_reduce_compact) {
+    DEV_ENTER();
+    if (!pow2(n) || n > 256) return fail(BSX_ERR_BAD_ARG, "reduce fan-in must be a power of two <= 256 (got %u)", n);
+    if (!d_records || !d_out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_reduce(S(ctx, stream), n_ranges, n, d_records, d_out, d_reduce_compact));
+    return BSX_OK;
+}
+
+int bsx_dev_finalize(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
+                     const bsx_shared_ctx* d_ranges, const bsx_subchain* d_results, const uint8_t* d_target_hashes,
+                     uint8_t* d_output64, uint32_t* d_status) {
+    DEV_ENTER();
+    if (!d_ranges || !d_results) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_finalize(S(ctx, stream), n_ranges, nb_map_jobs, batch_size, d_ranges, d_results, d_target_hashes, d_output64, d_status));
+    return BSX_OK;
+}
+
+int bsx_dev_expand_witness(bsx_ctx* ctx, void* stream, const bsx_witness_layout* layout, uint32_t n_jobs, const uint8_t* d_compact,
+                           uint64_t* d_witness) {
+    DEV_ENTER();
+    if (!layout || !d_compact || !d_witness) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (reinterpret_cast<uintptr_t>(d_witness) & 15) return fail(BSX_ERR_BAD_ARG, "witness buffer must be 16-byte aligned");
+    HIPCHK(bsxk_expand_witness(S(ctx, stream), layout, n_jobs, d_compact, d_witness));
+    return BSX_OK;
+}
+
+int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_shared_ctx* d_ranges, const uint8_t* d_hashes,
+                          uint64_t headers_per_range) {
+    DEV_ENTER();
+    if (!d_ranges || !d_hashes) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_fill_end_hash(S(ctx, stream), n_ranges, d_ranges, d_hashes, headers_per_range));
+    return BSX_OK;
+}
+
+int bsx_dev_sha512_challenge(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n, uint8_t* d_h, uint8_t* d_digest) {
+    DEV_ENTER();
+    if (n && (!d_validators || !d_h)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_sha512_challenge(S(ctx, stream), d_validators, n, d_h, d_digest));
+    return BSX_OK;
+}
+
+int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n, uint8_t* d_ok) {
+    DEV_ENTER();
+    if (n && (!d_validators || !d_h || !d_ok)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_ed25519_verify(S(ctx, stream), d_validators, d_h, n, d_ok));
+    return BSX_OK;
+}
+
+int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits, uint32_t v_max,
+                         const uint8_t* d_header_hashes, const uint8_t* d_ok, bsx_commit_result* d_results) {
+    DEV_ENTER();
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+    if (n_commits && (!d_validators || !d_results)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_commit_tally(S(ctx, stream), d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results));
+    return BSX_OK;
+}
+
+int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* d_ranges,
+                       const bsx_header* d_headers, uint64_t headers_per_range, const uint8_t* d_hashes, const bsx_validator* d_target,
+                       const bsx_validator* d_trusted, const uint8_t* d_target_ok, bsx_commit_result* d_target_res,
+                       const bsx_commit_result* d_trusted_res, uint32_t* d_skip_status, uint8_t* d_target_hashes) {
+    DEV_ENTER();
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+    if (!d_ranges || !d_headers || !d_hashes || !d_target || !d_trusted || !d_target_ok || !d_target_res || !d_trusted_res || !d_skip_status)
+        return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_skip_check(S(ctx, stream), n_ranges, v_max, d_ranges, d_headers, headers_per_range, d_hashes, d_target, d_trusted,
+                           d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes));
+    return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host tier
+#define H2D(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, st))
+#define D2H(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyDeviceToHost, st))
+#define SYNC() HIPCHK(hipStreamSynchronize(st))
+
+static int header_status_to_rc(uint32_t hs, uint32_t as) {
+    if (hs & 1u) return fail(BSX_ERR_BAD_HEADER, "a packed header violates the field-size rules of bsx_header");
+    if (as & 2u) return fail(BSX_ERR_BAD_HEADER, "an inclusion-proof leaf is not 34 / 72 bytes (circuits/input.rs:173,190)");
+    if (as & 4u) return fail(BSX_ERR_BAD_ARG, "the supplied headers do not cover [start, min(end, latest-2)] or latest < 2");
+    return BSX_OK;
+}
+
+int bsx_encode_data_root_tuple(bsx_ctx* ctx, const uint8_t data_hash[32], uint64_t height, uint8_t out[64]) {
+    DEV_ENTER();
+    if (!data_hash || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    hipStream_t st = ctx->stream;
+    DBuf d;
+    RET(d.alloc(96));
+    H2D(d.p, data_hash, 32);
+    HIPCHK(bsxk_encode_tuple(st, d.as<uint8_t>(), height, d.as<uint8_t>() + 32));
+    D2H(out, d.as<uint8_t>() + 32, 64);
+    SYNC();
+    return BSX_OK;
+}
+
+int bsx_get_data_commitment(bsx_ctx* ctx, const uint8_t* data_hashes, uint32_t max_leaves, uint64_t start_block, uint64_t end_block,
+                            uint8_t out_root[32]) {
+    DEV_ENTER();
+    if (!data_hashes || !out_root) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (!pow2(max_leaves) || max_leaves > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "MAX_LEAVES must be a power of two <= %d", BSX_MAX_BATCH);
+    hipStream_t st = ctx->stream;
+    DBuf d;
+    RET(d.alloc((size_t)max_leaves * 32 + 64));
+    uint8_t* dr = d.as<uint8_t>() + (size_t)max_leaves * 32;
+    H2D(d.p, data_hashes, (size_t)max_leaves * 32);
+    HIPCHK(bsxk_data_commitment(st, d.as<uint8_t>(), max_leaves, start_block, end_block, dr, reinterpret_cast<uint32_t*>(dr + 32)));
+    uint8_t tmp[36];
+    D2H(tmp, dr, 36);
+    SYNC();
+    memcpy(out_root, tmp, 32);
+    uint32_t flags;
+    memcpy(&flags, tmp + 32, 4);
+    if (flags) return fail(BSX_ERR_ASSERT, "get_data_commitment: assertion mask 0x%x (A1 end>=start builder.rs:113-114, A2 u32 range :128)", flags);
+    return BSX_OK;
+}
+
+int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8_t* out_hashes, bsx_data_hash_proof* out_dh,
+                      bsx_last_block_id_proof* out_lb) {
+    DEV_ENTER();
+    if (n && !headers) return fail(BSX_ERR_BAD_ARG, "null headers");
+    if (!n) return BSX_OK;
+    hipStream_t st = ctx->stream;
+    DBuf dh, dout, dst;
+    RET(dh.alloc(n * sizeof(bsx_header)));
+    RET(dout.alloc(n * (32 + 128 + 128)));
+    RET(dst.alloc(4));
+    uint8_t* d_hash = dout.as<uint8_t>();
+    uint8_t* d_dh = d_hash + n * 32;
+    uint8_t* d_lb = d_dh + n * 128;
+    H2D(dh.p, headers, n * sizeof(bsx_header));
+    HIPCHK(hipMemsetAsync(dst.p, 0, 4, st));
+    HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, dst.as<uint32_t>()));
+    std::vector<uint8_t> tmp(n * 288);
+    uint32_t hs = 0;
+    D2H(tmp.data(), d_hash, n * 288);
+    D2H(&hs, dst.p, 4);
+    SYNC();
+    RET(header_status_to_rc(hs, 0));
+    if (out_hashes) memcpy(out_hashes, tmp.data(), n * 32);
+    for (uint64_t i = 0; i < n; i++) {
+        if (out_dh) {   // circuits/input.rs:172-181: leaf = the encoded data_hash field
+            if (headers[i].len[BSX_DATA_HASH_INDEX] != BSX_PROTOBUF_HASH_SIZE) return fail(BSX_ERR_BAD_HEADER, "header %llu: data_hash leaf is %u bytes, not 34", (unsigned long long)i, headers[i].len[BSX_DATA_HASH_INDEX]);
+            memcpy(out_dh[i].aunts, tmp.data() + n * 32 + i * 128, 128);
+            memcpy(out_dh[i].leaf, headers[i].hash[1], BSX_PROTOBUF_HASH_SIZE);
+        }
+        if (out_lb) {   // circuits/input.rs:187-197
+            if (headers[i].len[BSX_LAST_BLOCK_ID_INDEX] != BSX_PROTOBUF_BLOCK_ID_SIZE) return fail(BSX_ERR_BAD_HEADER, "header %llu: last_block_id leaf is %u bytes, not 72", (unsigned long long)i, headers[i].len[BSX_LAST_BLOCK_ID_INDEX]);
+            memcpy(out_lb[i].aunts, tmp.data() + n * 160 + i * 128, 128);
+            memcpy(out_lb[i].leaf, headers[i].last_block_id, BSX_PROTOBUF_BLOCK_ID_SIZE);
+        }
+    }
+    return BSX_OK;
+}
+
+// Shared by the hint-level entry points: uploads headers [S .. ) of one range and runs P5.
+struct RangeDev {
+    DBuf headers, hashes, dh, lb, ranges, latest, hstatus, astatus;
+    uint64_t hpr = 0;
+};
+static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
+                        uint64_t S_, const bsx_shared_ctx& range, uint64_t latest_block, RangeDev& rd) {
+    if (!headers || !n_headers) return fail(BSX_ERR_BAD_ARG, "no headers supplied");
+    if (S_ < first_height || S_ - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "header for start block %llu not supplied (first_height %llu, n %llu)", (unsigned long long)S_, (unsigned long long)first_height, (unsigned long long)n_headers);
+    if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
+    const bsx_header* h0 = headers + (S_ - first_height);
+    rd.hpr = n_headers - (S_ - first_height);
+    RET(rd.headers.alloc(rd.hpr * sizeof(bsx_header)));
+    RET(rd.hashes.alloc(rd.hpr * 32));
+    RET(rd.dh.alloc(rd.hpr * 128));
+    RET(rd.lb.alloc(rd.hpr * 128));
+    RET(rd.ranges.alloc(sizeof(bsx_shared_ctx)));
+    RET(rd.latest.alloc(8));
+    RET(rd.hstatus.alloc(4));
+    RET(rd.astatus.alloc(4));
+    H2D(rd.headers.p, h0, rd.hpr * sizeof(bsx_header));
+    H2D(rd.ranges.p, &range, sizeof range);
+    H2D(rd.latest.p, &latest_block, 8);
+    HIPCHK(hipMemsetAsync(rd.hstatus.p, 0, 4, st));
+    HIPCHK(hipMemsetAsync(rd.astatus.p, 0, 4, st));
+    HIPCHK(bsxk_header_merkle(st, rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
+                              rd.hstatus.as<uint32_t>()));
+    (void)ctx;
+    return BSX_OK;
+}
+
+int bsx_data_commitment_inputs(bsx_ctx* ctx, const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
+                               uint64_t start_block, uint64_t end_block, uint32_t max_leaves, uint8_t out_start_header[32],
+                               uint8_t out_end_header[32], bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb,
+                               uint8_t out_expected_data_commitment[32]) {
+    DEV_ENTER();
+    if (!out_start_header || !out_end_header || !out_dh || !out_lb) return fail(BSX_ERR_BAD_ARG, "null output");
+    if (!max_leaves || max_leaves > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "MAX_LEAVES must be in 1..%d", BSX_MAX_BATCH);
+    if (end_block - start_block > (uint64_t)max_leaves) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start > MAX_LEAVES (circuits/input.rs:154)");
+    uint32_t P = 1;
+    while (P < max_leaves) P *= 2;                 // the kernels fold power-of-two batches; extra slots stay zero padded
+    hipStream_t st = ctx->stream;
+    bsx_shared_ctx range{};
+    range.start_block = start_block;
+    range.end_block = end_block;
+    RangeDev rd;
+    RET(upload_range(ctx, st, headers, first_height, n_headers, start_block, range, latest_block, rd));
+    const bsx_witness_layout L = bsx_map_layout(P);
+    DBuf cw, aux;
+    RET(cw.alloc(L.compact_stride));
+    RET(aux.alloc((size_t)P * 32 + 64));
+    HIPCHK(hipMemsetAsync(cw.p, 0, L.compact_stride, st));
+    HIPCHK(bsxk_assemble_inputs(st, 1, 1, P, 0, 1, (uint32_t)(end_block - start_block), rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(),
+                                rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
+                                cw.as<uint8_t>(), rd.astatus.as<uint32_t>()));
+    std::vector<uint8_t> img(L.compact_stride);
+    uint32_t hs = 0, as = 0;
+    D2H(img.data(), cw.p, L.compact_stride);
+    D2H(&hs, rd.hstatus.p, 4);
+    D2H(&as, rd.astatus.p, 4);
+    SYNC();
+    RET(header_status_to_rc(hs, as));
+    memcpy(out_start_header, img.data() + bsx_off_start_header(), 32);
+    memcpy(out_end_header, img.data() + bsx_off_end_header(), 32);
+    memcpy(out_dh, img.data() + bsx_off_dh_proofs(P), (size_t)max_leaves * sizeof(bsx_data_hash_proof));
+    memcpy(out_lb, img.data() + bsx_off_lb_proofs(P), (size_t)max_leaves * sizeof(bsx_last_block_id_proof));
+    if (out_expected_data_commitment) {
+        // input.rs:241-244 with :70-72: the node's commitment over [start, req_end) — zero when the range is empty
+        const uint64_t req_end = end_block < latest_block - 2 ? end_block : latest_block - 2;
+        if (req_end <= start_block) {
+            memset(out_expected_data_commitment, 0, 32);
+        } else {
+            std::vector<uint8_t> dhs((size_t)P * 32, 0);
+            for (uint32_t i = 0; i < max_leaves; i++) memcpy(dhs.data() + 32 * i, out_dh[i].leaf + 2, 32);
+            uint8_t* dr = aux.as<uint8_t>() + (size_t)P * 32;
+            H2D(aux.p, dhs.data(), dhs.size());
+            HIPCHK(bsxk_data_commitment(st, aux.as<uint8_t>(), P, start_block, req_end, dr, reinterpret_cast<uint32_t*>(dr + 32)));
+            D2H(out_expected_data_commitment, dr, 32);
+            SYNC();
+        }
+    }
+    return BSX_OK;
+}
+
+static int subchain_rc(const bsx_subchain& rec) {
+    if (rec.assert_fail)
+        return fail(BSX_ERR_ASSERT, "prove_subchain: assertion mask 0x%x, first failing slot %u (A3 builder.rs:205-207, A4 :210-212, A5 :216-219, A6 :229-232)",
+                    rec.assert_fail, rec.first_bad_slot);
+    return BSX_OK;
+}
+
+int bsx_prove_subchain(bsx_ctx* ctx, uint32_t batch_size, const uint8_t start_header[32], const uint8_t end_header[32],
+                       const bsx_data_hash_proof* dh, const bsx_last_block_id_proof* lb, uint64_t batch_start_block,
+                       uint64_t batch_end_block, uint64_t global_end_block, const uint8_t global_end_header_hash[32],
+                       bsx_subchain* out_record, uint64_t* witness) {
+    DEV_ENTER();
+    if (!start_header || !end_header || !dh || !lb || !global_end_header_hash || !out_record) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
+    const uint32_t B = batch_size;
+    const bsx_witness_layout L = bsx_map_layout(B);
+    hipStream_t st = ctx->stream;
+    // caller bytes -> compact witness image (no arithmetic: the kernel completes it)
+    std::vector<uint8_t> img(L.compact_stride, 0);
+    memcpy(img.data() + bsx_off_ctx_end_header(), global_end_header_hash, 32);
+    memcpy(img.data() + bsx_off_start_header(), start_header, 32);
+    memcpy(img.data() + bsx_off_end_header(), end_header, 32);
+    memcpy(img.data() + bsx_off_dh_proofs(B), dh, (size_t)B * sizeof *dh);
+    memcpy(img.data() + bsx_off_lb_proofs(B), lb, (size_t)B * sizeof *lb);
+    uint32_t* W = reinterpret_cast<uint32_t*>(img.data() + L.off_words);
+    W[BSX_W_CTX_END] = (uint32_t)global_end_block; W[BSX_W_CTX_END + 1] = (uint32_t)(global_end_block >> 32);
+    W[BSX_W_BATCH_START] = (uint32_t)batch_start_block; W[BSX_W_BATCH_START + 1] = (uint32_t)(batch_start_block >> 32);
+    W[BSX_W_BATCH_END] = (uint32_t)batch_end_block; W[BSX_W_BATCH_END + 1] = (uint32_t)(batch_end_block >> 32);
+    bsx_shared_ctx range{};
+    range.end_block = global_end_block;
+    memcpy(range.end_header_hash, global_end_header_hash, 32);
+    DBuf cw, rg, rec, wit;
+    RET(cw.alloc(L.compact_stride));
+    RET(rg.alloc(sizeof range));
+    RET(rec.alloc(sizeof(bsx_subchain)));
+    H2D(cw.p, img.data(), L.compact_stride);
+    H2D(rg.p, &range, sizeof range);
+    HIPCHK(bsxk_prove_subchain(st, 1, B, 1, rg.as<bsx_shared_ctx>(), cw.as<uint8_t>(), rec.as<bsx_subchain>()));
+    if (witness) {
+        RET(wit.alloc(L.n_elements * 8));
+        HIPCHK(bsxk_expand_witness(st, &L, 1, cw.as<uint8_t>(), wit.as<uint64_t>()));
+        D2H(witness, wit.p, L.n_elements * 8);
+    }
+    D2H(out_record, rec.p, sizeof(bsx_subchain));
+    SYNC();
+    return subchain_rc(*out_record);
+}
+
+int bsx_reduce(bsx_ctx* ctx, const bsx_subchain* records, uint32_t n, bsx_subchain* out) {
+    DEV_ENTER();
+    if (!records || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (!pow2(n) || n > 256) return fail(BSX_ERR_BAD_ARG, "reduce fan-in must be a power of two <= 256 (got %u)", n);
+    hipStream_t st = ctx->stream;
+    DBuf d;
+    RET(d.alloc((size_t)(n + 1) * sizeof(bsx_subchain)));
+    H2D(d.p, records, (size_t)n * sizeof(bsx_subchain));
+    HIPCHK(bsxk_reduce(st, 1, n, d.as<bsx_subchain>(), d.as<bsx_subchain>() + n, nullptr));
+    D2H(out, d.as<bsx_subchain>() + n, sizeof(bsx_subchain));
+    SYNC();
+    return BSX_OK;
+}
+
+// prove_data_commitment on one range whose device state (headers hashed) is in rd.  d_target_hashes optional.
+static int run_data_commitment(hipStream_t st, uint32_t J, uint32_t B, RangeDev& rd, const uint8_t* d_target_hashes,
+                               uint8_t out_commitment[32], uint8_t output64[64], bsx_subchain* out_result, bsx_subchain* records,
+                               uint64_t* witness, uint32_t* out_status) {
+    const bsx_witness_layout L = bsx_map_layout(B), R = bsx_reduce_layout();
+    DBuf cw, rcw, recs, res, o64, stw, wit;
+    RET(cw.alloc((size_t)J * L.compact_stride));
+    RET(rcw.alloc((size_t)(J > 1 ? J - 1 : 1) * R.compact_stride));
+    RET(recs.alloc((size_t)J * sizeof(bsx_subchain)));
+    RET(res.alloc(sizeof(bsx_subchain)));
+    RET(o64.alloc(64));
+    RET(stw.alloc(4));
+    HIPCHK(hipMemsetAsync(cw.p, 0, (size_t)J * L.compact_stride, st));
+    HIPCHK(bsxk_assemble_inputs(st, 1, J, B, 0, J, B, rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(), rd.headers.as<bsx_header>(), rd.hpr,
+                                rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(), cw.as<uint8_t>(), rd.astatus.as<uint32_t>()));
+    HIPCHK(bsxk_prove_subchain(st, 1, B, J, rd.ranges.as<bsx_shared_ctx>(), cw.as<uint8_t>(), recs.as<bsx_subchain>()));
+    HIPCHK(bsxk_reduce(st, 1, J, recs.as<bsx_subchain>(), res.as<bsx_subchain>(), rcw.as<uint8_t>()));
+    HIPCHK(bsxk_finalize(st, 1, J, B, rd.ranges.as<bsx_shared_ctx>(), res.as<bsx_subchain>(), d_target_hashes, o64.as<uint8_t>(), stw.as<uint32_t>()));
+    if (witness) {
+        const size_t nmap = (size_t)J * L.n_elements, nred = (size_t)(J - 1) * R.n_elements;
+        RET(wit.alloc((nmap + nred) * 8 + 16));
+        HIPCHK(bsxk_expand_witness(st, &L, J, cw.as<uint8_t>(), wit.as<uint64_t>()));
+        if (J > 1) {
+            // the reduce section starts at element nmap; keep the kernel's 16-byte pair alignment by expanding into an
+            // aligned scratch and copying out
+            DBuf wr;
+            RET(wr.alloc(nred * 8 + 16));
+            HIPCHK(bsxk_expand_witness(st, &R, J - 1, rcw.as<uint8_t>(), wr.as<uint64_t>()));
+            HIPCHK(hipMemcpyAsync(wit.as<uint64_t>() + nmap, wr.p, nred * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        D2H(witness, wit.p, (nmap + nred) * 8);
+    }
+    uint8_t o[64];
+    bsx_subchain result;
+    uint32_t hs = 0, as = 0, stv = 0;
+    D2H(o, o64.p, 64);
+    D2H(&result, res.p, sizeof result);
+    if (records) D2H(records, recs.p, (size_t)J * sizeof(bsx_subchain));
+    D2H(&hs, rd.hstatus.p, 4);
+    D2H(&as, rd.astatus.p, 4);
+    D2H(&stv, stw.p, 4);
+    SYNC();
+    RET(header_status_to_rc(hs, as));
+    if (out_commitment) memcpy(out_commitment, o + 32, 32);
+    if (output64) memcpy(output64, o, 64);
+    if (out_result) { *out_result = result; out_result->assert_fail = stv; }
+    if (out_status) *out_status = stv;
+    if (stv) return fail(BSX_ERR_ASSERT, "prove_data_commitment: assertion mask 0x%x (A7 builder.rs:292-297, A8 :350-355, A9 :401-406; A1-A6 from the map jobs)", stv);
+    return BSX_OK;
+}
+
+int bsx_prove_data_commitment(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const bsx_shared_ctx* range, const bsx_header* headers,
+                              uint64_t first_height, uint64_t n_headers, uint64_t latest_block, uint8_t out_data_commitment[32],
+                              bsx_subchain* out_result, bsx_subchain* records, uint64_t* witness) {
+    DEV_ENTER();
+    if (!range || !out_data_commitment) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (!pow2(nb_map_jobs) || nb_map_jobs > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
+    if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
+    hipStream_t st = ctx->stream;
+    RangeDev rd;
+    RET(upload_range(ctx, st, headers, first_height, n_headers, range->start_block, *range, latest_block, rd));
+    return run_data_commitment(st, nb_map_jobs, batch_size, rd, nullptr, out_data_commitment, nullptr, out_result, records, witness, nullptr);
+}
+
+int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_number, const uint8_t prev_header_hash[32],
+                                          uint64_t next_block_number, const bsx_header* header, uint64_t latest_block,
+                                          uint8_t out_data_commitment[32]) {
+    DEV_ENTER();
+    if (!prev_header_hash || !header || !out_data_commitment) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (next_block_number - prev_block_number > 1) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start > MAX_LEAVES = 1 (circuits/input.rs:154)");
+    if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
+    // builder.rs:415-423: hint with MAX_LEAVES = 1.  data_hash_proofs[0] is real iff prev < min(next, latest-2)
+    // (input.rs:162,172); the last_block_id proof the hint also returns is not used by this circuit.
+    const uint64_t req_end = next_block_number < latest_block - 2 ? next_block_number : latest_block - 2;
+    bsx_data_hash_proof dh;
+    bsx_last_block_id_proof lb;
+    memset(&dh, 0, sizeof dh);
+    memset(&lb, 0, sizeof lb);
+    if (prev_block_number < req_end) RET(bsx_header_hashes(ctx, header, 1, nullptr, &dh, nullptr));
+    // one-slot map job: slot.dh_path[4] = data_hash_proof_root (:429-433), leaf_hash[0] = leaf_hash(tuple) (:436-442)
+    const bsx_witness_layout L = bsx_map_layout(1);
+    hipStream_t st = ctx->stream;
+    std::vector<uint8_t> img(L.compact_stride, 0);
+    memcpy(img.data() + bsx_off_dh_proofs(1), &dh, sizeof dh);
+    memcpy(img.data() + bsx_off_lb_proofs(1), &lb, sizeof lb);
+    uint32_t* W = reinterpret_cast<uint32_t*>(img.data() + L.off_words);
+    W[BSX_W_BATCH_START] = (uint32_t)prev_block_number; W[BSX_W_BATCH_START + 1] = (uint32_t)(prev_block_number >> 32);
+    W[BSX_W_BATCH_END] = (uint32_t)next_block_number; W[BSX_W_BATCH_END + 1] = (uint32_t)(next_block_number >> 32);
+    bsx_shared_ctx range{};
+    range.end_block = next_block_number;
+    DBuf cw, rg, rec;
+    RET(cw.alloc(L.compact_stride));
+    RET(rg.alloc(sizeof range));
+    RET(rec.alloc(sizeof(bsx_subchain)));
+    H2D(cw.p, img.data(), L.compact_stride);
+    H2D(rg.p, &range, sizeof range);
+    HIPCHK(bsxk_prove_subchain(st, 1, 1, 1, rg.as<bsx_shared_ctx>(), cw.as<uint8_t>(), rec.as<bsx_subchain>()));
+    D2H(img.data(), cw.p, L.compact_stride);
+    SYNC();
+    memcpy(out_data_commitment, img.data() + bsx_off_leaf_hashes(1), 32);
+    if (memcmp(img.data() + bsx_off_slots(1) + 128, prev_header_hash, 32) != 0)   // :434 (A10)
+        return fail(BSX_ERR_ASSERT, "prove_next_header_data_commitment: data_hash proof root != prev_header_hash (A10, builder.rs:434)");
+    return BSX_OK;
+}
+
+int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,
+                       bsx_commit_result* out_results, uint8_t* out_sig_ok) {
+    DEV_ENTER();
+    if (!validators || !header_hashes || !out_results) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+    if (!n_commits) return BSX_OK;
+    hipStream_t st = ctx->stream;
+    const uint64_t n = (uint64_t)n_commits * v_max;
+    DBuf dv, dh, dok, dhh, dres;
+    RET(dv.alloc(n * sizeof(bsx_validator)));
+    RET(dh.alloc(n * 32));
+    RET(dok.alloc(n));
+    RET(dhh.alloc((size_t)n_commits * 32));
+    RET(dres.alloc((size_t)n_commits * sizeof(bsx_commit_result)));
+    H2D(dv.p, validators, n * sizeof(bsx_validator));
+    H2D(dhh.p, header_hashes, (size_t)n_commits * 32);
+    HIPCHK(bsxk_sha512_challenge(st, dv.as<bsx_validator>(), n, dh.as<uint8_t>(), nullptr));
+    HIPCHK(bsxk_ed25519_verify(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, dok.as<uint8_t>()));
+    HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
+    D2H(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result));
+    if (out_sig_ok) D2H(out_sig_ok, dok.p, n);
+    SYNC();
+    return BSX_OK;
+}
+
+int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const bsx_header* headers,
+                     uint64_t first_height, uint64_t n_headers, uint64_t latest_block, const bsx_validator* target_validators,
+                     const bsx_validator* trusted_validators, uint32_t v_max, uint8_t output64[64], bsx_commit_result* out_commit,
+                     uint64_t* witness) {
+    DEV_ENTER();
+    if (!input48 || !headers || !target_validators || !trusted_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (!pow2(nb_map_jobs) || nb_map_jobs > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
+    if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+    // header_range.rs:33-35: evm_read u64 (big endian), bytes32, u64
+    uint64_t trusted_block = 0, target_block = 0;
+    for (int i = 0; i < 8; i++) trusted_block = trusted_block << 8 | input48[i];
+    for (int i = 0; i < 8; i++) target_block = target_block << 8 | input48[40 + i];
+    if (!(target_block > trusted_block) || target_block - trusted_block > (uint64_t)nb_map_jobs * batch_size)
+        return fail(BSX_ERR_RANGE_TOO_LONG, "skip: need trusted < target <= trusted + %llu", (unsigned long long)nb_map_jobs * batch_size);
+    if (trusted_block < first_height || target_block - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "trusted/target header not supplied");
+    hipStream_t st = ctx->stream;
+    bsx_shared_ctx range{};
+    range.start_block = trusted_block;
+    range.end_block = target_block;
+    memcpy(range.start_header_hash, input48 + 8, 32);
+    RangeDev rd;
+    RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd));
+    // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash
+    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr));
+    DBuf dv, dtv, dh, dok, dres, dtres, dskip, dth;
+    RET(dv.alloc((size_t)v_max * sizeof(bsx_validator)));
+    RET(dtv.alloc((size_t)v_max * sizeof(bsx_validator)));
+    RET(dh.alloc((size_t)v_max * 32));
+    RET(dok.alloc(v_max));
+    RET(dres.alloc(sizeof(bsx_commit_result)));
+    RET(dtres.alloc(sizeof(bsx_commit_result)));
+    RET(dskip.alloc(4));
+    RET(dth.alloc(32));
+    H2D(dv.p, target_validators, (size_t)v_max * sizeof(bsx_validator));
+    H2D(dtv.p, trusted_validators, (size_t)v_max * sizeof(bsx_validator));
+    const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
+    HIPCHK(bsxk_sha512_challenge(st, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
+    HIPCHK(bsxk_ed25519_verify(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, dok.as<uint8_t>()));
+    HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
+    HIPCHK(bsxk_commit_tally(st, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
+    HIPCHK(bsxk_skip_check(st, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
+                           dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
+                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth.as<uint8_t>()));
+    // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58)
+    int rc = run_data_commitment(st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, output64, nullptr, nullptr, witness, nullptr);
+    if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
+    const std::string dc_err = g_err;
+    uint32_t skip = 0;
+    bsx_commit_result cr;
+    D2H(&skip, dskip.p, 4);
+    D2H(&cr, dres.p, sizeof cr);
+    SYNC();
+    if (out_commit) *out_commit = cr;
+    if (skip) return fail((int)skip, "skip verification failed: %s (bad signatures %u, first %u; bad messages %u; signed %llu of %llu; trusted overlap %llu)",
+                          bsx_status_str((int)skip), cr.n_bad_signature, cr.first_bad_signature, cr.n_bad_message,
+                          (unsigned long long)cr.signed_power, (unsigned long long)cr.total_power, (unsigned long long)cr.trusted_signed_power);
+    if (rc) g_err = dc_err;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// ed25519.h — scalar arithmetic mod L and the per-lane verification [s]B + [h](-A) == R.
+// Device side of P6 (reduction of the SHA-512 challenge) and P7; reference call sites
+// circuits/header_range.rs:42-48 (builder.skip) and circuits/next_header.rs:32-36 (builder.step).
+// Accept set = RFC 8032 cofactorless verification with canonical A, R, s (same as the test oracle).
+#pragma once
+#include "fe25519.h"
+
+namespace bsx {
+
+// 512-bit little-endian integer (16 dwords) mod L -> 8 dwords.  21-bit signed limbs; 2^252 = -c (mod L) with
+// -c = 666643 + 470296*2^21 + 654183*2^42 - 997805*2^63 + 136657*2^84 - 683901*2^105.
+BSX_HDI void sc_fold(int64_t* s, int i) {
+    const int64_t x = s[i];
+    s[i - 12] += x * 666643;
+    s[i - 11] += x * 470296;
+    s[i - 10] += x * 654183;
+    s[i - 9] -= x * 997805;
+    s[i - 8] += x * 136657;
+    s[i - 7] -= x * 683901;
+    s[i] = 0;
+}
+BSX_HDI void sc_carry_round(int64_t* s, int i) {  // balanced
+    const int64_t c = (s[i] + (1 << 20)) >> 21;
+    s[i + 1] += c;
+    s[i] -= c << 21;
+}
+BSX_HDI void sc_carry_floor(int64_t* s, int i) {
+    const int64_t c = s[i] >> 21;
+    s[i + 1] += c;
+    s[i] -= c << 21;
+}
+BSX_HDI void sc_reduce64(const uint32_t in[16], uint32_t out[8]) {
+    int64_t s[24];
+#pragma unroll
+    for (int i = 0; i < 23; i++) {
+        const int o = 21 * i, wd = o >> 5, sh = o & 31;
+        const uint64_t two = ((uint64_t)in[wd + 1] << 32) | in[wd];
+        s[i] = (int64_t)((two >> sh) & 0x1fffff);
+    }
+    s[23] = (int64_t)(in[15] >> 3);
+#pragma unroll
+    for (int i = 23; i >= 18; i--) sc_fold(s, i);
+#pragma unroll
+    for (int i = 6; i <= 16; i += 2) sc_carry_round(s, i);
+#pragma unroll
+    for (int i = 7; i <= 15; i += 2) sc_carry_round(s, i);
+#pragma unroll
+    for (int i = 17; i >= 12; i--) sc_fold(s, i);
+#pragma unroll
+    for (int i = 0; i <= 10; i += 2) sc_carry_round(s, i);
+#pragma unroll
+    for (int i = 1; i <= 11; i += 2) sc_carry_round(s, i);
+    sc_fold(s, 12);
+#pragma unroll
+    for (int i = 0; i <= 11; i++) sc_carry_floor(s, i);
+    sc_fold(s, 12);
+#pragma unroll
+    for (int i = 0; i <= 10; i++) sc_carry_floor(s, i);
+    // pack 12 limbs (21 bits each, the last one holds the remaining high bits) into 256 bits
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int o = 21 * i, wd = o >> 5, sh = o & 31;
+        const uint64_t v = (uint64_t)s[i] << sh;
+        out[wd] |= (uint32_t)v;
+        if (wd + 1 < 8) out[wd + 1] |= (uint32_t)(v >> 32);
+    }
+}
+
+// s < L ?  (8 LE dwords)
+BSX_HDI bool sc_is_canonical(const uint32_t s[8]) {
+    constexpr uint32_t Lw[8] = {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u};
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if (!decided && s[i] != Lw[i]) { lt = s[i] < Lw[i]; decided = true; }
+    }
+    return lt;
+}
+
+// signed radix-16 recoding without a carry chain: r = s + 0x888...8; digit_i = nibble_i(r) - 8 in [-8, 7]
+BSX_HDI void sc_recode(const uint32_t s[8], uint32_t r[8]) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)s[i] + 0x88888888u;
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+BSX_HDI uint32_t pick8(const uint32_t r[8], int w) {  // r[w] for a (wave-uniform) runtime w without private-memory indexing
+    uint32_t v = r[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) v = (w == k) ? r[k] : v;
+    return v;
+}
+BSX_HDI int sc_digit(const uint32_t r[8], int i) { return (int)((pick8(r, i >> 3) >> (4 * (i & 7))) & 15) - 8; }
+
+BSX_HDI ge_precomp ge_b_entry(int k) {  // (k+1) * B
+    ge_precomp e;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        e.yplusx.v[i] = ge_b_limb(k, i);
+        e.yminusx.v[i] = ge_b_limb(k, 10 + i);
+        e.xy2d.v[i] = ge_b_limb(k, 20 + i);
+    }
+    return e;
+}
+
+// true iff the signature (R, s) verifies for public key A with challenge h (already reduced mod L).
+// pk, sig_r, sig_s, h: 8 LE dwords each.
+BSX_HDI bool ed25519_verify_core(const uint32_t pk[8], const uint32_t sig_r[8], const uint32_t sig_s[8],
+                                 const uint32_t h[8]) {
+    bool ok = sc_is_canonical(sig_s);
+    ge_p3 negA;
+    ok = ge_frombytes_negate(negA, pk) && ok;
+
+    // table k * (-A), k = 1..8, cached form (per-lane: private memory)
+    ge_cached tab[8];
+    tab[0] = p3_to_cached(negA);
+    ge_p3 cur = negA;
+    for (int k = 1; k < 8; k++) {
+        cur = p1p1_to_p3(ge_add(cur, tab[0]));
+        tab[k] = p3_to_cached(cur);
+    }
+
+    uint32_t hr[8], sr[8];
+    sc_recode(h, hr);
+    sc_recode(sig_s, sr);
+
+    ge_p2 q{fe_zero(), fe_one(), fe_one()};
+    for (int i = 63; i >= 0; i--) {
+        ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
+        for (int d = 0; d < 3; d++) {
+            q = p1p1_to_p2(t);
+            t = ge_dbl(q.X, q.Y, q.Z);
+        }
+        ge_p3 p = p1p1_to_p3(t);
+
+        const int da = sc_digit(hr, i);
+        const int ia = da < 0 ? -da : da;
+        ge_cached ca = tab[ia ? ia - 1 : 0];
+        ca = cached_cneg(ca, da < 0);
+        if (ia == 0) ca = cached_identity();
+        p = p1p1_to_p3(ge_add(p, ca));
+
+        const int db = sc_digit(sr, i);
+        const int ib = db < 0 ? -db : db;
+        ge_precomp pb = ge_b_entry(ib ? ib - 1 : 0);
+        pb = precomp_cneg(pb, db < 0);
+        if (ib == 0) pb = precomp_identity();
+        q = p1p1_to_p2(ge_madd(p, pb));
+    }
+    uint32_t enc[8];
+    ge_tobytes(enc, q.X, q.Y, q.Z);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) diff |= enc[k] ^ sig_r[k];
+    return ok && diff == 0;
+}
+
+}  // namespace bsx

@@ -1,0 +1,352 @@
+// kernels_ed.hip — commit verification side of the header_range hot path for gfx950 (CDNA4, wave64):
+// the per-validator loop inside builder.skip / builder.step (circuits/header_range.rs:42-48,
+// circuits/next_header.rs:32-36; circuit body [UPSTREAM] tendermintx v1.0.0; host twin is_valid_skip,
+// circuits/fetcher.rs:76-80).
+//
+//   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, records staged via LDS
+//   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
+//   k_commit_tally      P8+P9 validator-set hash (masked Merkle tree), voting-power sums, message checks;
+//                           one workgroup per commit, wave-shuffle + LDS reductions
+//   k_skip_check        skip conditions of CombinedSkipCircuit (header_range.rs:42-48): header/validator-hash links,
+//                           2/3 of the target set, > 1/3 of the trusted set
+#include <hip/hip_runtime.h>
+
+#include "../../include/bsx.h"
+#include "ed25519.h"
+#include "sha256.h"
+#include "sha512.h"
+
+namespace bsx {
+
+// ------------------------------------------------------------------------------------------------ k_sha512_challenge
+constexpr int CH_THREADS = 128;
+constexpr int CH_BYTES = 240, CH_STRIDE = 61;   // staged bytes per record, LDS dwords per record (odd)
+
+__global__ __launch_bounds__(CH_THREADS) void k_sha512_challenge(const bsx_validator* __restrict__ vals, uint64_t n,
+                                                                 uint8_t* __restrict__ out_h, uint8_t* __restrict__ out_digest) {
+    __shared__ uint32_t lds[CH_THREADS * CH_STRIDE];
+    const int tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * CH_THREADS, me = base + tid;
+    for (int c = tid; c < CH_THREADS * (CH_BYTES / 16); c += CH_THREADS) {
+        const int vl = c / (CH_BYTES / 16), piece = c % (CH_BYTES / 16);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (base + vl < n) v = reinterpret_cast<const uint4*>(vals + base + vl)[piece];
+        uint32_t* d = lds + vl * CH_STRIDE + piece * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    if (me >= n) return;
+    const uint32_t* my = lds + tid * CH_STRIDE;
+    uint32_t a[8], r[8], m[31], dig[16], h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a[k] = my[k]; r[k] = my[8 + k]; }
+#pragma unroll
+    for (int k = 0; k < 31; k++) m[k] = my[24 + k];
+    int len = (int)my[55];
+    if (len > BSX_VALIDATOR_MSG_MAX) len = BSX_VALIDATOR_MSG_MAX;
+    sha512_ram(r, a, m, len, dig);
+    sc_reduce64(dig, h);
+    uint4* oh = reinterpret_cast<uint4*>(out_h + me * 32);
+    oh[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    oh[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    if (out_digest) {
+        uint4* od = reinterpret_cast<uint4*>(out_digest + me * 64);
+#pragma unroll
+        for (int k = 0; k < 4; k++) od[k] = make_uint4(dig[4 * k], dig[4 * k + 1], dig[4 * k + 2], dig[4 * k + 3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_ed25519_verify
+constexpr int ED_THREADS = 64;   // one wave per workgroup: a 100-signature commit spreads over 2 CUs, R commits over 2R
+__global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validator* __restrict__ vals,
+                                                               const uint8_t* __restrict__ hs, uint64_t n,
+                                                               uint8_t* __restrict__ ok_out) {
+    const uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
+    if (me >= n) return;
+    const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
+    const uint4 flags = rec[14];                    // bytes 224..239: voting_power (8), enabled, is_signed, present, pad
+    const bool active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
+    bool ok = false;
+    if (active) {
+        uint32_t pk[8], sr[8], ss[8], h[8];
+        const uint4 p0 = rec[0], p1 = rec[1], r0 = rec[2], r1 = rec[3], s0 = rec[4], s1 = rec[5];
+        pk[0] = p0.x; pk[1] = p0.y; pk[2] = p0.z; pk[3] = p0.w; pk[4] = p1.x; pk[5] = p1.y; pk[6] = p1.z; pk[7] = p1.w;
+        sr[0] = r0.x; sr[1] = r0.y; sr[2] = r0.z; sr[3] = r0.w; sr[4] = r1.x; sr[5] = r1.y; sr[6] = r1.z; sr[7] = r1.w;
+        ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
+        const uint4* hp = reinterpret_cast<const uint4*>(hs + me * 32);
+        const uint4 h0 = hp[0], h1 = hp[1];
+        h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
+        ok = ed25519_verify_core(pk, sr, ss, h);
+    }
+    ok_out[me] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ k_commit_tally
+constexpr int TL_THREADS = 256;
+constexpr int TL_VMAX = 512;     // padded power of two of the validator slots one workgroup folds
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// SimpleValidator leaf: 0a 22 0a 20 pk32 [10 varint(power)] as LE dwords; returns the byte length
+__device__ __forceinline__ int validator_leaf(const uint32_t pk[8], uint64_t power, uint32_t d[14]) {
+    d[0] = 0x200a220au;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[1 + k] = pk[k];
+    // field 2 (voting_power) is omitted when zero (proto3).  Static byte positions, no private-memory indexing:
+    // s[0] = 0x10, s[1+k] = 7-bit group k with the continuation bit while higher groups are non-zero
+    uint32_t s[12];
+    int nvar = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        const uint64_t rest = power >> (7 * k);
+        const bool present = (k == 0) ? (power != 0) : (rest != 0);
+        const bool more = (k < 9) && ((power >> (7 * (k + 1))) != 0);
+        s[1 + k] = present ? (uint32_t)((rest & 0x7f) | (more ? 0x80 : 0)) : 0u;
+        nvar += present ? 1 : 0;
+    }
+    s[0] = power ? 0x10u : 0u;
+    s[11] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) d[9 + k] = s[4 * k] | (s[4 * k + 1] << 8) | (s[4 * k + 2] << 16) | (s[4 * k + 3] << 24);
+    d[12] = 0; d[13] = 0;
+    return 36 + (power ? 1 + nvar : 0);
+}
+
+__global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator* __restrict__ vals, uint32_t v_max,
+                                                             const uint8_t* __restrict__ header_hashes,
+                                                             const uint8_t* __restrict__ ok_in,
+                                                             bsx_commit_result* __restrict__ results) {
+    __shared__ uint32_t nodes[2][TL_VMAX * 8];
+    __shared__ uint8_t en[2][TL_VMAX];
+    __shared__ unsigned long long s_total, s_signed, s_trusted;
+    __shared__ uint32_t s_nen, s_nsig, s_nbad, s_firstbad, s_nbadmsg;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const bsx_validator* cv = vals + (uint64_t)c * v_max;
+    uint32_t P = 1;
+    while (P < v_max) P *= 2;
+    if (tid == 0) { s_total = 0; s_signed = 0; s_trusted = 0; s_nen = 0; s_nsig = 0; s_nbad = 0; s_firstbad = 0xffffffffu; s_nbadmsg = 0; }
+    __syncthreads();
+    uint32_t hh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) hh[k] = header_hashes ? reinterpret_cast<const uint32_t*>(header_hashes + 32 * (uint64_t)c)[k] : 0u;
+
+    uint64_t total = 0, signedp = 0, trusted = 0;
+    uint32_t nen = 0, nsig = 0, nbad = 0, nbadmsg = 0;
+    for (uint32_t v = tid; v < P; v += TL_THREADS) {
+        uint32_t pk[8];
+        uint64_t power = 0;
+        bool enabled = false;
+        if (v < v_max) {
+            const uint4* rec = reinterpret_cast<const uint4*>(cv + v);
+            const uint4 p0 = rec[0], p1 = rec[1], fl = rec[14];
+            pk[0] = p0.x; pk[1] = p0.y; pk[2] = p0.z; pk[3] = p0.w; pk[4] = p1.x; pk[5] = p1.y; pk[6] = p1.z; pk[7] = p1.w;
+            power = (uint64_t)fl.x | ((uint64_t)fl.y << 32);
+            enabled = (fl.z & 0xffu) != 0;
+            const bool is_signed = ((fl.z >> 8) & 0xffu) != 0, present = ((fl.z >> 16) & 0xffu) != 0;
+            if (enabled) {
+                nen++;
+                total += power;
+                if (is_signed) {
+                    nsig++;
+                    const bool sig = ok_in ? (ok_in[(uint64_t)c * v_max + v] != 0) : false;
+                    // the signed message must carry the header hash at offset 16 (25 with a round field)
+                    const uint32_t* mw = reinterpret_cast<const uint32_t*>(cv[v].message);
+                    const uint32_t mlen = cv[v].message_len;
+                    const bool has_round = mlen > 12 && (mw[3] & 0xffu) == 0x19u;
+                    const uint32_t off = has_round ? 25u : 16u;
+                    bool msg = mlen <= BSX_VALIDATOR_MSG_MAX && mlen >= off + 32;
+                    uint32_t diff = 0;
+                    if (has_round) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) diff |= funnel_r(mw[7 + k], mw[6 + k], 8) ^ hh[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) diff |= mw[4 + k] ^ hh[k];
+                    }
+                    msg = msg && diff == 0;
+                    if (!sig) { nbad++; atomicMin(&s_firstbad, v); }
+                    if (!msg) nbadmsg++;
+                    if (sig && msg) { signedp += power; if (present) trusted += power; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) pk[k] = 0;
+        }
+        uint32_t d[14];
+        const int len = validator_leaf(pk, power, d);
+        {
+            const Digest lh = leaf_hash_1block(d, len);
+#pragma unroll
+            for (int k = 0; k < 8; k++) nodes[0][v * 8 + k] = lh.w[k];
+            en[0][v] = enabled ? 1 : 0;
+        }
+    }
+    // wave-level reduction, then one LDS atomic per wave
+    total = wave_sum_u64(total); signedp = wave_sum_u64(signedp); trusted = wave_sum_u64(trusted);
+    nen = wave_sum_u32(nen); nsig = wave_sum_u32(nsig); nbad = wave_sum_u32(nbad); nbadmsg = wave_sum_u32(nbadmsg);
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_total, (unsigned long long)total); atomicAdd(&s_signed, (unsigned long long)signedp);
+        atomicAdd(&s_trusted, (unsigned long long)trusted);
+        atomicAdd(&s_nen, nen); atomicAdd(&s_nsig, nsig); atomicAdd(&s_nbad, nbad); atomicAdd(&s_nbadmsg, nbadmsg);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t width = P / 2; width >= 1; width /= 2) {
+        for (uint32_t t = tid; t < width; t += TL_THREADS) {
+            Digest l, r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { l.w[k] = nodes[cur][(2 * t) * 8 + k]; r.w[k] = nodes[cur][(2 * t + 1) * 8 + k]; }
+            const bool el = en[cur][2 * t] != 0, er = en[cur][2 * t + 1] != 0;
+            const Digest in = inner_hash(l, r);
+            const Digest node = (el && er) ? in : l;
+#pragma unroll
+            for (int k = 0; k < 8; k++) nodes[cur ^ 1][t * 8 + k] = node.w[k];
+            en[cur ^ 1][t] = (el || er) ? 1 : 0;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tid == 0) {
+        bsx_commit_result* o = results + c;
+#pragma unroll
+        for (int k = 0; k < 8; k++) reinterpret_cast<uint32_t*>(o->validators_hash)[k] = bswap32(nodes[cur][k]);
+        o->total_power = s_total; o->signed_power = s_signed; o->trusted_signed_power = s_trusted;
+        o->n_enabled = s_nen; o->n_signed = s_nsig; o->n_bad_signature = s_nbad; o->first_bad_signature = s_firstbad;
+        o->n_bad_message = s_nbadmsg;
+        o->two_thirds_ok = ((unsigned __int128)s_signed * 3 > (unsigned __int128)s_total * 2) ? 1u : 0u;
+        o->_pad[0] = o->_pad[1] = o->_pad[2] = o->_pad[3] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_skip_check
+// One workgroup per range.  skip_status[r] = bsx_status of the skip part (BSX_OK when every condition holds).
+struct SkipArgs {
+    uint32_t n_ranges, v_max;
+    const bsx_shared_ctx* ranges;
+    const bsx_header* headers;          // range r: headers[r*hpr + (height - S_r)]
+    uint64_t headers_per_range;
+    const uint8_t* hashes;              // same indexing, 32 B each
+    const bsx_validator* target;        // n_ranges * v_max
+    const bsx_validator* trusted;       // n_ranges * v_max
+    const uint8_t* target_ok;           // n_ranges * v_max (signature valid)
+    bsx_commit_result* target_res;      // n_ranges (trusted_signed_power is overwritten with the trusted-set overlap)
+    const bsx_commit_result* trusted_res;   // n_ranges (validators_hash + total_power of the trusted set)
+    uint32_t* skip_status;              // n_ranges
+    uint8_t* target_hashes;             // n_ranges * 32 (out): hash of the target header
+};
+__global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
+    __shared__ uint32_t tpk[TL_VMAX * 8];
+    __shared__ uint8_t tsig[TL_VMAX];
+    __shared__ unsigned long long s_overlap;
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, V = a.v_max;
+    const bsx_shared_ctx rg = a.ranges[r];
+    const bsx_validator* tv = a.target + (uint64_t)r * V;
+    const bsx_validator* rv = a.trusted + (uint64_t)r * V;
+    if (tid == 0) s_overlap = 0;
+    for (uint32_t k = tid; k < V; k += 256) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(tv[k].pubkey);
+#pragma unroll
+        for (int q = 0; q < 8; q++) tpk[k * 8 + q] = p[q];
+        tsig[k] = (tv[k].enabled && tv[k].is_signed && a.target_ok[(uint64_t)r * V + k]) ? 1 : 0;
+    }
+    __syncthreads();
+    uint64_t ov = 0;
+    for (uint32_t i = tid; i < V; i += 256) {
+        if (!rv[i].enabled) continue;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(rv[i].pubkey);
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pk[q] = p[q];
+        bool found = false;
+        for (uint32_t k = 0; k < V && !found; k++) {
+            if (!tsig[k]) continue;
+            uint32_t d = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) d |= tpk[k * 8 + q] ^ pk[q];
+            found = d == 0;
+        }
+        if (found) ov += rv[i].voting_power;
+    }
+    ov = wave_sum_u64(ov);
+    if ((tid & 63) == 0) atomicAdd(&s_overlap, (unsigned long long)ov);
+    __syncthreads();
+    if (tid == 0) {
+        const uint64_t S = rg.start_block, E = rg.end_block;
+        const bsx_header* th = a.headers + (uint64_t)r * a.headers_per_range + (E - S);
+        const bsx_header* tr = a.headers + (uint64_t)r * a.headers_per_range;
+        const uint8_t* thash = a.hashes + ((uint64_t)r * a.headers_per_range + (E - S)) * 32;
+        const uint8_t* trhash = a.hashes + ((uint64_t)r * a.headers_per_range) * 32;
+        bsx_commit_result* cr = a.target_res + r;
+        const bsx_commit_result* trc = a.trusted_res + r;
+        uint32_t st = BSX_OK;
+        bool eq = true;
+        for (int q = 0; q < 32; q++) eq = eq && trhash[q] == rg.start_header_hash[q];
+        if (!eq) st = BSX_ERR_ASSERT;                                         // trusted header hash is the public input
+        // the target header's height leaf must encode the target block (varint)
+        uint8_t hf[12];
+        int hn = 0;
+        hf[hn++] = 0x08;
+        uint64_t hv = E;
+        while (hv >= 0x80) { hf[hn++] = (uint8_t)(hv | 0x80); hv >>= 7; }
+        hf[hn++] = (uint8_t)hv;
+        bool heq = th->len[BSX_BLOCK_HEIGHT_INDEX] == hn;
+        for (int q = 0; q < hn && heq; q++) heq = th->height[q] == hf[q];
+        if (!st && !heq) st = BSX_ERR_ASSERT;
+        if (!st && (cr->n_bad_signature || cr->n_bad_message)) st = BSX_ERR_BAD_SIGNATURE;
+        bool veq = th->len[7] == 34, treq = tr->len[7] == 34;
+        for (int q = 0; q < 32; q++) {
+            veq = veq && th->hash[2][2 + q] == cr->validators_hash[q];
+            treq = treq && tr->hash[2][2 + q] == trc->validators_hash[q];
+        }
+        if (!st && !veq) st = BSX_ERR_ASSERT;
+        if (!st && !treq) st = BSX_ERR_ASSERT;
+        if (!st && !cr->two_thirds_ok) st = BSX_ERR_VOTING_POWER;
+        const unsigned __int128 overlap = s_overlap, ttotal = trc->total_power;
+        if (!st && !(overlap * 3 > ttotal)) st = BSX_ERR_VOTING_POWER;
+        cr->trusted_signed_power = s_overlap;
+        a.skip_status[r] = st;
+        if (a.target_hashes) for (int q = 0; q < 32; q++) a.target_hashes[32 * (uint64_t)r + q] = thash[q];
+    }
+}
+
+}  // namespace bsx
+
+extern "C" {
+using namespace bsx;
+hipError_t bsxk_sha512_challenge(hipStream_t s, const bsx_validator* vals, uint64_t n, uint8_t* h, uint8_t* digest) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_sha512_challenge, dim3((uint32_t)((n + CH_THREADS - 1) / CH_THREADS)), dim3(CH_THREADS), 0, s, vals, n, h, digest);
+    return hipGetLastError();
+}
+hipError_t bsxk_ed25519_verify(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint8_t* ok) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_ed25519_verify, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
+    return hipGetLastError();
+}
+hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,
+                             const uint8_t* ok, bsx_commit_result* results) {
+    if (!n_commits) return hipSuccess;
+    hipLaunchKernelGGL(k_commit_tally, dim3(n_commits), dim3(TL_THREADS), 0, s, vals, v_max, header_hashes, ok, results);
+    return hipGetLastError();
+}
+hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* ranges, const bsx_header* headers,
+                           uint64_t hpr, const uint8_t* hashes, const bsx_validator* target, const bsx_validator* trusted,
+                           const uint8_t* target_ok, bsx_commit_result* target_res, const bsx_commit_result* trusted_res,
+                           uint32_t* skip_status, uint8_t* target_hashes) {
+    if (!n_ranges) return hipSuccess;
+    SkipArgs a{n_ranges, v_max, ranges, headers, hpr, hashes, target, trusted, target_ok, target_res, trusted_res, skip_status, target_hashes};
+    hipLaunchKernelGGL(k_skip_check, dim3(n_ranges), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+int bsxk_tally_vmax(void) { return TL_VMAX; }
+}

@@ -1,0 +1,738 @@
+// kernels_sha.hip — SHA-256 side of the header_range hot path for gfx950 (CDNA4, wave64).
+//
+//   k_header_merkle    P5   tendermint Header::hash + inclusion proofs (circuits/input.rs:175-179,188-195,250-261)
+//   k_assemble_inputs  hint DataCommitmentOffchainInputs::hint -> get_data_commitment_inputs (circuits/data_commitment.rs:22-44,
+//                           circuits/input.rs:149-271): gathers proofs into each map job's compact witness, zero padding rules
+//   k_prove_subchain   P1-P4 prove_subchain + get_data_commitment (circuits/builder.rs:105-148,150-271)
+//   k_reduce           reduce closure of prove_data_commitment (circuits/builder.rs:337-395)
+//   k_finalize         range check + final asserts + public output (builder.rs:292-297,400-406; header_range.rs:57-58)
+//   k_expand_witness   P10  bytes -> Goldilocks elements ([UPSTREAM] plonky2x ByteVariable = 8 bools MSB first)
+//
+// Mapping: one lane = one independent hash chain (header / slot / tree node); digests stay in VGPRs between tree
+// levels; byte inputs are staged global -> LDS with 16-byte coalesced loads and read back per lane at an odd dword
+// stride (bank-conflict free); assertion predicates are reduced with wave ballots.  No MFMA: bitwise integer work.
+#include <hip/hip_runtime.h>
+
+#include "../../include/bsx.h"
+#include "../../include/bsx_layout.h"
+#include "sha256.h"
+
+namespace bsx {
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ void store_u32_a2(uint8_t* dst, uint32_t v) {  // dst 2-byte aligned (odd batch sizes only)
+    if (reinterpret_cast<uintptr_t>(dst) & 2) {
+        reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;
+        reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);
+    } else {
+        *reinterpret_cast<uint32_t*>(dst) = v;
+    }
+}
+__device__ __forceinline__ uint32_t load_u32_a2(const uint8_t* src) {
+    if (reinterpret_cast<uintptr_t>(src) & 2)
+        return (uint32_t)reinterpret_cast<const uint16_t*>(src)[0] | ((uint32_t)reinterpret_cast<const uint16_t*>(src)[1] << 16);
+    return *reinterpret_cast<const uint32_t*>(src);
+}
+// digest <-> 32 bytes in global memory; the byte sections of the compact witness are 4-byte aligned for even
+// batch sizes and only 2-byte aligned for B == 1, hence the _a2 accessors
+__device__ __forceinline__ void store_digest_global(uint8_t* dst, const Digest& d) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) store_u32_a2(dst + 4 * k, bswap32(d.w[k]));
+}
+__device__ __forceinline__ void store_digest_global16(uint8_t* dst, const Digest& d) {  // dst 16-byte aligned
+    uint4* p = reinterpret_cast<uint4*>(dst);
+    p[0] = make_uint4(bswap32(d.w[0]), bswap32(d.w[1]), bswap32(d.w[2]), bswap32(d.w[3]));
+    p[1] = make_uint4(bswap32(d.w[4]), bswap32(d.w[5]), bswap32(d.w[6]), bswap32(d.w[7]));
+}
+__device__ __forceinline__ Digest load_digest_global(const uint8_t* src) {
+    Digest d;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d.w[k] = bswap32(load_u32_a2(src + 4 * k));
+    return d;
+}
+__device__ __forceinline__ void store_digest_lds(uint32_t* dst, const Digest& d) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k] = d.w[k];
+}
+__device__ __forceinline__ Digest load_digest_lds(const uint32_t* src) {
+    Digest d;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d.w[k] = src[k];
+    return d;
+}
+
+// one-block leaf with only ND dwords of capacity behind the pointer (LDS), len <= 4*ND
+template <int ND>
+__device__ __forceinline__ Digest leaf_from_lds(const uint32_t* f, int len) {
+    uint32_t d[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) d[j] = (j < ND) ? f[j] : 0u;
+    return leaf_hash_1block(d, len);
+}
+
+// ------------------------------------------------------------------------------------------------ k_header_merkle
+// 128 headers per workgroup, one lane per header.  Two staging phases keep LDS at 41.5 KB/WG (3 WG = 6 waves per CU):
+//   phase A bytes [0,320): len table + fields 0..7  -> left subtree (8 leaves)
+//   phase B bytes [304,512): fields 8..13           -> right subtree (6 leaves), root
+constexpr int HM_THREADS = 128;
+constexpr int HM_A_BYTES = 320, HM_A_STRIDE = 81;   // dwords per header in LDS (odd: conflict-free per-lane reads)
+constexpr int HM_B_OFF = 304, HM_B_BYTES = 208, HM_B_STRIDE = 53;
+
+__global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
+                                                              uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
+                                                              uint8_t* __restrict__ lb_aunts, uint32_t* __restrict__ status) {
+    __shared__ uint32_t lds[HM_THREADS * HM_A_STRIDE];
+    const int tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * HM_THREADS;
+    const uint64_t me = base + tid;
+    const bool live = me < n;
+
+    // ---- stage A (coalesced 16-byte loads, 20 pieces per header)
+    for (int c = tid; c < HM_THREADS * (HM_A_BYTES / 16); c += HM_THREADS) {
+        const int hl = c / (HM_A_BYTES / 16), piece = c % (HM_A_BYTES / 16);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (base + hl < n) v = reinterpret_cast<const uint4*>(hdr + base + hl)[piece];
+        uint32_t* d = lds + hl * HM_A_STRIDE + piece * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+
+    const uint32_t* my = lds + tid * HM_A_STRIDE;
+    int len[14];
+    {
+        const uint32_t l0 = my[0], l1 = my[1], l2 = my[2], l3 = my[3];
+        const uint32_t lw[4] = {l0, l1, l2, l3};
+#pragma unroll
+        for (int i = 0; i < 14; i++) len[i] = (int)((lw[i >> 2] >> (8 * (i & 3))) & 0xff);
+    }
+    // capacity rules (bsx.h): violations flagged, lengths clamped so nothing reads out of bounds
+    bool bad = false;
+    {
+        constexpr int cap[14] = {24, 52, 12, 20, 76, 36, 36, 36, 36, 36, 36, 36, 36, 24};
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            if (len[i] > cap[i]) { bad = true; len[i] = cap[i]; }
+        }
+    }
+    Digest left, n0123, n45, n67, L5, L7;
+    {
+        Digest L0 = leaf_from_lds<6>(my + 4, len[0]);        // version   @16
+        Digest L1 = leaf_from_lds<13>(my + 10, len[1]);      // chain_id  @40
+        Digest n01 = inner_hash(L0, L1);
+        Digest L2 = leaf_from_lds<3>(my + 23, len[2]);       // height    @92
+        Digest L3 = leaf_from_lds<5>(my + 26, len[3]);       // time      @104
+        Digest n23 = inner_hash(L2, L3);
+        n0123 = inner_hash(n01, n23);
+        Digest L4;
+        {
+            uint32_t d[19];                                  // last_block_id @124 (76 B capacity)
+#pragma unroll
+            for (int j = 0; j < 19; j++) d[j] = my[31 + j];
+            L4 = (len[4] <= 54) ? leaf_hash_1block(d, len[4]) : leaf_hash_2block(d, len[4]);
+        }
+        L5 = leaf_from_lds<9>(my + 50, len[5]);              // hash[0]   @200
+        n45 = inner_hash(L4, L5);
+        Digest L6 = leaf_from_lds<9>(my + 59, len[6]);       // hash[1]   @236  (data_hash)
+        L7 = leaf_from_lds<9>(my + 68, len[7]);              // hash[2]   @272
+        n67 = inner_hash(L6, L7);
+        left = inner_hash(n0123, inner_hash(n45, n67));
+    }
+    if (live) {
+        if (lb_aunts) {  // index 4: [L5, n67, n0123, right]
+            store_digest_global16(lb_aunts + me * 128, L5);
+            store_digest_global16(lb_aunts + me * 128 + 32, n67);
+            store_digest_global16(lb_aunts + me * 128 + 64, n0123);
+        }
+        if (dh_aunts) {  // index 6: [L7, n45, n0123, right]
+            store_digest_global16(dh_aunts + me * 128, L7);
+            store_digest_global16(dh_aunts + me * 128 + 32, n45);
+            store_digest_global16(dh_aunts + me * 128 + 64, n0123);
+        }
+    }
+    __syncthreads();
+
+    // ---- stage B
+    for (int c = tid; c < HM_THREADS * (HM_B_BYTES / 16); c += HM_THREADS) {
+        const int hl = c / (HM_B_BYTES / 16), piece = c % (HM_B_BYTES / 16);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (base + hl < n) v = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(hdr + base + hl) + HM_B_OFF)[piece];
+        uint32_t* d = lds + hl * HM_B_STRIDE + piece * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const uint32_t* mb = lds + tid * HM_B_STRIDE;
+    Digest right;
+    {
+        Digest L8 = leaf_from_lds<9>(mb + 1, len[8]);        // hash[3] @308 -> local 4
+        Digest L9 = leaf_from_lds<9>(mb + 10, len[9]);       // hash[4] @344
+        Digest n89 = inner_hash(L8, L9);
+        Digest L10 = leaf_from_lds<9>(mb + 19, len[10]);     // hash[5] @380
+        Digest L11 = leaf_from_lds<9>(mb + 28, len[11]);     // hash[6] @416
+        Digest n8_11 = inner_hash(n89, inner_hash(L10, L11));
+        Digest L12 = leaf_from_lds<9>(mb + 37, len[12]);     // hash[7] @452
+        Digest L13 = leaf_from_lds<6>(mb + 46, len[13]);     // proposer @488
+        right = inner_hash(n8_11, inner_hash(L12, L13));
+    }
+    const Digest root = inner_hash(left, right);
+    if (live) {
+        if (hashes) store_digest_global16(hashes + me * 32, root);
+        if (lb_aunts) store_digest_global16(lb_aunts + me * 128 + 96, right);
+        if (dh_aunts) store_digest_global16(dh_aunts + me * 128 + 96, right);
+    }
+    // wave-ballot reduction of the "bad header" predicate: one atomic per wave
+    const unsigned long long m = __ballot(live && bad);
+    if (m && (tid & 63) == 0 && status) atomicOr(status, 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ k_assemble_inputs
+// One workgroup per (range, owned job).  Byte-exact gather of the hint output into the compact witness.
+struct AssembleArgs {
+    uint32_t n_ranges, nb_map_jobs, batch, job_first, job_count, span;   // span = batch_end - batch_start (== batch for map jobs)
+    const bsx_shared_ctx* ranges;
+    const uint64_t* latest;
+    const bsx_header* headers;
+    uint64_t headers_per_range;
+    const uint8_t *hashes, *dh_aunts, *lb_aunts;
+    uint8_t* compact;
+    uint32_t compact_stride, off_words;
+    uint32_t* status;
+};
+
+__global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
+    const uint32_t r = blockIdx.x / a.job_count, jl = blockIdx.x % a.job_count, j = a.job_first + jl;
+    const uint32_t B = a.batch;
+    const bsx_shared_ctx rg = a.ranges[r];
+    const uint64_t S = rg.start_block;
+    const uint64_t batch_start = S + (uint64_t)j * B;          // builder.rs:315-316
+    const uint64_t batch_end = batch_start + a.span;           // builder.rs:317-322 (span == B for map jobs)
+    const uint64_t latest = a.latest[r];
+    const uint64_t latest_safe = latest - 2;                   // input.rs:160-161
+    const uint64_t req_end = batch_end < latest_safe ? batch_end : latest_safe;  // input.rs:162
+    // number of real proofs: dh for [start, req_end), lb for (start, req_end]  (input.rs:167-198)
+    const uint64_t n_real = (batch_start <= req_end) ? (req_end - batch_start) : 0;
+    const bool have_hdrs = batch_start < req_end;              // input.rs:249
+    const uint64_t hbase = (uint64_t)r * a.headers_per_range;  // header index of height S
+    bool oob = false;
+    if (batch_start <= req_end && (req_end - S) >= a.headers_per_range) oob = true;  // caller did not supply the headers
+    uint8_t* cw = a.compact + ((uint64_t)r * a.job_count + jl) * a.compact_stride;
+    uint32_t* cw32 = reinterpret_cast<uint32_t*>(cw);
+
+    // bytes [0,128): ctx hashes, start/end header
+    for (uint32_t t = threadIdx.x; t < 32; t += blockDim.x) {
+        uint32_t v;
+        const uint32_t k = t & 7;
+        if (t < 8) v = reinterpret_cast<const uint32_t*>(a.ranges[r].start_header_hash)[k];
+        else if (t < 16) v = reinterpret_cast<const uint32_t*>(a.ranges[r].end_header_hash)[k];
+        else if (t < 24) v = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (batch_start - S)) * 32)[k] : 0u;
+        else v = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (req_end - S)) * 32)[k] : 0u;
+        cw32[t] = v;
+    }
+    // proofs: flat dword stream over [128, 128 + 362*B)
+    const uint32_t lb_off = bsx_off_lb_proofs(B) - 128;         // byte offset of the lb array inside the stream
+    const uint32_t total = (BSX_DH_PROOF_SIZE + BSX_LB_PROOF_SIZE) * B;  // multiple of 4? 362*B: B even -> yes; B == 1 -> 362
+    const uint32_t ndw = (total + 3) / 4;
+    bool bad_leaf = false;
+    for (uint32_t w = threadIdx.x; w < ndw; w += blockDim.x) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t o = 4 * w + b;
+            uint8_t byte = 0;
+            if (o < total && !oob) {
+                const bool is_lb = o >= lb_off;
+                const uint32_t oo = is_lb ? o - lb_off : o;
+                const uint32_t psz = is_lb ? BSX_LB_PROOF_SIZE : BSX_DH_PROOF_SIZE;
+                const uint32_t slot = oo / psz, within = oo % psz;
+                if (slot < n_real) {
+                    const uint64_t hidx = hbase + (batch_start - S) + slot + (is_lb ? 1 : 0);
+                    if (within < 128) {
+                        byte = (is_lb ? a.lb_aunts : a.dh_aunts)[hidx * 128 + within];
+                    } else {
+                        const bsx_header* h = a.headers + hidx;
+                        byte = is_lb ? h->last_block_id[within - 128] : h->hash[1][within - 128];
+                        if (within == 128) {  // input.rs:173,190: the leaf must be exactly 34 / 72 bytes
+                            const uint8_t l = is_lb ? h->len[BSX_LAST_BLOCK_ID_INDEX] : h->len[BSX_DATA_HASH_INDEX];
+                            if (l != (is_lb ? BSX_PROTOBUF_BLOCK_ID_SIZE : BSX_PROTOBUF_HASH_SIZE)) bad_leaf = true;
+                        }
+                    }
+                }
+            }
+            v |= (uint32_t)byte << (8 * b);
+        }
+        cw32[32 + w] = v;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
+        W[BSX_W_CTX_START] = (uint32_t)rg.start_block; W[BSX_W_CTX_START + 1] = (uint32_t)(rg.start_block >> 32);
+        W[BSX_W_CTX_END] = (uint32_t)rg.end_block; W[BSX_W_CTX_END + 1] = (uint32_t)(rg.end_block >> 32);
+        W[BSX_W_BATCH_START] = (uint32_t)batch_start; W[BSX_W_BATCH_START + 1] = (uint32_t)(batch_start >> 32);
+        W[BSX_W_BATCH_END] = (uint32_t)batch_end; W[BSX_W_BATCH_END + 1] = (uint32_t)(batch_end >> 32);
+        if (a.status) {
+            if (oob || latest < 2) atomicOr(a.status, 4u);
+        }
+    }
+    if (__ballot(bad_leaf) && (threadIdx.x & 63) == 0 && a.status) atomicOr(a.status, 2u);
+}
+
+// ------------------------------------------------------------------------------------------------ k_prove_subchain
+// 256 consecutive slots of one range per workgroup (256/B map jobs when B < 256).  LDS: proof staging (<= 51.2 KB,
+// reused for the tree) -> 3 WG / CU.
+struct SubchainArgs {
+    uint32_t n_ranges, batch, job_count;     // job_count = map jobs per range owned by this call
+    const bsx_shared_ctx* ranges;
+    uint8_t* compact;
+    uint32_t compact_stride, off_words, off_bools;
+    bsx_subchain* records;
+};
+constexpr int SC_THREADS = 256;
+constexpr int SC_LDS_DWORDS = 256 * 52;        // 256 lb proofs (200 B) + per-job funnel slack (worst case B == 1)
+
+// dword k of a byte region that starts at LDS byte offset `boff` (2-byte aligned) — funnel of two aligned dwords
+__device__ __forceinline__ uint32_t lds_dword_at(const uint32_t* lds, uint32_t boff, int k) {
+    const uint32_t a = (boff >> 2) + k, sh = (boff & 3) * 8;
+    return funnel_r(lds[a + 1], lds[a], sh);
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_prove_subchain(SubchainArgs a) {
+    __shared__ uint32_t lds[SC_LDS_DWORDS];
+    __shared__ uint32_t job_fail[256];       // per local job: OR of failed assertion bits
+    __shared__ uint32_t job_first_bad[256];  // per local job: lowest failing slot
+    const uint32_t B = a.batch;
+    const uint32_t slots_per_range = a.job_count * B;
+    const uint32_t blocks_per_range = (slots_per_range + SC_THREADS - 1) / SC_THREADS;
+    const uint32_t r = blockIdx.x / blocks_per_range, blk = blockIdx.x % blocks_per_range;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slot0 = blk * SC_THREADS;                       // first slot of this block within the range
+    const uint32_t nslots = min((uint32_t)SC_THREADS, slots_per_range - slot0);
+    const uint32_t jobs_here = (nslots + B - 1) / B;               // B <= 256 and aligned: nslots is a multiple of B
+    const uint32_t job0 = slot0 / B;
+    const bool live = tid < nslots;
+    const uint32_t jl = live ? tid / B : 0, i = live ? tid % B : 0;   // local job, slot in job
+    uint8_t* cw = a.compact + ((uint64_t)r * a.job_count + job0 + jl) * a.compact_stride;
+    uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
+    uint8_t* Bo = cw + a.off_bools;
+    const bsx_shared_ctx* rg = a.ranges + r;
+    const uint64_t E = rg->end_block;
+    const uint64_t batch_start = (uint64_t)W[BSX_W_BATCH_START] | ((uint64_t)W[BSX_W_BATCH_START + 1] << 32);
+    const uint64_t batch_end = (uint64_t)W[BSX_W_BATCH_END] | ((uint64_t)W[BSX_W_BATCH_END + 1] << 32);
+
+    if (tid < 256) { job_fail[tid] = 0; job_first_bad[tid] = 0xffffffffu; }
+
+    // ---- stage the data_hash proofs of every local job: bytes [128, 128+162*B) of each compact witness
+    const uint32_t dh_dw = (BSX_DH_PROOF_SIZE * B + 3) / 4 + 1;      // dwords per job region (+1 funnel slack)
+    for (uint32_t c = tid; c < jobs_here * dh_dw; c += SC_THREADS) {
+        const uint32_t q = c / dh_dw, k = c % dh_dw;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.compact + ((uint64_t)r * a.job_count + job0 + q) * a.compact_stride + 128);
+        lds[q * dh_dw + k] = (k * 4 < BSX_DH_PROOF_SIZE * B) ? src[k] : 0u;
+    }
+    __syncthreads();
+
+    Digest dh_root, dh_leafhash;
+    uint32_t data_hash_le[8];   // leaf[2..34] as LE dwords
+    {
+        const uint32_t boff = jl * dh_dw * 4 + i * BSX_DH_PROOF_SIZE;
+        uint32_t lf[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) lf[k] = lds_dword_at(lds, boff + 128, k);
+        lf[8] &= 0xffffu;
+#pragma unroll
+        for (int k = 0; k < 8; k++) data_hash_le[k] = funnel_r(lf[k + 1], lf[k], 16);   // bytes 2.. of the leaf
+        Digest h = leaf_hash_34(lf);
+        dh_leafhash = h;
+        uint8_t* sl = cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i;
+        if (live) store_digest_global(sl, h);
+        // path [0,1,1,0] (builder.rs:166-167): h = bit ? inner(aunt, h) : inner(h, aunt)
+#pragma unroll
+        for (int lvl = 0; lvl < 4; lvl++) {
+            uint32_t al[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) al[k] = lds_dword_at(lds, boff + 32 * lvl, k);
+            const Digest aunt = digest_from_le(al);
+            h = (lvl == 1 || lvl == 2) ? inner_hash(aunt, h) : inner_hash(h, aunt);
+            if (live) store_digest_global(sl + 32 * (lvl + 1), h);
+        }
+        dh_root = h;
+    }
+    __syncthreads();
+
+    // ---- stage the last_block_id proofs: bytes [128+162*B, 128+362*B)
+    const uint32_t lb_byte0 = bsx_off_lb_proofs(B);                  // 2-byte aligned when B is odd (B == 1)
+    const uint32_t lb_dw = (BSX_LB_PROOF_SIZE * B + (lb_byte0 & 3) + 3) / 4 + 1;
+    for (uint32_t c = tid; c < jobs_here * lb_dw; c += SC_THREADS) {
+        const uint32_t q = c / lb_dw, k = c % lb_dw;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.compact + ((uint64_t)r * a.job_count + job0 + q) * a.compact_stride + (lb_byte0 & ~3u));
+        lds[q * lb_dw + k] = (k * 4 < BSX_LB_PROOF_SIZE * B + (lb_byte0 & 3)) ? src[k] : 0u;
+    }
+    __syncthreads();
+
+    Digest lb_root, claimed;   // claimed = last_block_id_proofs[i].leaf[2..34] (builder.rs:204)
+    {
+        const uint32_t boff = jl * lb_dw * 4 + (lb_byte0 & 3) + i * BSX_LB_PROOF_SIZE;
+        uint32_t lf[19];
+#pragma unroll
+        for (int k = 0; k < 18; k++) lf[k] = lds_dword_at(lds, boff + 128, k);
+        lf[18] = 0;
+        {
+            uint32_t c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = funnel_r(lf[k + 1], lf[k], 16);
+            claimed = digest_from_le(c);
+        }
+        Digest h = leaf_hash_72(lf);
+        uint8_t* sl = cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i + 160;
+        if (live) store_digest_global(sl, h);
+        // path [0,0,1,0] (builder.rs:168-169)
+#pragma unroll
+        for (int lvl = 0; lvl < 4; lvl++) {
+            uint32_t al[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) al[k] = lds_dword_at(lds, boff + 32 * lvl, k);
+            const Digest aunt = digest_from_le(al);
+            h = (lvl == 2) ? inner_hash(aunt, h) : inner_hash(h, aunt);
+            if (live) store_digest_global(sl + 32 * (lvl + 1), h);
+        }
+        lb_root = h;
+    }
+    __syncthreads();   // staging area is free from here on
+
+    // ---- LDS reuse: lb roots [256][8], tree nodes ping/pong [256][8] x2
+    uint32_t* lds_lbroot = lds;
+    uint32_t* lds_tree0 = lds + 256 * 8;
+    uint32_t* lds_tree1 = lds + 2 * 256 * 8;
+    store_digest_lds(lds_lbroot + tid * 8, lb_root);
+
+    // data-root tuple (builder.rs:82-103,134-137) and its leaf hash
+    const uint64_t curr_idx = batch_start + i;                       // builder.rs:182 / :134 (same value)
+    Digest tleaf;
+    {
+        uint32_t t[16];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = 0;
+        t[6] = (uint32_t)(curr_idx >> 32);
+        t[7] = (uint32_t)curr_idx;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[8 + k] = bswap32(data_hash_le[k]);
+        tleaf = leaf_hash_tuple(t);
+        if (live) {
+            uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
+#pragma unroll
+            for (int k = 0; k < 16; k++) store_u32_a2(tp + 4 * k, bswap32(t[k]));
+            store_digest_global(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
+        }
+    }
+    store_digest_lds(lds_tree0 + tid * 8, tleaf);
+    __syncthreads();
+
+    // ---- chain-link predicates (builder.rs:174-226).  Enabled slots form a prefix [0, m) of the batch.
+    const bool batch_enabled = batch_start < E;                      // :174
+    const uint64_t last_to_process = E - 1;                          // :177
+    const uint64_t jstar = last_to_process - batch_start;            // slot index of the last block (wrapping)
+    const uint32_t m = batch_enabled ? (uint32_t)((jstar < (uint64_t)B) ? jstar + 1 : B) : 0u;
+    const bool en_before = i < m;                                    // curr_block_enabled entering slot i
+    const bool is_last = (last_to_process == curr_idx);              // :185
+    // curr_header entering slot i = start_header (i == 0 or m == 0) else lb_root of slot min(i, m) - 1
+    const Digest start_header = load_digest_global(cw + bsx_off_start_header());
+    Digest curr_before = start_header, curr_after = start_header;
+    if (i > 0 && m > 0) curr_before = load_digest_lds(lds_lbroot + (jl * B + min(i, m) - 1) * 8);
+    if (m > 0) curr_after = load_digest_lds(lds_lbroot + (jl * B + min(i + 1, m) - 1) * 8);
+    const Digest H_E = load_digest_global(rg->end_header_hash);
+    const bool valid_prev = digest_eq(curr_before, claimed);         // :205
+    const bool prev_check = !en_before || valid_prev;                // :206
+    const bool dh_valid = digest_eq(dh_root, claimed);               // :210
+    const bool dh_check = !en_before || dh_valid;                    // :211
+    const bool root_matches_end = digest_eq(lb_root, H_E);           // :216
+    const bool end_check = !is_last || root_matches_end;             // :218
+    const bool en_after = en_before && !is_last;                     // :225
+    if (live) {
+        store_digest_global(cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i + 320, curr_after);   // :223
+        W[BSX_W_CURR_IDX + 2 * i] = (uint32_t)curr_idx; W[BSX_W_CURR_IDX + 2 * i + 1] = (uint32_t)(curr_idx >> 32);
+        W[bsx_w_block_height(B) + 2 * i] = (uint32_t)curr_idx; W[bsx_w_block_height(B) + 2 * i + 1] = (uint32_t)(curr_idx >> 32);
+        uint8_t* b = Bo + BSX_B_SLOTS + BSX_SLOT_BOOLS * i;
+        b[0] = !en_before; b[1] = is_last; b[2] = valid_prev; b[3] = prev_check; b[4] = dh_valid; b[5] = dh_check;
+        b[6] = root_matches_end; b[7] = end_check; b[8] = en_after;
+    }
+    // wave-ballot reduction of the three per-slot assertions; one LDS atomic per (wave, job) instead of per lane
+    {
+        const uint32_t f = live ? ((prev_check ? 0u : BSX_A3_PREV_HEADER) | (dh_check ? 0u : BSX_A4_DATA_HASH_PROOF) |
+                                   (end_check ? 0u : BSX_A5_END_HEADER)) : 0u;
+        if (__ballot(f != 0)) {          // rare path
+            if (f) { atomicOr(&job_fail[jl], f); atomicMin(&job_first_bad[jl], i); }
+        }
+    }
+
+    // ---- get_data_commitment (builder.rs:105-148): masked tree over the B tuple leaf hashes of each job
+    const uint64_t temp_end = (batch_end < E) ? batch_end : E;       // :235-240
+    const bool end_lt_start = temp_end < batch_start;                // :241
+    const uint64_t end_block_num = end_lt_start ? batch_start : temp_end;   // :242-243
+    const bool gte = end_block_num >= batch_start;                   // :113 (A1)
+    const uint64_t nb_blocks = end_block_num - batch_start;          // :119
+    const uint32_t nb_enabled = (uint32_t)nb_blocks;                 // :124 (low limb)
+    if (live) Bo[bsx_b_leaf_enabled(B) + i] = i < nb_enabled;
+    uint32_t* cur = lds_tree0;
+    uint32_t* nxt = lds_tree1;
+    uint32_t level_off = 0;
+    for (uint32_t width = B / 2, span = 2; width >= 1; width /= 2, span *= 2) {   // width = nodes per job at this level
+        const uint32_t total_nodes = jobs_here * width;
+        if (tid < total_nodes) {
+            const uint32_t q = tid / width, t = tid % width;          // job, node in job
+            const Digest l = load_digest_lds(cur + (q * width * 2 + 2 * t) * 8);
+            const Digest rr = load_digest_lds(cur + (q * width * 2 + 2 * t + 1) * 8);
+            const Digest in = inner_hash(l, rr);
+            // enabled(left child) = t*span < nb ; enabled(right child) = t*span + span/2 < nb   (prefix mask)
+            uint8_t* cwq = a.compact + ((uint64_t)r * a.job_count + job0 + q) * a.compact_stride;
+            const uint32_t* Wq = reinterpret_cast<const uint32_t*>(cwq + a.off_words);
+            const uint64_t bs = (uint64_t)Wq[BSX_W_BATCH_START] | ((uint64_t)Wq[BSX_W_BATCH_START + 1] << 32);
+            const uint64_t be = (uint64_t)Wq[BSX_W_BATCH_END] | ((uint64_t)Wq[BSX_W_BATCH_END + 1] << 32);
+            const uint64_t te = (be < E) ? be : E;
+            const uint64_t ebn = (te < bs) ? bs : te;
+            const uint32_t nbq = (uint32_t)(ebn - bs);
+            const bool en_l = t * span < nbq, en_r = t * span + span / 2 < nbq;
+            const Digest node = (en_l && en_r) ? in : l;
+            store_digest_lds(nxt + (q * width + t) * 8, node);
+            store_digest_global(cwq + bsx_off_inner(B) + 32 * (level_off + t), in);
+            store_digest_global(cwq + bsx_off_nodes(B) + 32 * (level_off + t), node);
+            cwq[a.off_bools + bsx_b_node_enabled(B) + level_off + t] = en_l || en_r;
+        }
+        level_off += width;
+        __syncthreads();
+        uint32_t* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // B == 1: no loop iteration; root = the leaf hash.  `cur` holds one root per job at [q*8].
+    __syncthreads();
+
+    // ---- batch tail + record (builder.rs:229-270): one lane per job
+    if (live && i == 0) {
+        const Digest root = load_digest_lds(cur + jl * 8);
+        // enabled after slot B-1 <=> all B slots enabled and slot B-1 is not the last block <=> jstar >= B (or batch disabled -> false)
+        const bool curr_enabled_end = batch_enabled && !(jstar < (uint64_t)B);
+        const Digest curr_final = (m > 0) ? load_digest_lds(lds_lbroot + (jl * B + m - 1) * 8) : start_header;
+        const Digest end_header = load_digest_global(cw + bsx_off_end_header());
+        const bool last_disabled = !curr_enabled_end;                     // :229
+        const bool last_matches = digest_eq(curr_final, end_header);      // :230
+        const bool end_header_check = last_disabled || last_matches;      // :231
+        uint32_t fail = job_fail[jl];
+        uint32_t first_bad = job_first_bad[jl];
+        if (!end_header_check) { fail |= BSX_A6_BATCH_END; if (first_bad == 0xffffffffu) first_bad = B; }
+        if (!gte) { fail |= BSX_A1_END_GTE_START; if (first_bad == 0xffffffffu) first_bad = B; }
+        if ((nb_blocks >> 32) != 0) { fail |= BSX_A2_NB_BLOCKS_U32; if (first_bad == 0xffffffffu) first_bad = B; }
+        uint8_t* t = Bo + bsx_b_tail(B);
+        t[0] = last_disabled; t[1] = last_matches; t[2] = end_header_check; t[3] = batch_end < E; t[4] = end_lt_start; t[5] = gte;
+        Bo[BSX_B_BATCH_ENABLED] = batch_enabled;
+        Bo[bsx_b_rec_enabled(B)] = batch_enabled;
+        W[BSX_W_LAST_TO_PROCESS] = (uint32_t)last_to_process; W[BSX_W_LAST_TO_PROCESS + 1] = (uint32_t)(last_to_process >> 32);
+        W[bsx_w_temp_end(B)] = (uint32_t)temp_end; W[bsx_w_temp_end(B) + 1] = (uint32_t)(temp_end >> 32);
+        W[bsx_w_end_block_num(B)] = (uint32_t)end_block_num; W[bsx_w_end_block_num(B) + 1] = (uint32_t)(end_block_num >> 32);
+        W[bsx_w_nb_blocks(B)] = (uint32_t)nb_blocks; W[bsx_w_nb_blocks(B) + 1] = (uint32_t)(nb_blocks >> 32);
+        W[bsx_w_rec_start(B)] = (uint32_t)batch_start; W[bsx_w_rec_start(B) + 1] = (uint32_t)(batch_start >> 32);
+        W[bsx_w_rec_end(B)] = (uint32_t)end_block_num; W[bsx_w_rec_end(B) + 1] = (uint32_t)(end_block_num >> 32);
+        uint8_t* rec_b = cw + bsx_off_record(B);
+        store_digest_global(rec_b, start_header);
+        store_digest_global(rec_b + 32, curr_final);
+        store_digest_global(rec_b + 64, root);
+        bsx_subchain* out = a.records + (uint64_t)r * a.job_count + job0 + jl;
+        out->start_block = batch_start;
+        out->end_block = end_block_num;
+        store_digest_global(out->start_header, start_header);
+        store_digest_global(out->end_header, curr_final);
+        store_digest_global(out->data_merkle_root, root);
+        out->is_enabled = batch_enabled ? 1u : 0u;
+        out->assert_fail = fail;
+        out->first_bad_slot = first_bad;
+        out->_pad = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_reduce
+// One workgroup per range: n (power of two <= 256) records -> 1, level by level in LDS.
+struct ReduceArgs {
+    uint32_t n_ranges, n;
+    const bsx_subchain* records;
+    bsx_subchain* out;
+    uint8_t* reduce_compact;       // optional: (n-1) node witnesses per range
+    uint32_t compact_stride, off_words, off_bools;
+};
+__global__ __launch_bounds__(128) void k_reduce(ReduceArgs a) {
+    __shared__ bsx_subchain rec[256];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, n = a.n;
+    {   // coalesced copy in: n * 128 bytes
+        const uint4* src = reinterpret_cast<const uint4*>(a.records + (uint64_t)r * n);
+        uint4* dst = reinterpret_cast<uint4*>(rec);
+        for (uint32_t c = tid; c < n * 8; c += blockDim.x) dst[c] = src[c];
+    }
+    __syncthreads();
+    uint32_t k0 = 0;
+    for (uint32_t mcount = n; mcount > 1; mcount /= 2) {
+        bsx_subchain o;
+        const bool act = tid < mcount / 2;
+        if (act) {
+            const bsx_subchain& l = rec[2 * tid];
+            const bsx_subchain& rt = rec[2 * tid + 1];
+            const Digest l_end = load_digest_global(l.end_header), r_start = load_digest_global(rt.start_header);
+            const Digest l_root = load_digest_global(l.data_merkle_root), r_root = load_digest_global(rt.data_merkle_root);
+            const bool right_disabled = rt.is_enabled == 0;                       // builder.rs:344
+            const bool headers_linked = digest_eq(l_end, r_start);                // :348-349
+            const bool blocks_linked = l.end_block == rt.start_block;             // :350
+            const bool linked = headers_linked && blocks_linked;                  // :351
+            const bool link_check = right_disabled || linked;                     // :352
+            const Digest computed = inner_hash(l_root, r_root);                   // :357-364
+            const Digest root = right_disabled ? l_root : computed;               // :367-371
+            o.start_block = l.start_block;                                        // :389
+            o.end_block = right_disabled ? l.end_block : rt.end_block;            // :374-378
+            for (int q = 0; q < 32; q++) {
+                o.start_header[q] = l.start_header[q];                            // :390
+                o.end_header[q] = right_disabled ? l.end_header[q] : rt.end_header[q];   // :379-383
+            }
+            store_digest_global(o.data_merkle_root, root);
+            o.is_enabled = l.is_enabled;                                          // :388
+            const uint32_t child = l.assert_fail | rt.assert_fail;
+            o.assert_fail = child | (link_check ? 0u : BSX_A8_REDUCE_LINK);
+            const uint32_t k = k0 + tid;
+            if (!link_check && !(child & BSX_A8_REDUCE_LINK)) o.first_bad_slot = k;
+            else o.first_bad_slot = (l.first_bad_slot != 0xffffffffu) ? l.first_bad_slot : rt.first_bad_slot;
+            o._pad = 0;
+            if (a.reduce_compact) {
+                uint8_t* cw = a.reduce_compact + ((uint64_t)r * (n - 1) + k) * a.compact_stride;
+                store_digest_global(cw, computed);
+                for (int q = 0; q < 32; q++) { cw[32 + q] = o.start_header[q]; cw[64 + q] = o.end_header[q]; cw[96 + q] = o.data_merkle_root[q]; }
+                uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
+                W[0] = (uint32_t)o.start_block; W[1] = (uint32_t)(o.start_block >> 32);
+                W[2] = (uint32_t)o.end_block; W[3] = (uint32_t)(o.end_block >> 32);
+                uint8_t* b = cw + a.off_bools;
+                b[0] = right_disabled; b[1] = headers_linked; b[2] = blocks_linked; b[3] = linked; b[4] = link_check; b[5] = (uint8_t)o.is_enabled;
+            }
+        }
+        __syncthreads();
+        if (act) rec[tid] = o;
+        __syncthreads();
+        k0 += mcount / 2;
+    }
+    if (tid < 8) reinterpret_cast<uint4*>(a.out + r)[tid] = reinterpret_cast<uint4*>(rec)[tid];
+}
+
+// ------------------------------------------------------------------------------------------------ k_finalize
+__global__ void k_finalize(uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch, const bsx_shared_ctx* ranges,
+                           const bsx_subchain* results, const uint8_t* target_hashes, uint8_t* output64, uint32_t* status) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranges) return;
+    const bsx_shared_ctx& rg = ranges[r];
+    const bsx_subchain& res = results[r];
+    uint32_t st = res.assert_fail;
+    const uint64_t max_blocks = (uint64_t)nb_map_jobs * batch;
+    if (!(rg.end_block <= rg.start_block + max_blocks)) st |= BSX_A7_RANGE;            // builder.rs:292-297
+    bool ok = res.start_block == rg.start_block && res.end_block == rg.end_block;        // :400-406
+    for (int q = 0; q < 32; q++) ok = ok && res.start_header[q] == rg.start_header_hash[q] && res.end_header[q] == rg.end_header_hash[q];
+    if (!ok) st |= BSX_A9_FINAL;
+    if (output64) {
+        const uint8_t* th = target_hashes ? target_hashes + 32 * (uint64_t)r : rg.end_header_hash;
+        for (int q = 0; q < 32; q++) { output64[64 * (uint64_t)r + q] = th[q]; output64[64 * (uint64_t)r + 32 + q] = res.data_merkle_root[q]; }  // header_range.rs:57-58
+    }
+    if (status) status[r] = st;
+}
+
+// ------------------------------------------------------------------------------------------------ k_expand_witness
+// HBM-write bound: every lane emits 16 bytes (two Goldilocks elements) per store, lane-contiguous (1 KiB per wave
+// store).  grid.y = job; a job's expanded image starts at job * n_elements * 8 bytes (8-byte aligned only), so lanes
+// are aligned to GLOBAL 16-byte pairs and the (at most two) straddling elements fall back to 8-byte stores.
+struct ExpandArgs {
+    bsx_witness_layout lay;
+    uint32_t n_jobs;
+    const uint8_t* compact;
+    uint64_t* out;
+};
+__device__ __forceinline__ uint64_t expand_elem(const ExpandArgs& a, const uint8_t* c, int64_t e) {
+    const int64_t nbits = 8ll * a.lay.n_bytes;
+    if (e < nbits) return (c[e >> 3] >> (7 - (e & 7))) & 1u;
+    e -= nbits;
+    if (e < (int64_t)a.lay.n_words) return reinterpret_cast<const uint32_t*>(c + a.lay.off_words)[e];
+    e -= a.lay.n_words;
+    return c[a.lay.off_bools + e];
+}
+constexpr int EX_THREADS = 256, EX_PAIRS_PER_THREAD = 8;
+__global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
+    const uint32_t job = blockIdx.y;
+    const uint8_t* c = a.compact + (uint64_t)job * a.lay.compact_stride;
+    const uint64_t nel = a.lay.n_elements;
+    const uint64_t g0 = (uint64_t)job * nel;                 // global element index of this job's first element
+    const uint64_t odd = g0 & 1;
+    uint64_t* out = a.out;
+    const int64_t nbits = 8ll * a.lay.n_bytes;
+    // local pair p covers local elements 2p - odd, 2p - odd + 1
+    const uint64_t npairs = (nel + odd + 1) / 2;
+    const uint64_t p0 = (uint64_t)blockIdx.x * (EX_THREADS * EX_PAIRS_PER_THREAD);
+#pragma unroll
+    for (int u = 0; u < EX_PAIRS_PER_THREAD; u++) {
+        const uint64_t p = p0 + (uint64_t)u * EX_THREADS + threadIdx.x;
+        if (p >= npairs) continue;
+        const int64_t e0 = (int64_t)(2 * p) - (int64_t)odd, e1 = e0 + 1;
+        const bool in0 = e0 >= 0, in1 = e1 < (int64_t)nel;
+        uint64_t v0 = 0, v1 = 0;
+        if (in0 && e1 < nbits) {           // fast path: both bits come from the same source byte (e0 even or same byte)
+            const uint32_t by0 = c[e0 >> 3], by1 = c[e1 >> 3];
+            v0 = (by0 >> (7 - (e0 & 7))) & 1u;
+            v1 = (by1 >> (7 - (e1 & 7))) & 1u;
+        } else {
+            if (in0) v0 = expand_elem(a, c, e0);
+            if (in1) v1 = expand_elem(a, c, e1);
+        }
+        uint64_t* dst = out + g0 + e0;     // 16-byte aligned when both are in range
+        if (in0 && in1) {
+            *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(v0, v1);
+        } else {
+            if (in0) dst[0] = v0;
+            if (in1) dst[1] = v1;
+        }
+    }
+}
+
+}  // namespace bsx
+
+// ------------------------------------------------------------------------------------------------ launchers (called by api.hip)
+extern "C" {
+using namespace bsx;
+
+hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint32_t* status) {
+    if (!n) return hipSuccess;
+    const uint32_t grid = (uint32_t)((n + HM_THREADS - 1) / HM_THREADS);
+    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, status);
+    return hipGetLastError();
+}
+hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
+                                const bsx_shared_ctx* ranges, const uint64_t* latest, const bsx_header* headers, uint64_t hpr,
+                                const uint8_t* hashes, const uint8_t* dh, const uint8_t* lb, uint8_t* compact, uint32_t* status) {
+    if (!n_ranges || !job_count) return hipSuccess;
+    const bsx_witness_layout L = bsx_map_layout(B);
+    AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status};
+    hipLaunchKernelGGL(k_assemble_inputs, dim3(n_ranges * job_count), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_t job_count, const bsx_shared_ctx* ranges,
+                               uint8_t* compact, bsx_subchain* records) {
+    if (!n_ranges || !job_count) return hipSuccess;
+    const bsx_witness_layout L = bsx_map_layout(B);
+    SubchainArgs a{n_ranges, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records};
+    const uint32_t bpr = (job_count * B + SC_THREADS - 1) / SC_THREADS;
+    hipLaunchKernelGGL(k_prove_subchain, dim3(n_ranges * bpr), dim3(SC_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, bsx_subchain* out, uint8_t* reduce_compact) {
+    if (!n_ranges) return hipSuccess;
+    const bsx_witness_layout L = bsx_reduce_layout();
+    ReduceArgs a{n_ranges, n, records, out, reduce_compact, L.compact_stride, L.off_words, L.off_bools};
+    hipLaunchKernelGGL(k_reduce, dim3(n_ranges), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t bsxk_finalize(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, const bsx_shared_ctx* ranges, const bsx_subchain* results,
+                         const uint8_t* target_hashes, uint8_t* output64, uint32_t* status) {
+    if (!n_ranges) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize, dim3((n_ranges + 63) / 64), dim3(64), 0, s, n_ranges, J, B, ranges, results, target_hashes, output64, status);
+    return hipGetLastError();
+}
+hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uint32_t n_jobs, const uint8_t* compact, uint64_t* out) {
+    if (!n_jobs) return hipSuccess;
+    ExpandArgs a{*lay, n_jobs, compact, out};
+    const uint64_t npairs = (lay->n_elements + 2) / 2;
+    const uint32_t gx = (uint32_t)((npairs + EX_THREADS * EX_PAIRS_PER_THREAD - 1) / (EX_THREADS * EX_PAIRS_PER_THREAD));
+    hipLaunchKernelGGL(k_expand_witness, dim3(gx, n_jobs), dim3(EX_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+}

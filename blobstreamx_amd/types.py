@@ -80,7 +80,7 @@ def pack_header(fields):
     h = np.zeros((), dtype=HEADER)
     for i, f in enumerate(fields):
         cap = HEADER_FIELD_CAP[i]
-        if len(f) > cap or (i != 4 and len(f) > 55):
+        if len(f) > cap or (i != 4 and len(f) > 54):
             raise ValueError(f"header field {i} is {len(f)} bytes (capacity {cap})")
         h["len"][i] = len(f)
         dst = h["hash"][i - 5] if 5 <= i <= 12 else h[HEADER_FIELD_NAMES[i]]

@@ -80,8 +80,8 @@ typedef enum bsx_status {
  * input.rs:175-179,188-195).  Fixed 512-byte record, every field 4-byte aligned so a wave
  * can stage records with 16-byte coalesced loads.  len[i] is the encoded length of field i
  * (0 = empty field, hashed as the empty leaf 0x00).  Capacity rules (violations ->
- * BSX_ERR_BAD_HEADER): every field except 4 is <= 55 bytes (one SHA-256 block with the
- * 0x00 leaf prefix); field 4 (last_block_id) is <= 76. */
+ * BSX_ERR_BAD_HEADER): every field except 4 is <= 54 bytes (0x00 prefix + field fit one
+ * SHA-256 block; the capacities below already guarantee it); field 4 (last_block_id) is <= 76. */
 typedef struct bsx_header {
     uint8_t len[BSX_HEADER_FIELDS];
     uint8_t _pad[2];
@@ -272,54 +272,76 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness);
 
-/* ------------------------------------------------------------------ device tier (async; d_* = device memory) */
+/* ------------------------------------------------------------------ device tier (async; d_* = device memory)
+ * Every call only enqueues kernels on `stream` (hipStream_t as void*; NULL = the context's own stream) and returns.
+ * Device status words are ORed into, never cleared: the caller zeroes them (hipMemsetAsync) before a pass. */
 
-/* P5: one lane per header. d_hashes n×32; d_dh_aunts / d_lb_aunts n×128 (4 aunts, leaf-adjacent first). */
+/* P5: one lane per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be
+ * NULL.  d_status (1 u32, optional): bit0 = a header violates the field-size rules. */
 int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n,
                           uint8_t* d_hashes, uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint32_t* d_status);
 
 /* The hint for many map jobs at once (input.rs:149-271): job j of range r covers
- * [S_r + j*B, S_r + (j+1)*B).  d_ranges: n_ranges bsx_shared_ctx.  Headers of range r start at
- * d_headers[r*headers_per_range] = height S_r.  Writes the DataCommitmentProofVariable part of each
- * job's compact witness (d_compact, stride layout.compact_stride). */
+ * [S_r + j*B, S_r + j*B + span) (span == B for map jobs, input.rs:154 requires span <= B).  Headers of range r start
+ * at d_headers[r*headers_per_range] = height S_r; d_latest[r] is the chain head the hint clamps against
+ * (input.rs:160-162).  Only jobs [job_first, job_first+job_count) are written (multi-GPU sharding); compact witnesses
+ * are indexed [range][job - job_first] with stride bsx_map_witness_layout(B).compact_stride.  Writes the
+ * DataCommitmentProofVariable part, the ctx and the batch bounds of each job's compact witness.
+ * d_status bits: 1 = inclusion-proof leaf is not 34/72 bytes (input.rs:173,190), 2 = headers not supplied / latest < 2. */
 int bsx_dev_assemble_inputs(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
-                            const bsx_shared_ctx* d_ranges, const uint64_t* d_latest_block,
+                            uint32_t job_first, uint32_t job_count, uint32_t span,
+                            const bsx_shared_ctx* d_ranges, const uint64_t* d_latest,
                             const bsx_header* d_headers, uint64_t headers_per_range,
                             const uint8_t* d_hashes, const uint8_t* d_dh_aunts, const uint8_t* d_lb_aunts,
-                            uint8_t* d_compact);
+                            uint8_t* d_compact, uint32_t* d_status);
 
-/* prove_subchain for n_ranges*nb_map_jobs map jobs (builder.rs:150-271 incl. get_data_commitment
- * :105-148).  job_first/job_count select the slice of map jobs of every range this device owns
- * (multi-GPU sharding); compact witnesses and records are indexed [range][job - job_first]. */
-int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
-                           uint32_t job_first, uint32_t job_count,
+/* prove_subchain for n_ranges*job_count map jobs (builder.rs:150-271 incl. get_data_commitment :105-148).  Reads the
+ * proofs, start/end header and batch bounds from each compact witness, global end block/hash from d_ranges[r];
+ * completes the compact witness and writes d_records[range][job]. */
+int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t batch_size, uint32_t job_count,
                            const bsx_shared_ctx* d_ranges, uint8_t* d_compact, bsx_subchain* d_records);
 
-/* Binary reduce (builder.rs:337-395) of `n` consecutive records per range -> 1, n a power of two.
+/* Binary reduce (builder.rs:337-395) of `n` consecutive records per range -> 1, n a power of two <= 256.
  * d_reduce_compact (optional) receives n-1 reduce-node compact witnesses per range. */
 int bsx_dev_reduce(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t n,
                    const bsx_subchain* d_records, bsx_subchain* d_out, uint8_t* d_reduce_compact);
 
-/* Final assertions of prove_data_commitment (builder.rs:292-297,400-406) + the 64-byte public
- * output (header_range.rs:57-58).  d_status: n_ranges u32 (OR of failed BSX_A* bits). */
+/* Final assertions of prove_data_commitment (builder.rs:292-297,400-406) + the 64-byte public output
+ * (header_range.rs:57-58).  d_target_hashes (optional, n_ranges*32): first half of the output; NULL = ctx end hash.
+ * d_status: n_ranges u32 (OR of failed BSX_A* bits; overwritten). */
 int bsx_dev_finalize(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
-                     const bsx_shared_ctx* d_ranges, const bsx_subchain* d_results,
+                     const bsx_shared_ctx* d_ranges, const bsx_subchain* d_results, const uint8_t* d_target_hashes,
                      uint8_t* d_output64, uint32_t* d_status);
 
-/* P10: compact -> Goldilocks.  n_jobs compact witnesses (layout) -> n_jobs*layout.n_elements u64. */
+/* P10: compact -> Goldilocks.  n_jobs compact witnesses (layout) -> n_jobs*layout.n_elements u64, 16-byte aligned. */
 int bsx_dev_expand_witness(bsx_ctx* ctx, void* stream, const bsx_witness_layout* layout, uint32_t n_jobs,
                            const uint8_t* d_compact, uint64_t* d_witness);
 
-/* P6: h = SHA512(R ‖ A ‖ M) mod L per validator slot. d_h: n×32 (LE scalar), d_digest (optional) n×64. */
+/* d_ranges[r].end_header_hash := d_hashes[r*headers_per_range + (end_block - start_block)] (the target header hash
+ * builder.skip returns and prove_data_commitment consumes, header_range.rs:42-55). */
+int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_shared_ctx* d_ranges,
+                          const uint8_t* d_hashes, uint64_t headers_per_range);
+
+/* P6: h = SHA512(R ‖ A ‖ M) mod L per validator slot. d_h: n*32 (LE scalar), d_digest (optional) n*64. */
 int bsx_dev_sha512_challenge(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n,
                              uint8_t* d_h, uint8_t* d_digest);
 /* P7: [s]B == R + [h]A per validator slot. d_ok: n bytes (1 valid, 0 invalid or not signed/enabled). */
 int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
                            uint64_t n, uint8_t* d_ok);
-/* P8+P9: validator-set hash, voting-power tallies and message checks; one workgroup per commit. */
+/* P8+P9: validator-set hash, voting-power tallies and message checks; one workgroup per commit; v_max <= 512.
+ * d_header_hashes / d_ok may be NULL (then only validators_hash, total_power, n_enabled are meaningful). */
 int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits,
                          uint32_t v_max, const uint8_t* d_header_hashes, const uint8_t* d_ok,
                          bsx_commit_result* d_results);
+/* Skip conditions of CombinedSkipCircuit per range ([UPSTREAM] tendermintx skip; fetcher.rs:76-80): trusted header
+ * hash == public input, target height leaf, signatures, both validator-set hashes against the headers' field 7,
+ * 2/3 of the target power, > 1/3 of the trusted power.  d_skip_status[r] = bsx_status; d_target_hashes (optional)
+ * receives the target header hashes; d_target_res[r].trusted_signed_power := trusted-set overlap. */
+int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* d_ranges,
+                       const bsx_header* d_headers, uint64_t headers_per_range, const uint8_t* d_hashes,
+                       const bsx_validator* d_target, const bsx_validator* d_trusted, const uint8_t* d_target_ok,
+                       bsx_commit_result* d_target_res, const bsx_commit_result* d_trusted_res,
+                       uint32_t* d_skip_status, uint8_t* d_target_hashes);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,7 @@ int orc_header_check(const bsx_header* h) {
     static const uint8_t cap[14] = {24, 52, 12, 20, 76, 36, 36, 36, 36, 36, 36, 36, 36, 24};
     for (int i = 0; i < 14; i++) {
         if (h->len[i] > cap[i]) return BSX_ERR_BAD_HEADER;
-        if (i != 4 && h->len[i] > 55) return BSX_ERR_BAD_HEADER;
+        if (i != 4 && h->len[i] > 54) return BSX_ERR_BAD_HEADER;
     }
     return BSX_OK;
 }

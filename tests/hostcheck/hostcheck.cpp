@@ -1,0 +1,90 @@
+// tests/hostcheck/hostcheck.cpp — TEST HARNESS: compiles the device arithmetic headers
+// (blobstreamx_amd/csrc/*.h, written __host__ __device__) with g++ so the exact kernel source can be
+// checked against the oracle and hashlib on a machine without a GPU.  Never loaded by the product.
+#include <cstring>
+#include <cstdint>
+
+#include "../../blobstreamx_amd/csrc/sha256.h"
+#include "../../blobstreamx_amd/csrc/sha512.h"
+#include "../../blobstreamx_amd/csrc/ed25519.h"
+
+using namespace bsx;
+
+static void load_le(uint32_t* d, const uint8_t* p, int nbytes, int ndw) {
+    for (int i = 0; i < ndw; i++) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4; b++) {
+            int idx = 4 * i + b;
+            if (idx < nbytes) v |= (uint32_t)p[idx] << (8 * b);
+        }
+        d[i] = v;
+    }
+}
+static void store_digest(uint8_t* out, const Digest& x) {
+    for (int k = 0; k < 8; k++) { out[4 * k] = x.w[k] >> 24; out[4 * k + 1] = x.w[k] >> 16; out[4 * k + 2] = x.w[k] >> 8; out[4 * k + 3] = x.w[k]; }
+}
+static Digest load_digest(const uint8_t* p) {
+    uint32_t d[8];
+    load_le(d, p, 32, 8);
+    return digest_from_le(d);
+}
+
+extern "C" {
+// garbage: bytes beyond len inside the dword view are filled with 0xa5 to prove they are ignored
+void hc_leaf_hash_var(const uint8_t* data, int len, uint8_t out[32]) {
+    uint8_t buf[80];
+    memset(buf, 0xa5, sizeof buf);
+    memcpy(buf, data, len);
+    uint32_t d[20];
+    load_le(d, buf, 80, 20);
+    Digest r = (len <= 54) ? leaf_hash_1block(d, len) : leaf_hash_2block(d, len);
+    store_digest(out, r);
+}
+void hc_leaf_hash_34(const uint8_t* data, uint8_t out[32]) { uint32_t d[9]; load_le(d, data, 34, 9); d[8] |= 0xa5a50000u; store_digest(out, leaf_hash_34(d)); }
+void hc_leaf_hash_72(const uint8_t* data, uint8_t out[32]) { uint32_t d[18]; load_le(d, data, 72, 18); store_digest(out, leaf_hash_72(d)); }
+void hc_leaf_hash_tuple(const uint8_t* data, uint8_t out[32]) {
+    uint32_t t[16];
+    for (int k = 0; k < 16; k++) t[k] = (uint32_t)data[4 * k] << 24 | (uint32_t)data[4 * k + 1] << 16 | (uint32_t)data[4 * k + 2] << 8 | data[4 * k + 3];
+    store_digest(out, leaf_hash_tuple(t));
+}
+void hc_inner_hash(const uint8_t* l, const uint8_t* r, uint8_t out[32]) { store_digest(out, inner_hash(load_digest(l), load_digest(r))); }
+void hc_sha512_ram(const uint8_t* r, const uint8_t* a, const uint8_t* m, int len, uint8_t out[64]) {
+    uint32_t rd[8], ad[8], md[31], o[16];
+    uint8_t buf[124];
+    memset(buf, 0x5a, sizeof buf);
+    memcpy(buf, m, len);
+    load_le(rd, r, 32, 8); load_le(ad, a, 32, 8); load_le(md, buf, 124, 31);
+    sha512_ram(rd, ad, md, len, o);
+    memcpy(out, o, 64);
+}
+void hc_sc_reduce64(const uint8_t* in, uint8_t out[32]) {
+    uint32_t i[16], o[8];
+    load_le(i, in, 64, 16);
+    sc_reduce64(i, o);
+    memcpy(out, o, 32);
+}
+int hc_sc_is_canonical(const uint8_t* s) { uint32_t d[8]; load_le(d, s, 32, 8); return sc_is_canonical(d); }
+int hc_ed25519_verify(const uint8_t* pk, const uint8_t* sig, const uint8_t* h) {
+    uint32_t p[8], r[8], s[8], hh[8];
+    load_le(p, pk, 32, 8); load_le(r, sig, 32, 8); load_le(s, sig + 32, 32, 8); load_le(hh, h, 32, 8);
+    return ed25519_verify_core(p, r, s, hh) ? 1 : 0;
+}
+void hc_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t out[32]) {
+    uint32_t x[8], y[8], o[8];
+    load_le(x, a, 32, 8); load_le(y, b, 32, 8);
+    fe_tobytes(o, fe_mul(fe_frombytes(x), fe_frombytes(y)));
+    memcpy(out, o, 32);
+}
+void hc_fe_sq(const uint8_t* a, int dbl, uint8_t out[32]) {
+    uint32_t x[8], o[8];
+    load_le(x, a, 32, 8);
+    fe_tobytes(o, dbl ? fe_sq2(fe_frombytes(x)) : fe_sq(fe_frombytes(x)));
+    memcpy(out, o, 32);
+}
+void hc_fe_invert(const uint8_t* a, uint8_t out[32]) {
+    uint32_t x[8], o[8];
+    load_le(x, a, 32, 8);
+    fe_tobytes(o, fe_invert(fe_frombytes(x)));
+    memcpy(out, o, 32);
+}
+}

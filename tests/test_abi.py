@@ -1,0 +1,60 @@
+"""CPU suite: the C-ABI library builds/loads and exports every symbol include/bsx.h declares; without a GPU it
+refuses to run (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from blobstreamx_amd import _lib
+from blobstreamx_amd import types as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_is_built_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "bsx.h")).read()
+    declared = set(re.findall(r"\b(bsx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"bsx_status"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/bsx.h but not exported by libbsx.so"
+    assert set(_lib.SYMBOLS) == declared
+    assert L.bsx_version() == 0x00010000
+    assert L.bsx_status_str(C.c_int(T.ERR_ASSERT)) == b"BSX_ERR_ASSERT"
+
+
+def test_layout_queries_match_python_twin():
+    L = _lib.lib()
+    for B in (1, 2, 4, 32, 64, 256):
+        lay = np.zeros(1, T.WITNESS_LAYOUT)
+        assert L.bsx_map_witness_layout(C.c_uint32(B), _lib.p(lay)) == T.OK
+        assert lay[0].tobytes() == T.map_layout(B).tobytes()
+    lay = np.zeros(1, T.WITNESS_LAYOUT)
+    assert L.bsx_reduce_witness_layout(_lib.p(lay)) == T.OK
+    assert lay[0].tobytes() == T.reduce_layout().tobytes()
+    assert L.bsx_map_witness_layout(C.c_uint32(3), _lib.p(lay)) == T.ERR_BAD_ARG
+    # the documented production sizes: B = 64 -> 56,096 compact bytes, 449,755 elements per map job
+    assert int(T.map_layout(64)["n_bytes"]) == 56096 and int(T.map_layout(64)["n_elements"]) == 449755
+
+
+def test_no_gpu_means_no_service():
+    L = _lib.lib()
+    if L.bsx_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    assert L.bsx_init(C.c_int(0), C.byref(h)) == T.ERR_NO_DEVICE
+    assert b"no CPU fallback" in L.bsx_last_error()
+    with pytest.raises(_lib.BsxError):
+        _lib.context(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "blobstreamx_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src and "orc_" not in src, f

@@ -1,0 +1,417 @@
+"""GPU suite (`-m gpu`): the HIP path, called through the C ABI (libbsx.so), against
+  (1) the golden vectors derived from the reference's fixtures (tests/golden/mocha4.json), and
+  (2) the CPU oracle (oracle/) on seeded synthetic inputs — bit-exact for every byte, record, status and
+      Goldilocks witness element.
+Mirrors the reference's tests test_get_data_commitment / test_prove_header_chain / test_encode_data_root_tuple
+(circuits/builder.rs:488-608) and the header_range / next_header end-to-end shapes (circuits/header_range.rs:193-266,
+circuits/next_header.rs:130-179)."""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from blobstreamx_amd import _lib
+from blobstreamx_amd import types as T
+from blobstreamx_amd.builder import CombinedSkipCircuit, DataCommitmentBuilder, InputDataFetcher, verify_commits
+
+pytestmark = pytest.mark.gpu
+
+
+def rec_bytes(r):
+    r = np.array(r, dtype=T.SUBCHAIN).copy()
+    r["_pad"] = 0
+    return r.tobytes()
+
+
+def res_bytes(r):
+    r = np.array(r, dtype=T.COMMIT_RESULT).copy()
+    r["_pad"] = 0
+    return r.tobytes()
+
+
+@pytest.fixture(scope="module")
+def builder():
+    return DataCommitmentBuilder()
+
+
+@pytest.fixture(scope="module")
+def fetcher(mocha):
+    return InputDataFetcher(mocha["headers"], mocha["first_height"], mocha["latest"])
+
+
+# ------------------------------------------------------------------ golden vectors (reference fixtures)
+def test_golden_header_hashes_and_proofs(golden, mocha, fetcher):
+    hashes, dh, lb = fetcher.get_inclusion_proofs()
+    for i, h in enumerate(mocha["heights"]):
+        b = golden["blocks"][str(h)]
+        assert hashes[i].tobytes().hex() == b["header_hash"]
+        assert [bytes(a).hex() for a in dh[i]["aunts"]] == b["data_hash_proof"]["aunts"]
+        assert bytes(dh[i]["leaf"]).hex() == b["data_hash_proof"]["leaf"]
+        assert [bytes(a).hex() for a in lb[i]["aunts"]] == b["last_block_id_proof"]["aunts"]
+        assert bytes(lb[i]["leaf"]).hex() == b["last_block_id_proof"]["leaf"]
+
+
+def test_golden_encode_data_root_tuple(golden, builder):
+    k = golden["kats"]["encode_data_root_tuple"]          # circuits/builder.rs:584-605
+    assert builder.encode_data_root_tuple(bytes.fromhex(k["data_hash"]), k["height"]).hex() == k["expected"]
+
+
+def test_golden_get_data_commitment(golden, mocha, fetcher, builder):
+    for name, want in golden["data_commitments"].items():  # circuits/builder.rs:488-529, MAX_LEAVES = 4
+        s, e = map(int, name.split("-"))
+        inp = fetcher.get_data_commitment_inputs(s, e, 4)
+        assert inp["expected_data_commitment"].hex() == want
+        dhs = np.stack([p["leaf"][2:34] for p in inp["data_hash_proofs"]])
+        assert builder.get_data_commitment(dhs, s, e).hex() == want
+
+
+def test_golden_prove_header_chain(golden, mocha, fetcher, builder):
+    inp = fetcher.get_data_commitment_inputs(10000, 10004, 4)   # circuits/builder.rs:531-564
+    assert inp["start_header_hash"] == mocha["hashes"][0] and inp["end_header_hash"] == mocha["hashes"][4]
+    rec, _ = builder.prove_subchain(inp, 10000, 10004, 10004, inp["end_header_hash"])
+    assert rec["assert_fail"] == 0 and rec["is_enabled"] == 1
+    assert bytes(rec["data_merkle_root"]).hex() == golden["data_commitments"]["10000-10004"]
+    assert bytes(rec["end_header"]) == mocha["hashes"][4] and rec["end_block"] == 10004
+
+
+def test_golden_prove_data_commitment_shapes(golden, mocha, fetcher, builder):
+    hh = mocha["hashes"]
+    for (J, B, s, e) in [(2, 2, 10000, 10004), (4, 4, 10000, 10002), (2, 8, 10002, 10004), (1, 4, 10000, 10004),
+                         (4, 1, 10000, 10004), (8, 2, 10000, 10001)]:
+        out = builder.prove_data_commitment(fetcher, J, B, s, hh[s - 10000], e, hh[e - 10000], want_witness=True)
+        assert out["data_commitment"].hex() == golden["data_commitments"][f"{s}-{e}"], (J, B, s, e)
+        ctx = oracle.make_ctx(s, hh[s - 10000], e, hh[e - 10000])
+        rc, ref = oracle.prove_data_commitment(J, B, ctx, mocha["headers"], 10000, mocha["latest"], want_witness=True)
+        assert rc == T.OK
+        assert [rec_bytes(r) for r in out["records"]] == [rec_bytes(r) for r in ref["records"]]
+        assert (out["witness"] == oracle.expand_range_witness(J, B, ref["compact"])).all(), (J, B, s, e)
+
+
+def test_golden_next_header(golden, mocha, fetcher, builder):
+    dc = builder.prove_next_header_data_commitment(fetcher, 10000, mocha["hashes"][0], 10001)   # builder.rs:411-443
+    assert dc.hex() == golden["data_commitments"]["10000-10001"]
+    with pytest.raises(_lib.BsxError) as ei:
+        builder.prove_next_header_data_commitment(fetcher, 10000, mocha["hashes"][1], 10001)
+    assert ei.value.status == T.ERR_ASSERT
+
+
+def test_golden_commits(golden, mocha):
+    vals = np.stack(mocha["commits"])
+    res, ok = verify_commits(vals, np.frombuffer(b"".join(mocha["hashes"]), np.uint8).reshape(5, 32))
+    for i, h in enumerate(mocha["heights"]):
+        b = golden["blocks"][str(h)]
+        assert bytes(res[i]["validators_hash"]).hex() == b["validators_hash"]
+        assert res[i]["n_signed"] == 2 and res[i]["n_bad_signature"] == 0 and res[i]["n_bad_message"] == 0
+        assert res[i]["two_thirds_ok"] == 1 and res[i]["signed_power"] == 50_000_000
+        assert list(ok[i]) == [1, 1, 0, 0]
+        ref, rok = oracle.verify_commit(mocha["commits"][i], mocha["hashes"][i])
+        assert res_bytes(res[i]) == res_bytes(ref) and (ok[i] == rok).all()
+
+
+def test_golden_reject_paths(mocha, fetcher, builder):
+    hh = mocha["hashes"]
+    for (J, B, s, sh, e, eh) in [(2, 2, 10000, hh[0], 10004, hh[3]), (2, 2, 10000, hh[1], 10004, hh[4]),
+                                 (1, 2, 10000, hh[0], 10004, hh[4])]:
+        out = builder.prove_data_commitment(fetcher, J, B, s, sh, e, eh, raise_on_assert=False)
+        rc, ref = oracle.prove_data_commitment(J, B, oracle.make_ctx(s, sh, e, eh), mocha["headers"], 10000, mocha["latest"])
+        assert out["rc"] == rc == T.ERR_ASSERT
+        assert out["result"]["assert_fail"] == ref["status"]
+        assert [rec_bytes(r) for r in out["records"]] == [rec_bytes(r) for r in ref["records"]]
+
+
+# ------------------------------------------------------------------ synthetic vs oracle
+def random_headers(n, seed):
+    """headers with edge-case field lengths: empty fields, long chain ids, first-block last_block_id, 73-byte block id"""
+    rnd = np.random.default_rng(seed)
+    out = np.zeros(n, T.HEADER)
+    for i in range(n):
+        f = []
+        f.append(bytes([0x08, 11, 0x10, 1]) if i % 7 else b"")
+        cid = bytes(rnd.integers(97, 123, size=int(rnd.integers(0, 51)), dtype=np.uint8))
+        f.append((b"\x0a" + bytes([len(cid)]) + cid) if cid else b"")
+        f.append(b"\x08" + bytes(rnd.integers(1, 128, size=int(rnd.integers(1, 10)), dtype=np.uint8) | 0x80)[:-1] + b"\x01")
+        f.append(bytes(rnd.integers(0, 256, size=int(rnd.integers(0, 21)), dtype=np.uint8)))
+        kind = i % 5
+        lbi = {0: 72, 1: 72, 2: 2, 3: 73, 4: 76}[kind] if i % 11 else 0
+        f.append(bytes(rnd.integers(0, 256, size=lbi, dtype=np.uint8)))
+        for j in range(8):
+            ln = 34 if (i + j) % 13 else 0
+            f.append(bytes(rnd.integers(0, 256, size=ln, dtype=np.uint8)))
+        f.append(bytes(rnd.integers(0, 256, size=int(rnd.integers(0, 25)), dtype=np.uint8)))
+        out[i] = T.pack_header(f)
+    return out
+
+
+def test_header_hashes_vs_oracle_edge_lengths():
+    hdrs = random_headers(700, 3)
+    f = InputDataFetcher(hdrs, 1, 10_000)
+    got = f.header_hashes()
+    want = oracle.header_hash_only(hdrs)
+    assert (got == want).all()
+
+
+def test_header_hashes_garbage_beyond_len_is_ignored():
+    w = synth.Workload(5, 1, 2, 8, v=3)
+    hdrs = w.headers[0].copy()
+    want = oracle.header_hash_only(hdrs)
+    raw = hdrs.view(np.uint8).reshape(-1, 512)
+    dirty = raw.copy()
+    # fill the unused tail of every field with 0xEE
+    offs = [16, 40, 92, 104, 124] + [200 + 36 * j for j in range(8)] + [488]
+    caps = T.HEADER_FIELD_CAP
+    for i in range(dirty.shape[0]):
+        for k in range(14):
+            ln = int(raw[i, k])
+            dirty[i, offs[k] + ln:offs[k] + caps[k]] = 0xEE
+    got = InputDataFetcher(dirty.view(T.HEADER).reshape(-1), 1, 100).header_hashes()
+    assert (got == want).all()
+
+
+def test_bad_header_is_an_error_not_a_crash():
+    hdrs = random_headers(3, 9)
+    hdrs[1]["len"][5] = 40   # > capacity 36
+    with pytest.raises(_lib.BsxError) as ei:
+        InputDataFetcher(hdrs, 1, 100).header_hashes()
+    assert ei.value.status == T.ERR_BAD_HEADER
+
+
+@pytest.mark.parametrize("B,latest_off,span", [(4, 2, 4), (4, 0, 4), (8, -3, 8), (8, -20, 8), (16, 2, 5), (2, 2, 0), (1, 2, 1)])
+def test_data_commitment_inputs_vs_oracle(B, latest_off, span):
+    w = synth.Workload(11, 1, 2, 16, v=2)
+    S = int(w.first_height[0])
+    start = S + 3
+    latest = start + B + 2 + latest_off
+    f = InputDataFetcher(w.headers[0], S, latest)
+    got = f.get_data_commitment_inputs(start, start + span, B)
+    rc, ref = oracle.data_commitment_inputs(w.headers[0], S, latest, start, start + span, B)
+    assert rc == T.OK
+    assert got["start_header_hash"] == ref["start_header"] and got["end_header_hash"] == ref["end_header"]
+    assert got["data_hash_proofs"].tobytes() == ref["data_hash_proofs"].tobytes()
+    assert got["last_block_id_proofs"].tobytes() == ref["last_block_id_proofs"].tobytes()
+    assert got["expected_data_commitment"] == ref["expected_data_commitment"]
+
+
+def test_data_commitment_inputs_range_too_long():
+    w = synth.Workload(11, 1, 2, 16, v=2)
+    S = int(w.first_height[0])
+    with pytest.raises(_lib.BsxError) as ei:
+        InputDataFetcher(w.headers[0], S, S + 40).get_data_commitment_inputs(S, S + 5, 4)   # circuits/input.rs:154
+    assert ei.value.status == T.ERR_RANGE_TOO_LONG
+
+
+@pytest.mark.parametrize("B", [1, 2, 4, 32, 64, 256])
+def test_prove_subchain_vs_oracle(B, builder):
+    w = synth.Workload(20 + B, 1, 1, B, v=2)
+    S = int(w.first_height[0])
+    hdrs, hs = w.headers[0], w.hashes[0]
+    f = InputDataFetcher(hdrs, S, S + B + 2)
+    inp = f.get_data_commitment_inputs(S, S + B, B)
+    # global end positions: at the batch end, in the middle, at the first block, before the batch, far after
+    for E in sorted({S + B, S + B // 2 + (1 if B > 1 else 0), S + 1, S, S + B + 7}):
+        Eh = hs[E - S].tobytes() if E - S <= B else bytes(32)
+        rec, wit = builder.prove_subchain(inp, S, S + B, E, Eh, want_witness=True, raise_on_assert=False)
+        ctx = oracle.make_ctx(0, bytes(32), E, Eh)
+        rc, ref, cw = oracle.prove_subchain(B, inp["start_header_hash"], inp["end_header_hash"], inp["data_hash_proofs"],
+                                            inp["last_block_id_proofs"], S, S + B, E, Eh, ctx=ctx, want_witness=True)
+        assert rec_bytes(rec) == rec_bytes(ref), (B, E - S)
+        want = oracle.expand_witness(T.map_layout(B), 1, cw)
+        assert wit.shape == want.shape
+        bad = np.nonzero(wit != want)[0]
+        assert bad.size == 0, (B, E - S, bad[:8], wit[bad[:8]], want[bad[:8]])
+
+
+def test_prove_subchain_detects_every_tamper(builder):
+    B = 8
+    w = synth.Workload(77, 1, 1, B, v=2)
+    S = int(w.first_height[0])
+    f = InputDataFetcher(w.headers[0], S, S + B + 2)
+    base = f.get_data_commitment_inputs(S, S + B, B)
+    Eh = w.hashes[0, B].tobytes()
+    cases = []
+    t = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in base.items()}
+    t["data_hash_proofs"][3]["leaf"][10] ^= 1
+    cases.append(t)                                        # A4 at slot 3
+    t = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in base.items()}
+    t["last_block_id_proofs"][5]["aunts"][2][0] ^= 0x80
+    cases.append(t)                                        # lb root of slot 5 changes -> A3 at slot 6 (and A5/A6 later)
+    t = dict(base)
+    t["start_header_hash"] = bytes(32)
+    cases.append(t)                                        # A3 at slot 0
+    t = dict(base)
+    t["end_header_hash"] = bytes(32)
+    cases.append(t)                                        # only matters when the batch ends before E
+    for E in (S + B, S + B + 5):
+        for c in cases:
+            rec, _ = builder.prove_subchain(c, S, S + B, E, Eh, raise_on_assert=False)
+            rc, ref, _ = oracle.prove_subchain(B, c["start_header_hash"], c["end_header_hash"], c["data_hash_proofs"],
+                                               c["last_block_id_proofs"], S, S + B, E, Eh)
+            assert rec_bytes(rec) == rec_bytes(ref)
+    rec, _ = builder.prove_subchain(cases[0], S, S + B, S + B, Eh, raise_on_assert=False)
+    assert rec["assert_fail"] & T.A4_DATA_HASH_PROOF and rec["first_bad_slot"] == 3
+    with pytest.raises(_lib.BsxError) as ei:
+        builder.prove_subchain(cases[0], S, S + B, S + B, Eh)
+    assert ei.value.status == T.ERR_ASSERT
+
+
+@pytest.mark.parametrize("J,B,n_blocks", [(2, 32, 64), (2, 32, 35), (8, 32, 256), (8, 32, 131), (16, 16, 1), (32, 32, 1024),
+                                          (32, 64, 2048), (32, 64, 1027)])
+def test_prove_data_commitment_vs_oracle(J, B, n_blocks, builder):
+    """BASELINE configs: 64 = 2x32, 1024 = 32x32, 2048 = 32x64; plus E = S + J*B/2 + 3 (disabled slots and batches)."""
+    w = synth.Workload(2, 1, J, B, v=1, n_blocks=n_blocks)
+    S = int(w.first_height[0])
+    rg = w.ranges[0]
+    f = InputDataFetcher(w.headers[0], S, int(w.latest[0]))
+    out = builder.prove_data_commitment(f, J, B, S, bytes(rg["start_header_hash"]), int(rg["end_block"]), bytes(rg["end_header_hash"]),
+                                        want_witness=True)
+    rc, ref = oracle.prove_data_commitment(J, B, w.ranges[0:1], w.headers[0], S, int(w.latest[0]), want_witness=True)
+    assert rc == T.OK and out["rc"] == T.OK
+    assert out["data_commitment"] == ref["data_commitment"]
+    assert [rec_bytes(r) for r in out["records"]] == [rec_bytes(r) for r in ref["records"]]
+    want = oracle.expand_range_witness(J, B, ref["compact"])
+    assert out["witness"].shape == want.shape
+    assert (out["witness"] == want).all()
+    # size-independent property: the commitment is the RFC 6962 root over the n_blocks tuples
+    import hashlib
+
+    def root(items):
+        if len(items) == 1:
+            return hashlib.sha256(b"\x00" + items[0]).digest()
+        k = 1
+        while k * 2 < len(items):
+            k *= 2
+        return hashlib.sha256(b"\x01" + root(items[:k]) + root(items[k:])).digest()
+    tuples = [bytes(24) + (S + i).to_bytes(8, "big") + w.headers[0][i]["hash"][1][2:34].tobytes() for i in range(n_blocks)]
+    assert out["data_commitment"] == root(tuples)
+
+
+def test_prove_data_commitment_broken_chain_matches_oracle(builder):
+    J, B = 4, 8
+    w = synth.Workload(3, 1, J, B, v=1)
+    S = int(w.first_height[0])
+    hdrs = w.headers[0].copy()
+    hdrs[13]["hash"][1][7] ^= 0x55          # data hash of header 13 changes -> its hash changes -> link 13->14 breaks
+    rg = w.ranges[0]
+    f = InputDataFetcher(hdrs, S, int(w.latest[0]))
+    out = builder.prove_data_commitment(f, J, B, S, bytes(rg["start_header_hash"]), int(rg["end_block"]), bytes(rg["end_header_hash"]),
+                                        raise_on_assert=False)
+    rc, ref = oracle.prove_data_commitment(J, B, w.ranges[0:1], hdrs, S, int(w.latest[0]))
+    assert out["rc"] == rc == T.ERR_ASSERT
+    assert out["result"]["assert_fail"] == ref["status"] != 0
+    assert [rec_bytes(r) for r in out["records"]] == [rec_bytes(r) for r in ref["records"]]
+
+
+@pytest.mark.parametrize("v,v_max,absent", [(100, 100, 0), (100, 128, 150), (7, 8, 0), (512, 512, 300), (1, 1, 0)])
+def test_verify_commits_vs_oracle(v, v_max, absent):
+    w = synth.Workload(40 + v, 3, 1, 2, v=v, v_max=v_max, absent_permille=absent)
+    vals = w.validators.copy()                      # [3, v_max]
+    hh = w.commit_hashes.copy()
+    rnd = np.random.default_rng(v)
+    # tamper: flip a signature bit, a message byte inside the hash, a pubkey bit; make s non-canonical
+    for c in range(3):
+        signed = np.nonzero(vals[c]["is_signed"])[0]
+        if signed.size >= 4:
+            a, b, d, e = signed[rnd.permutation(signed.size)[:4]]
+            vals[c, a]["signature"][int(rnd.integers(0, 64))] ^= 1 << int(rnd.integers(0, 8))
+            vals[c, b]["message"][20] ^= 1
+            vals[c, d]["pubkey"][int(rnd.integers(0, 32))] ^= 1 << int(rnd.integers(0, 8))
+            s = int.from_bytes(bytes(vals[c, e]["signature"][32:]), "little") + (2 ** 252 + 27742317777372353535851937790883648493)
+            vals[c, e]["signature"][32:] = np.frombuffer((s % 2 ** 256).to_bytes(32, "little"), np.uint8)
+    res, ok = verify_commits(vals, hh)
+    for c in range(3):
+        ref, rok = oracle.verify_commit(vals[c], hh[c].tobytes())
+        assert (ok[c] == rok).all(), (c, np.nonzero(ok[c] != rok))
+        assert res_bytes(res[c]) == res_bytes(ref), c
+
+
+def test_sha512_challenge_vs_oracle():
+    import ctypes as C
+    import torch
+    w = synth.Workload(50, 2, 1, 2, v=64)
+    vals = w.validators.reshape(-1).copy()
+    vals[5]["message_len"] = 0
+    vals[6]["message_len"] = 47
+    vals[7]["message_len"] = 48
+    vals[8]["message_len"] = 124
+    vals[8]["message"][:] = 0xAB
+    n = vals.size
+    dv = torch.from_numpy(vals.view(np.uint8).copy()).cuda()
+    dh = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    dd = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().bsx_dev_sha512_challenge(_lib.context(0), st, _lib.dp(dv), C.c_uint64(n), _lib.dp(dh), _lib.dp(dd)))
+    torch.cuda.synchronize()
+    h, dig = oracle.sha512_challenge(vals)
+    assert (dh.cpu().numpy().reshape(n, 32) == h).all()
+    assert (dd.cpu().numpy().reshape(n, 64) == dig).all()
+
+
+@pytest.mark.parametrize("J,B,v,n_blocks", [(2, 32, 100, 64), (2, 32, 100, 35), (32, 32, 100, 1024), (32, 64, 100, 2048)])
+def test_header_range_vs_oracle(J, B, v, n_blocks):
+    """BASELINE configs #2-#4 on one GPU, mode F (one commit per range), full witness diff."""
+    w = synth.Workload(1, 1, J, B, v=v, n_blocks=n_blocks)
+    S = int(w.first_height[0])
+    f = InputDataFetcher(w.headers[0], S, int(w.latest[0]))
+    circ = CombinedSkipCircuit(v, J, B)
+    out, res, wit = circ.prove(w.input48(0), f, w.validators[0], w.trusted[0], want_witness=True)
+    rc, ref_out, ref_res, cw = oracle.header_range(J, B, w.input48(0), w.headers[0], S, int(w.latest[0]), w.validators[0], w.trusted[0],
+                                                   want_witness=True)
+    assert rc == T.OK
+    assert out == ref_out and out[:32] == w.hashes[0, n_blocks].tobytes()
+    assert res_bytes(res) == res_bytes(ref_res)
+    assert (wit == oracle.expand_range_witness(J, B, cw)).all()
+
+
+def test_header_range_failure_codes_match_oracle():
+    J, B, v = 2, 4, 10
+    circ = CombinedSkipCircuit(v, J, B)
+
+    def both(w, vals=None, trusted=None, inp=None):
+        vals = w.validators[0] if vals is None else vals
+        trusted = w.trusted[0] if trusted is None else trusted
+        inp = w.input48(0) if inp is None else inp
+        S = int(w.first_height[0])
+        rc_ref = oracle.header_range(J, B, inp, w.headers[0], S, int(w.latest[0]), vals, trusted)[0]
+        try:
+            circ.prove(inp, InputDataFetcher(w.headers[0], S, int(w.latest[0])), vals, trusted)
+            rc = T.OK
+        except _lib.BsxError as e:
+            rc = e.status
+        assert rc == rc_ref, (rc, rc_ref)
+        return rc
+
+    w = synth.Workload(60, 1, J, B, v=v)
+    assert both(w) == T.OK
+    bad = w.validators[0].copy()
+    bad[2]["signature"][1] ^= 4
+    assert both(w, vals=bad) == T.ERR_BAD_SIGNATURE
+    w2 = synth.Workload(61, 1, J, B, v=v, absent_permille=600)      # < 2/3 signed
+    assert both(w2) == T.ERR_VOTING_POWER
+    tr = w.trusted[0].copy()
+    tr[0]["voting_power"] += 1                                        # trusted set no longer hashes to the header's field 7
+    assert both(w, trusted=tr) == T.ERR_ASSERT
+    inp = bytearray(w.input48(0))
+    inp[10] ^= 1                                                      # wrong trusted header hash
+    assert both(w, inp=bytes(inp)) == T.ERR_ASSERT
+    inp = w.input48(0)[:40] + (int(w.ranges[0]["start_block"]) + J * B + 1).to_bytes(8, "big")
+    assert both(w, inp=inp) == T.ERR_RANGE_TOO_LONG
+
+
+def test_expand_witness_property_full_size():
+    """size-independent property at the 2048 shape: packing the bit elements back gives the compact bytes, i.e. the
+    expansion kernel is the exact inverse of np.packbits over every byte of every map job."""
+    import ctypes as C
+    import torch
+    B, J = 64, 32
+    lay = T.map_layout(B)
+    stride, n_el = int(lay["compact_stride"]), int(lay["n_elements"])
+    rnd = np.random.default_rng(1)
+    compact = rnd.integers(0, 256, size=J * stride, dtype=np.uint8)
+    dc = torch.from_numpy(compact).cuda()
+    dw = torch.zeros(J * n_el, dtype=torch.int64, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    layout = np.array(lay).reshape(1)
+    _lib.check(_lib.lib().bsx_dev_expand_witness(_lib.context(0), st, _lib.p(layout), C.c_uint32(J), _lib.dp(dc), _lib.dp(dw)))
+    torch.cuda.synchronize()
+    got = dw.cpu().numpy().view(np.uint64)
+    want = oracle.expand_witness(lay, J, compact)
+    assert (got == want).all()
