@@ -6,6 +6,7 @@ fallback anywhere in this package.
 import ctypes as C
 import os
 import subprocess
+import sys
 import threading
 
 from . import types as T
@@ -50,6 +51,14 @@ def lib():
         if _lib is None:
             if not os.path.exists(_SO):
                 raise BsxError(T.ERR_NO_DEVICE, f"{_SO} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+            # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7; loading it FIRST makes
+            # libbsx.so (NEEDED libamdhip64.so.7) bind to the same copy, so torch tensors / streams / RCCL and our
+            # kernels share one runtime.  The reverse order leaves torch without visible GPUs.
+            if "torch" not in sys.modules and os.environ.get("BSX_NO_TORCH") != "1":
+                try:
+                    import torch  # noqa: F401
+                except Exception:  # torch is plumbing, not a requirement of the C ABI
+                    pass
             L = C.CDLL(_SO)
             L.bsx_version.restype = C.c_uint32
             L.bsx_last_error.restype = C.c_char_p
