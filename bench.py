@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — headers/sec of header_range witness generation on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the whole hot path (header hashing + hint assembly + prove_subchain + reduce + final
+asserts + target-commit verification + Goldilocks witness expansion) over one batch of R synthetic header_range_2048
+instances (32 map jobs x 64 headers, 100 validators, mode F = one commit per range, exactly what one reference proof
+does) whose inputs are already resident in HBM.  value = N * R * 2048 headers / step time, all ranks, max over ranks.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): every rank computes its 32/N-job slice of all
+N*R ranges, ONE all-gather of 128-byte records, the owner finishes its R ranges — weak scaling (blobstreamx_amd/engine.py).
+
+Extra objects on the JSON line: `roofline` (dominant kernel = witness expansion, HBM-write bound), `kernels` (the SHA
+kernels' compact-byte rates, never mixed with the expanded figure), `cpu_baseline` (the C oracle timed on this box's
+host cores on a bounded sample, N = 1 only), `stress` (mode S: one 100-signature commit per header, Ed25519 bound).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ranges", type=int, default=48, help="header_range instances per GPU per step (R)")
+    ap.add_argument("--jobs", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--validators", type=int, default=100)
+    ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stress", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(w, J, B, V, seconds, gpu_out64):
+    """Oracle (oracle/, C) timed on the host cores on a bounded sample of the SAME workload; its outputs double as a
+    check of the GPU's public outputs for the sampled ranges."""
+    import oracle
+    cores = os.cpu_count() or 1
+    def run(n):
+        t = time.perf_counter()
+        rc, out64, _ = oracle.bench_header_range(J, B, w.ranges[:n], w.headers[:n], w.hpr, w.latest[:n], w.validators[:n],
+                                                 w.trusted[:n], V, True, cores)
+        return time.perf_counter() - t, rc, out64
+    n0 = min(cores, w.R)
+    dt, rc, out = run(n0)
+    n = int(max(n0, min(w.R, round(n0 * seconds / max(dt, 1e-3)))))
+    if n > n0:
+        dt, rc, out = run(n)
+    assert rc == 0, f"oracle status {rc}"
+    assert (out == gpu_out64[:n]).all(), "GPU public outputs differ from the oracle on the sampled ranges"
+    return {"value": n * J * B / dt, "unit": "headers/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the {w.R} header_range_{J * B} instances of the GPU step (same inputs, witness expansion included), "
+                      f"{dt:.1f} s wall on {cores} threads; outputs checked equal to the GPU's",
+            "sha_ni": bool(oracle.has_shani())}
+
+
+def stress(args, dev):
+    """Mode S (BASELINE configs' 'N headers x V validators'): every header of one 2048-range carries its own
+    100-signature commit: 204,800 Ed25519 verifications + SHA-512 challenges + 2048 validator-set hashes per range."""
+    import ctypes as C
+    import synth
+    from blobstreamx_amd import _lib
+    nh, V = 256, args.validators       # one 256-header sub-range = what one GPU owns at N = 8 (config #4)
+    w = synth.Workload(4, 1, 4, 64, v=V, mode="S")
+    vals = w.validators.reshape(-1)
+    n = vals.size
+    L, ctx, dp = _lib.lib(), _lib.context(dev.index or 0), _lib.dp
+    dv = torch.from_numpy(vals.view(np.uint8).copy()).to(dev)
+    dh = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+    dok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    dhh = torch.from_numpy(w.commit_hashes.copy()).to(dev)
+    dres = torch.zeros(nh * 96, dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    def once():
+        ev[0].record()
+        _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(dv), C.c_uint64(n), dp(dh), None))
+        ev[1].record()
+        _lib.check(L.bsx_dev_ed25519_verify(ctx, st, dp(dv), dp(dh), C.c_uint64(n), dp(dok)))
+        ev[2].record()
+        _lib.check(L.bsx_dev_commit_tally(ctx, st, dp(dv), C.c_uint32(nh), C.c_uint32(V), dp(dhh), dp(dok), dp(dres)))
+        ev[3].record()
+    once()
+    torch.cuda.synchronize(dev)
+    assert int(dok.sum().item()) == n, "stress: a signature failed to verify"
+    reps = 3
+    t_sha = t_ed = t_tally = 0.0
+    for _ in range(reps):
+        once()
+        torch.cuda.synchronize(dev)
+        t_sha += ev[0].elapsed_time(ev[1]); t_ed += ev[1].elapsed_time(ev[2]); t_tally += ev[2].elapsed_time(ev[3])
+    t_sha, t_ed, t_tally = t_sha / reps, t_ed / reps, t_tally / reps
+    tot = t_sha + t_ed + t_tally
+    return {"workload": f"mode S: {nh} headers x {V} validators = {n} signatures (one 256-header sub-range)",
+            "headers_per_s": nh / tot * 1e3, "ed25519_verifies_per_s": n / t_ed * 1e3,
+            "sha512_challenge": {"ms": t_sha, "algorithmic_GBps": n * 237 / t_sha / 1e6, "frac_of_hbm_peak": n * 237 / t_sha / 1e6 / HBM_PEAK_GBS,
+                                 "bytes_per_unit": 237},
+            "ed25519_ms": t_ed, "tally_validator_hash_ms": t_tally}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import synth
+    from blobstreamx_amd.engine import HeaderRangeEngine
+
+    J, B, V, R = args.jobs, args.batch, args.validators, args.ranges
+    t0 = time.perf_counter()
+    w = synth.Workload(4, R * world, J, B, v=V)          # config #4 seed; identical on every rank
+    t_gen = time.perf_counter() - t0
+    eng = HeaderRangeEngine(J, B, V, R, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
+    eng.upload_workload(w)
+    eng.enable_timing()
+
+    # correctness gate before timing: statuses clean, public output = (target header hash, commitment) for every owned range
+    eng.step()
+    res = eng.download()
+    own = slice(rank * R, (rank + 1) * R)
+    assert res["header_status"] == 0 and res["assemble_status"] == 0, res
+    assert not res["range_status"].any() and not res["skip_status"].any(), (res["range_status"], res["skip_status"])
+    assert (res["output64"][:, :32] == w.hashes[own, w.n_blocks]).all(), "target header hash mismatch"
+    gpu_out64 = res["output64"].copy()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.step()
+    barrier()
+    t_sub = t_exp = 0.0
+    t0 = time.perf_counter()
+    pending = []
+    for _ in range(args.steps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        eng.events = evs
+        eng.step(time_kernels=True)
+        pending.append(evs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    for evs in pending:
+        t_sub += evs[0].elapsed_time(evs[1])
+        if not args.no_witness:
+            t_exp += evs[2].elapsed_time(evs[3])
+    t_sub /= args.steps
+    t_exp /= args.steps
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    headers_per_step = world * R * J * B
+    value = headers_per_step / (elapsed / args.steps)
+
+    if rank == 0:
+        ml = eng.ml
+        n_jobs = eng.RT * eng.jc
+        # algorithmic bytes: expansion reads the compact witness once and writes 8 B per element
+        exp_bytes = n_jobs * (int(ml["n_bytes"]) + 4 * int(ml["n_words"]) + int(ml["n_bools"]) + 8 * int(ml["n_elements"]))
+        slots = n_jobs * B
+        sub_bytes = slots * (362 + 352 + 64 + 32 + 64)      # per slot: proofs read; paths+curr, tuple, leaf hash, 2 tree nodes written
+        out = {
+            "metric": "headers/sec witness-gen, header_range_2048 (SHA HBM GB/s vs roofline in `roofline`/`kernels`)",
+            "value": value, "unit": "headers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"header_range_{J * B} ({J} map jobs x {B} headers), {V} validators, mode F (one target commit per range), "
+                                   f"{R} ranges per GPU per step, Goldilocks witness {'off' if args.no_witness else 'materialised'}",
+                       "ranges_per_gpu": R, "headers_per_step": headers_per_step,
+                       "parallelism": f"{world} x ({J // world} of {J} map jobs per range), 1 all-gather of 128-B records" if world > 1 else "1 GPU",
+                       "witness_bytes_per_step_per_gpu": int(n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
+                       "input_generation_s": round(t_gen, 2)},
+        }
+        if not args.no_witness:
+            out["roofline"] = {"kernel": "k_expand_witness (map-job section)", "bound": "hbm", "achieved": exp_bytes / t_exp / 1e6,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exp_bytes / t_exp / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_ms": t_exp, "algorithmic_bytes_per_launch": exp_bytes,
+                               "note": "expanded (witness-emitting) byte count: 8 B written per Goldilocks element + the compact read"}
+        out["kernels"] = [{"kernel": "k_prove_subchain", "avg_launch_ms": t_sub, "slots_per_launch": slots,
+                           "compact_bytes_per_slot": 874, "achieved_GBps": sub_bytes / t_sub / 1e6,
+                           "frac_of_hbm_peak": sub_bytes / t_sub / 1e6 / HBM_PEAK_GBS,
+                           "sha256_compressions_per_s": slots * 23 / t_sub * 1e3,
+                           "note": "compact bytes (362 B proofs in + 512 B digests/tuple out per slot); integer-ALU bound, see DESIGN.md"}]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, J, B, V, args.cpu_seconds, gpu_out64)
+        if world == 1 and not args.no_stress:
+            out["stress"] = stress(args, dev)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@
 extern "C" {
 hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*);
 hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
-                                const uint64_t*, const bsx_header*, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
+                                const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
                                 uint8_t*, uint32_t*);
 hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*);
 hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, bsx_subchain*, uint8_t*);
@@ -31,10 +31,10 @@ hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*
 hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
                            const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
-                           uint32_t*, uint8_t*);
+                           uint32_t*, uint8_t*, const uint32_t*);
 hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
 hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
-hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t);
+hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*);
 int bsxk_tally_vmax(void);
 }
 
@@ -165,15 +165,15 @@ int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_header
 int bsx_dev_assemble_inputs(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
                             uint32_t job_first, uint32_t job_count, uint32_t span, const bsx_shared_ctx* d_ranges,
                             const uint64_t* d_latest, const bsx_header* d_headers, uint64_t headers_per_range,
-                            const uint8_t* d_hashes, const uint8_t* d_dh_aunts, const uint8_t* d_lb_aunts, uint8_t* d_compact,
-                            uint32_t* d_status) {
+                            uint64_t header_first_rel, const uint8_t* d_hashes, const uint8_t* d_dh_aunts,
+                            const uint8_t* d_lb_aunts, uint8_t* d_compact, uint32_t* d_status) {
     DEV_ENTER();
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "batch_size must be a power of two <= %d", BSX_MAX_BATCH);
     if (span > batch_size) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start = %u > MAX_LEAVES = %u (input.rs:154)", span, batch_size);
     if (job_first + job_count > nb_map_jobs) return fail(BSX_ERR_BAD_ARG, "job slice [%u,%u) exceeds nb_map_jobs %u", job_first, job_first + job_count, nb_map_jobs);
     if (!d_ranges || !d_latest || !d_headers || !d_hashes || !d_dh_aunts || !d_lb_aunts || !d_compact) return fail(BSX_ERR_BAD_ARG, "null pointer");
     HIPCHK(bsxk_assemble_inputs(S(ctx, stream), n_ranges, nb_map_jobs, batch_size, job_first, job_count, span, d_ranges, d_latest,
-                                d_headers, headers_per_range, d_hashes, d_dh_aunts, d_lb_aunts, d_compact, d_status));
+                                d_headers, headers_per_range, header_first_rel, d_hashes, d_dh_aunts, d_lb_aunts, d_compact, d_status));
     return BSX_OK;
 }
 
@@ -214,10 +214,10 @@ int bsx_dev_expand_witness(bsx_ctx* ctx, void* stream, const bsx_witness_layout*
 }
 
 int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_shared_ctx* d_ranges, const uint8_t* d_hashes,
-                          uint64_t headers_per_range) {
+                          uint64_t headers_per_range, const uint32_t* d_target_index) {
     DEV_ENTER();
     if (!d_ranges || !d_hashes) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_fill_end_hash(S(ctx, stream), n_ranges, d_ranges, d_hashes, headers_per_range));
+    HIPCHK(bsxk_fill_end_hash(S(ctx, stream), n_ranges, d_ranges, d_hashes, headers_per_range, d_target_index));
     return BSX_OK;
 }
 
@@ -247,13 +247,14 @@ int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_vali
 int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* d_ranges,
                        const bsx_header* d_headers, uint64_t headers_per_range, const uint8_t* d_hashes, const bsx_validator* d_target,
                        const bsx_validator* d_trusted, const uint8_t* d_target_ok, bsx_commit_result* d_target_res,
-                       const bsx_commit_result* d_trusted_res, uint32_t* d_skip_status, uint8_t* d_target_hashes) {
+                       const bsx_commit_result* d_trusted_res, uint32_t* d_skip_status, uint8_t* d_target_hashes,
+                       const uint32_t* d_target_index) {
     DEV_ENTER();
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
     if (!d_ranges || !d_headers || !d_hashes || !d_target || !d_trusted || !d_target_ok || !d_target_res || !d_trusted_res || !d_skip_status)
         return fail(BSX_ERR_BAD_ARG, "null pointer");
     HIPCHK(bsxk_skip_check(S(ctx, stream), n_ranges, v_max, d_ranges, d_headers, headers_per_range, d_hashes, d_target, d_trusted,
-                           d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes));
+                           d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes, d_target_index));
     return BSX_OK;
 }
 
@@ -394,7 +395,7 @@ int bsx_data_commitment_inputs(bsx_ctx* ctx, const bsx_header* headers, uint64_t
     RET(aux.alloc((size_t)P * 32 + 64));
     HIPCHK(hipMemsetAsync(cw.p, 0, L.compact_stride, st));
     HIPCHK(bsxk_assemble_inputs(st, 1, 1, P, 0, 1, (uint32_t)(end_block - start_block), rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(),
-                                rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
+                                rd.headers.as<bsx_header>(), rd.hpr, 0, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
                                 cw.as<uint8_t>(), rd.astatus.as<uint32_t>()));
     std::vector<uint8_t> img(L.compact_stride);
     uint32_t hs = 0, as = 0;
@@ -500,7 +501,7 @@ static int run_data_commitment(hipStream_t st, uint32_t J, uint32_t B, RangeDev&
     RET(o64.alloc(64));
     RET(stw.alloc(4));
     HIPCHK(hipMemsetAsync(cw.p, 0, (size_t)J * L.compact_stride, st));
-    HIPCHK(bsxk_assemble_inputs(st, 1, J, B, 0, J, B, rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(), rd.headers.as<bsx_header>(), rd.hpr,
+    HIPCHK(bsxk_assemble_inputs(st, 1, J, B, 0, J, B, rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(), rd.headers.as<bsx_header>(), rd.hpr, 0,
                                 rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(), cw.as<uint8_t>(), rd.astatus.as<uint32_t>()));
     HIPCHK(bsxk_prove_subchain(st, 1, B, J, rd.ranges.as<bsx_shared_ctx>(), cw.as<uint8_t>(), recs.as<bsx_subchain>()));
     HIPCHK(bsxk_reduce(st, 1, J, recs.as<bsx_subchain>(), res.as<bsx_subchain>(), rcw.as<uint8_t>()));
@@ -642,7 +643,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     RangeDev rd;
     RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd));
     // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash
-    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr));
+    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr));
     DBuf dv, dtv, dh, dok, dres, dtres, dskip, dth;
     RET(dv.alloc((size_t)v_max * sizeof(bsx_validator)));
     RET(dtv.alloc((size_t)v_max * sizeof(bsx_validator)));
@@ -661,7 +662,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     HIPCHK(bsxk_commit_tally(st, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
     HIPCHK(bsxk_skip_check(st, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
-                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth.as<uint8_t>()));
+                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth.as<uint8_t>(), nullptr));
     // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58)
     int rc = run_data_commitment(st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, output64, nullptr, nullptr, witness, nullptr);
     if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;

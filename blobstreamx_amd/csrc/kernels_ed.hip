@@ -243,6 +243,7 @@ struct SkipArgs {
     const bsx_commit_result* trusted_res;   // n_ranges (validators_hash + total_power of the trusted set)
     uint32_t* skip_status;              // n_ranges
     uint8_t* target_hashes;             // n_ranges * 32 (out): hash of the target header
+    const uint32_t* target_idx;         // optional: index of the target header inside the range's header block (default E - S)
 };
 __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
     __shared__ uint32_t tpk[TL_VMAX * 8];
@@ -282,9 +283,10 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
     __syncthreads();
     if (tid == 0) {
         const uint64_t S = rg.start_block, E = rg.end_block;
-        const bsx_header* th = a.headers + (uint64_t)r * a.headers_per_range + (E - S);
+        const uint64_t ti = a.target_idx ? (uint64_t)a.target_idx[r] : (E - S);
+        const bsx_header* th = a.headers + (uint64_t)r * a.headers_per_range + ti;
         const bsx_header* tr = a.headers + (uint64_t)r * a.headers_per_range;
-        const uint8_t* thash = a.hashes + ((uint64_t)r * a.headers_per_range + (E - S)) * 32;
+        const uint8_t* thash = a.hashes + ((uint64_t)r * a.headers_per_range + ti) * 32;
         const uint8_t* trhash = a.hashes + ((uint64_t)r * a.headers_per_range) * 32;
         bsx_commit_result* cr = a.target_res + r;
         const bsx_commit_result* trc = a.trusted_res + r;
@@ -342,9 +344,9 @@ hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t 
 hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* ranges, const bsx_header* headers,
                            uint64_t hpr, const uint8_t* hashes, const bsx_validator* target, const bsx_validator* trusted,
                            const uint8_t* target_ok, bsx_commit_result* target_res, const bsx_commit_result* trusted_res,
-                           uint32_t* skip_status, uint8_t* target_hashes) {
+                           uint32_t* skip_status, uint8_t* target_hashes, const uint32_t* target_idx) {
     if (!n_ranges) return hipSuccess;
-    SkipArgs a{n_ranges, v_max, ranges, headers, hpr, hashes, target, trusted, target_ok, target_res, trusted_res, skip_status, target_hashes};
+    SkipArgs a{n_ranges, v_max, ranges, headers, hpr, hashes, target, trusted, target_ok, target_res, trusted_res, skip_status, target_hashes, target_idx};
     hipLaunchKernelGGL(k_skip_check, dim3(n_ranges), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -66,10 +66,11 @@ __global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_has
     if (tid == 0) *out_flags = (gte ? 0u : BSX_A1_END_GTE_START) | ((nb >> 32) ? BSX_A2_NB_BLOCKS_U32 : 0u);
 }
 
-__global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr) {
+__global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
+                                const uint32_t* target_idx) {
     const uint32_t r = blockIdx.x, t = threadIdx.x;   // 32 lanes
     if (r >= n_ranges) return;
-    const uint64_t idx = (uint64_t)r * hpr + (ranges[r].end_block - ranges[r].start_block);
+    const uint64_t idx = (uint64_t)r * hpr + (target_idx ? (uint64_t)target_idx[r] : ranges[r].end_block - ranges[r].start_block);
     const uint8_t b = hashes[idx * 32 + t];
     ranges[r].end_header_hash[t] = b;
 }
@@ -87,9 +88,10 @@ hipError_t bsxk_data_commitment(hipStream_t s, const uint8_t* data_hashes, uint3
     hipLaunchKernelGGL(k_data_commitment, dim3(1), dim3(256), 0, s, data_hashes, max_leaves, start, end, out_root, out_flags);
     return hipGetLastError();
 }
-hipError_t bsxk_fill_end_hash(hipStream_t s, uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr) {
+hipError_t bsxk_fill_end_hash(hipStream_t s, uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
+                              const uint32_t* target_idx) {
     if (!n_ranges) return hipSuccess;
-    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr);
+    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr, target_idx);
     return hipGetLastError();
 }
 }

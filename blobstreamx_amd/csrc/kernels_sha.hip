@@ -191,7 +191,7 @@ struct AssembleArgs {
     const bsx_shared_ctx* ranges;
     const uint64_t* latest;
     const bsx_header* headers;
-    uint64_t headers_per_range;
+    uint64_t headers_per_range, header_first_rel;   // headers[r*hpr + k] is the header at height S_r + header_first_rel + k
     const uint8_t *hashes, *dh_aunts, *lb_aunts;
     uint8_t* compact;
     uint32_t compact_stride, off_words;
@@ -211,9 +211,9 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     // number of real proofs: dh for [start, req_end), lb for (start, req_end]  (input.rs:167-198)
     const uint64_t n_real = (batch_start <= req_end) ? (req_end - batch_start) : 0;
     const bool have_hdrs = batch_start < req_end;              // input.rs:249
-    const uint64_t hbase = (uint64_t)r * a.headers_per_range;  // header index of height S
+    const uint64_t hbase = (uint64_t)r * a.headers_per_range - a.header_first_rel;  // virtual index of height S (never dereferenced below rel)
     bool oob = false;
-    if (batch_start <= req_end && (req_end - S) >= a.headers_per_range) oob = true;  // caller did not supply the headers
+    if (batch_start <= req_end && ((batch_start - S) < a.header_first_rel || (req_end - S - a.header_first_rel) >= a.headers_per_range)) oob = true;  // headers not supplied
     uint8_t* cw = a.compact + ((uint64_t)r * a.job_count + jl) * a.compact_stride;
     uint32_t* cw32 = reinterpret_cast<uint32_t*>(cw);
 
@@ -697,11 +697,11 @@ hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, 
     return hipGetLastError();
 }
 hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
-                                const bsx_shared_ctx* ranges, const uint64_t* latest, const bsx_header* headers, uint64_t hpr,
+                                const bsx_shared_ctx* ranges, const uint64_t* latest, const bsx_header* headers, uint64_t hpr, uint64_t hfr,
                                 const uint8_t* hashes, const uint8_t* dh, const uint8_t* lb, uint8_t* compact, uint32_t* status) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
-    AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status};
+    AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hfr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status};
     hipLaunchKernelGGL(k_assemble_inputs, dim3(n_ranges * job_count), dim3(256), 0, s, a);
     return hipGetLastError();
 }

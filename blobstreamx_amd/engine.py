@@ -1,0 +1,266 @@
+"""Device-resident batched header_range pipeline (the throughput path bench.py times).
+
+R independent header_range instances per pass, inputs already in HBM, every kernel enqueued on one HIP stream through
+the device tier of the C ABI (include/bsx.h, bsx_dev_*).  PyTorch only owns the device buffers, the stream and — across
+GPUs — the one collective; no torch op touches the data path.
+
+Pass over R ranges of J map jobs x B headers (reference shapes 32x32 / 32x64, bin/header_range_{1024,2048}.rs:6-17):
+
+  1 header_merkle     tendermint Header::hash + inclusion proofs for every supplied header   (input.rs:175-195,250-261)
+  2 fill_end_hash     ctx.end_header_hash := target header hash (output of builder.skip)     (header_range.rs:42-55)
+  3 commit            SHA-512 challenge -> Ed25519 -> tallies/validator hashes -> skip check  (header_range.rs:42-48)
+  4 assemble_inputs   the hint of every map job                                               (data_commitment.rs:22-44)
+  5 prove_subchain    map stage                                                               (builder.rs:150-271,305-336)
+  6 reduce            local fold of this device's jobs, [all-gather across GPUs], top fold    (builder.rs:337-395)
+  7 finalize          range check, final asserts, 64-byte public output                       (builder.rs:292-297,400-406)
+  8 expand_witness    compact witness -> Goldilocks elements (map jobs + reduce nodes)
+
+Multi-GPU: rank g owns map jobs [g*J/N, (g+1)*J/N) of EVERY range of the global batch (N*R ranges, so the
+per-GPU slot count is the same as at N = 1: weak scaling), folds them locally, and ONE all-gather of a 128-byte
+record per (range, rank) replaces the reference's map->reduce hand-off; the owner of a range (range index // R) does
+the last log2(N) reduce levels, the final assertions and that range's commit verification.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import types as T
+
+
+def _u8(n, dev):
+    return torch.zeros(max(int(n), 16), dtype=torch.uint8, device=dev)
+
+
+def job_slice(nb_map_jobs, rank, world):
+    """Map jobs [first, first+count) of every range that `rank` owns (aligned power-of-two slices so the
+    local fold + top fold is the same binary tree plonky2x mapreduce builds, circuits/builder.rs:301-302)."""
+    assert nb_map_jobs % world == 0, "world size must divide NB_MAP_JOBS"
+    count = nb_map_jobs // world
+    assert count & (count - 1) == 0, "each rank needs a power-of-two slice of the map jobs"
+    return rank * count, count
+
+
+def gather_partials(partial, rank, world, n_ranges_local, out_gathered=None, out_top=None):
+    """THE collective of the multi-GPU path: all-gather one 128-byte MapReduceSubchainVariable record per
+    (range, rank), then lay the owned ranges out as [range][rank] for the top log2(world) reduce levels.
+    partial: uint8 tensor [world*n_ranges_local*128] (this rank's locally folded record of every range).
+    Works on CUDA tensors over RCCL ("nccl") and on CPU tensors over gloo (tests)."""
+    import torch.distributed as dist
+    RT = world * n_ranges_local
+    flat = partial[:RT * 128].contiguous()
+    gathered = out_gathered[:world * RT * 128] if out_gathered is not None else torch.empty(world * RT * 128, dtype=torch.uint8, device=flat.device)
+    dist.all_gather_into_tensor(gathered, flat)
+    g = gathered.view(world, RT, 128)
+    own = g[:, rank * n_ranges_local:(rank + 1) * n_ranges_local, :]            # [rank, owned range, 128]
+    top = out_top[:n_ranges_local * world * 128] if out_top is not None else torch.empty(n_ranges_local * world * 128, dtype=torch.uint8, device=flat.device)
+    top.view(n_ranges_local, world, 128).copy_(own.transpose(0, 1))
+    return top
+
+
+class HeaderRangeEngine:
+    def __init__(self, nb_map_jobs, batch_size, v_max, n_ranges_local, rank=0, world=1, device=None, with_witness=True,
+                 with_commit=True):
+        self.J, self.B, self.V = nb_map_jobs, batch_size, v_max
+        self.rank, self.world = rank, world
+        self.R = n_ranges_local                     # ranges owned by this rank (commit + final reduce)
+        self.RT = n_ranges_local * world            # ranges whose job slice this rank computes
+        self.jf, self.jc = job_slice(nb_map_jobs, rank, world)   # first job / jobs per range on this rank
+        self.with_witness, self.with_commit = with_witness, with_commit
+        self.dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.ctx = _lib.context(self.dev.index if self.dev.index is not None else 0)
+        self.L = _lib.lib()
+        self.ml, self.rl = T.map_layout(batch_size), T.reduce_layout()
+        self._ml = np.array(self.ml).reshape(1)
+        self._rl = np.array(self.rl).reshape(1)
+        d = self.dev
+        B, jc, RT, R, V = batch_size, self.jc, self.RT, self.R, v_max
+        self.hpr = jc * B + 1                       # headers this rank holds per range: its slice + the next one
+        self.hfr = self.jf * B                      # height offset of the first of them (header_first_rel)
+        self.headers = _u8(RT * self.hpr * 512, d)
+        self.hashes = _u8(RT * self.hpr * 32, d)
+        self.dh_aunts = _u8(RT * self.hpr * 128, d)
+        self.lb_aunts = _u8(RT * self.hpr * 128, d)
+        self.ranges = _u8(RT * 80, d)
+        self.latest = _u8(RT * 8, d)
+        self.status = torch.zeros(8, dtype=torch.int32, device=d)       # [0] header, [1] assemble
+        self.compact = _u8(RT * jc * int(self.ml["compact_stride"]), d)
+        self.records = _u8(RT * jc * 128, d)
+        self.partial = _u8(RT * 128, d)              # local fold: one record per range
+        n_local_nodes = RT * max(jc - 1, 0)
+        self.red_compact_local = _u8(n_local_nodes * int(self.rl["compact_stride"]), d)
+        self.gathered = _u8(world * RT * 128, d)     # all-gather output [rank][range]
+        self.top_in = _u8(R * world * 128, d)        # owned ranges, [range][rank]
+        self.red_compact_top = _u8(R * max(world - 1, 0) * int(self.rl["compact_stride"]), d)
+        self.results = _u8(R * 128, d)
+        self.output64 = _u8(R * 64, d)
+        self.range_status = torch.zeros(max(R, 1), dtype=torch.int32, device=d)
+        # commit (owned ranges): the trusted header and the target header as a 2-header block per range
+        self.skip_headers = _u8(R * 2 * 512, d)
+        self.skip_hashes = _u8(R * 2 * 32, d)
+        self.skip_ranges = _u8(R * 80, d)
+        self.target_idx = torch.ones(max(R, 1), dtype=torch.int32, device=d)
+        self.validators = _u8(R * V * 256, d)
+        self.trusted = _u8(R * V * 256, d)
+        self.h = _u8(R * V * 32, d)
+        self.ok = _u8(R * V, d)
+        self.commit_res = _u8(R * 96, d)
+        self.trusted_res = _u8(R * 96, d)
+        self.skip_status = torch.zeros(max(R, 1), dtype=torch.int32, device=d)
+        self.target_hashes = _u8(R * 32, d)
+        self.n_map_el = RT * jc * int(self.ml["n_elements"])
+        self.n_red_local_el = n_local_nodes * int(self.rl["n_elements"])
+        self.n_red_top_el = R * max(world - 1, 0) * int(self.rl["n_elements"])
+        if with_witness:
+            self.witness_map = torch.zeros(self.n_map_el + 2, dtype=torch.int64, device=d)
+            self.witness_red_local = torch.zeros(self.n_red_local_el + 2, dtype=torch.int64, device=d)
+            self.witness_red_top = torch.zeros(self.n_red_top_el + 2, dtype=torch.int64, device=d)
+        self.events = None
+        self.side = torch.cuda.Stream(device=d)
+
+    # ------------------------------------------------------------------ data
+    def upload(self, headers_slice, ranges, latest, skip_headers=None, skip_ranges=None, validators=None, trusted=None):
+        """headers_slice: [RT, hpr] HEADER (heights S_r + hfr ..); ranges: [RT] SHARED_CTX; latest: [RT] u64.
+        Owned ranges: skip_headers [R, 2] HEADER (trusted, target), skip_ranges [R] SHARED_CTX, validators/trusted
+        [R, V] VALIDATOR."""
+        def put(dst, arr):
+            a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+            assert a.size <= dst.numel(), (a.size, dst.numel())
+            dst[:a.size].copy_(torch.from_numpy(a), non_blocking=False)
+        put(self.headers, headers_slice)
+        put(self.ranges, ranges)
+        put(self.latest, np.ascontiguousarray(latest, np.uint64))
+        if self.with_commit:
+            put(self.skip_headers, skip_headers)
+            put(self.skip_ranges, skip_ranges)
+            put(self.validators, validators)
+            put(self.trusted, trusted)
+        torch.cuda.synchronize(self.dev)
+
+    def upload_workload(self, w, ranges_global=None):
+        """Convenience for a synth.Workload holding the RT ranges this rank touches (single GPU: all of them)."""
+        assert w.R == self.RT and w.J == self.J and w.B == self.B and w.v_max == self.V
+        lo = self.hfr
+        hs = w.headers[:, lo:lo + self.hpr]
+        own = slice(self.rank * self.R, (self.rank + 1) * self.R)
+        sk = np.stack([w.headers[own, 0], w.headers[own, w.n_blocks]], axis=1)
+        self.upload(hs, w.ranges, w.latest, sk, w.ranges[own], w.validators[own], w.trusted[own])
+
+    # ------------------------------------------------------------------ one pass
+    def _st(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def step_local(self, time_kernels=False):
+        """Stages 1-5 + local fold: everything before the cross-GPU exchange.  The commit verification of the owned
+        ranges (stage 3, ~1 ms of latency-bound Ed25519) runs on a side stream beside the SHA/witness stream."""
+        L, ctx, dp, chk = self.L, self.ctx, _lib.dp, _lib.check
+        B, jc, RT, R, V = self.B, self.jc, self.RT, self.R, self.V
+        main = torch.cuda.current_stream(self.dev)
+        st = self._st()
+        ev = self.events if time_kernels else None
+        self.status.zero_()
+        if self.with_commit and R:
+            chk(L.bsx_dev_header_merkle(ctx, st, dp(self.skip_headers), C.c_uint64(R * 2), dp(self.skip_hashes), None, None,
+                                        dp(self.status)))
+            self._target_hash_view()
+            chk(L.bsx_dev_fill_end_hash(ctx, st, C.c_uint32(R), dp(self.skip_ranges), dp(self.skip_hashes), C.c_uint64(2),
+                                        dp(self.target_idx)))
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._commit(self._st())
+        chk(L.bsx_dev_header_merkle(ctx, st, dp(self.headers), C.c_uint64(RT * self.hpr), dp(self.hashes), dp(self.dh_aunts),
+                                    dp(self.lb_aunts), dp(self.status)))
+        chk(L.bsx_dev_assemble_inputs(ctx, st, C.c_uint32(RT), C.c_uint32(self.J), C.c_uint32(B), C.c_uint32(self.jf),
+                                      C.c_uint32(jc), C.c_uint32(B), dp(self.ranges), dp(self.latest), dp(self.headers),
+                                      C.c_uint64(self.hpr), C.c_uint64(self.hfr), dp(self.hashes), dp(self.dh_aunts),
+                                      dp(self.lb_aunts), dp(self.compact), dp(self.status[1:])))
+        if ev:
+            ev[0].record(main)
+        chk(L.bsx_dev_prove_subchain(ctx, st, C.c_uint32(RT), C.c_uint32(B), C.c_uint32(jc), dp(self.ranges), dp(self.compact),
+                                     dp(self.records)))
+        if ev:
+            ev[1].record(main)
+        chk(L.bsx_dev_reduce(ctx, st, C.c_uint32(RT), C.c_uint32(jc), dp(self.records), dp(self.partial),
+                             dp(self.red_compact_local) if jc > 1 else None))
+
+    def _commit(self, st):
+        """Stage 3 for the owned ranges on stream `st` (builder.skip, header_range.rs:42-48)."""
+        L, ctx, dp, chk = self.L, self.ctx, _lib.dp, _lib.check
+        R, V = self.R, self.V
+        n = R * V
+        chk(L.bsx_dev_sha512_challenge(ctx, st, dp(self.validators), C.c_uint64(n), dp(self.h), None))
+        chk(L.bsx_dev_ed25519_verify(ctx, st, dp(self.validators), dp(self.h), C.c_uint64(n), dp(self.ok)))
+        chk(L.bsx_dev_commit_tally(ctx, st, dp(self.trusted), C.c_uint32(R), C.c_uint32(V), None, None, dp(self.trusted_res)))
+        chk(L.bsx_dev_commit_tally(ctx, st, dp(self.validators), C.c_uint32(R), C.c_uint32(V), dp(self.target_hashes), dp(self.ok),
+                                   dp(self.commit_res)))
+        chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges), dp(self.skip_headers), C.c_uint64(2),
+                                 dp(self.skip_hashes), dp(self.validators), dp(self.trusted), dp(self.ok), dp(self.commit_res),
+                                 dp(self.trusted_res), dp(self.skip_status), None, dp(self.target_idx)))
+
+    def _target_hash_view(self):
+        # device-side strided copy (hipMemcpy2DAsync under torch): rows of 64 bytes, take bytes 32..64
+        src = self.skip_hashes[:self.R * 64].view(self.R, 64)[:, 32:]
+        self.target_hashes[:self.R * 32].view(self.R, 32).copy_(src)
+
+    def step_exchange(self):
+        """Stage 6: the one collective.  Single GPU: the local fold already is the range result."""
+        if self.world == 1:
+            return self.partial
+        gather_partials(self.partial, self.rank, self.world, self.R, self.gathered, self.top_in)
+        L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
+        chk(L.bsx_dev_reduce(ctx, st, C.c_uint32(self.R), C.c_uint32(self.world), dp(self.top_in), dp(self.results),
+                             dp(self.red_compact_top)))
+        return self.results
+
+    def step_final(self, result_records, time_kernels=False):
+        L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
+        ev = self.events if time_kernels else None
+        own_ranges = self.skip_ranges if self.with_commit else self.ranges[self.rank * self.R * 80:]
+        chk(L.bsx_dev_finalize(ctx, st, C.c_uint32(self.R), C.c_uint32(self.J), C.c_uint32(self.B), dp(own_ranges),
+                               dp(result_records), dp(self.target_hashes) if self.with_commit else None, dp(self.output64),
+                               dp(self.range_status)))
+        if self.with_witness:
+            if ev:
+                ev[2].record(torch.cuda.current_stream(self.dev))
+            chk(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._ml), C.c_uint32(self.RT * self.jc), dp(self.compact),
+                                         dp(self.witness_map)))
+            if ev:
+                ev[3].record(torch.cuda.current_stream(self.dev))
+            if self.jc > 1:
+                chk(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._rl), C.c_uint32(self.RT * (self.jc - 1)),
+                                             dp(self.red_compact_local), dp(self.witness_red_local)))
+            if self.world > 1:
+                chk(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._rl), C.c_uint32(self.R * (self.world - 1)),
+                                             dp(self.red_compact_top), dp(self.witness_red_top)))
+
+    def step(self, time_kernels=False):
+        self.step_local(time_kernels)
+        res = self.step_exchange()
+        self.step_final(res, time_kernels)
+        if self.with_commit and self.R:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+
+    def enable_timing(self):
+        self.events = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    # ------------------------------------------------------------------ results
+    def download(self):
+        torch.cuda.synchronize(self.dev)
+        out = dict(
+            output64=self.output64[:self.R * 64].cpu().numpy().reshape(self.R, 64),
+            range_status=self.range_status[:self.R].cpu().numpy().astype(np.uint32),
+            header_status=int(self.status[0].item()), assemble_status=int(self.status[1].item()),
+            records=self.records[:self.RT * self.jc * 128].cpu().numpy().view(T.SUBCHAIN).reshape(self.RT, self.jc),
+        )
+        if self.with_commit:
+            out["skip_status"] = self.skip_status[:self.R].cpu().numpy().astype(np.uint32)
+            out["commit"] = self.commit_res[:self.R * 96].cpu().numpy().view(T.COMMIT_RESULT)
+        return out
+
+    def witness_numpy(self):
+        torch.cuda.synchronize(self.dev)
+        m = self.witness_map[:self.n_map_el].cpu().numpy().view(np.uint64)
+        rl = self.witness_red_local[:self.n_red_local_el].cpu().numpy().view(np.uint64)
+        rt = self.witness_red_top[:self.n_red_top_el].cpu().numpy().view(np.uint64)
+        return m, rl, rt

@@ -283,7 +283,8 @@ int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_header
 
 /* The hint for many map jobs at once (input.rs:149-271): job j of range r covers
  * [S_r + j*B, S_r + j*B + span) (span == B for map jobs, input.rs:154 requires span <= B).  Headers of range r start
- * at d_headers[r*headers_per_range] = height S_r; d_latest[r] is the chain head the hint clamps against
+ * at d_headers[r*headers_per_range] = height S_r + header_first_rel (0 unless a device holds only the headers of
+ * its own job slice); d_latest[r] is the chain head the hint clamps against
  * (input.rs:160-162).  Only jobs [job_first, job_first+job_count) are written (multi-GPU sharding); compact witnesses
  * are indexed [range][job - job_first] with stride bsx_map_witness_layout(B).compact_stride.  Writes the
  * DataCommitmentProofVariable part, the ctx and the batch bounds of each job's compact witness.
@@ -291,7 +292,7 @@ int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_header
 int bsx_dev_assemble_inputs(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
                             uint32_t job_first, uint32_t job_count, uint32_t span,
                             const bsx_shared_ctx* d_ranges, const uint64_t* d_latest,
-                            const bsx_header* d_headers, uint64_t headers_per_range,
+                            const bsx_header* d_headers, uint64_t headers_per_range, uint64_t header_first_rel,
                             const uint8_t* d_hashes, const uint8_t* d_dh_aunts, const uint8_t* d_lb_aunts,
                             uint8_t* d_compact, uint32_t* d_status);
 
@@ -318,9 +319,10 @@ int bsx_dev_expand_witness(bsx_ctx* ctx, void* stream, const bsx_witness_layout*
                            const uint8_t* d_compact, uint64_t* d_witness);
 
 /* d_ranges[r].end_header_hash := d_hashes[r*headers_per_range + (end_block - start_block)] (the target header hash
- * builder.skip returns and prove_data_commitment consumes, header_range.rs:42-55). */
+ * builder.skip returns and prove_data_commitment consumes, header_range.rs:42-55).  d_target_index (optional,
+ * n_ranges u32) overrides the position of the target header inside the range's header block. */
 int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_shared_ctx* d_ranges,
-                          const uint8_t* d_hashes, uint64_t headers_per_range);
+                          const uint8_t* d_hashes, uint64_t headers_per_range, const uint32_t* d_target_index);
 
 /* P6: h = SHA512(R ‖ A ‖ M) mod L per validator slot. d_h: n*32 (LE scalar), d_digest (optional) n*64. */
 int bsx_dev_sha512_challenge(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n,
@@ -341,7 +343,7 @@ int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v
                        const bsx_header* d_headers, uint64_t headers_per_range, const uint8_t* d_hashes,
                        const bsx_validator* d_target, const bsx_validator* d_trusted, const uint8_t* d_target_ok,
                        bsx_commit_result* d_target_res, const bsx_commit_result* d_trusted_res,
-                       uint32_t* d_skip_status, uint8_t* d_target_hashes);
+                       uint32_t* d_skip_status, uint8_t* d_target_hashes, const uint32_t* d_target_index);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,95 @@
+"""CPU suite: the multi-GPU path's partition + exchange logic over gloo (world_size 2 and 4).
+
+Each rank computes the records of ITS slice of the map jobs (with the oracle standing in for the HIP kernels — the
+kernels themselves are covered by the GPU suite), folds them locally, runs the product's one collective
+(blobstreamx_amd.engine.gather_partials) and the top fold; the owner's result must equal the single-process
+prove_data_commitment of the full range (circuits/builder.rs:299-395)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+import synth
+from blobstreamx_amd import types as T
+from blobstreamx_amd.engine import gather_partials, job_slice
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, J, B, R, n_blocks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = synth.Workload(8, R * world, J, B, v=1, n_blocks=n_blocks)     # same seed on every rank
+        jf, jc = job_slice(J, rank, world)
+        RT = R * world
+        partial = np.zeros(RT, T.SUBCHAIN)
+        for r in range(RT):
+            S = int(w.first_height[r])
+            recs = []
+            for j in range(jf, jf + jc):
+                bs = S + j * B
+                # this rank only looks at the headers of its own slice (+1): heights [S + jf*B, S + (jf+jc)*B]
+                lo, hi = jf * B, (jf + jc) * B + 1
+                rc, inp = oracle.data_commitment_inputs(w.headers[r, lo:hi], S + lo, int(w.latest[r]), bs, bs + B, B)
+                assert rc == T.OK
+                rc, rec, _ = oracle.prove_subchain(B, inp["start_header"], inp["end_header"], inp["data_hash_proofs"],
+                                                   inp["last_block_id_proofs"], bs, bs + B, int(w.ranges[r]["end_block"]),
+                                                   bytes(w.ranges[r]["end_header_hash"]))
+                recs.append(rec)
+            _, partial[r], _ = oracle.reduce(np.array(recs, T.SUBCHAIN))
+        top = gather_partials(torch.from_numpy(partial.view(np.uint8).reshape(-1).copy()), rank, world, R)
+        top = top.numpy().view(T.SUBCHAIN).reshape(R, world)
+        res = []
+        for k in range(R):
+            _, out, _ = oracle.reduce(top[k])
+            res.append(bytes(out["data_merkle_root"]) + bytes(out["end_header"]) + int(out["end_block"]).to_bytes(8, "big") +
+                       int(out["assert_fail"]).to_bytes(4, "big"))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,J,B,n_blocks", [(2, 4, 8, 32), (2, 4, 8, 19), (4, 8, 4, 32), (2, 2, 16, 5)])
+def test_sharded_map_reduce_equals_single_process(world, J, B, n_blocks):
+    R = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, J, B, R, n_blocks, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = synth.Workload(8, R * world, J, B, v=1, n_blocks=n_blocks)
+    for rk in range(world):
+        for k in range(R):
+            r = rk * R + k
+            rc, ref = oracle.prove_data_commitment(J, B, w.ranges[r:r + 1], w.headers[r], int(w.first_height[r]), int(w.latest[r]))
+            assert rc == T.OK
+            want = ref["data_commitment"] + bytes(ref["result"]["end_header"]) + int(ref["result"]["end_block"]).to_bytes(8, "big") + \
+                (0).to_bytes(4, "big")
+            assert got[rk][k] == want, (rk, k)
+
+
+def test_job_slice_rules():
+    assert job_slice(32, 0, 8) == (0, 4) and job_slice(32, 7, 8) == (28, 4)
+    assert job_slice(32, 0, 1) == (0, 32)
+    with pytest.raises(AssertionError):
+        job_slice(32, 0, 3)
+    with pytest.raises(AssertionError):
+        job_slice(24, 0, 4)     # 6 jobs per rank is not a power-of-two subtree
