@@ -87,7 +87,9 @@ struct DBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
-hipStream_t S(bsx_ctx* c, void* s) { return s ? static_cast<hipStream_t>(s) : c->stream; }
+// device tier: the caller's stream exactly as given (NULL = the HIP default stream, which is what PyTorch's default
+// stream is), so bsx_dev_* calls are ordered with the caller's own work on that stream
+hipStream_t S(bsx_ctx*, void* s) { return static_cast<hipStream_t>(s); }
 
 int use(bsx_ctx* ctx) {
     if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");

@@ -273,7 +273,8 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness);
 
 /* ------------------------------------------------------------------ device tier (async; d_* = device memory)
- * Every call only enqueues kernels on `stream` (hipStream_t as void*; NULL = the context's own stream) and returns.
+ * Every call only enqueues kernels on `stream` (hipStream_t as void*; NULL = the HIP default stream, i.e. PyTorch's
+ * default stream) and returns, so calls are ordered with the caller's own work on that stream.
  * Device status words are ORed into, never cleared: the caller zeroes them (hipMemsetAsync) before a pass. */
 
 /* P5: one lane per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be

@@ -252,13 +252,13 @@ def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest
 
 
 def bench_header_range(nb_map_jobs, batch_size, ranges, headers, headers_per_range, latest, target, trusted, v_max,
-                       with_witness, n_threads):
+                       with_witness, n_threads, reps=1):
     ranges = np.ascontiguousarray(ranges, T.SHARED_CTX).reshape(-1)
     n = ranges.size
     out64 = np.zeros((n, 64), np.uint8)
     cs = C.c_uint64(0)
     latest = np.ascontiguousarray(latest, np.uint64)
-    rc = lib().orc_bench_header_range(C.c_uint32(n), C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(ranges),
+    rc = lib().orc_bench_header_range(C.c_uint32(n), C.c_uint32(reps), C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(ranges),
                                       _p(headers), C.c_uint64(headers_per_range), _p(latest), _p(target), _p(trusted),
                                       C.c_uint32(v_max), C.c_int(int(with_witness)), C.c_int(n_threads), _p(out64),
                                       C.byref(cs))

@@ -184,7 +184,7 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
 
 /* ------------------------------------------------------------------ cpu_baseline driver */
 typedef struct {
-    uint32_t n_ranges, J, B, v_max;
+    uint32_t n_ranges, J, B, v_max, reps;
     const bsx_shared_ctx* ranges;
     const bsx_header* headers;
     uint64_t headers_per_range;
@@ -201,9 +201,14 @@ static void* worker(void* arg) {
     bsx_witness_layout L = bsx_map_layout(jb->B), R = bsx_reduce_layout();
     size_t csz = (size_t)jb->J * L.compact_stride + (size_t)(jb->J - 1) * R.compact_stride;
     uint8_t* compact = jb->with_witness ? malloc(csz) : NULL;
-    uint64_t* wit = jb->with_witness ? malloc(((size_t)jb->J * L.n_elements + (size_t)(jb->J - 1) * R.n_elements) * 8) : NULL;
+    /* one map job's worth of expanded elements at a time (3.6 MB at B = 64): same work, bounded memory per thread */
+    size_t wel = L.n_elements > (size_t)(jb->J - 1) * R.n_elements ? L.n_elements : (size_t)(jb->J - 1) * R.n_elements;
+    uint64_t* wit = jb->with_witness ? malloc(wel * 8) : NULL;
     uint64_t cs = 0;
-    for (uint32_t r = (uint32_t)jb->tid; r < jb->n_ranges; r += (uint32_t)jb->n_threads) {
+    uint8_t o64[64];
+    const uint32_t n_tasks = jb->n_ranges * jb->reps;
+    for (uint32_t t = (uint32_t)jb->tid; t < n_tasks; t += (uint32_t)jb->n_threads) {
+        const uint32_t r = t % jb->n_ranges;
         uint8_t in48[48];
         const bsx_shared_ctx* rg = &jb->ranges[r];
         for (int i = 0; i < 8; i++) in48[i] = (uint8_t)(rg->start_block >> (56 - 8 * i));
@@ -211,15 +216,20 @@ static void* worker(void* arg) {
         for (int i = 0; i < 8; i++) in48[40 + i] = (uint8_t)(rg->end_block >> (56 - 8 * i));
         int rc = orc_header_range(jb->J, jb->B, in48, jb->headers + (size_t)r * jb->headers_per_range, rg->start_block,
                                   jb->headers_per_range, jb->latest[r], jb->target + (size_t)r * jb->v_max,
-                                  jb->trusted + (size_t)r * jb->v_max, jb->v_max, jb->out64 + 64 * (size_t)r, NULL, compact);
+                                  jb->trusted + (size_t)r * jb->v_max, jb->v_max, o64, NULL, compact);
         if (rc) jb->rc = rc;
+        if (t < jb->n_ranges) memcpy(jb->out64 + 64 * (size_t)r, o64, 64);
         if (compact) {
-            orc_expand_witness(&L, jb->J, compact, wit);
-            orc_expand_witness(&R, jb->J - 1, compact + (size_t)jb->J * L.compact_stride, wit + (size_t)jb->J * L.n_elements);
-            size_t n = (size_t)jb->J * L.n_elements + (size_t)(jb->J - 1) * R.n_elements;
-            for (size_t i = 0; i < n; i += 4099) cs += wit[i] * (i + 1);
+            for (uint32_t j = 0; j < jb->J; j++) {
+                orc_expand_witness(&L, 1, compact + (size_t)j * L.compact_stride, wit);
+                for (size_t i = 0; i < L.n_elements; i += 4099) cs += wit[i] * (i + 1);
+            }
+            if (jb->J > 1) {
+                orc_expand_witness(&R, jb->J - 1, compact + (size_t)jb->J * L.compact_stride, wit);
+                for (size_t i = 0; i < (size_t)(jb->J - 1) * R.n_elements; i += 61) cs += wit[i] * (i + 1);
+            }
         }
-        for (int i = 0; i < 8; i++) cs += ((const uint64_t*)(const void*)(jb->out64 + 64 * (size_t)r))[i];
+        for (int i = 0; i < 64; i++) cs += o64[i];
     }
     jb->checksum = cs;
     free(compact);
@@ -227,16 +237,18 @@ static void* worker(void* arg) {
     return NULL;
 }
 
-int orc_bench_header_range(uint32_t n_ranges, uint32_t J, uint32_t B, const bsx_shared_ctx* ranges,
+/* n_ranges * reps independent header_range tasks (task t works on range t % n_ranges) over n_threads threads */
+int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t J, uint32_t B, const bsx_shared_ctx* ranges,
                            const bsx_header* headers, uint64_t headers_per_range, const uint64_t* latest_block,
                            const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
                            int with_witness, int n_threads, uint8_t* out64, uint64_t* checksum) {
     if (n_threads < 1) n_threads = 1;
-    if (n_threads > 256) n_threads = 256;
-    job_t jobs[256];
-    pthread_t th[256];
+    if (n_threads > 1024) n_threads = 1024;
+    if (reps < 1) reps = 1;
+    job_t* jobs = calloc((size_t)n_threads, sizeof *jobs);
+    pthread_t* th = calloc((size_t)n_threads, sizeof *th);
     for (int t = 0; t < n_threads; t++) {
-        job_t j = {n_ranges, J, B, v_max, ranges, headers, headers_per_range, latest_block, target_validators,
+        job_t j = {n_ranges, J, B, v_max, reps, ranges, headers, headers_per_range, latest_block, target_validators,
                    trusted_validators, with_witness, n_threads, t, out64, 0, 0};
         jobs[t] = j;
         pthread_create(&th[t], NULL, worker, &jobs[t]);
@@ -249,5 +261,7 @@ int orc_bench_header_range(uint32_t n_ranges, uint32_t J, uint32_t B, const bsx_
         if (jobs[t].rc) rc = jobs[t].rc;
     }
     if (checksum) *checksum = cs;
+    free(jobs);
+    free(th);
     return rc;
 }

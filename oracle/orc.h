@@ -94,7 +94,7 @@ int orc_header_range(uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t in
                      uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact);
 
 /* ---- batch drivers for the cpu_baseline leg (pthread pool, n_threads >= 1) */
-int orc_bench_header_range(uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
+int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t nb_map_jobs, uint32_t batch_size,
                            const bsx_shared_ctx* ranges, const bsx_header* headers, uint64_t headers_per_range,
                            const uint64_t* latest_block, const bsx_validator* target_validators,
                            const bsx_validator* trusted_validators, uint32_t v_max, int with_witness, int n_threads,
