@@ -3,14 +3,19 @@
 //   k_header_merkle    P5   tendermint Header::hash + inclusion proofs (circuits/input.rs:175-179,188-195,250-261)
 //   k_assemble_inputs  hint DataCommitmentOffchainInputs::hint -> get_data_commitment_inputs (circuits/data_commitment.rs:22-44,
 //                           circuits/input.rs:149-271): gathers proofs into each map job's compact witness, zero padding rules
-//   k_prove_subchain   P1-P4 prove_subchain + get_data_commitment (circuits/builder.rs:105-148,150-271)
+//   prove_subchain (circuits/builder.rs:150-271 incl. get_data_commitment :105-148) as three barrier-free stages:
+//     k_slot_hashes    P1-P3 one lane per header slot: both inclusion-proof paths, the data-root tuple and its leaf hash
+//     k_tree_level     P2   one lane per tree node of one level of compute_root_from_leaves, across ALL map jobs
+//     k_batch_finish   P4   chain-link predicates (wave ballots), batch tail, MapReduceSubchainVariable record
 //   k_reduce           reduce closure of prove_data_commitment (circuits/builder.rs:337-395)
 //   k_finalize         range check + final asserts + public output (builder.rs:292-297,400-406; header_range.rs:57-58)
 //   k_expand_witness   P10  bytes -> Goldilocks elements ([UPSTREAM] plonky2x ByteVariable = 8 bools MSB first)
 //
-// Mapping: one lane = one independent hash chain (header / slot / tree node); digests stay in VGPRs between tree
-// levels; byte inputs are staged global -> LDS with 16-byte coalesced loads and read back per lane at an odd dword
-// stride (bank-conflict free); assertion predicates are reduced with wave ballots.  No MFMA: bitwise integer work.
+// Mapping: one lane = one independent hash chain (header / slot / tree node); digests stay in VGPRs between the
+// hashes of a chain and go to HBM exactly once (they ARE the witness).  The SHA kernels are integer-ALU bound
+// (measured ceiling on MI355X: ~28 G compressions/s, tools/microbench.hip), so they are built for occupancy: no LDS,
+// no block barriers, every lane busy at every tree level.  Round-1 measurements (profiles/) showed the LDS-staged,
+// barrier-synchronised variant parked 51 % of its wave cycles.  No MFMA: bitwise integer work.
 #include <hip/hip_runtime.h>
 
 #include "../../include/bsx.h"
@@ -34,10 +39,16 @@ __device__ __forceinline__ uint32_t load_u32_a2(const uint8_t* src) {
     return *reinterpret_cast<const uint32_t*>(src);
 }
 // digest <-> 32 bytes in global memory; the byte sections of the compact witness are 4-byte aligned for even
-// batch sizes and only 2-byte aligned for B == 1, hence the _a2 accessors
+// batch sizes and only 2-byte aligned for B == 1, hence the _a2 accessors (the branch is wave-uniform per job)
 __device__ __forceinline__ void store_digest_global(uint8_t* dst, const Digest& d) {
+    if (reinterpret_cast<uintptr_t>(dst) & 2) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) store_u32_a2(dst + 4 * k, bswap32(d.w[k]));
+        for (int k = 0; k < 8; k++) store_u32_a2(dst + 4 * k, bswap32(d.w[k]));
+    } else {
+        uint32_t* p = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll
+        for (int k = 0; k < 8; k++) p[k] = bswap32(d.w[k]);
+    }
 }
 __device__ __forceinline__ void store_digest_global16(uint8_t* dst, const Digest& d) {  // dst 16-byte aligned
     uint4* p = reinterpret_cast<uint4*>(dst);
@@ -46,24 +57,20 @@ __device__ __forceinline__ void store_digest_global16(uint8_t* dst, const Digest
 }
 __device__ __forceinline__ Digest load_digest_global(const uint8_t* src) {
     Digest d;
+    if (reinterpret_cast<uintptr_t>(src) & 2) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) d.w[k] = bswap32(load_u32_a2(src + 4 * k));
-    return d;
-}
-__device__ __forceinline__ void store_digest_lds(uint32_t* dst, const Digest& d) {
+        for (int k = 0; k < 8; k++) d.w[k] = bswap32(load_u32_a2(src + 4 * k));
+    } else {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
 #pragma unroll
-    for (int k = 0; k < 8; k++) dst[k] = d.w[k];
-}
-__device__ __forceinline__ Digest load_digest_lds(const uint32_t* src) {
-    Digest d;
-#pragma unroll
-    for (int k = 0; k < 8; k++) d.w[k] = src[k];
+        for (int k = 0; k < 8; k++) d.w[k] = bswap32(p[k]);
+    }
     return d;
 }
 
-// one-block leaf with only ND dwords of capacity behind the pointer (LDS), len <= 4*ND
+// ND dwords of a field that starts at a 4-byte aligned global address
 template <int ND>
-__device__ __forceinline__ Digest leaf_from_lds(const uint32_t* f, int len) {
+__device__ __forceinline__ Digest leaf_from_global(const uint32_t* f, int len) {
     uint32_t d[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) d[j] = (j < ND) ? f[j] : 0u;
@@ -71,37 +78,21 @@ __device__ __forceinline__ Digest leaf_from_lds(const uint32_t* f, int len) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_header_merkle
-// 128 headers per workgroup, one lane per header.  Two staging phases keep LDS at 41.5 KB/WG (3 WG = 6 waves per CU):
-//   phase A bytes [0,320): len table + fields 0..7  -> left subtree (8 leaves)
-//   phase B bytes [304,512): fields 8..13           -> right subtree (6 leaves), root
-constexpr int HM_THREADS = 128;
-constexpr int HM_A_BYTES = 320, HM_A_STRIDE = 81;   // dwords per header in LDS (odd: conflict-free per-lane reads)
-constexpr int HM_B_OFF = 304, HM_B_BYTES = 208, HM_B_STRIDE = 53;
+// One lane per header; each lane streams its own 512-byte record with dword loads (every fetched line is consumed
+// completely by the same lane, so HBM traffic equals the algorithmic 512 B/header) and keeps the 14-leaf tree in
+// registers: 15 leaf blocks + 13 x 2 inner blocks = 41 compressions.
+constexpr int HM_THREADS = 256;
 
 __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
                                                               uint8_t* __restrict__ lb_aunts, uint32_t* __restrict__ status) {
-    __shared__ uint32_t lds[HM_THREADS * HM_A_STRIDE];
-    const int tid = threadIdx.x;
-    const uint64_t base = (uint64_t)blockIdx.x * HM_THREADS;
-    const uint64_t me = base + tid;
+    const uint64_t me = (uint64_t)blockIdx.x * HM_THREADS + threadIdx.x;
     const bool live = me < n;
-
-    // ---- stage A (coalesced 16-byte loads, 20 pieces per header)
-    for (int c = tid; c < HM_THREADS * (HM_A_BYTES / 16); c += HM_THREADS) {
-        const int hl = c / (HM_A_BYTES / 16), piece = c % (HM_A_BYTES / 16);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (base + hl < n) v = reinterpret_cast<const uint4*>(hdr + base + hl)[piece];
-        uint32_t* d = lds + hl * HM_A_STRIDE + piece * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
-
-    const uint32_t* my = lds + tid * HM_A_STRIDE;
+    const uint32_t* my = reinterpret_cast<const uint32_t*>(hdr + (live ? me : 0));
     int len[14];
     {
-        const uint32_t l0 = my[0], l1 = my[1], l2 = my[2], l3 = my[3];
-        const uint32_t lw[4] = {l0, l1, l2, l3};
+        const uint4 l = *reinterpret_cast<const uint4*>(my);
+        const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
         for (int i = 0; i < 14; i++) len[i] = (int)((lw[i >> 2] >> (8 * (i & 3))) & 0xff);
     }
@@ -114,63 +105,55 @@ __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* 
             if (len[i] > cap[i]) { bad = true; len[i] = cap[i]; }
         }
     }
-    Digest left, n0123, n45, n67, L5, L7;
+    // byte offsets: version 16, chain_id 40, height 92, time 104, last_block_id 124, hash[j] 200+36j, proposer 488
+    Digest left, right;
     {
-        Digest L0 = leaf_from_lds<6>(my + 4, len[0]);        // version   @16
-        Digest L1 = leaf_from_lds<13>(my + 10, len[1]);      // chain_id  @40
-        Digest n01 = inner_hash(L0, L1);
-        Digest L2 = leaf_from_lds<3>(my + 23, len[2]);       // height    @92
-        Digest L3 = leaf_from_lds<5>(my + 26, len[3]);       // time      @104
-        Digest n23 = inner_hash(L2, L3);
-        n0123 = inner_hash(n01, n23);
-        Digest L4;
+        Digest n0123, n45, n67, L5, L7;
         {
-            uint32_t d[19];                                  // last_block_id @124 (76 B capacity)
+            const Digest L0 = leaf_from_global<6>(my + 4, len[0]);
+            const Digest L1 = leaf_from_global<13>(my + 10, len[1]);
+            const Digest n01 = inner_hash(L0, L1);
+            const Digest L2 = leaf_from_global<3>(my + 23, len[2]);
+            const Digest L3 = leaf_from_global<5>(my + 26, len[3]);
+            n0123 = inner_hash(n01, inner_hash(L2, L3));
+        }
+        {
+            Digest L4;
+            uint32_t d[19];
 #pragma unroll
             for (int j = 0; j < 19; j++) d[j] = my[31 + j];
             L4 = (len[4] <= 54) ? leaf_hash_1block(d, len[4]) : leaf_hash_2block(d, len[4]);
+            L5 = leaf_from_global<9>(my + 50, len[5]);
+            n45 = inner_hash(L4, L5);
         }
-        L5 = leaf_from_lds<9>(my + 50, len[5]);              // hash[0]   @200
-        n45 = inner_hash(L4, L5);
-        Digest L6 = leaf_from_lds<9>(my + 59, len[6]);       // hash[1]   @236  (data_hash)
-        L7 = leaf_from_lds<9>(my + 68, len[7]);              // hash[2]   @272
-        n67 = inner_hash(L6, L7);
+        {
+            const Digest L6 = leaf_from_global<9>(my + 59, len[6]);   // data_hash
+            L7 = leaf_from_global<9>(my + 68, len[7]);
+            n67 = inner_hash(L6, L7);
+        }
         left = inner_hash(n0123, inner_hash(n45, n67));
-    }
-    if (live) {
-        if (lb_aunts) {  // index 4: [L5, n67, n0123, right]
-            store_digest_global16(lb_aunts + me * 128, L5);
-            store_digest_global16(lb_aunts + me * 128 + 32, n67);
-            store_digest_global16(lb_aunts + me * 128 + 64, n0123);
+        if (live) {
+            if (lb_aunts) {  // index 4: [L5, n67, n0123, right]
+                store_digest_global16(lb_aunts + me * 128, L5);
+                store_digest_global16(lb_aunts + me * 128 + 32, n67);
+                store_digest_global16(lb_aunts + me * 128 + 64, n0123);
+            }
+            if (dh_aunts) {  // index 6: [L7, n45, n0123, right]
+                store_digest_global16(dh_aunts + me * 128, L7);
+                store_digest_global16(dh_aunts + me * 128 + 32, n45);
+                store_digest_global16(dh_aunts + me * 128 + 64, n0123);
+            }
         }
-        if (dh_aunts) {  // index 6: [L7, n45, n0123, right]
-            store_digest_global16(dh_aunts + me * 128, L7);
-            store_digest_global16(dh_aunts + me * 128 + 32, n45);
-            store_digest_global16(dh_aunts + me * 128 + 64, n0123);
-        }
     }
-    __syncthreads();
-
-    // ---- stage B
-    for (int c = tid; c < HM_THREADS * (HM_B_BYTES / 16); c += HM_THREADS) {
-        const int hl = c / (HM_B_BYTES / 16), piece = c % (HM_B_BYTES / 16);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (base + hl < n) v = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(hdr + base + hl) + HM_B_OFF)[piece];
-        uint32_t* d = lds + hl * HM_B_STRIDE + piece * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
-    const uint32_t* mb = lds + tid * HM_B_STRIDE;
-    Digest right;
     {
-        Digest L8 = leaf_from_lds<9>(mb + 1, len[8]);        // hash[3] @308 -> local 4
-        Digest L9 = leaf_from_lds<9>(mb + 10, len[9]);       // hash[4] @344
-        Digest n89 = inner_hash(L8, L9);
-        Digest L10 = leaf_from_lds<9>(mb + 19, len[10]);     // hash[5] @380
-        Digest L11 = leaf_from_lds<9>(mb + 28, len[11]);     // hash[6] @416
-        Digest n8_11 = inner_hash(n89, inner_hash(L10, L11));
-        Digest L12 = leaf_from_lds<9>(mb + 37, len[12]);     // hash[7] @452
-        Digest L13 = leaf_from_lds<6>(mb + 46, len[13]);     // proposer @488
+        const Digest L8 = leaf_from_global<9>(my + 77, len[8]);
+        const Digest L9 = leaf_from_global<9>(my + 86, len[9]);
+        const Digest n89 = inner_hash(L8, L9);
+        const Digest L10 = leaf_from_global<9>(my + 95, len[10]);
+        const Digest L11 = leaf_from_global<9>(my + 104, len[11]);
+        const Digest n8_11 = inner_hash(n89, inner_hash(L10, L11));
+        const Digest L12 = leaf_from_global<9>(my + 113, len[12]);
+        const Digest L13 = leaf_from_global<6>(my + 122, len[13]);
         right = inner_hash(n8_11, inner_hash(L12, L13));
     }
     const Digest root = inner_hash(left, right);
@@ -181,7 +164,7 @@ __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* 
     }
     // wave-ballot reduction of the "bad header" predicate: one atomic per wave
     const unsigned long long m = __ballot(live && bad);
-    if (m && (tid & 63) == 0 && status) atomicOr(status, 1u);
+    if (m && (threadIdx.x & 63) == 0 && status) atomicOr(status, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ k_assemble_inputs
@@ -211,9 +194,9 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     // number of real proofs: dh for [start, req_end), lb for (start, req_end]  (input.rs:167-198)
     const uint64_t n_real = (batch_start <= req_end) ? (req_end - batch_start) : 0;
     const bool have_hdrs = batch_start < req_end;              // input.rs:249
-    const uint64_t hbase = (uint64_t)r * a.headers_per_range - a.header_first_rel;  // virtual index of height S (never dereferenced below rel)
+    const uint64_t hbase = (uint64_t)r * a.headers_per_range - a.header_first_rel;  // virtual index of height S
     bool oob = false;
-    if (batch_start <= req_end && ((batch_start - S) < a.header_first_rel || (req_end - S - a.header_first_rel) >= a.headers_per_range)) oob = true;  // headers not supplied
+    if (batch_start <= req_end && ((batch_start - S) < a.header_first_rel || (req_end - S - a.header_first_rel) >= a.headers_per_range)) oob = true;
     uint8_t* cw = a.compact + ((uint64_t)r * a.job_count + jl) * a.compact_stride;
     uint32_t* cw32 = reinterpret_cast<uint32_t*>(cw);
 
@@ -229,7 +212,7 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     }
     // proofs: flat dword stream over [128, 128 + 362*B)
     const uint32_t lb_off = bsx_off_lb_proofs(B) - 128;         // byte offset of the lb array inside the stream
-    const uint32_t total = (BSX_DH_PROOF_SIZE + BSX_LB_PROOF_SIZE) * B;  // multiple of 4? 362*B: B even -> yes; B == 1 -> 362
+    const uint32_t total = (BSX_DH_PROOF_SIZE + BSX_LB_PROOF_SIZE) * B;
     const uint32_t ndw = (total + 3) / 4;
     bool bad_leaf = false;
     for (uint32_t w = threadIdx.x; w < ndw; w += blockDim.x) {
@@ -274,167 +257,177 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     if (__ballot(bad_leaf) && (threadIdx.x & 63) == 0 && a.status) atomicOr(a.status, 2u);
 }
 
-// ------------------------------------------------------------------------------------------------ k_prove_subchain
-// 256 consecutive slots of one range per workgroup (256/B map jobs when B < 256).  LDS: proof staging (<= 51.2 KB,
-// reused for the tree) -> 3 WG / CU.
+// ------------------------------------------------------------------------------------------------ prove_subchain
 struct SubchainArgs {
-    uint32_t n_ranges, batch, job_count;     // job_count = map jobs per range owned by this call
+    uint32_t n_jobs, batch;                  // n_jobs = n_ranges * job_count (compact witnesses are consecutive)
+    uint32_t job_count;                      // map jobs per range in this call (range of job q = q / job_count)
     const bsx_shared_ctx* ranges;
     uint8_t* compact;
     uint32_t compact_stride, off_words, off_bools;
     bsx_subchain* records;
+    uint32_t level, width, level_off;        // k_tree_level: nodes per job at this level, offset of the level in inner[]/node[]
 };
-constexpr int SC_THREADS = 256;
-constexpr int SC_LDS_DWORDS = 256 * 52;        // 256 lb proofs (200 B) + per-job funnel slack (worst case B == 1)
 
-// dword k of a byte region that starts at LDS byte offset `boff` (2-byte aligned) — funnel of two aligned dwords
-__device__ __forceinline__ uint32_t lds_dword_at(const uint32_t* lds, uint32_t boff, int k) {
-    const uint32_t a = (boff >> 2) + k, sh = (boff & 3) * 8;
-    return funnel_r(lds[a + 1], lds[a], sh);
+// dword k of a byte region starting at global byte address p (2-byte aligned): funnel of two aligned dwords
+__device__ __forceinline__ uint32_t gdword_at(const uint8_t* p, int k) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3) + k;
+    const uint32_t sh = (uint32_t)(a & 3) * 8;
+    return sh ? funnel_r(q[1], q[0], sh) : q[0];
 }
 
-__global__ __launch_bounds__(SC_THREADS) void k_prove_subchain(SubchainArgs a) {
-    __shared__ uint32_t lds[SC_LDS_DWORDS];
-    __shared__ uint32_t job_fail[256];       // per local job: OR of failed assertion bits
-    __shared__ uint32_t job_first_bad[256];  // per local job: lowest failing slot
+// ---- stage 1: one lane per slot, no communication (builder.rs:180-199, 134-137 + leaf hashes of :144-147)
+constexpr int SH_THREADS = 256;
+__global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
     const uint32_t B = a.batch;
-    const uint32_t slots_per_range = a.job_count * B;
-    const uint32_t blocks_per_range = (slots_per_range + SC_THREADS - 1) / SC_THREADS;
-    const uint32_t r = blockIdx.x / blocks_per_range, blk = blockIdx.x % blocks_per_range;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t slot0 = blk * SC_THREADS;                       // first slot of this block within the range
-    const uint32_t nslots = min((uint32_t)SC_THREADS, slots_per_range - slot0);
-    const uint32_t jobs_here = (nslots + B - 1) / B;               // B <= 256 and aligned: nslots is a multiple of B
-    const uint32_t job0 = slot0 / B;
-    const bool live = tid < nslots;
-    const uint32_t jl = live ? tid / B : 0, i = live ? tid % B : 0;   // local job, slot in job
-    uint8_t* cw = a.compact + ((uint64_t)r * a.job_count + job0 + jl) * a.compact_stride;
-    uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
-    uint8_t* Bo = cw + a.off_bools;
-    const bsx_shared_ctx* rg = a.ranges + r;
-    const uint64_t E = rg->end_block;
+    const uint64_t gs = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x;     // global slot index
+    if (gs >= (uint64_t)a.n_jobs * B) return;
+    const uint32_t q = (uint32_t)(gs / B), i = (uint32_t)(gs % B);
+    uint8_t* cw = a.compact + (uint64_t)q * a.compact_stride;
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(cw + a.off_words);
     const uint64_t batch_start = (uint64_t)W[BSX_W_BATCH_START] | ((uint64_t)W[BSX_W_BATCH_START + 1] << 32);
-    const uint64_t batch_end = (uint64_t)W[BSX_W_BATCH_END] | ((uint64_t)W[BSX_W_BATCH_END + 1] << 32);
+    uint8_t* sl = cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i;
 
-    if (tid < 256) { job_fail[tid] = 0; job_first_bad[tid] = 0xffffffffu; }
-
-    // ---- stage the data_hash proofs of every local job: bytes [128, 128+162*B) of each compact witness
-    const uint32_t dh_dw = (BSX_DH_PROOF_SIZE * B + 3) / 4 + 1;      // dwords per job region (+1 funnel slack)
-    for (uint32_t c = tid; c < jobs_here * dh_dw; c += SC_THREADS) {
-        const uint32_t q = c / dh_dw, k = c % dh_dw;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.compact + ((uint64_t)r * a.job_count + job0 + q) * a.compact_stride + 128);
-        lds[q * dh_dw + k] = (k * 4 < BSX_DH_PROOF_SIZE * B) ? src[k] : 0u;
-    }
-    __syncthreads();
-
-    Digest dh_root, dh_leafhash;
-    uint32_t data_hash_le[8];   // leaf[2..34] as LE dwords
+    uint32_t data_hash_le[8];   // data_hash_proofs[i].leaf[2..34] as LE dwords (builder.rs:250)
     {
-        const uint32_t boff = jl * dh_dw * 4 + i * BSX_DH_PROOF_SIZE;
+        const uint8_t* pr = cw + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * i;
         uint32_t lf[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) lf[k] = lds_dword_at(lds, boff + 128, k);
-        lf[8] &= 0xffffu;
+        for (int k = 0; k < 8; k++) lf[k] = gdword_at(pr + 128, k);
+        lf[8] = (uint32_t)reinterpret_cast<const uint16_t*>(pr + 160)[0];
 #pragma unroll
-        for (int k = 0; k < 8; k++) data_hash_le[k] = funnel_r(lf[k + 1], lf[k], 16);   // bytes 2.. of the leaf
+        for (int k = 0; k < 8; k++) data_hash_le[k] = funnel_r(lf[k + 1], lf[k], 16);
         Digest h = leaf_hash_34(lf);
-        dh_leafhash = h;
-        uint8_t* sl = cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i;
-        if (live) store_digest_global(sl, h);
+        store_digest_global(sl, h);
         // path [0,1,1,0] (builder.rs:166-167): h = bit ? inner(aunt, h) : inner(h, aunt)
 #pragma unroll
         for (int lvl = 0; lvl < 4; lvl++) {
             uint32_t al[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) al[k] = lds_dword_at(lds, boff + 32 * lvl, k);
+            for (int k = 0; k < 8; k++) al[k] = gdword_at(pr + 32 * lvl, k);
             const Digest aunt = digest_from_le(al);
             h = (lvl == 1 || lvl == 2) ? inner_hash(aunt, h) : inner_hash(h, aunt);
-            if (live) store_digest_global(sl + 32 * (lvl + 1), h);
+            store_digest_global(sl + 32 * (lvl + 1), h);
         }
-        dh_root = h;
     }
-    __syncthreads();
-
-    // ---- stage the last_block_id proofs: bytes [128+162*B, 128+362*B)
-    const uint32_t lb_byte0 = bsx_off_lb_proofs(B);                  // 2-byte aligned when B is odd (B == 1)
-    const uint32_t lb_dw = (BSX_LB_PROOF_SIZE * B + (lb_byte0 & 3) + 3) / 4 + 1;
-    for (uint32_t c = tid; c < jobs_here * lb_dw; c += SC_THREADS) {
-        const uint32_t q = c / lb_dw, k = c % lb_dw;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.compact + ((uint64_t)r * a.job_count + job0 + q) * a.compact_stride + (lb_byte0 & ~3u));
-        lds[q * lb_dw + k] = (k * 4 < BSX_LB_PROOF_SIZE * B + (lb_byte0 & 3)) ? src[k] : 0u;
-    }
-    __syncthreads();
-
-    Digest lb_root, claimed;   // claimed = last_block_id_proofs[i].leaf[2..34] (builder.rs:204)
     {
-        const uint32_t boff = jl * lb_dw * 4 + (lb_byte0 & 3) + i * BSX_LB_PROOF_SIZE;
-        uint32_t lf[19];
+        const uint8_t* pr = cw + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * i;
+        uint32_t lf[18];
 #pragma unroll
-        for (int k = 0; k < 18; k++) lf[k] = lds_dword_at(lds, boff + 128, k);
-        lf[18] = 0;
-        {
-            uint32_t c[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) c[k] = funnel_r(lf[k + 1], lf[k], 16);
-            claimed = digest_from_le(c);
-        }
+        for (int k = 0; k < 18; k++) lf[k] = gdword_at(pr + 128, k);
         Digest h = leaf_hash_72(lf);
-        uint8_t* sl = cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i + 160;
-        if (live) store_digest_global(sl, h);
+        store_digest_global(sl + 160, h);
         // path [0,0,1,0] (builder.rs:168-169)
 #pragma unroll
         for (int lvl = 0; lvl < 4; lvl++) {
             uint32_t al[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) al[k] = lds_dword_at(lds, boff + 32 * lvl, k);
+            for (int k = 0; k < 8; k++) al[k] = gdword_at(pr + 32 * lvl, k);
             const Digest aunt = digest_from_le(al);
             h = (lvl == 2) ? inner_hash(aunt, h) : inner_hash(h, aunt);
-            if (live) store_digest_global(sl + 32 * (lvl + 1), h);
+            store_digest_global(sl + 160 + 32 * (lvl + 1), h);
         }
-        lb_root = h;
     }
-    __syncthreads();   // staging area is free from here on
-
-    // ---- LDS reuse: lb roots [256][8], tree nodes ping/pong [256][8] x2
-    uint32_t* lds_lbroot = lds;
-    uint32_t* lds_tree0 = lds + 256 * 8;
-    uint32_t* lds_tree1 = lds + 2 * 256 * 8;
-    store_digest_lds(lds_lbroot + tid * 8, lb_root);
-
     // data-root tuple (builder.rs:82-103,134-137) and its leaf hash
-    const uint64_t curr_idx = batch_start + i;                       // builder.rs:182 / :134 (same value)
-    Digest tleaf;
-    {
-        uint32_t t[16];
+    const uint64_t curr_idx = batch_start + i;
+    uint32_t t[16];
 #pragma unroll
-        for (int k = 0; k < 6; k++) t[k] = 0;
-        t[6] = (uint32_t)(curr_idx >> 32);
-        t[7] = (uint32_t)curr_idx;
+    for (int k = 0; k < 6; k++) t[k] = 0;
+    t[6] = (uint32_t)(curr_idx >> 32);
+    t[7] = (uint32_t)curr_idx;
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[8 + k] = bswap32(data_hash_le[k]);
-        tleaf = leaf_hash_tuple(t);
-        if (live) {
-            uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
+    for (int k = 0; k < 8; k++) t[8 + k] = bswap32(data_hash_le[k]);
+    const Digest tleaf = leaf_hash_tuple(t);
+    uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
 #pragma unroll
-            for (int k = 0; k < 16; k++) store_u32_a2(tp + 4 * k, bswap32(t[k]));
-            store_digest_global(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
-        }
-    }
-    store_digest_lds(lds_tree0 + tid * 8, tleaf);
-    __syncthreads();
+    for (int k = 0; k < 16; k++) store_u32_a2(tp + 4 * k, bswap32(t[k]));
+    store_digest_global(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
+}
 
-    // ---- chain-link predicates (builder.rs:174-226).  Enabled slots form a prefix [0, m) of the batch.
+// batch bounds of a job (builder.rs:235-243) from its compact witness and the global end block
+__device__ __forceinline__ void batch_bounds(const uint32_t* W, uint64_t E, uint64_t& bs, uint64_t& be, uint64_t& temp_end,
+                                             uint64_t& end_block_num) {
+    bs = (uint64_t)W[BSX_W_BATCH_START] | ((uint64_t)W[BSX_W_BATCH_START + 1] << 32);
+    be = (uint64_t)W[BSX_W_BATCH_END] | ((uint64_t)W[BSX_W_BATCH_END + 1] << 32);
+    temp_end = (be < E) ? be : E;                       // :235-240
+    end_block_num = (temp_end < bs) ? bs : temp_end;    // :241-243
+}
+
+// ---- stage 2: one level of compute_root_from_leaves [UPSTREAM plonky2x; SURVEY App. B] for all jobs at once:
+// inner = inner_hash(l, r) always; node = both children enabled ? inner : l; enabled = l || r (prefix mask).
+constexpr int TR_THREADS = 256;
+__global__ __launch_bounds__(TR_THREADS) void k_tree_level(SubchainArgs a) {
+    const uint32_t B = a.batch, width = a.width;
+    const uint64_t g = (uint64_t)blockIdx.x * TR_THREADS + threadIdx.x;
+    if (g >= (uint64_t)a.n_jobs * width) return;
+    const uint32_t q = (uint32_t)(g / width), t = (uint32_t)(g % width);
+    uint8_t* cw = a.compact + (uint64_t)q * a.compact_stride;
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(cw + a.off_words);
+    const uint64_t E = a.ranges[q / a.job_count].end_block;
+    uint64_t bs, be, te, ebn;
+    batch_bounds(W, E, bs, be, te, ebn);
+    const uint32_t nb = (uint32_t)(ebn - bs);           // builder.rs:119,124 nb_enabled_leaves (low limb)
+    const uint32_t span = 1u << a.level;                 // leaves under a node of this level
+    // children: level 1 reads the leaf hashes, upper levels the previous level's selected nodes
+    const uint8_t* ch = (a.level == 1) ? cw + bsx_off_leaf_hashes(B) + 64 * t
+                                       : cw + bsx_off_nodes(B) + 32 * (a.level_off - 2 * width + 2 * t);
+    const Digest l = load_digest_global(ch), r = load_digest_global(ch + 32);
+    const Digest in = inner_hash(l, r);
+    const bool en_l = t * span < nb, en_r = t * span + span / 2 < nb;
+    const Digest node = (en_l && en_r) ? in : l;
+    store_digest_global(cw + bsx_off_inner(B) + 32 * (a.level_off + t), in);
+    store_digest_global(cw + bsx_off_nodes(B) + 32 * (a.level_off + t), node);
+    cw[a.off_bools + bsx_b_node_enabled(B) + a.level_off + t] = en_l || en_r;
+}
+
+// ---- stage 3: predicates + batch tail (builder.rs:174-270), no hashing.  256 consecutive slots per workgroup;
+// per-slot assertion bits are reduced with a wave ballot and at most one LDS atomic per failing lane.
+constexpr int BF_THREADS = 256;
+__global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
+    __shared__ uint32_t job_fail[BF_THREADS];
+    __shared__ uint32_t job_first_bad[BF_THREADS];
+    const uint32_t B = a.batch, tid = threadIdx.x;
+    const uint64_t total = (uint64_t)a.n_jobs * B;
+    const uint64_t gs0 = (uint64_t)blockIdx.x * BF_THREADS;
+    const uint64_t gs = gs0 + tid;
+    const bool live = gs < total;
+    const uint32_t q = live ? (uint32_t)(gs / B) : 0, i = live ? (uint32_t)(gs % B) : 0;
+    const uint32_t jl = live ? q - (uint32_t)(gs0 / B) : 0;          // job index inside the block (B <= BF_THREADS, aligned)
+    job_fail[tid] = 0;
+    job_first_bad[tid] = 0xffffffffu;
+    __syncthreads();
+    uint8_t* cw = a.compact + (uint64_t)q * a.compact_stride;
+    uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
+    uint8_t* Bo = cw + a.off_bools;
+    const bsx_shared_ctx* rg = a.ranges + q / a.job_count;
+    const uint64_t E = rg->end_block;
+    uint64_t batch_start, batch_end, temp_end, end_block_num;
+    batch_bounds(W, E, batch_start, batch_end, temp_end, end_block_num);
+    const uint64_t curr_idx = batch_start + i;                       // builder.rs:182 / :134
+
+    // Enabled slots form a prefix [0, m) of the batch (closed form of the :174-175,:225 recurrence).
     const bool batch_enabled = batch_start < E;                      // :174
     const uint64_t last_to_process = E - 1;                          // :177
     const uint64_t jstar = last_to_process - batch_start;            // slot index of the last block (wrapping)
     const uint32_t m = batch_enabled ? (uint32_t)((jstar < (uint64_t)B) ? jstar + 1 : B) : 0u;
     const bool en_before = i < m;                                    // curr_block_enabled entering slot i
     const bool is_last = (last_to_process == curr_idx);              // :185
+    const uint8_t* slots = cw + bsx_off_slots(B);
     // curr_header entering slot i = start_header (i == 0 or m == 0) else lb_root of slot min(i, m) - 1
     const Digest start_header = load_digest_global(cw + bsx_off_start_header());
     Digest curr_before = start_header, curr_after = start_header;
-    if (i > 0 && m > 0) curr_before = load_digest_lds(lds_lbroot + (jl * B + min(i, m) - 1) * 8);
-    if (m > 0) curr_after = load_digest_lds(lds_lbroot + (jl * B + min(i + 1, m) - 1) * 8);
+    if (i > 0 && m > 0) curr_before = load_digest_global(slots + BSX_SLOT_BYTES * (min(i, m) - 1) + 160 + 128);
+    if (m > 0) curr_after = load_digest_global(slots + BSX_SLOT_BYTES * (min(i + 1, m) - 1) + 160 + 128);
+    const Digest dh_root = load_digest_global(slots + BSX_SLOT_BYTES * i + 128);
+    const Digest lb_root = load_digest_global(slots + BSX_SLOT_BYTES * i + 160 + 128);
+    Digest claimed;                                                  // last_block_id_proofs[i].leaf[2..34] (:204)
+    {
+        const uint8_t* lf = cw + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * i + 128 + 2;
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = gdword_at(lf, k);
+        claimed = digest_from_le(c);
+    }
     const Digest H_E = load_digest_global(rg->end_header_hash);
     const bool valid_prev = digest_eq(curr_before, claimed);         // :205
     const bool prev_check = !en_before || valid_prev;                // :206
@@ -443,6 +436,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_prove_subchain(SubchainArgs a) {
     const bool root_matches_end = digest_eq(lb_root, H_E);           // :216
     const bool end_check = !is_last || root_matches_end;             // :218
     const bool en_after = en_before && !is_last;                     // :225
+    const uint32_t nb_enabled = (uint32_t)(end_block_num - batch_start);   // :119,124
     if (live) {
         store_digest_global(cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i + 320, curr_after);   // :223
         W[BSX_W_CURR_IDX + 2 * i] = (uint32_t)curr_idx; W[BSX_W_CURR_IDX + 2 * i + 1] = (uint32_t)(curr_idx >> 32);
@@ -450,73 +444,34 @@ __global__ __launch_bounds__(SC_THREADS) void k_prove_subchain(SubchainArgs a) {
         uint8_t* b = Bo + BSX_B_SLOTS + BSX_SLOT_BOOLS * i;
         b[0] = !en_before; b[1] = is_last; b[2] = valid_prev; b[3] = prev_check; b[4] = dh_valid; b[5] = dh_check;
         b[6] = root_matches_end; b[7] = end_check; b[8] = en_after;
+        Bo[bsx_b_leaf_enabled(B) + i] = i < nb_enabled;
     }
-    // wave-ballot reduction of the three per-slot assertions; one LDS atomic per (wave, job) instead of per lane
     {
         const uint32_t f = live ? ((prev_check ? 0u : BSX_A3_PREV_HEADER) | (dh_check ? 0u : BSX_A4_DATA_HASH_PROOF) |
                                    (end_check ? 0u : BSX_A5_END_HEADER)) : 0u;
-        if (__ballot(f != 0)) {          // rare path
+        if (__ballot(f != 0)) {          // rare path: some lane of this wave failed an assertion
             if (f) { atomicOr(&job_fail[jl], f); atomicMin(&job_first_bad[jl], i); }
         }
     }
-
-    // ---- get_data_commitment (builder.rs:105-148): masked tree over the B tuple leaf hashes of each job
-    const uint64_t temp_end = (batch_end < E) ? batch_end : E;       // :235-240
-    const bool end_lt_start = temp_end < batch_start;                // :241
-    const uint64_t end_block_num = end_lt_start ? batch_start : temp_end;   // :242-243
-    const bool gte = end_block_num >= batch_start;                   // :113 (A1)
-    const uint64_t nb_blocks = end_block_num - batch_start;          // :119
-    const uint32_t nb_enabled = (uint32_t)nb_blocks;                 // :124 (low limb)
-    if (live) Bo[bsx_b_leaf_enabled(B) + i] = i < nb_enabled;
-    uint32_t* cur = lds_tree0;
-    uint32_t* nxt = lds_tree1;
-    uint32_t level_off = 0;
-    for (uint32_t width = B / 2, span = 2; width >= 1; width /= 2, span *= 2) {   // width = nodes per job at this level
-        const uint32_t total_nodes = jobs_here * width;
-        if (tid < total_nodes) {
-            const uint32_t q = tid / width, t = tid % width;          // job, node in job
-            const Digest l = load_digest_lds(cur + (q * width * 2 + 2 * t) * 8);
-            const Digest rr = load_digest_lds(cur + (q * width * 2 + 2 * t + 1) * 8);
-            const Digest in = inner_hash(l, rr);
-            // enabled(left child) = t*span < nb ; enabled(right child) = t*span + span/2 < nb   (prefix mask)
-            uint8_t* cwq = a.compact + ((uint64_t)r * a.job_count + job0 + q) * a.compact_stride;
-            const uint32_t* Wq = reinterpret_cast<const uint32_t*>(cwq + a.off_words);
-            const uint64_t bs = (uint64_t)Wq[BSX_W_BATCH_START] | ((uint64_t)Wq[BSX_W_BATCH_START + 1] << 32);
-            const uint64_t be = (uint64_t)Wq[BSX_W_BATCH_END] | ((uint64_t)Wq[BSX_W_BATCH_END + 1] << 32);
-            const uint64_t te = (be < E) ? be : E;
-            const uint64_t ebn = (te < bs) ? bs : te;
-            const uint32_t nbq = (uint32_t)(ebn - bs);
-            const bool en_l = t * span < nbq, en_r = t * span + span / 2 < nbq;
-            const Digest node = (en_l && en_r) ? in : l;
-            store_digest_lds(nxt + (q * width + t) * 8, node);
-            store_digest_global(cwq + bsx_off_inner(B) + 32 * (level_off + t), in);
-            store_digest_global(cwq + bsx_off_nodes(B) + 32 * (level_off + t), node);
-            cwq[a.off_bools + bsx_b_node_enabled(B) + level_off + t] = en_l || en_r;
-        }
-        level_off += width;
-        __syncthreads();
-        uint32_t* tmp = cur; cur = nxt; nxt = tmp;
-    }
-    // B == 1: no loop iteration; root = the leaf hash.  `cur` holds one root per job at [q*8].
     __syncthreads();
-
-    // ---- batch tail + record (builder.rs:229-270): one lane per job
+    // batch tail + record (builder.rs:229-270): one lane per job
     if (live && i == 0) {
-        const Digest root = load_digest_lds(cur + jl * 8);
-        // enabled after slot B-1 <=> all B slots enabled and slot B-1 is not the last block <=> jstar >= B (or batch disabled -> false)
-        const bool curr_enabled_end = batch_enabled && !(jstar < (uint64_t)B);
-        const Digest curr_final = (m > 0) ? load_digest_lds(lds_lbroot + (jl * B + m - 1) * 8) : start_header;
+        const Digest root = load_digest_global(B > 1 ? cw + bsx_off_nodes(B) + 32 * (B - 2) : cw + bsx_off_leaf_hashes(B));
+        const bool curr_enabled_end = batch_enabled && !(jstar < (uint64_t)B);   // enabled after the last slot
+        const Digest curr_final = (m > 0) ? load_digest_global(slots + BSX_SLOT_BYTES * (m - 1) + 160 + 128) : start_header;
         const Digest end_header = load_digest_global(cw + bsx_off_end_header());
         const bool last_disabled = !curr_enabled_end;                     // :229
         const bool last_matches = digest_eq(curr_final, end_header);      // :230
         const bool end_header_check = last_disabled || last_matches;      // :231
+        const bool gte = end_block_num >= batch_start;                    // :113 (A1)
+        const uint64_t nb_blocks = end_block_num - batch_start;           // :119
         uint32_t fail = job_fail[jl];
         uint32_t first_bad = job_first_bad[jl];
         if (!end_header_check) { fail |= BSX_A6_BATCH_END; if (first_bad == 0xffffffffu) first_bad = B; }
         if (!gte) { fail |= BSX_A1_END_GTE_START; if (first_bad == 0xffffffffu) first_bad = B; }
         if ((nb_blocks >> 32) != 0) { fail |= BSX_A2_NB_BLOCKS_U32; if (first_bad == 0xffffffffu) first_bad = B; }
         uint8_t* t = Bo + bsx_b_tail(B);
-        t[0] = last_disabled; t[1] = last_matches; t[2] = end_header_check; t[3] = batch_end < E; t[4] = end_lt_start; t[5] = gte;
+        t[0] = last_disabled; t[1] = last_matches; t[2] = end_header_check; t[3] = batch_end < E; t[4] = temp_end < batch_start; t[5] = gte;
         Bo[BSX_B_BATCH_ENABLED] = batch_enabled;
         Bo[bsx_b_rec_enabled(B)] = batch_enabled;
         W[BSX_W_LAST_TO_PROCESS] = (uint32_t)last_to_process; W[BSX_W_LAST_TO_PROCESS + 1] = (uint32_t)(last_to_process >> 32);
@@ -529,7 +484,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_prove_subchain(SubchainArgs a) {
         store_digest_global(rec_b, start_header);
         store_digest_global(rec_b + 32, curr_final);
         store_digest_global(rec_b + 64, root);
-        bsx_subchain* out = a.records + (uint64_t)r * a.job_count + job0 + jl;
+        bsx_subchain* out = a.records + q;
         out->start_block = batch_start;
         out->end_block = end_block_num;
         store_digest_global(out->start_header, start_header);
@@ -647,34 +602,45 @@ __device__ __forceinline__ uint64_t expand_elem(const ExpandArgs& a, const uint8
     e -= a.lay.n_words;
     return c[a.lay.off_bools + e];
 }
-constexpr int EX_THREADS = 256, EX_PAIRS_PER_THREAD = 8;
+// Each workgroup stages EX_CHUNK source bytes in LDS with ONE coalesced dword load per lane, then every lane reads
+// the byte(s) of its pair from LDS: the vector-memory pipe carries (almost) nothing but the 16-byte stores.
+constexpr int EX_THREADS = 256, EX_CHUNK = 1024, EX_PAIRS_PER_BLOCK = EX_CHUNK * 4;
 __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
-    const uint32_t job = blockIdx.y;
+    __shared__ uint32_t lds[EX_CHUNK / 4 + 2];
+    const uint32_t job = blockIdx.y, tid = threadIdx.x;
     const uint8_t* c = a.compact + (uint64_t)job * a.lay.compact_stride;
     const uint64_t nel = a.lay.n_elements;
     const uint64_t g0 = (uint64_t)job * nel;                 // global element index of this job's first element
-    const uint64_t odd = g0 & 1;
-    uint64_t* out = a.out;
-    const int64_t nbits = 8ll * a.lay.n_bytes;
+    const uint32_t odd = (uint32_t)(g0 & 1);
+    const uint32_t nbits = 8u * a.lay.n_bytes;
     // local pair p covers local elements 2p - odd, 2p - odd + 1
-    const uint64_t npairs = (nel + odd + 1) / 2;
-    const uint64_t p0 = (uint64_t)blockIdx.x * (EX_THREADS * EX_PAIRS_PER_THREAD);
-#pragma unroll
-    for (int u = 0; u < EX_PAIRS_PER_THREAD; u++) {
-        const uint64_t p = p0 + (uint64_t)u * EX_THREADS + threadIdx.x;
-        if (p >= npairs) continue;
-        const int64_t e0 = (int64_t)(2 * p) - (int64_t)odd, e1 = e0 + 1;
-        const bool in0 = e0 >= 0, in1 = e1 < (int64_t)nel;
-        uint64_t v0 = 0, v1 = 0;
-        if (in0 && e1 < nbits) {           // fast path: both bits come from the same source byte (e0 even or same byte)
-            const uint32_t by0 = c[e0 >> 3], by1 = c[e1 >> 3];
+    const uint32_t npairs = (uint32_t)((nel + odd + 1) / 2);
+    const uint32_t pbase = blockIdx.x * EX_PAIRS_PER_BLOCK;
+    const int32_t byte0 = (int32_t)(pbase / 4) - 4;          // staged window starts one dword early (odd jobs look back one bit)
+    for (uint32_t t = tid; t < EX_CHUNK / 4 + 2; t += EX_THREADS) {
+        const int32_t bi = byte0 + 4 * (int32_t)t;
+        lds[t] = (bi >= 0 && (uint32_t)bi < a.lay.compact_stride) ? reinterpret_cast<const uint32_t*>(c)[bi >> 2] : 0u;
+    }
+    __syncthreads();
+    const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
+    uint64_t* base = a.out + g0 - odd;                       // 16-byte aligned
+#pragma unroll 4
+    for (int u = 0; u < EX_PAIRS_PER_BLOCK / EX_THREADS; u++) {
+        const uint32_t p = pbase + (uint32_t)u * EX_THREADS + tid;
+        if (p >= npairs) break;
+        const uint32_t e1 = 2 * p + 1 - odd;                 // local index of the pair's second element (>= 0)
+        const bool in0 = (2 * p >= odd), in1 = e1 < nel;
+        uint64_t v0, v1;
+        if (in0 && e1 < nbits) {                             // both elements are bits (the overwhelmingly common case)
+            const uint32_t e0 = e1 - 1;
+            const uint32_t by0 = lb[(int32_t)(e0 >> 3) - byte0], by1 = lb[(int32_t)(e1 >> 3) - byte0];
             v0 = (by0 >> (7 - (e0 & 7))) & 1u;
             v1 = (by1 >> (7 - (e1 & 7))) & 1u;
         } else {
-            if (in0) v0 = expand_elem(a, c, e0);
-            if (in1) v1 = expand_elem(a, c, e1);
+            v0 = in0 ? expand_elem(a, c, (int64_t)e1 - 1) : 0;
+            v1 = in1 ? expand_elem(a, c, (int64_t)e1) : 0;
         }
-        uint64_t* dst = out + g0 + e0;     // 16-byte aligned when both are in range
+        uint64_t* dst = base + 2 * (uint64_t)p;
         if (in0 && in1) {
             *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(v0, v1);
         } else {
@@ -709,9 +675,18 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
                                uint8_t* compact, bsx_subchain* records) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
-    SubchainArgs a{n_ranges, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records};
-    const uint32_t bpr = (job_count * B + SC_THREADS - 1) / SC_THREADS;
-    hipLaunchKernelGGL(k_prove_subchain, dim3(n_ranges * bpr), dim3(SC_THREADS), 0, s, a);
+    const uint32_t n_jobs = n_ranges * job_count;
+    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
+    const uint64_t slots = (uint64_t)n_jobs * B;
+    hipLaunchKernelGGL(k_slot_hashes, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
+    uint32_t level_off = 0, level = 1;
+    for (uint32_t width = B / 2; width >= 1; width /= 2, level++) {
+        a.level = level; a.width = width; a.level_off = level_off;
+        const uint64_t nodes = (uint64_t)n_jobs * width;
+        hipLaunchKernelGGL(k_tree_level, dim3((uint32_t)((nodes + TR_THREADS - 1) / TR_THREADS)), dim3(TR_THREADS), 0, s, a);
+        level_off += width;
+    }
+    hipLaunchKernelGGL(k_batch_finish, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, bsx_subchain* out, uint8_t* reduce_compact) {
@@ -731,7 +706,7 @@ hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uin
     if (!n_jobs) return hipSuccess;
     ExpandArgs a{*lay, n_jobs, compact, out};
     const uint64_t npairs = (lay->n_elements + 2) / 2;
-    const uint32_t gx = (uint32_t)((npairs + EX_THREADS * EX_PAIRS_PER_THREAD - 1) / (EX_THREADS * EX_PAIRS_PER_THREAD));
+    const uint32_t gx = (uint32_t)((npairs + EX_PAIRS_PER_BLOCK - 1) / EX_PAIRS_PER_BLOCK);
     hipLaunchKernelGGL(k_expand_witness, dim3(gx, n_jobs), dim3(EX_THREADS), 0, s, a);
     return hipGetLastError();
 }
