@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ranges", type=int, default=48, help="header_range instances per GPU per step (R)")
+    ap.add_argument("--ranges", type=int, default=256, help="header_range instances per GPU per step (R)")
     ap.add_argument("--jobs", type=int, default=32)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--validators", type=int, default=100)

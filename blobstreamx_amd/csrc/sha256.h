@@ -35,12 +35,18 @@ struct Block16 {
     uint32_t w[16];  // message block, big-endian words
 };
 
+typedef uint32_t u32x8 __attribute__((vector_size(32)));
+typedef uint32_t u32x16 __attribute__((vector_size(64)));
+
 // One compression, by value in / by value out, NOT inlined on the device: the kernels call it from ~40 sites and a
-// fully unrolled body is ~13 KB of code; one shared copy keeps the instruction cache warm.  24 VGPR arguments,
-// 8 VGPR results (AMDGPU calling convention passes them in v0..v31).
-BSX_HD_NOINLINE Digest sha256_compress_fn(Digest st, Block16 blk) {
-    uint32_t a = st.w[0], b = st.w[1], c = st.w[2], d = st.w[3], e = st.w[4], f = st.w[5], g = st.w[6], h = st.w[7];
-    uint32_t* w = blk.w;
+// fully unrolled body is ~13 KB of code; one shared copy keeps the instruction cache warm.  Native vector types so
+// that the AMDGPU calling convention keeps all 24 argument dwords and the 8 result dwords in VGPRs (a 64-byte struct
+// argument is passed byval through scratch memory instead).
+BSX_HD_NOINLINE u32x8 sha256_compress_v(u32x8 stv, u32x16 wv) {
+    uint32_t a = stv[0], b = stv[1], c = stv[2], d = stv[3], e = stv[4], f = stv[5], g = stv[6], h = stv[7];
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = wv[k];
 #pragma unroll
     for (int i = 0; i < 64; i++) {
         if (i >= 16) {
@@ -57,22 +63,35 @@ BSX_HD_NOINLINE Digest sha256_compress_fn(Digest st, Block16 blk) {
         uint32_t t2 = S0 + maj;
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
+    u32x8 o;
+    o[0] = stv[0] + a; o[1] = stv[1] + b; o[2] = stv[2] + c; o[3] = stv[3] + d;
+    o[4] = stv[4] + e; o[5] = stv[5] + f; o[6] = stv[6] + g; o[7] = stv[7] + h;
+    return o;
+}
+BSX_HDI Digest sha256_compress_fn(Digest st, Block16 blk) {
+    u32x8 s;
+    u32x16 b;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = st.w[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = blk.w[k];
+    s = sha256_compress_v(s, b);
     Digest o;
-    o.w[0] = st.w[0] + a; o.w[1] = st.w[1] + b; o.w[2] = st.w[2] + c; o.w[3] = st.w[3] + d;
-    o.w[4] = st.w[4] + e; o.w[5] = st.w[5] + f; o.w[6] = st.w[6] + g; o.w[7] = st.w[7] + h;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o.w[k] = s[k];
     return o;
 }
 // array-style wrapper used by the message builders below
 BSX_HDI void sha256_compress(uint32_t st[8], uint32_t w[16]) {
-    Digest s;
-    Block16 b;
+    u32x8 s;
+    u32x16 b;
 #pragma unroll
-    for (int k = 0; k < 8; k++) s.w[k] = st[k];
+    for (int k = 0; k < 8; k++) s[k] = st[k];
 #pragma unroll
-    for (int k = 0; k < 16; k++) b.w[k] = w[k];
-    s = sha256_compress_fn(s, b);
+    for (int k = 0; k < 16; k++) b[k] = w[k];
+    s = sha256_compress_v(s, b);
 #pragma unroll
-    for (int k = 0; k < 8; k++) st[k] = s.w[k];
+    for (int k = 0; k < 8; k++) st[k] = s[k];
 }
 
 // inner_hash(l, r) = SHA256(0x01 ‖ l ‖ r): 65 bytes -> 2 blocks, built from the two register digests with
