@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--jobs", type=int, default=32)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--validators", type=int, default=100)
+    ap.add_argument("--engines", type=int, default=1, help="chunks of the step issued on separate HIP streams (measured on MI355X: "
+                    "stream-level overlap of the ALU-bound hashing with the HBM-bound expansion does NOT pay: 59.8 / 53.0 / 44.9 M "
+                    "headers/s at 1 / 2 / 4 chunks, DESIGN.md §5)")
     ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
@@ -76,8 +79,8 @@ def stress(args, dev):
     import ctypes as C
     import synth
     from blobstreamx_amd import _lib
-    nh, V = 256, args.validators       # one 256-header sub-range = what one GPU owns at N = 8 (config #4)
-    w = synth.Workload(4, 1, 4, 64, v=V, mode="S")
+    nh, V = args.jobs * args.batch, args.validators       # one whole header_range_2048 with a commit on every header
+    w = synth.Workload(4, 1, args.jobs, args.batch, v=V, mode="S")
     vals = w.validators.reshape(-1)
     n = vals.size
     L, ctx, dp = _lib.lib(), _lib.context(dev.index or 0), _lib.dp
@@ -107,7 +110,7 @@ def stress(args, dev):
         t_sha += ev[0].elapsed_time(ev[1]); t_ed += ev[1].elapsed_time(ev[2]); t_tally += ev[2].elapsed_time(ev[3])
     t_sha, t_ed, t_tally = t_sha / reps, t_ed / reps, t_tally / reps
     tot = t_sha + t_ed + t_tally
-    return {"workload": f"mode S: {nh} headers x {V} validators = {n} signatures (one 256-header sub-range)",
+    return {"workload": f"mode S: {nh} headers x {V} validators = {n} signatures (one header_range_{nh}, a commit per header)",
             "headers_per_s": nh / tot * 1e3, "ed25519_verifies_per_s": n / t_ed * 1e3,
             "sha512_challenge": {"ms": t_sha, "algorithmic_GBps": n * 237 / t_sha / 1e6, "frac_of_hbm_peak": n * 237 / t_sha / 1e6 / HBM_PEAK_GBS,
                                  "bytes_per_unit": 237},
@@ -129,15 +132,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import synth
-    from blobstreamx_amd.engine import HeaderRangeEngine
+    from blobstreamx_amd.engine import PipelinedEngines
 
     J, B, V, R = args.jobs, args.batch, args.validators, args.ranges
     t0 = time.perf_counter()
     w = synth.Workload(4, R * world, J, B, v=V)          # config #4 seed; identical on every rank
     t_gen = time.perf_counter() - t0
-    eng = HeaderRangeEngine(J, B, V, R, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
+    E = args.engines
+    eng = PipelinedEngines(J, B, V, R, n_engines=E, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
     eng.upload_workload(w)
-    eng.enable_timing()
 
     # correctness gate before timing: statuses clean, public output = (target header hash, commitment) for every owned range
     eng.step()
@@ -149,6 +152,7 @@ def main():
     gpu_out64 = res["output64"].copy()
 
     def barrier():
+        eng.join()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
@@ -160,18 +164,18 @@ def main():
     t0 = time.perf_counter()
     pending = []
     for _ in range(args.steps):
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        eng.events = evs
-        eng.step(time_kernels=True)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(E)]
+        eng.step(time_kernels=True, events=evs)
         pending.append(evs)
     barrier()
     elapsed = time.perf_counter() - t0
-    for evs in pending:
-        t_sub += evs[0].elapsed_time(evs[1])
-        if not args.no_witness:
-            t_exp += evs[2].elapsed_time(evs[3])
-    t_sub /= args.steps
-    t_exp /= args.steps
+    for step_evs in pending:             # HIP events on the launch stream of each engine; per-launch averages
+        for evs in step_evs:
+            t_sub += evs[0].elapsed_time(evs[1])
+            if not args.no_witness:
+                t_exp += evs[2].elapsed_time(evs[3])
+    t_sub /= args.steps * E
+    t_exp /= args.steps * E
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -181,8 +185,9 @@ def main():
     value = headers_per_step / (elapsed / args.steps)
 
     if rank == 0:
-        ml = eng.ml
-        n_jobs = eng.RT * eng.jc
+        e0 = eng.engines[0]
+        ml = e0.ml
+        n_jobs = e0.RT * e0.jc           # map jobs per launch (one engine = 1/E of the step)
         # algorithmic bytes: expansion reads the compact witness once and writes 8 B per element
         exp_bytes = n_jobs * (int(ml["n_bytes"]) + 4 * int(ml["n_words"]) + int(ml["n_bools"]) + 8 * int(ml["n_elements"]))
         slots = n_jobs * B
@@ -194,9 +199,9 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"header_range_{J * B} ({J} map jobs x {B} headers), {V} validators, mode F (one target commit per range), "
                                    f"{R} ranges per GPU per step, Goldilocks witness {'off' if args.no_witness else 'materialised'}",
-                       "ranges_per_gpu": R, "headers_per_step": headers_per_step,
+                       "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": E,
                        "parallelism": f"{world} x ({J // world} of {J} map jobs per range), 1 all-gather of 128-B records" if world > 1 else "1 GPU",
-                       "witness_bytes_per_step_per_gpu": int(n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
+                       "witness_bytes_per_step_per_gpu": int(E * n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
                        "input_generation_s": round(t_gen, 2)},
         }
         if not args.no_witness:

@@ -18,6 +18,8 @@
 // barrier-synchronised variant parked 51 % of its wave cycles.  No MFMA: bitwise integer work.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/bsx.h"
 #include "../../include/bsx_layout.h"
 #include "sha256.h"
@@ -210,37 +212,47 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
         else v = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (req_end - S)) * 32)[k] : 0u;
         cw32[t] = v;
     }
-    // proofs: flat dword stream over [128, 128 + 362*B)
-    const uint32_t lb_off = bsx_off_lb_proofs(B) - 128;         // byte offset of the lb array inside the stream
-    const uint32_t total = (BSX_DH_PROOF_SIZE + BSX_LB_PROOF_SIZE) * B;
-    const uint32_t ndw = (total + 3) / 4;
+    // proofs: the packed stream [128, 128 + 362*B) in 16-bit units (every proof boundary is 2-byte aligned): unit u of
+    // the stream is unit k of proof `slot`; each lane assembles one output dword from two source units.
+    const uint32_t n_dh_units = (BSX_DH_PROOF_SIZE / 2) * B, total_units = n_dh_units + (BSX_LB_PROOF_SIZE / 2) * B;
+    const uint32_t ndw = (total_units + 1) / 2;
+    const uint16_t* dh16 = reinterpret_cast<const uint16_t*>(a.dh_aunts);
+    const uint16_t* lb16 = reinterpret_cast<const uint16_t*>(a.lb_aunts);
+    const uint64_t h0 = hbase + (batch_start - S);
     bool bad_leaf = false;
     for (uint32_t w = threadIdx.x; w < ndw; w += blockDim.x) {
         uint32_t v = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint32_t o = 4 * w + b;
-            uint8_t byte = 0;
-            if (o < total && !oob) {
-                const bool is_lb = o >= lb_off;
-                const uint32_t oo = is_lb ? o - lb_off : o;
-                const uint32_t psz = is_lb ? BSX_LB_PROOF_SIZE : BSX_DH_PROOF_SIZE;
-                const uint32_t slot = oo / psz, within = oo % psz;
-                if (slot < n_real) {
-                    const uint64_t hidx = hbase + (batch_start - S) + slot + (is_lb ? 1 : 0);
-                    if (within < 128) {
-                        byte = (is_lb ? a.lb_aunts : a.dh_aunts)[hidx * 128 + within];
-                    } else {
-                        const bsx_header* h = a.headers + hidx;
-                        byte = is_lb ? h->last_block_id[within - 128] : h->hash[1][within - 128];
-                        if (within == 128) {  // input.rs:173,190: the leaf must be exactly 34 / 72 bytes
-                            const uint8_t l = is_lb ? h->len[BSX_LAST_BLOCK_ID_INDEX] : h->len[BSX_DATA_HASH_INDEX];
-                            if (l != (is_lb ? BSX_PROTOBUF_BLOCK_ID_SIZE : BSX_PROTOBUF_HASH_SIZE)) bad_leaf = true;
+        for (int half = 0; half < 2; half++) {
+            const uint32_t u = 2 * w + half;
+            uint32_t x = 0;
+            if (u < total_units && !oob) {
+                if (u < n_dh_units) {
+                    const uint32_t slot = u / (BSX_DH_PROOF_SIZE / 2), k = u % (BSX_DH_PROOF_SIZE / 2);
+                    if (slot < n_real) {
+                        const uint64_t hidx = h0 + slot;
+                        if (k < 64) x = dh16[hidx * 64 + k];
+                        else {
+                            const bsx_header* h = a.headers + hidx;
+                            x = reinterpret_cast<const uint16_t*>(h->hash[1])[k - 64];
+                            if (k == 64 && h->len[BSX_DATA_HASH_INDEX] != BSX_PROTOBUF_HASH_SIZE) bad_leaf = true;   // input.rs:173
+                        }
+                    }
+                } else {
+                    const uint32_t uu = u - n_dh_units;
+                    const uint32_t slot = uu / (BSX_LB_PROOF_SIZE / 2), k = uu % (BSX_LB_PROOF_SIZE / 2);
+                    if (slot < n_real) {
+                        const uint64_t hidx = h0 + slot + 1;
+                        if (k < 64) x = lb16[hidx * 64 + k];
+                        else {
+                            const bsx_header* h = a.headers + hidx;
+                            x = reinterpret_cast<const uint16_t*>(h->last_block_id)[k - 64];
+                            if (k == 64 && h->len[BSX_LAST_BLOCK_ID_INDEX] != BSX_PROTOBUF_BLOCK_ID_SIZE) bad_leaf = true;   // input.rs:190
                         }
                     }
                 }
             }
-            v |= (uint32_t)byte << (8 * b);
+            v |= x << (16 * half);
         }
         cw32[32 + w] = v;
     }
@@ -590,7 +602,7 @@ __global__ void k_finalize(uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t bat
 // are aligned to GLOBAL 16-byte pairs and the (at most two) straddling elements fall back to 8-byte stores.
 struct ExpandArgs {
     bsx_witness_layout lay;
-    uint32_t n_jobs;
+    uint32_t n_jobs, blocks_per_job;
     const uint8_t* compact;
     uint64_t* out;
 };
@@ -604,10 +616,15 @@ __device__ __forceinline__ uint64_t expand_elem(const ExpandArgs& a, const uint8
 }
 // Each workgroup stages EX_CHUNK source bytes in LDS with ONE coalesced dword load per lane, then every lane reads
 // the byte(s) of its pair from LDS: the vector-memory pipe carries (almost) nothing but the 16-byte stores.
-constexpr int EX_THREADS = 256, EX_CHUNK = 1024, EX_PAIRS_PER_BLOCK = EX_CHUNK * 4;
+constexpr int EX_THREADS = 256;
+template <int EX_CHUNK, bool NT>
 __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
+    constexpr int EX_PAIRS_PER_BLOCK = EX_CHUNK * 4;
     __shared__ uint32_t lds[EX_CHUNK / 4 + 2];
-    const uint32_t job = blockIdx.y, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    // work item = (job, 1 KiB source chunk); a one-shot grid has one item per workgroup, a capped grid strides
+    for (uint32_t item = blockIdx.x; item < a.n_jobs * a.blocks_per_job; item += gridDim.x) {
+    const uint32_t job = item / a.blocks_per_job, bx = item % a.blocks_per_job;
     const uint8_t* c = a.compact + (uint64_t)job * a.lay.compact_stride;
     const uint64_t nel = a.lay.n_elements;
     const uint64_t g0 = (uint64_t)job * nel;                 // global element index of this job's first element
@@ -615,7 +632,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
     const uint32_t nbits = 8u * a.lay.n_bytes;
     // local pair p covers local elements 2p - odd, 2p - odd + 1
     const uint32_t npairs = (uint32_t)((nel + odd + 1) / 2);
-    const uint32_t pbase = blockIdx.x * EX_PAIRS_PER_BLOCK;
+    const uint32_t pbase = bx * EX_PAIRS_PER_BLOCK;
     const int32_t byte0 = (int32_t)(pbase / 4) - 4;          // staged window starts one dword early (odd jobs look back one bit)
     for (uint32_t t = tid; t < EX_CHUNK / 4 + 2; t += EX_THREADS) {
         const int32_t bi = byte0 + 4 * (int32_t)t;
@@ -642,11 +659,16 @@ __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
         }
         uint64_t* dst = base + 2 * (uint64_t)p;
         if (in0 && in1) {
-            *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(v0, v1);
+            typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+            const v2u64 vv = {v0, v1};
+            if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v2u64*>(dst));
+            else *reinterpret_cast<v2u64*>(dst) = vv;
         } else {
             if (in0) dst[0] = v0;
             if (in1) dst[1] = v1;
         }
+    }
+    __syncthreads();   // the staging buffer is reused by the next item
     }
 }
 
@@ -704,10 +726,23 @@ hipError_t bsxk_finalize(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t 
 }
 hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uint32_t n_jobs, const uint8_t* compact, uint64_t* out) {
     if (!n_jobs) return hipSuccess;
-    ExpandArgs a{*lay, n_jobs, compact, out};
     const uint64_t npairs = (lay->n_elements + 2) / 2;
-    const uint32_t gx = (uint32_t)((npairs + EX_PAIRS_PER_BLOCK - 1) / EX_PAIRS_PER_BLOCK);
-    hipLaunchKernelGGL(k_expand_witness, dim3(gx, n_jobs), dim3(EX_THREADS), 0, s, a);
+    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 1024;
+    static const long nt = getenv("BSX_EXPAND_NT") ? atol(getenv("BSX_EXPAND_NT")) : 0;
+    const uint32_t ppb = (uint32_t)chunk * 4;
+    const uint32_t gx = (uint32_t)((npairs + ppb - 1) / ppb);
+    ExpandArgs a{*lay, n_jobs, gx, compact, out};
+    // BSX_EXPAND_BLOCKS caps the grid (workgroups stride over the items) so that the HBM-bound expansion leaves wave
+    // slots for an ALU-bound kernel running beside it on another stream; 0 / unset = one workgroup per item
+    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 0;
+    uint64_t grid = (uint64_t)gx * n_jobs;
+    if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
+#define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)
+    if (chunk == 512) { if (nt) BSX_EX_LAUNCH(512, true); else BSX_EX_LAUNCH(512, false); }
+    else if (chunk == 2048) { if (nt) BSX_EX_LAUNCH(2048, true); else BSX_EX_LAUNCH(2048, false); }
+    else if (chunk == 4096) { if (nt) BSX_EX_LAUNCH(4096, true); else BSX_EX_LAUNCH(4096, false); }
+    else { if (nt) BSX_EX_LAUNCH(1024, true); else BSX_EX_LAUNCH(1024, false); }
+#undef BSX_EX_LAUNCH
     return hipGetLastError();
 }
 }

@@ -138,14 +138,16 @@ class HeaderRangeEngine:
             put(self.trusted, trusted)
         torch.cuda.synchronize(self.dev)
 
-    def upload_workload(self, w, ranges_global=None):
-        """Convenience for a synth.Workload holding the RT ranges this rank touches (single GPU: all of them)."""
-        assert w.R == self.RT and w.J == self.J and w.B == self.B and w.v_max == self.V
+    def upload_workload(self, w, sel=None):
+        """Convenience for a synth.Workload.  sel: the RT workload ranges this engine touches, ordered [rank][k]
+        (default: all of them, single engine); the block `self.rank` of that list is the owned set."""
+        sel = np.arange(w.R) if sel is None else np.asarray(sel)
+        assert sel.size == self.RT and w.J == self.J and w.B == self.B and w.v_max == self.V
         lo = self.hfr
-        hs = w.headers[:, lo:lo + self.hpr]
-        own = slice(self.rank * self.R, (self.rank + 1) * self.R)
+        hs = w.headers[sel][:, lo:lo + self.hpr]
+        own = sel[self.rank * self.R:(self.rank + 1) * self.R]
         sk = np.stack([w.headers[own, 0], w.headers[own, w.n_blocks]], axis=1)
-        self.upload(hs, w.ranges, w.latest, sk, w.ranges[own], w.validators[own], w.trusted[own])
+        self.upload(hs, w.ranges[sel], w.latest[sel], sk, w.ranges[own], w.validators[own], w.trusted[own])
 
     # ------------------------------------------------------------------ one pass
     def _st(self):
@@ -264,3 +266,59 @@ class HeaderRangeEngine:
         rl = self.witness_red_local[:self.n_red_local_el].cpu().numpy().view(np.uint64)
         rt = self.witness_red_top[:self.n_red_top_el].cpu().numpy().view(np.uint64)
         return m, rl, rt
+
+
+class PipelinedEngines:
+    """E engines, each over 1/E of the step's ranges on its own HIP stream.  The SHA kernels are integer-ALU bound and
+    the witness expansion is HBM-write bound, so running chunk e+1's hashing beside chunk e's expansion overlaps the
+    two resources; consecutive steps pipeline the same way (each engine's buffers are only touched on its own stream)."""
+
+    def __init__(self, nb_map_jobs, batch_size, v_max, n_ranges_local, n_engines=2, rank=0, world=1, device=None, **kw):
+        assert n_ranges_local % n_engines == 0
+        self.E, self.Rc, self.R, self.rank, self.world = n_engines, n_ranges_local // n_engines, n_ranges_local, rank, world
+        self.engines = [HeaderRangeEngine(nb_map_jobs, batch_size, v_max, self.Rc, rank=rank, world=world, device=device, **kw)
+                        for _ in range(n_engines)]
+        self.dev = self.engines[0].dev
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_engines)]
+        self._first = True
+
+    def sel(self, e):
+        return np.concatenate([np.arange(g * self.R + e * self.Rc, g * self.R + (e + 1) * self.Rc) for g in range(self.world)])
+
+    def upload_workload(self, w):
+        assert w.R == self.R * self.world
+        for e, eng in enumerate(self.engines):
+            eng.upload_workload(w, self.sel(e))
+
+    def step(self, time_kernels=False, events=None):
+        cur = torch.cuda.current_stream(self.dev)
+        for e, (eng, s) in enumerate(zip(self.engines, self.streams)):
+            s.wait_stream(cur)
+            if self._first and e > 0:
+                s.wait_event(self._stagger)      # first pass only: start chunk e once chunk e-1 has finished hashing
+            with torch.cuda.stream(s):
+                if events is not None:
+                    eng.events = events[e]
+                eng.step_local(time_kernels)
+                if self._first:
+                    self._stagger = torch.cuda.Event()
+                    self._stagger.record(s)
+                res = eng.step_exchange()
+                eng.step_final(res, time_kernels)
+                if eng.with_commit and eng.R:
+                    s.wait_stream(eng.side)
+        self._first = False
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.dev)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def download(self):
+        self.join()
+        outs = [eng.download() for eng in self.engines]
+        merged = {}
+        for k in outs[0]:
+            v0 = outs[0][k]
+            merged[k] = np.concatenate([o[k] for o in outs]) if isinstance(v0, np.ndarray) else max(o[k] for o in outs)
+        return merged
