@@ -27,6 +27,7 @@ SYMBOLS = [
     "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_finalize",
     "bsx_dev_expand_witness", "bsx_dev_fill_end_hash", "bsx_dev_sha512_challenge", "bsx_dev_ed25519_verify",
     "bsx_dev_commit_tally", "bsx_dev_skip_check",
+    "bsx_ingest_last_error", "bsx_ingest_header_json", "bsx_ingest_signed_block_json", "bsx_ingest_data_commitment_json",
 ]
 
 
@@ -63,6 +64,7 @@ def lib():
             L.bsx_version.restype = C.c_uint32
             L.bsx_last_error.restype = C.c_char_p
             L.bsx_status_str.restype = C.c_char_p
+            L.bsx_ingest_last_error.restype = C.c_char_p
             for s in SYMBOLS:
                 getattr(L, s)   # AttributeError here = header/library drift
             _lib = L

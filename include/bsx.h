@@ -272,6 +272,22 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness);
 
+/* ------------------------------------------------------------------ wire-format ingest
+ * Tendermint RPC JSON -> the packed layouts above; host-side byte formatting only (works without a GPU).
+ * Replaces serde + tendermint-rs decoding at circuits/input.rs:19-27,67-110,120-145 and circuits/fetcher.rs:44-58,89-132;
+ * accepts the reference's fixture files (circuits/fixtures/mocha-4) verbatim. */
+const char* bsx_ingest_last_error(void);
+/* header.json, or any response carrying result.header / result.signed_header.header */
+int bsx_ingest_header_json(const char* json, size_t len, bsx_header* out_header, uint64_t* out_height);
+/* signed_block.json (result.{header, commit, validator_set}) or a /commit response plus, in validators_json, the
+ * /validators response.  out_validators (optional): v_max slots in validator-set order, each with the sign-bytes it
+ * signed; out_block_hash = commit.block_id.hash (the node's own header hash, for cross-checking). */
+int bsx_ingest_signed_block_json(const char* json, size_t len, const char* validators_json, size_t validators_len,
+                                 bsx_header* out_header, uint8_t out_block_hash[32], bsx_validator* out_validators,
+                                 uint32_t v_max, uint32_t* out_n_validators, uint64_t* out_height);
+/* data_commitment.json -> the 32-byte commitment the node reports (circuits/input.rs:104-109) */
+int bsx_ingest_data_commitment_json(const char* json, size_t len, uint8_t out[32]);
+
 /* ------------------------------------------------------------------ device tier (async; d_* = device memory)
  * Every call only enqueues kernels on `stream` (hipStream_t as void*; NULL = the HIP default stream, i.e. PyTorch's
  * default stream) and returns, so calls are ordered with the caller's own work on that stream.

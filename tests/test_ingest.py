@@ -1,0 +1,106 @@
+"""Wire-format ingest.  CPU part: the reference's fixture files, VERBATIM
+(tests/golden/mocha-4/** are copies of circuits/fixtures/mocha-4 data files), decode to exactly the golden encoded
+fields / sign-bytes.  GPU part: fixture JSON -> HIP path end to end, mirroring the reference's fixture-mode tests
+test_get_data_commitment / test_prove_header_chain (circuits/builder.rs:488-564)."""
+import os
+
+import numpy as np
+import pytest
+
+from blobstreamx_amd import _lib
+from blobstreamx_amd import ingest
+from blobstreamx_amd import types as T
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mocha-4")
+
+
+def test_signed_block_fixture_decodes_to_golden_fields(golden):
+    f = ingest.FixtureFetcher(FIX)
+    for h in range(10000, 10005):
+        sb = f.signed_block(h)
+        b = golden["blocks"][str(h)]
+        assert sb["height"] == h and sb["n_validators"] == 2
+        assert [x.hex() for x in T.header_fields(sb["header"])] == b["fields"]
+        assert sb["block_hash"].hex() == b["header_hash"]
+        for i, v in enumerate(b["validators"]):
+            assert bytes(sb["validators"][i]["pubkey"]).hex() == v["pubkey"]
+            assert sb["validators"][i]["voting_power"] == v["power"] and sb["validators"][i]["enabled"] == 1
+        for s in b["commit"]["signatures"]:
+            v = sb["validators"][s["validator_index"]]
+            assert v["is_signed"] == 1
+            assert bytes(v["signature"]).hex() == s["signature"]
+            assert bytes(v["message"][:v["message_len"]]).hex() == s["sign_bytes"]
+        assert sb["validators"][2]["enabled"] == 0 and sb["validators"][3]["enabled"] == 0
+        hdr, height = ingest.header_from_json(open(os.path.join(FIX, str(h), "header.json")).read())
+        assert height == h and hdr.tobytes() == sb["header"].tobytes()
+
+
+def test_data_commitment_fixtures(golden):
+    f = ingest.FixtureFetcher(FIX)
+    for name, want in golden["data_commitments"].items():
+        s, e = map(int, name.split("-"))
+        assert f.get_data_commitment(s, e).hex() == want
+    assert f.get_data_commitment(10002, 10002) == bytes(32)      # circuits/input.rs:70-72
+
+
+def test_ingest_rejects_garbage():
+    for bad in ["", "{", '{"result": {}}', '{"result": {"header": {"chain_id": 5}}}']:
+        with pytest.raises(_lib.BsxError):
+            ingest.header_from_json(bad)
+    blk = open(os.path.join(FIX, "10000", "signed_block.json")).read()
+    with pytest.raises(_lib.BsxError) as ei:
+        ingest.signed_block_from_json(blk, 1)        # 2 validators do not fit MAX_VALIDATOR_SET_SIZE = 1
+    assert ei.value.status == T.ERR_RANGE_TOO_LONG
+    with pytest.raises(_lib.BsxError):
+        ingest.signed_block_from_json(blk.replace("2023-09-07T12:45:59.767207173Z", "yesterday"), 4)
+
+
+def test_time_and_varint_edge_cases():
+    import json
+    blk = json.load(open(os.path.join(FIX, "10000", "signed_block.json")))
+    hdr = blk["result"]["header"]
+    for t, secs, nanos in [("1970-01-01T00:00:00Z", 0, 0), ("2000-02-29T23:59:59.5Z", 951868799, 500000000),
+                           ("2024-12-31T00:00:00.000000001Z", 1735603200, 1), ("2262-04-11T23:47:16.854775807Z", 9223372036, 854775807)]:
+        hdr["time"] = t
+        h, _ = ingest.header_from_json(json.dumps(blk))
+
+        def varint(n):
+            out = bytearray()
+            while n >= 0x80:
+                out.append((n & 0x7f) | 0x80)
+                n >>= 7
+            out.append(n)
+            return bytes(out)
+        want = (b"\x08" + varint(secs) if secs else b"") + (b"\x10" + varint(nanos) if nanos else b"")
+        assert T.header_fields(h)[3] == want, t
+
+
+@pytest.mark.gpu
+def test_fixture_json_to_gpu_end_to_end(golden):
+    """JSON files -> ingest -> HIP path: header hashes equal the node's own block ids, the commit verifies, the
+    node-reported data commitments come out, next_header and header_range produce the fixture answers."""
+    from blobstreamx_amd.builder import CombinedSkipCircuit, DataCommitmentBuilder, InputDataFetcher, verify_commits
+    f = ingest.FixtureFetcher(FIX, v_max=4)
+    blocks = [f.signed_block(h) for h in range(10000, 10005)]
+    headers = np.array([b["header"] for b in blocks], dtype=T.HEADER)
+    fetcher = InputDataFetcher(headers, 10000, 10006)
+    hashes = fetcher.header_hashes()
+    for i, b in enumerate(blocks):
+        assert hashes[i].tobytes() == b["block_hash"]                      # our hash == commit.block_id.hash from the node
+    res, ok = verify_commits(np.stack([b["validators"] for b in blocks]), hashes)
+    assert (res["n_bad_signature"] == 0).all() and (res["n_bad_message"] == 0).all() and (res["two_thirds_ok"] == 1).all()
+    for i, b in enumerate(blocks):
+        assert bytes(res[i]["validators_hash"]) == bytes(b["header"]["hash"][2][2:34])
+    bld = DataCommitmentBuilder()
+    for (s, e) in [(10000, 10001), (10000, 10002), (10000, 10004), (10002, 10004)]:
+        out = bld.prove_data_commitment(fetcher, 2, 2, s, hashes[s - 10000].tobytes(), e, hashes[e - 10000].tobytes())
+        assert out["data_commitment"] == f.get_data_commitment(s, e)
+    assert bld.prove_next_header_data_commitment(fetcher, 10000, hashes[0].tobytes(), 10001) == f.get_data_commitment(10000, 10001)
+    # header_range 10000 -> 10004: trusted set = validators of 10000 (unchanged on mocha-4 here), target commit = block 10004's
+    inp = (10000).to_bytes(8, "big") + hashes[0].tobytes() + (10004).to_bytes(8, "big")
+    assert inp.hex() == golden["kats"]["header_range_input_10000_10004"]
+    trusted = blocks[0]["validators"].copy()
+    trusted["is_signed"] = 0
+    out, cres, _ = CombinedSkipCircuit(4, 2, 2).prove(inp, fetcher, blocks[4]["validators"], trusted)
+    assert out[:32] == hashes[4].tobytes() and out[32:] == f.get_data_commitment(10000, 10004)
+    assert cres["trusted_signed_power"] == 50_000_000
