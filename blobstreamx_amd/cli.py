@@ -1,0 +1,107 @@
+"""`<circuit> build | prove input.json` — the process boundary of the reference's entrypoint binaries
+(bin/header_range_{1024,2048,mocha}.rs:6-17, bin/next_header{,_mocha}.rs:5-8 via plonky2x `Plonky2xFunction::entrypoint`;
+`succinct.json:5-46` runs `./build/<circuit> prove input.json`), SURVEY §8f rank 2.
+
+    python -m blobstreamx_amd.cli header_range_2048 prove input.json --fixtures DIR [--output output.json] [--witness w.bin]
+    python -m blobstreamx_amd.cli next_header prove input.json --fixtures DIR
+    python -m blobstreamx_amd.cli header_range_mocha build
+
+input.json  [UPSTREAM plonky2x ProofRequest, bytes flavour]: {"type": "req_bytes", "data": {"input": "0x<hex>"}} with
+            48 bytes abi.encodePacked(uint64 trusted_block, bytes32 trusted_header_hash, uint64 target_block) for
+            header_range (circuits/header_range.rs:33-35, contracts/src/BlobstreamX.sol:142-146) or 40 bytes
+            (uint64 prev_block, bytes32 prev_header_hash) for next_header (circuits/next_header.rs:26-27).
+output.json {"type": "res_bytes", "data": {"output": "0x<64 bytes>"}} = abi.encode(bytes32, bytes32)
+            (header_range.rs:57-58, BlobstreamX.sol:155-158).  No proof is produced: this engine generates the WITNESS
+            (optionally dumped as little-endian u64 Goldilocks elements); proving stays with plonky2x.
+Chain data comes from a fixture directory in the reference's own layout (`InputDataMode::Fixture`,
+circuits/input.rs:97-101): <dir>/<height>/signed_block.json.
+"""
+import argparse
+import json
+import sys
+
+import numpy as np
+
+from . import ingest
+from . import types as T
+
+# const-generic instantiations of the reference's bins: (MAX_VALIDATOR_SET_SIZE, NB_MAP_JOBS, BATCH_SIZE)
+CIRCUITS = {
+    "header_range_1024": (100, 32, 32),    # bin/header_range_1024.rs:7-9
+    "header_range_2048": (100, 32, 64),    # bin/header_range_2048.rs:7-9
+    "header_range_mocha": (100, 32, 32),   # bin/header_range_mocha.rs (Mocha4BlobstreamXConfig1024, config.rs:22-28)
+    "next_header": (100, 1, 1),            # bin/next_header.rs:5-8
+    "next_header_mocha": (100, 1, 1),
+}
+
+
+def _read_input(path):
+    req = json.load(open(path))
+    data = req.get("data", req)
+    hexs = data["input"]
+    return bytes.fromhex(hexs[2:] if hexs.startswith("0x") else hexs)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="blobstreamx_amd.cli")
+    ap.add_argument("circuit", choices=sorted(CIRCUITS))
+    ap.add_argument("command", choices=["build", "prove"])
+    ap.add_argument("input", nargs="?")
+    ap.add_argument("--fixtures", help="fixture directory (<dir>/<height>/signed_block.json)")
+    ap.add_argument("--latest", type=int, help="chain head (default: highest fixture height + 2)")
+    ap.add_argument("--jobs", type=int)
+    ap.add_argument("--batch", type=int)
+    ap.add_argument("--validators", type=int)
+    ap.add_argument("--output", default="output.json")
+    ap.add_argument("--witness")
+    a = ap.parse_args(argv)
+    V, J, B = CIRCUITS[a.circuit]
+    V, J, B = a.validators or V, a.jobs or J, a.batch or B
+    if a.command == "build":
+        # the reference compiles circuits here; the witness engine has nothing to build beyond its layout
+        ml, rl = T.map_layout(B), T.reduce_layout()
+        print(json.dumps({"circuit": a.circuit, "max_validators": V, "nb_map_jobs": J, "batch_size": B,
+                          "witness_elements": int(J * int(ml["n_elements"]) + (J - 1) * int(rl["n_elements"]))}))
+        return 0
+    if not a.input or not a.fixtures:
+        ap.error("prove needs input.json and --fixtures")
+    from .builder import CombinedSkipCircuit, DataCommitmentBuilder, InputDataFetcher, verify_commits
+    inp = _read_input(a.input)
+    fx = ingest.FixtureFetcher(a.fixtures, v_max=V)
+    if a.circuit.startswith("header_range"):
+        if len(inp) != 48:
+            raise SystemExit("header_range input must be 48 bytes (uint64 ‖ bytes32 ‖ uint64)")
+        trusted, target = int.from_bytes(inp[:8], "big"), int.from_bytes(inp[40:], "big")
+        blocks = {h: fx.signed_block(h) for h in range(trusted, target + 1)}
+        headers = np.array([blocks[h]["header"] for h in range(trusted, target + 1)], dtype=T.HEADER)
+        fetcher = InputDataFetcher(headers, trusted, a.latest or target + 2)
+        tr = blocks[trusted]["validators"].copy()
+        tr["is_signed"] = 0
+        out, commit, wit = CombinedSkipCircuit(V, J, B).prove(inp, fetcher, blocks[target]["validators"], tr,
+                                                              want_witness=bool(a.witness))
+    else:
+        if len(inp) != 40:
+            raise SystemExit("next_header input must be 40 bytes (uint64 ‖ bytes32)")
+        prev = int.from_bytes(inp[:8], "big")
+        blocks = {h: fx.signed_block(h) for h in (prev, prev + 1)}
+        headers = np.array([blocks[prev]["header"], blocks[prev + 1]["header"]], dtype=T.HEADER)
+        fetcher = InputDataFetcher(headers, prev, a.latest or prev + 3)
+        hashes = fetcher.header_hashes()
+        # builder.step (circuits/next_header.rs:32-36) [UPSTREAM]: commit of prev+1 verified against its validator set,
+        # last_block_id linkage to prev_header_hash
+        res, _ = verify_commits(blocks[prev + 1]["validators"].reshape(1, -1), hashes[1:2])
+        if res[0]["n_bad_signature"] or res[0]["n_bad_message"] or not res[0]["two_thirds_ok"]:
+            raise SystemExit("step: commit of the next header does not verify")
+        if bytes(blocks[prev + 1]["header"]["last_block_id"][2:34]) != inp[8:40] or hashes[0].tobytes() != inp[8:40]:
+            raise SystemExit("step: next header does not link to prev_header_hash")
+        dc = DataCommitmentBuilder().prove_next_header_data_commitment(fetcher, prev, inp[8:40], prev + 1)   # :38-42
+        out, wit = hashes[1].tobytes() + dc, None
+    json.dump({"type": "res_bytes", "data": {"output": "0x" + out.hex()}}, open(a.output, "w"))
+    if a.witness and wit is not None:
+        wit.astype("<u8").tofile(a.witness)
+    print("0x" + out.hex())
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

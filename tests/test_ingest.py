@@ -104,3 +104,25 @@ def test_fixture_json_to_gpu_end_to_end(golden):
     out, cres, _ = CombinedSkipCircuit(4, 2, 2).prove(inp, fetcher, blocks[4]["validators"], trusted)
     assert out[:32] == hashes[4].tobytes() and out[32:] == f.get_data_commitment(10000, 10004)
     assert cres["trusted_signed_power"] == 50_000_000
+
+
+@pytest.mark.gpu
+def test_cli_prove_input_json(tmp_path, golden):
+    """`<circuit> prove input.json` (succinct.json:5-46): packed EVM input in, abi.encode(bytes32, bytes32) out."""
+    import json
+    from blobstreamx_amd import cli
+    h0 = golden["blocks"]["10000"]["header_hash"]
+    inp = tmp_path / "input.json"
+    out = tmp_path / "output.json"
+    wit = tmp_path / "w.bin"
+    inp.write_text(json.dumps({"type": "req_bytes", "releaseId": "x", "data": {"input": "0x" + golden["kats"]["header_range_input_10000_10004"]}}))
+    assert cli.main(["header_range_mocha", "prove", str(inp), "--fixtures", FIX, "--jobs", "2", "--batch", "2", "--validators", "4",
+                     "--output", str(out), "--witness", str(wit)]) == 0
+    got = json.load(open(out))["data"]["output"]
+    assert got == "0x" + golden["blocks"]["10004"]["header_hash"] + golden["data_commitments"]["10000-10004"]
+    ml, rl = T.map_layout(2), T.reduce_layout()
+    assert wit.stat().st_size == 8 * (2 * int(ml["n_elements"]) + int(rl["n_elements"]))
+    inp.write_text(json.dumps({"type": "req_bytes", "data": {"input": "0x" + (10000).to_bytes(8, "big").hex() + h0}}))
+    assert cli.main(["next_header_mocha", "prove", str(inp), "--fixtures", FIX, "--validators", "4", "--output", str(out)]) == 0
+    got = json.load(open(out))["data"]["output"]
+    assert got == "0x" + golden["blocks"]["10001"]["header_hash"] + golden["data_commitments"]["10000-10001"]   # SURVEY §3.4
