@@ -205,11 +205,17 @@ class HeaderRangeEngine:
         src = self.skip_hashes[:self.R * 64].view(self.R, 64)[:, 32:]
         self.target_hashes[:self.R * 32].view(self.R, 32).copy_(src)
 
-    def step_exchange(self):
-        """Stage 6: the one collective.  Single GPU: the local fold already is the range result."""
+    def step_exchange(self, gathered=None):
+        """Stage 6: the one collective.  Single GPU: the local fold already is the range result.
+        gathered (tests only): a [world, RT, 128] uint8 tensor standing in for the all-gather result, so that all
+        ranks' engines can be exercised on ONE GPU without a process group."""
         if self.world == 1:
             return self.partial
-        gather_partials(self.partial, self.rank, self.world, self.R, self.gathered, self.top_in)
+        if gathered is None:
+            gather_partials(self.partial, self.rank, self.world, self.R, self.gathered, self.top_in)
+        else:
+            own = gathered.view(self.world, self.RT, 128)[:, self.rank * self.R:(self.rank + 1) * self.R, :]
+            self.top_in[:self.R * self.world * 128].view(self.R, self.world, 128).copy_(own.transpose(0, 1))
         L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
         chk(L.bsx_dev_reduce(ctx, st, C.c_uint32(self.R), C.c_uint32(self.world), dp(self.top_in), dp(self.results),
                              dp(self.red_compact_top)))

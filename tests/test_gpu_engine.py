@@ -62,3 +62,43 @@ def test_engine_reports_failures_per_range():
         rc = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])[0]
         mine = res["skip_status"][r] if res["skip_status"][r] else (T.ERR_ASSERT if res["range_status"][r] else T.OK)
         assert mine == rc, (r, mine, rc)
+
+
+@pytest.mark.parametrize("world,J,B,R,n_blocks", [(2, 4, 8, 2, 32), (4, 8, 8, 2, 37), (8, 32, 64, 1, 2048), (2, 2, 32, 3, 64)])
+def test_sharded_engines_on_one_gpu(world, J, B, R, n_blocks):
+    """Every rank's engine of an N-GPU run, executed on ONE GPU with the all-gather emulated by concatenating the ranks'
+    partial buffers: job slices + header_first_rel + local fold + top fold + owner's commit/finalize/witness must
+    reproduce the oracle for every range (the real collective is covered over gloo in tests/test_distributed_cpu.py)."""
+    import torch
+    from blobstreamx_amd.engine import HeaderRangeEngine
+    V = 12
+    w = synth.Workload(9, R * world, J, B, v=V, n_blocks=n_blocks)
+    engs = [HeaderRangeEngine(J, B, V, R, rank=g, world=world) for g in range(world)]
+    for e in engs:
+        e.upload_workload(w)
+        e.step_local()
+    torch.cuda.synchronize()
+    gathered = torch.stack([e.partial[:e.RT * 128].clone() for e in engs])          # [world, RT*128] == all_gather_into_tensor
+    ml, rl = T.map_layout(B), T.reduce_layout()
+    jc = J // world
+    nm = jc * int(ml["n_elements"])
+    for g, e in enumerate(engs):
+        res = e.step_exchange(gathered)
+        e.step_final(res)
+        torch.cuda.current_stream().wait_stream(e.side)
+        out = e.download()
+        wm, wrl, wrt = e.witness_numpy()
+        for k in range(R):
+            r = g * R + k
+            rc, ref_out, cres, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
+                                                        w.validators[r], w.trusted[r], want_witness=True)
+            assert rc == T.OK
+            assert out["output64"][k].tobytes() == ref_out, (g, k)
+            assert out["range_status"][k] == 0 and out["skip_status"][k] == 0
+        # map-job witnesses of this rank's slice of EVERY range equal the oracle's jobs [g*jc, (g+1)*jc)
+        for r in range(R * world):
+            rc, ref = oracle.prove_data_commitment(J, B, w.ranges[r:r + 1], w.headers[r], int(w.first_height[r]), int(w.latest[r]),
+                                                   want_witness=True)
+            full = oracle.expand_witness(ml, J, ref["compact"])
+            want = full[g * nm:(g + 1) * nm]
+            assert (wm[r * nm:(r + 1) * nm] == want).all(), (g, r)
