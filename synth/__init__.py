@@ -143,9 +143,14 @@ class Workload:
         self.ranges = np.zeros(n_ranges, T.SHARED_CTX)
         self.latest = np.zeros(n_ranges, np.uint64)
         self.first_height = np.zeros(n_ranges, np.uint64)
+        def gen(r):      # chains are independent: generate them on a thread pool (the C call releases the GIL)
+            return chain(seed * 1000003 + r, self.hpr, self.valset.hash, start_height=START_HEIGHT + r * 10_000, chain_id=chain_id)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
+            chains = list(pool.map(gen, range(n_ranges)))
         for r in range(n_ranges):
             S = START_HEIGHT + r * 10_000
-            hd, hs = chain(seed * 1000003 + r, self.hpr, self.valset.hash, start_height=S, chain_id=chain_id)
+            hd, hs = chains[r]
             self.headers[r], self.hashes[r] = hd, hs
             self.first_height[r] = S
             self.latest[r] = S + J * B + 2

@@ -60,14 +60,13 @@ static void sha256_block(u32 st[8], const u8* p) {
         w[i] = w[i - 16] + (R32(w[i - 15], 7) ^ R32(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
                (R32(w[i - 2], 17) ^ R32(w[i - 2], 19) ^ (w[i - 2] >> 10));
     memcpy(v, st, 32);
+    u32 a = v[0], b = v[1], c = v[2], d = v[3], e = v[4], f = v[5], g = v[6], h = v[7];
     for (int i = 0; i < 64; i++) {
-        u32 t1 = v[7] + (R32(v[4], 6) ^ R32(v[4], 11) ^ R32(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K256[i] + w[i];
-        u32 t2 = (R32(v[0], 2) ^ R32(v[0], 13) ^ R32(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
-        memmove(v + 1, v, 28);
-        v[4] += t1;
-        v[0] = t1 + t2;
+        u32 t1 = h + (R32(e, 6) ^ R32(e, 11) ^ R32(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+        u32 t2 = (R32(a, 2) ^ R32(a, 13) ^ R32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
-    for (int i = 0; i < 8; i++) st[i] += v[i];
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }
 static void sha256(const u8* m, size_t n, u8 out[32]) {
     u32 st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
