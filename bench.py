@@ -23,6 +23,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Two pipelined chunks need four independent hardware queues (2 main + 2 commit side streams); HIP's default of 4
+# maps the second chunk's main stream onto the first chunk's side-stream queue and serialises them (profiles/README.md).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -38,9 +42,10 @@ def parse():
     ap.add_argument("--jobs", type=int, default=32)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--validators", type=int, default=100)
-    ap.add_argument("--engines", type=int, default=1, help="chunks of the step issued on separate HIP streams (measured on MI355X: "
-                    "stream-level overlap of the ALU-bound hashing with the HBM-bound expansion does NOT pay: 59.8 / 53.0 / 44.9 M "
-                    "headers/s at 1 / 2 / 4 chunks, DESIGN.md §5)")
+    ap.add_argument("--engines", type=int, default=1, help="chunks of the step pipelined on separate HIP streams (the ALU-bound hashing "
+                    "of one chunk beside the HBM-bound expansion of the other).  Measured on MI355X with GPU_MAX_HW_QUEUES=8 and "
+                    "phase tokens: 59.8 / 61-62 / 46.8 M headers/s at 1 / 2 / 4 chunks — the co-running kernels slow each other "
+                    "almost as much as the overlap gains, so the default stays 1 (one all-gather per step at N > 1)")
     ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
@@ -205,10 +210,29 @@ def main():
                        "input_generation_s": round(t_gen, 2)},
         }
         if not args.no_witness:
+            # the same kernel alone on an idle GPU (after the timed region): what the overlap with the other chunk's hashing costs it
+            import ctypes as C
+            from blobstreamx_amd import _lib
+            iso = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            t_iso = 0.0
+            for _ in range(5):
+                iso[0].record()
+                _lib.check(e0.L.bsx_dev_expand_witness(e0.ctx, st, _lib.p(e0._ml), C.c_uint32(n_jobs), _lib.dp(e0.compact), _lib.dp(e0.witness_map)))
+                iso[1].record()
+                torch.cuda.synchronize(dev)
+                t_iso += iso[0].elapsed_time(iso[1]) / 5
+            # HBM bytes per map job from the PMC passes in profiles/r1_pmc_hbm_traffic.csv (WRITE_SIZE 29,905,572 KB +
+            # FETCH_SIZE 275,383 KB for a launch of 8192 jobs; rocprofv3 units are KB; FETCH_SIZE not doubled: dword loads)
+            pmc_bytes_per_job = (29905572 + 275383) * 1024 / 8192
             out["roofline"] = {"kernel": "k_expand_witness (map-job section)", "bound": "hbm", "achieved": exp_bytes / t_exp / 1e6,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exp_bytes / t_exp / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exp_bytes / t_exp / 1e6 / HBM_PEAK_GBS,
+                               "traffic": pmc_bytes_per_job * n_jobs,
                                "avg_launch_ms": t_exp, "algorithmic_bytes_per_launch": exp_bytes,
-                               "note": "expanded (witness-emitting) byte count: 8 B written per Goldilocks element + the compact read"}
+                               "isolated": {"avg_launch_ms": t_iso, "achieved": exp_bytes / t_iso / 1e6, "frac": exp_bytes / t_iso / 1e6 / HBM_PEAK_GBS},
+                               "note": "expanded (witness-emitting) byte count: 8 B written per Goldilocks element + the compact read; "
+                                       "`achieved` is measured inside the timed region where the kernel co-runs with the other chunk's "
+                                       "ALU-bound hashing; `isolated` is the same launch alone; `traffic` = PMC bytes (profiles/) scaled per map job"}
         out["kernels"] = [{"kernel": "k_prove_subchain", "avg_launch_ms": t_sub, "slots_per_launch": slots,
                            "compact_bytes_per_slot": 874, "achieved_GBps": sub_bytes / t_sub / 1e6,
                            "frac_of_hbm_peak": sub_bytes / t_sub / 1e6 / HBM_PEAK_GBS,

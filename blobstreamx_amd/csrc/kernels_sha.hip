@@ -727,14 +727,15 @@ hipError_t bsxk_finalize(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t 
 hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uint32_t n_jobs, const uint8_t* compact, uint64_t* out) {
     if (!n_jobs) return hipSuccess;
     const uint64_t npairs = (lay->n_elements + 2) / 2;
-    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 1024;
+    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 2048;
     static const long nt = getenv("BSX_EXPAND_NT") ? atol(getenv("BSX_EXPAND_NT")) : 0;
     const uint32_t ppb = (uint32_t)chunk * 4;
     const uint32_t gx = (uint32_t)((npairs + ppb - 1) / ppb);
     ExpandArgs a{*lay, n_jobs, gx, compact, out};
     // BSX_EXPAND_BLOCKS caps the grid (workgroups stride over the items) so that the HBM-bound expansion leaves wave
     // slots for an ALU-bound kernel running beside it on another stream; 0 / unset = one workgroup per item
-    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 0;
+    // (measured: 8192 workgroups = 32 per CU keep ~5 TB/s alone and give the best overlapped step time)
+    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 8192;
     uint64_t grid = (uint64_t)gx * n_jobs;
     if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
 #define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)

@@ -286,7 +286,8 @@ class PipelinedEngines:
                         for _ in range(n_engines)]
         self.dev = self.engines[0].dev
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_engines)]
-        self._first = True
+        self._hash_token = None
+        self._expand_token = None
 
     def sel(self, e):
         return np.concatenate([np.arange(g * self.R + e * self.Rc, g * self.R + (e + 1) * self.Rc) for g in range(self.world)])
@@ -297,23 +298,28 @@ class PipelinedEngines:
             eng.upload_workload(w, self.sel(e))
 
     def step(self, time_kernels=False, events=None):
-        cur = torch.cuda.current_stream(self.dev)
+        """One pass over all chunks.  Two tokens keep the chunks in complementary phases: only one chunk hashes at a time
+        and only one expands at a time, so chunk e+1's (ALU-bound) hashing always runs beside chunk e's (HBM-bound)
+        expansion — without the tokens the streams drift into the same phase and the overlap is lost."""
         for e, (eng, s) in enumerate(zip(self.engines, self.streams)):
-            s.wait_stream(cur)
-            if self._first and e > 0:
-                s.wait_event(self._stagger)      # first pass only: start chunk e once chunk e-1 has finished hashing
             with torch.cuda.stream(s):
                 if events is not None:
                     eng.events = events[e]
+                if self.E > 1 and self._hash_token is not None:
+                    s.wait_event(self._hash_token)
                 eng.step_local(time_kernels)
-                if self._first:
-                    self._stagger = torch.cuda.Event()
-                    self._stagger.record(s)
                 res = eng.step_exchange()
+                if self.E > 1:
+                    self._hash_token = torch.cuda.Event()
+                    self._hash_token.record(s)
+                    if self._expand_token is not None:
+                        s.wait_event(self._expand_token)
                 eng.step_final(res, time_kernels)
+                if self.E > 1:
+                    self._expand_token = torch.cuda.Event()
+                    self._expand_token.record(s)
                 if eng.with_commit and eng.R:
                     s.wait_stream(eng.side)
-        self._first = False
 
     def join(self):
         cur = torch.cuda.current_stream(self.dev)
