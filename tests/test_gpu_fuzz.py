@@ -1,0 +1,53 @@
+"""GPU suite: seeded differential fuzz — random shapes, global-end positions, chain heads (hint clamp / zero padding)
+and random single-byte tampering of headers; the HIP path must agree with the oracle on the status, the assertion
+mask, every per-job record and the full witness, pass or fail."""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from blobstreamx_amd import _lib
+from blobstreamx_amd import types as T
+from blobstreamx_amd.builder import DataCommitmentBuilder, InputDataFetcher
+
+pytestmark = pytest.mark.gpu
+
+
+def _rec(r):
+    r = np.array(r, dtype=T.SUBCHAIN).copy()
+    r["_pad"] = 0
+    return r.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_prove_data_commitment_fuzz(seed):
+    rnd = np.random.default_rng(1000 + seed)
+    J = int(rnd.choice([1, 2, 4, 8, 16]))
+    B = int(rnd.choice([1, 2, 4, 8, 16, 32]))
+    w = synth.Workload(100 + seed, 1, J, B, v=1)
+    S = int(w.first_height[0])
+    bld = DataCommitmentBuilder()
+    for trial in range(6):
+        n_blocks = int(rnd.integers(0, J * B + 3))                 # 0 (end == start) .. beyond J*B (A7)
+        latest = S + int(rnd.integers(1, J * B + 6))               # chain head anywhere: exercises the latest-2 clamp
+        hdrs = w.headers[0].copy()
+        if trial >= 3:                                             # tamper one byte of one header
+            k = int(rnd.integers(0, hdrs.size))
+            raw = hdrs.view(np.uint8).reshape(-1, 512)
+            raw[k, int(rnd.integers(16, 512))] ^= 1 << int(rnd.integers(0, 8))
+        e_idx = min(n_blocks, J * B)
+        ctx = oracle.make_ctx(S, w.hashes[0, 0].tobytes(), S + n_blocks, w.hashes[0, e_idx].tobytes())
+        rc_ref, ref = oracle.prove_data_commitment(J, B, ctx, hdrs, S, latest, want_witness=True)
+        f = InputDataFetcher(hdrs, S, latest)
+        try:
+            out = bld.prove_data_commitment(f, J, B, S, w.hashes[0, 0].tobytes(), S + n_blocks, w.hashes[0, e_idx].tobytes(),
+                                            want_witness=True, raise_on_assert=False)
+            rc = out["rc"]
+        except _lib.BsxError as e:
+            rc, out = e.status, None
+        assert rc == rc_ref, (seed, trial, J, B, n_blocks, latest - S, rc, rc_ref)
+        if rc in (T.OK, T.ERR_ASSERT):
+            assert out["result"]["assert_fail"] == ref["status"], (seed, trial, hex(out["result"]["assert_fail"]), hex(ref["status"]))
+            assert [_rec(r) for r in out["records"]] == [_rec(r) for r in ref["records"]], (seed, trial)
+            assert out["data_commitment"] == ref["data_commitment"]
+            assert (out["witness"] == oracle.expand_range_witness(J, B, ref["compact"])).all(), (seed, trial)
