@@ -12,7 +12,7 @@ import threading
 from . import types as T
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_DIR, "lib", "libbsx.so")
+_SO = os.environ.get("BSX_LIB_OVERRIDE") or os.path.join(_DIR, "lib", "libbsx.so")   # override: kernel A/B experiments
 _lib = None
 _lock = threading.Lock()
 _ctx = {}

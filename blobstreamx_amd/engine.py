@@ -21,6 +21,7 @@ record per (range, rank) replaces the reference's map->reduce hand-off; the owne
 the last log2(N) reduce levels, the final assertions and that range's commit verification.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -118,6 +119,9 @@ class HeaderRangeEngine:
             self.witness_red_top = torch.zeros(self.n_red_top_el + 2, dtype=torch.int64, device=d)
         self.events = None
         self.side = torch.cuda.Stream(device=d)
+        # which phase the commit side stream starts beside.  Measured (same box, tools/prio_test.py): beside the hashing
+        # 8.0-8.6 ms/step, beside the expansion 8.8-10.6 ms/step, no commit at all 7.2-7.6 ms/step
+        self.commit_with = os.environ.get("BSX_COMMIT_WITH", "hash")
 
     # ------------------------------------------------------------------ data
     def upload(self, headers_slice, ranges, latest, skip_headers=None, skip_ranges=None, validators=None, trusted=None):
@@ -168,9 +172,10 @@ class HeaderRangeEngine:
             self._target_hash_view()
             chk(L.bsx_dev_fill_end_hash(ctx, st, C.c_uint32(R), dp(self.skip_ranges), dp(self.skip_hashes), C.c_uint64(2),
                                         dp(self.target_idx)))
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                self._commit(self._st())
+            if self.commit_with == "hash":
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self._commit(self._st())
         chk(L.bsx_dev_header_merkle(ctx, st, dp(self.headers), C.c_uint64(RT * self.hpr), dp(self.hashes), dp(self.dh_aunts),
                                     dp(self.lb_aunts), dp(self.status)))
         chk(L.bsx_dev_assemble_inputs(ctx, st, C.c_uint32(RT), C.c_uint32(self.J), C.c_uint32(B), C.c_uint32(self.jf),
@@ -228,6 +233,12 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_finalize(ctx, st, C.c_uint32(self.R), C.c_uint32(self.J), C.c_uint32(self.B), dp(own_ranges),
                                dp(result_records), dp(self.target_hashes) if self.with_commit else None, dp(self.output64),
                                dp(self.range_status)))
+        if self.with_commit and self.R and self.commit_with == "expand":
+            # the commit verification is integer-ALU work: start it beside the HBM-bound expansion, not beside the hashing
+            main = torch.cuda.current_stream(self.dev)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._commit(self._st())
         if self.with_witness:
             if ev:
                 ev[2].record(torch.cuda.current_stream(self.dev))
