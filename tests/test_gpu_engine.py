@@ -16,7 +16,10 @@ def _rec(r):
     return r.tobytes()
 
 
-@pytest.mark.parametrize("J,B,V,R,n_blocks", [(2, 32, 100, 3, 64), (32, 64, 100, 2, 2048), (8, 32, 20, 4, 131), (32, 32, 100, 2, 1024)])
+# BASELINE configs: #2 64 = 2x32 / V=100, #3 1024 = 32x32, #4 2048 = 32x64, #5 2048 / V=512 (here on one GPU; the sharded
+# form of #4/#5 is test_sharded_engines_on_one_gpu)
+@pytest.mark.parametrize("J,B,V,R,n_blocks", [(2, 32, 100, 3, 64), (32, 64, 100, 2, 2048), (8, 32, 20, 4, 131), (32, 32, 100, 2, 1024),
+                                              (32, 64, 512, 1, 2048)])
 def test_engine_batch_vs_oracle(J, B, V, R, n_blocks):
     from blobstreamx_amd.engine import HeaderRangeEngine
     w = synth.Workload(4, R, J, B, v=V, n_blocks=n_blocks)
