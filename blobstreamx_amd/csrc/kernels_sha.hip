@@ -622,6 +622,9 @@ __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
     constexpr int EX_PAIRS_PER_BLOCK = EX_CHUNK * 4;
     __shared__ uint32_t lds[EX_CHUNK / 4 + 2];
     const uint32_t tid = threadIdx.x;
+    // memory-bound waves issue first; the ALU-bound commit-verification waves co-resident on the CU fill the gaps
+    // (measured +1.5 % on the step with the Ed25519 side stream running)
+    __builtin_amdgcn_s_setprio(3);
     // work item = (job, 1 KiB source chunk); a one-shot grid has one item per workgroup, a capped grid strides
     for (uint32_t item = blockIdx.x; item < a.n_jobs * a.blocks_per_job; item += gridDim.x) {
     const uint32_t job = item / a.blocks_per_job, bx = item % a.blocks_per_job;
