@@ -27,6 +27,7 @@ SYMBOLS = [
     "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_finalize",
     "bsx_dev_expand_witness", "bsx_dev_fill_end_hash", "bsx_dev_sha512_challenge", "bsx_dev_ed25519_verify",
     "bsx_dev_commit_tally", "bsx_dev_skip_check",
+    "bsx_ed25519_keytable_bytes", "bsx_dev_ed25519_keytable", "bsx_dev_ed25519_verify_keyed",
     "bsx_ingest_last_error", "bsx_ingest_header_json", "bsx_ingest_signed_block_json", "bsx_ingest_data_commitment_json",
 ]
 
@@ -62,6 +63,7 @@ def lib():
                     pass
             L = C.CDLL(_SO)
             L.bsx_version.restype = C.c_uint32
+            L.bsx_ed25519_keytable_bytes.restype = C.c_uint64
             L.bsx_last_error.restype = C.c_char_p
             L.bsx_status_str.restype = C.c_char_p
             L.bsx_ingest_last_error.restype = C.c_char_p

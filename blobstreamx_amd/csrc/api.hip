@@ -28,6 +28,9 @@ hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_sh
 hipError_t bsxk_expand_witness(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, uint64_t*);
 hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, uint8_t*, uint8_t*);
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
+uint64_t bsxk_keytable_bytes(uint32_t);
+hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
+hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, uint8_t*);
 hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
                            const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
@@ -234,6 +237,26 @@ int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     DEV_ENTER();
     if (n && (!d_validators || !d_h || !d_ok)) return fail(BSX_ERR_BAD_ARG, "null pointer");
     HIPCHK(bsxk_ed25519_verify(S(ctx, stream), d_validators, d_h, n, d_ok));
+    return BSX_OK;
+}
+
+uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys) { return bsxk_keytable_bytes(n_keys); }
+
+int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys, void* d_table) {
+    DEV_ENTER();
+    if (n_keys && (!d_validators || !d_table)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (((uintptr_t)d_table & 15) != 0) return fail(BSX_ERR_BAD_ARG, "key table must be 16-byte aligned");
+    HIPCHK(bsxk_ed25519_keytable(S(ctx, stream), d_validators, n_keys, static_cast<uint8_t*>(d_table)));
+    return BSX_OK;
+}
+
+int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n,
+                                 uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok) {
+    DEV_ENTER();
+    if (n && (!d_validators || !d_h || !d_ok)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
+    if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, d_ok));
     return BSX_OK;
 }
 

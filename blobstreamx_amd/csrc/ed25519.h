@@ -160,4 +160,132 @@ BSX_HDI bool ed25519_verify_core(const uint32_t pk[8], const uint32_t sig_r[8], 
     return ok && diff == 0;
 }
 
+// ------------------------------------------------------------------------------------------------ fixed-key path
+// A validator set signs every commit of a range batch with the same keys, so the per-key work (decompression and
+// the multiples table) is hoisted out of the per-signature lane: per key we keep j*(-A) and j*(-2^128 A), j = 1..128
+// (cached form, 40 int32 each), and the 253-bit scalars h and s are split at bit 128 and recoded into signed
+// radix-256 digits.  One signature then costs 128 doublings + 64 additions instead of 256 + 128 and no decompression.
+#include "ed25519_btab8.h"   // ge_b8_limb: j*B and j*2^128*B, j = 1..128 (generated)
+
+constexpr int KT_ENTRY_I32 = 40;          // one cached point
+constexpr int KT_HALF_ENTRIES = 128;      // j = 1..128
+constexpr int KT_KEY_I32 = 2 * KT_HALF_ENTRIES * KT_ENTRY_I32;
+
+// r = x + 0x8080...80 (x < 2^253, so no carry out); digit_i = byte_i(r) - 128 in [-128, 127]
+BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)s[i] + 0x80808080u;
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+BSX_HDI int sc_digit8(const uint32_t r[8], int i) { return (int)((pick8(r, i >> 2) >> (8 * (i & 3))) & 255) - 128; }
+
+// per key: base[0] = -A, base[1] = 2^128 * (-A); false when the key does not decode (RFC 8032 strict)
+BSX_HDI bool ge_keytable_bases(const uint32_t pk[8], ge_p3& negA, ge_p3& hi) {
+    const bool ok = ge_frombytes_negate(negA, pk);
+    ge_p2 q{negA.X, negA.Y, negA.Z};
+    ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
+    for (int i = 1; i < 128; i++) {
+        q = p1p1_to_p2(t);
+        t = ge_dbl(q.X, q.Y, q.Z);
+    }
+    hi = p1p1_to_p3(t);
+    return ok;
+}
+// j * base, j in 1..128, by an 8-step double-and-add that is uniform across lanes (the addition is selected, not branched)
+BSX_HDI ge_cached ge_keytable_entry(const ge_p3& base, int j) {
+    const ge_cached cb = p3_to_cached(base);
+    ge_p3 acc{fe_zero(), fe_one(), fe_one(), fe_zero()};
+    for (int bit = 7; bit >= 0; bit--) {
+        acc = p1p1_to_p3(ge_dbl(acc.X, acc.Y, acc.Z));
+        const ge_p3 sum = p1p1_to_p3(ge_add(acc, cb));
+        const bool take = ((j >> bit) & 1) != 0;
+        acc.X = fe_select(take, sum.X, acc.X);
+        acc.Y = fe_select(take, sum.Y, acc.Y);
+        acc.Z = fe_select(take, sum.Z, acc.Z);
+        acc.T = fe_select(take, sum.T, acc.T);
+    }
+    return p3_to_cached(acc);
+}
+BSX_HDI void cached_store(int32_t* dst, const ge_cached& c) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        dst[i] = c.YplusX.v[i];
+        dst[10 + i] = c.YminusX.v[i];
+        dst[20 + i] = c.Z.v[i];
+        dst[30 + i] = c.T2d.v[i];
+    }
+}
+BSX_HDI ge_cached cached_load(const int32_t* src_) {
+    const int32_t* src = static_cast<const int32_t*>(__builtin_assume_aligned(src_, 16));
+    ge_cached c;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        c.YplusX.v[i] = src[i];
+        c.YminusX.v[i] = src[10 + i];
+        c.Z.v[i] = src[20 + i];
+        c.T2d.v[i] = src[30 + i];
+    }
+    return c;
+}
+BSX_HDI ge_precomp ge_b8_entry(int half, int k) {  // (k+1) * 2^(128*half) * B
+    ge_precomp e;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        e.yplusx.v[i] = ge_b8_limb(half, k, i);
+        e.yminusx.v[i] = ge_b8_limb(half, k, 10 + i);
+        e.xy2d.v[i] = ge_b8_limb(half, k, 20 + i);
+    }
+    return e;
+}
+BSX_HDI ge_cached keytable_pick(const int32_t* half_tab, int d) {
+    const int a = d < 0 ? -d : d;
+    ge_cached c = cached_load(half_tab + (a ? a - 1 : 0) * KT_ENTRY_I32);
+    c = cached_cneg(c, d < 0);
+    if (a == 0) c = cached_identity();
+    return c;
+}
+BSX_HDI ge_precomp b8_pick(int half, int d) {
+    const int a = d < 0 ? -d : d;
+    ge_precomp e = ge_b8_entry(half, a ? a - 1 : 0);
+    e = precomp_cneg(e, d < 0);
+    if (a == 0) e = precomp_identity();
+    return e;
+}
+
+// Same accept set as ed25519_verify_core for a key whose table was built by ge_keytable_bases/entry
+// (key_tab: KT_KEY_I32 int32: [half][j-1][40]); the caller has already established that the key decodes.
+BSX_HDI bool ed25519_verify_keyed_core(const int32_t* key_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
+                                       const uint32_t h[8]) {
+    const bool ok = sc_is_canonical(sig_s);
+    uint32_t hr[8], sr[8];
+    sc_recode8(h, hr);
+    sc_recode8(sig_s, sr);
+    const int32_t* lo = key_tab;
+    const int32_t* hi = key_tab + KT_HALF_ENTRIES * KT_ENTRY_I32;
+
+    ge_p2 q{fe_zero(), fe_one(), fe_one()};
+    for (int i = 15; i >= 0; i--) {
+        ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
+        for (int d = 0; d < 7; d++) {
+            q = p1p1_to_p2(t);
+            t = ge_dbl(q.X, q.Y, q.Z);
+        }
+        ge_p3 p = p1p1_to_p3(t);
+        p = p1p1_to_p3(ge_add(p, keytable_pick(lo, sc_digit8(hr, i))));
+        p = p1p1_to_p3(ge_add(p, keytable_pick(hi, sc_digit8(hr, 16 + i))));
+        p = p1p1_to_p3(ge_madd(p, b8_pick(0, sc_digit8(sr, i))));
+        q = p1p1_to_p2(ge_madd(p, b8_pick(1, sc_digit8(sr, 16 + i))));
+    }
+    uint32_t enc[8];
+    ge_tobytes(enc, q.X, q.Y, q.Z);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) diff |= enc[k] ^ sig_r[k];
+    return ok && diff == 0;
+}
+
 }  // namespace bsx

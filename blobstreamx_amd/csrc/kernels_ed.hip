@@ -81,6 +81,107 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validat
     ok_out[me] = ok ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------------ fixed-key tables
+// Key table in HBM (bsx_ed25519_keytable_bytes): [n_keys x 64 B key records: pubkey, decodes flag]
+//                                                [n_keys x 2 x 40 i32 base points -A, -2^128 A (X, Y, Z, T)]
+//                                                [n_keys x 2 x 128 x 40 i32 cached multiples]
+constexpr uint64_t KT_REC_BYTES = 64, KT_BASE_I32 = 80;
+__host__ __device__ inline uint64_t kt_bases_off(uint64_t n_keys) { return n_keys * KT_REC_BYTES; }
+__host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys) { return n_keys * (KT_REC_BYTES + KT_BASE_I32 * 4); }
+__host__ __device__ inline uint64_t kt_bytes(uint64_t n_keys) { return kt_entries_off(n_keys) + n_keys * (uint64_t)KT_KEY_I32 * 4; }
+
+__device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) {
+    const uint4* rec = reinterpret_cast<const uint4*>(v);
+    const uint4 p0 = rec[0], p1 = rec[1];
+    pk[0] = p0.x; pk[1] = p0.y; pk[2] = p0.z; pk[3] = p0.w; pk[4] = p1.x; pk[5] = p1.y; pk[6] = p1.z; pk[7] = p1.w;
+}
+
+// one lane per key: decode, negate, and run the 128 doublings that give the high-half base point
+__global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validator* __restrict__ vals, uint32_t n_keys,
+                                                               uint8_t* __restrict__ table) {
+    const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
+    if (k >= n_keys) return;
+    uint32_t pk[8];
+    load_pk(vals + k, pk);
+    ge_p3 b[2];
+    const bool ok = ge_keytable_bases(pk, b[0], b[1]);
+    uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
+    rec[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    rec[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    rec[2] = make_uint4(ok ? 1u : 0u, 0u, 0u, 0u);
+    rec[3] = make_uint4(0u, 0u, 0u, 0u);
+    int32_t* dst = reinterpret_cast<int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)k * KT_BASE_I32;
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            dst[half * 40 + i] = b[half].X.v[i];
+            dst[half * 40 + 10 + i] = b[half].Y.v[i];
+            dst[half * 40 + 20 + i] = b[half].Z.v[i];
+            dst[half * 40 + 30 + i] = b[half].T.v[i];
+        }
+}
+
+// one lane per (key, half, j): j * base in cached form
+__global__ __launch_bounds__(ED_THREADS) void k_keytable_entries(uint32_t n_keys, uint8_t* __restrict__ table) {
+    const uint32_t idx = blockIdx.x * ED_THREADS + threadIdx.x;
+    if (idx >= n_keys * 2u * KT_HALF_ENTRIES) return;
+    const uint32_t kh = idx / KT_HALF_ENTRIES, j = idx % KT_HALF_ENTRIES + 1;
+    const int32_t* src = reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)kh * 40;
+    ge_p3 base;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        base.X.v[i] = src[i];
+        base.Y.v[i] = src[10 + i];
+        base.Z.v[i] = src[20 + i];
+        base.T.v[i] = src[30 + i];
+    }
+    const ge_cached e = ge_keytable_entry(base, (int)j);
+    cached_store(reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)idx * KT_ENTRY_I32, e);
+}
+
+// one lane per validator slot; slot (me % v_max) uses key table row (me % v_max) when the record's public key is the
+// table's key, and falls back to the generic per-signature path otherwise (a validator-set change inside the batch)
+__global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
+                                                                     const uint8_t* __restrict__ hs, uint64_t n,
+                                                                     uint32_t v_max, const uint8_t* __restrict__ table,
+                                                                     uint32_t n_keys, uint8_t* __restrict__ ok_out) {
+    const uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
+    if (me >= n) return;
+    const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
+    const uint4 flags = rec[14];
+    const bool active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
+    bool ok = false;
+    if (active) {
+        uint32_t pk[8], sr[8], ss[8], h[8];
+        load_pk(vals + me, pk);
+        const uint4 r0 = rec[2], r1 = rec[3], s0 = rec[4], s1 = rec[5];
+        sr[0] = r0.x; sr[1] = r0.y; sr[2] = r0.z; sr[3] = r0.w; sr[4] = r1.x; sr[5] = r1.y; sr[6] = r1.z; sr[7] = r1.w;
+        ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
+        const uint4* hp = reinterpret_cast<const uint4*>(hs + me * 32);
+        const uint4 h0 = hp[0], h1 = hp[1];
+        h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
+
+        const uint32_t slot = (uint32_t)(me % v_max);
+        bool keyed = slot < n_keys;
+        bool decodes = false;
+        if (keyed) {
+            const uint4* kr = reinterpret_cast<const uint4*>(table + (uint64_t)slot * KT_REC_BYTES);
+            const uint4 k0 = kr[0], k1 = kr[1];
+            keyed = k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] && k1.x == pk[4] && k1.y == pk[5] &&
+                    k1.z == pk[6] && k1.w == pk[7];
+            decodes = kr[2].x != 0;
+        }
+        if (keyed) {
+            const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
+            ok = decodes && ed25519_verify_keyed_core(kt, sr, ss, h);
+        } else {
+            ok = ed25519_verify_core(pk, sr, ss, h);
+        }
+    }
+    ok_out[me] = ok ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------ k_commit_tally
 constexpr int TL_THREADS = 256;
 constexpr int TL_VMAX = 512;     // padded power of two of the validator slots one workgroup folds
@@ -333,6 +434,21 @@ hipError_t bsxk_sha512_challenge(hipStream_t s, const bsx_validator* vals, uint6
 hipError_t bsxk_ed25519_verify(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint8_t* ok) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_ed25519_verify, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
+    return hipGetLastError();
+}
+uint64_t bsxk_keytable_bytes(uint32_t n_keys) { return kt_bytes(n_keys); }
+hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint32_t n_keys, uint8_t* table) {
+    if (n_keys == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_keytable_bases, dim3((n_keys + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, vals, n_keys, table);
+    const uint32_t n_entries = n_keys * 2u * KT_HALF_ENTRIES;
+    hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, n_keys, table);
+    return hipGetLastError();
+}
+hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
+                                     const uint8_t* table, uint32_t n_keys, uint8_t* ok) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ed25519_verify_keyed, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n,
+                       v_max, table, n_keys, ok);
     return hipGetLastError();
 }
 hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,

@@ -122,6 +122,12 @@ class HeaderRangeEngine:
         # which phase the commit side stream starts beside.  Measured (same box, tools/prio_test.py): beside the hashing
         # 8.0-8.6 ms/step, beside the expansion 8.8-10.6 ms/step, no commit at all 7.2-7.6 ms/step
         self.commit_with = os.environ.get("BSX_COMMIT_WITH", "hash")
+        # P7 form: "keyed" rebuilds the per-validator tables from range 0's validator slots every step (nothing is carried
+        # between steps) and verifies all R commits against them; a slot whose key differs falls back inside the kernel.
+        self.ed_path = os.environ.get("BSX_ED_PATH", "keyed" if R >= 8 else "generic")
+        if self.ed_path not in ("keyed", "generic"):
+            raise ValueError(f"BSX_ED_PATH={self.ed_path!r}")
+        self.keytable = _u8(int(self.L.bsx_ed25519_keytable_bytes(C.c_uint32(V))), d) if self.ed_path == "keyed" else None
 
     # ------------------------------------------------------------------ data
     def upload(self, headers_slice, ranges, latest, skip_headers=None, skip_ranges=None, validators=None, trusted=None):
@@ -197,7 +203,12 @@ class HeaderRangeEngine:
         R, V = self.R, self.V
         n = R * V
         chk(L.bsx_dev_sha512_challenge(ctx, st, dp(self.validators), C.c_uint64(n), dp(self.h), None))
-        chk(L.bsx_dev_ed25519_verify(ctx, st, dp(self.validators), dp(self.h), C.c_uint64(n), dp(self.ok)))
+        if self.ed_path == "keyed":
+            chk(L.bsx_dev_ed25519_keytable(ctx, st, dp(self.validators), C.c_uint32(V), dp(self.keytable)))
+            chk(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(self.validators), dp(self.h), C.c_uint64(n), C.c_uint32(V),
+                                               dp(self.keytable), C.c_uint32(V), dp(self.ok)))
+        else:
+            chk(L.bsx_dev_ed25519_verify(ctx, st, dp(self.validators), dp(self.h), C.c_uint64(n), dp(self.ok)))
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.trusted), C.c_uint32(R), C.c_uint32(V), None, None, dp(self.trusted_res)))
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.validators), C.c_uint32(R), C.c_uint32(V), dp(self.target_hashes), dp(self.ok),
                                    dp(self.commit_res)))

@@ -347,6 +347,18 @@ int bsx_dev_sha512_challenge(bsx_ctx* ctx, void* stream, const bsx_validator* d_
 /* P7: [s]B == R + [h]A per validator slot. d_ok: n bytes (1 valid, 0 invalid or not signed/enabled). */
 int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
                            uint64_t n, uint8_t* d_ok);
+/* P7, fixed-key form.  A range batch is signed by one validator set, so the per-key work of P7 (decoding A and its
+ * multiples table) is done once per key instead of once per signature.  bsx_dev_ed25519_keytable builds the table
+ * for the public keys of d_validators[0..n_keys) into d_table (bsx_ed25519_keytable_bytes(n_keys) bytes, 16-byte
+ * aligned); bsx_dev_ed25519_verify_keyed then checks n = n_commits*v_max slots, slot i of every commit against
+ * table row i.  A slot whose public key differs from its table row (validator-set change inside the batch, or
+ * i >= n_keys) is verified by the generic per-signature path inside the same kernel, so the accept set is
+ * exactly bsx_dev_ed25519_verify's for any input. */
+uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys);
+int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys,
+                             void* d_table);
+int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
+                                 uint64_t n, uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok);
 /* P8+P9: validator-set hash, voting-power tallies and message checks; one workgroup per commit; v_max <= 512.
  * d_header_hashes / d_ok may be NULL (then only validators_hash, total_power, n_enabled are meaningful). */
 int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits,

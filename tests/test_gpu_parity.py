@@ -323,6 +323,54 @@ def test_verify_commits_vs_oracle(v, v_max, absent):
         assert res_bytes(res[c]) == res_bytes(ref), c
 
 
+@pytest.mark.parametrize("n_keys", [24, 10, 0])
+def test_ed25519_fixed_key_path_matches_generic_and_oracle(n_keys):
+    """bsx_dev_ed25519_verify_keyed (per-validator tables) against bsx_dev_ed25519_verify and the oracle, with slots
+    that must take the table path, slots that must fall back (key differs from the table row, row missing) and a
+    table row whose key does not decode."""
+    import ctypes as C
+    import torch
+    n_commits, v, v_max = 6, 22, 24
+    w = synth.Workload(77, n_commits, 1, 2, v=v, v_max=v_max, absent_permille=100)
+    vals = w.validators.copy()
+    hh = w.commit_hashes.copy()
+    L_ = 2 ** 252 + 27742317777372353535851937790883648493
+    vals[1, 1]["signature"][7] ^= 4                      # bad R, table path
+    vals[1, 3]["signature"][40] ^= 1                     # bad s, table path
+    vals[2, 4]["pubkey"][9] ^= 2                         # key differs from row 4 -> fallback, and it does not verify
+    vals[3, 5] = vals[3, 6]                              # another validator's valid record in slot 5 -> fallback, verifies
+    vals[3, 5]["enabled"] = 1
+    s = int.from_bytes(bytes(vals[4, 8]["signature"][32:]), "little") + L_
+    vals[4, 8]["signature"][32:] = np.frombuffer((s % 2 ** 256).to_bytes(32, "little"), np.uint8)   # s + L
+    bad_key = np.frombuffer((2).to_bytes(32, "little"), np.uint8)    # y = 2 is not on the curve
+    for c in range(n_commits):
+        vals[c, 7]["pubkey"] = bad_key                   # table row 7 does not decode; every commit carries the same key
+    vals[5, 9]["message"][30] ^= 1                       # challenge changes, table path
+    flat = vals.reshape(-1)
+    n = flat.size
+    L, ctx, dp = _lib.lib(), _lib.context(0), _lib.dp
+    dv = torch.from_numpy(flat.view(np.uint8).copy()).cuda()
+    dh = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    ok_g = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ok_k = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+    tab = torch.zeros(max(int(L.bsx_ed25519_keytable_bytes(C.c_uint32(n_keys))), 16), dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(dv), C.c_uint64(n), dp(dh), None))
+    _lib.check(L.bsx_dev_ed25519_verify(ctx, st, dp(dv), dp(dh), C.c_uint64(n), dp(ok_g)))
+    _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab)))
+    _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v_max), dp(tab),
+                                              C.c_uint32(n_keys), dp(ok_k)))
+    torch.cuda.synchronize()
+    ok_g, ok_k = ok_g.cpu().numpy().reshape(n_commits, v_max), ok_k.cpu().numpy().reshape(n_commits, v_max)
+    for c in range(n_commits):
+        _, rok = oracle.verify_commit(vals[c], hh[c].tobytes())
+        assert (ok_k[c] == rok).all(), (c, np.nonzero(ok_k[c] != rok))
+        assert (ok_g[c] == rok).all(), c
+    assert ok_k[3, 5] == 1 and ok_k[2, 4] == 0 and ok_k[1, 1] == 0 and ok_k[1, 3] == 0 and ok_k[4, 8] == 0
+    assert (ok_k[:, 7] == 0).all() and ok_k[5, 9] == 0
+    assert ok_k.sum() > n_commits * v // 2
+
+
 def test_sha512_challenge_vs_oracle():
     import ctypes as C
     import torch

@@ -1,0 +1,187 @@
+"""The device arithmetic headers (blobstreamx_amd/csrc/*.h are __host__ __device__) compiled with g++ and checked
+against hashlib, Python integers and the oracle — the exact kernel source, on a machine without a GPU.
+
+tests/hostcheck is a harness; it is never loaded by the product.
+"""
+import ctypes as C
+import hashlib
+import os
+import random
+import subprocess
+
+import pytest
+
+import oracle
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P25519 = 2**255 - 19
+L = 2**252 + 27742317777372353535851937790883648493
+
+
+@pytest.fixture(scope="module")
+def hc():
+    d = os.path.join(HERE, "hostcheck")
+    subprocess.run(["make", "-C", d], check=True, capture_output=True)
+    lib = C.CDLL(os.path.join(d, "libhostcheck.so"))
+    lib.hc_ed25519_verify.restype = C.c_int
+    lib.hc_ed25519_verify_keyed.restype = C.c_int
+    lib.hc_sc_is_canonical.restype = C.c_int
+    return lib
+
+
+def _tm_leaf(x):
+    return hashlib.sha256(b"\x00" + x).digest()
+
+
+def test_leaf_and_inner_hashes_match_hashlib(hc):
+    rng = random.Random(1)
+    out = C.create_string_buffer(32)
+    for n in list(range(0, 55)) + [55, 63, 64, 70, 76]:
+        data = bytes(rng.randrange(256) for _ in range(n))
+        hc.hc_leaf_hash_var(data, n, out)
+        assert out.raw == _tm_leaf(data), n
+    for _ in range(8):
+        d34, d72, d64 = (bytes(rng.randrange(256) for _ in range(k)) for k in (34, 72, 64))
+        hc.hc_leaf_hash_34(d34, out)
+        assert out.raw == _tm_leaf(d34)
+        hc.hc_leaf_hash_72(d72, out)
+        assert out.raw == _tm_leaf(d72)
+        hc.hc_leaf_hash_tuple(d64, out)
+        assert out.raw == _tm_leaf(d64)
+        hc.hc_inner_hash(d64[:32], d64[32:], out)
+        assert out.raw == hashlib.sha256(b"\x01" + d64).digest()
+
+
+def test_sha512_challenge_and_scalar_reduction(hc):
+    rng = random.Random(2)
+    o64, o32 = C.create_string_buffer(64), C.create_string_buffer(32)
+    for n in (0, 1, 47, 48, 63, 64, 100, 111, 112, 124):
+        r, a = (bytes(rng.randrange(256) for _ in range(32)) for _ in range(2))
+        m = bytes(rng.randrange(256) for _ in range(n))
+        hc.hc_sha512_ram(r, a, m, n, o64)
+        assert o64.raw == hashlib.sha512(r + a + m).digest(), n
+    edge = [0, 1, L - 1, L, L + 1, 2**252, 2**512 - 1, (L << 256) - 1, L * L]
+    for x in edge + [rng.getrandbits(512) for _ in range(200)]:
+        hc.hc_sc_reduce64((x % 2**512).to_bytes(64, "little"), o32)
+        assert int.from_bytes(o32.raw, "little") == (x % 2**512) % L
+    for x in (0, 1, L - 1, L, L + 1, 2**256 - 1):
+        assert hc.hc_sc_is_canonical(x.to_bytes(32, "little")) == int(x < L)
+
+
+def test_field_arithmetic(hc):
+    rng = random.Random(3)
+    o = C.create_string_buffer(32)
+    vals = [0, 1, 2, 19, P25519 - 1, P25519 - 19, 2**255 - 20, 2**254, 2**255 - 1] + [rng.getrandbits(255) for _ in range(100)]
+    for a in vals:
+        ab = a.to_bytes(32, "little")
+        for b in vals[:12]:
+            hc.hc_fe_mul(ab, b.to_bytes(32, "little"), o)
+            assert int.from_bytes(o.raw, "little") == a * b % P25519
+        hc.hc_fe_sq(ab, 0, o)
+        assert int.from_bytes(o.raw, "little") == a * a % P25519
+        hc.hc_fe_sq(ab, 1, o)
+        assert int.from_bytes(o.raw, "little") == 2 * a * a % P25519
+        hc.hc_fe_invert(ab, o)
+        assert int.from_bytes(o.raw, "little") == pow(a, P25519 - 2, P25519)
+
+
+def _cases(golden):
+    """(pk, sig, h, note) — fixture signatures, synthetic ones, and corruptions of each part."""
+    out = []
+    for blk in golden["blocks"].values():
+        for c in blk["commit"]["signatures"]:
+            if not c.get("signature"):
+                continue
+            pk = bytes.fromhex(blk["validators"][c["validator_index"]]["pubkey"])
+            out.append((pk, bytes.fromhex(c["signature"]), bytes.fromhex(c["sign_bytes"]), "fixture"))
+    rng = random.Random(4)
+    for i in range(12):
+        seed = bytes(rng.randrange(256) for _ in range(32))
+        msg = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 120)))
+        out.append((synth.ed25519_keypair(seed), synth.ed25519_sign(seed, msg), msg, "synth"))
+    cases = []
+    for pk, sig, msg, note in out:
+        h = (int.from_bytes(hashlib.sha512(sig[:32] + pk + msg).digest(), "little") % L).to_bytes(32, "little")
+        cases.append((pk, sig, h, note))
+        flip = lambda b, i: b[:i] + bytes([b[i] ^ 1]) + b[i + 1:]
+        cases.append((pk, flip(sig, 3), h, note + "/badR"))
+        cases.append((pk, flip(sig, 40), h, note + "/badS"))
+        cases.append((pk, sig, flip(h, 9), note + "/badH"))
+        cases.append((flip(pk, 5), sig, h, note + "/badA"))
+        s_plus_l = (int.from_bytes(sig[32:], "little") + L).to_bytes(32, "little")
+        cases.append((pk, sig[:32] + s_plus_l, h, note + "/s+L"))
+    return cases
+
+
+def test_ed25519_generic_and_fixed_key_paths_match_the_oracle(hc, golden):
+    cases = _cases(golden)
+    assert sum(1 for c in cases if c[3] == "fixture") >= 10
+    n_ok = 0
+    for pk, sig, h, note in cases:
+        want = int(bool(oracle.ed25519_verify_h(pk, sig, h)))
+        assert hc.hc_ed25519_verify(pk, sig, h) == want, note
+        assert hc.hc_ed25519_verify_keyed(pk, sig, h) == want, note
+        if "/" not in note:
+            assert want == 1, note
+        n_ok += want
+    assert 0 < n_ok < len(cases)
+
+
+# -- tiny Python Edwards arithmetic to forge signatures for CHOSEN (h, s): R = [(s - h a) mod L] B
+_D = -121665 * pow(121666, P25519 - 2, P25519) % P25519
+_BY = 4 * pow(5, P25519 - 2, P25519) % P25519
+
+
+def _recover_x(y, sign):
+    x2 = (y * y - 1) * pow(_D * y * y + 1, P25519 - 2, P25519) % P25519
+    x = pow(x2, (P25519 + 3) // 8, P25519)
+    if (x * x - x2) % P25519:
+        x = x * pow(2, (P25519 - 1) // 4, P25519) % P25519
+    return P25519 - x if (x & 1) != sign else x
+
+
+def _add(p, q):
+    (x1, y1), (x2, y2) = p, q
+    k = _D * x1 * x2 * y1 * y2 % P25519
+    x3 = (x1 * y2 + x2 * y1) * pow(1 + k, P25519 - 2, P25519) % P25519
+    y3 = (y1 * y2 + x1 * x2) * pow(1 - k, P25519 - 2, P25519) % P25519
+    return x3, y3
+
+
+def _mul(k, p):
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = _add(acc, p)
+        p = _add(p, p)
+        k >>= 1
+    return acc
+
+
+def _enc(p):
+    return (p[1] | ((p[0] & 1) << 255)).to_bytes(32, "little")
+
+
+def test_fixed_key_path_digit_edges(hc):
+    """Valid signatures forged for scalars whose radix-256 recoding hits the extreme digits (-128, 127, 0) in both
+    halves, for h and for s."""
+    B = (_recover_x(_BY, 0), _BY)
+    seed = bytes(range(32))
+    pk = synth.ed25519_keypair(seed)
+    d = bytearray(hashlib.sha512(seed).digest()[:32])
+    d[0] &= 248; d[31] &= 127; d[31] |= 64
+    a = int.from_bytes(d, "little")
+    assert _enc(_mul(a, B)) == pk
+    edges = [0, 1, 2**128 - 1, 2**128, 2**128 + 1, int("80" * 31, 16), int("7f" * 31, 16), int("ff" * 31, 16), L - 1,
+             2**252, 2**252 + 2**127, int("0080" * 15, 16), int("7f80" * 15, 16)]
+    pairs = [(h, s) for h in edges for s in (edges[3], edges[5], edges[8])] + [(edges[1], s) for s in edges]
+    for h, s in pairs:
+        h, s = h % L, s % L
+        R = _enc(_mul((s - h * a) % L, B))
+        sig, hb = R + s.to_bytes(32, "little"), h.to_bytes(32, "little")
+        assert oracle.ed25519_verify_h(pk, sig, hb)
+        assert hc.hc_ed25519_verify(pk, sig, hb) == 1, (hex(h), hex(s))
+        assert hc.hc_ed25519_verify_keyed(pk, sig, hb) == 1, (hex(h), hex(s))
+        bad = ((h + 1) % L).to_bytes(32, "little")
+        assert hc.hc_ed25519_verify_keyed(pk, sig, bad) == 0
