@@ -45,8 +45,24 @@ BSX_HDI fe fe_carry64(int64_t h[10]) {
 }
 
 // h = f * g.  Preconditions as in the classic 25.5-bit schoolbook: |f|,|g| limbs <= 1.65*2^26 (even) / 2^25 (odd).
-// By value and NOT inlined on the device (20 VGPR arguments, 10 results): ~70 call sites share one ~2 KB body.
-BSX_HD_NOINLINE fe fe_mul(fe f, fe g) {
+// NOT inlined on the device: ~70 call sites share one ~2 KB body.  The operands travel as native vectors (8 + 2 limbs
+// each): the AMDGPU calling convention gives aggregates at most 16 argument registers, so a second `fe` struct would
+// be passed through scratch memory — a store/load round trip per multiplication that stalls behind the HBM-bound
+// witness expansion sharing the CU.  Vector arguments are not aggregates; all 20 limbs arrive in VGPRs.
+typedef int32_t i32x8 __attribute__((vector_size(32)));
+typedef int32_t i32x2 __attribute__((vector_size(8)));
+BSX_HDI fe fe_from_v(i32x8 a, i32x2 b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a[i];
+    r.v[8] = b[0]; r.v[9] = b[1];
+    return r;
+}
+BSX_HDI i32x8 fe_lo8(const fe& f) { return i32x8{f.v[0], f.v[1], f.v[2], f.v[3], f.v[4], f.v[5], f.v[6], f.v[7]}; }
+BSX_HDI i32x2 fe_hi2(const fe& f) { return i32x2{f.v[8], f.v[9]}; }
+
+BSX_HD_NOINLINE fe fe_mul_v(i32x8 fa, i32x2 fb, i32x8 ga, i32x2 gb) {
+    const fe f = fe_from_v(fa, fb), g = fe_from_v(ga, gb);
     int32_t g19[10], f2[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) { g19[i] = 19 * g.v[i]; f2[i] = 2 * f.v[i]; }
@@ -65,6 +81,7 @@ BSX_HD_NOINLINE fe fe_mul(fe f, fe g) {
     }
     return fe_carry64(h);
 }
+BSX_HDI fe fe_mul(const fe& f, const fe& g) { return fe_mul_v(fe_lo8(f), fe_hi2(f), fe_lo8(g), fe_hi2(g)); }
 
 // h = f^2 (DBL == false) or 2 f^2 (DBL == true)
 template <bool DBL>

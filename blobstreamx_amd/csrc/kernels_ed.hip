@@ -58,11 +58,16 @@ __global__ __launch_bounds__(CH_THREADS) void k_sha512_challenge(const bsx_valid
 
 // ------------------------------------------------------------------------------------------------ k_ed25519_verify
 constexpr int ED_THREADS = 64;   // one wave per workgroup: a 100-signature commit spreads over 2 CUs, R commits over 2R
+constexpr uint8_t ED_DEFERRED = 2;   // ok_out marker: the fixed-key kernel left this slot to the generic one
+// ONLY_DEFERRED: second pass behind k_ed25519_verify_keyed — touch only the slots it marked (normally none: the
+// waves read one byte per lane and retire)
+template <bool ONLY_DEFERRED>
 __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validator* __restrict__ vals,
                                                                const uint8_t* __restrict__ hs, uint64_t n,
                                                                uint8_t* __restrict__ ok_out) {
     const uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
     if (me >= n) return;
+    if (ONLY_DEFERRED && ok_out[me] != ED_DEFERRED) return;
     const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
     const uint4 flags = rec[14];                    // bytes 224..239: voting_power (8), enabled, is_signed, present, pad
     const bool active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_entries(uint32_t n_keys
 
 // one lane per validator slot; slot (me % v_max) uses key table row (me % v_max) when the record's public key is the
 // table's key, and falls back to the generic per-signature path otherwise (a validator-set change inside the batch)
-__global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
+__global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
                                                                      const uint8_t* __restrict__ hs, uint64_t n,
                                                                      uint32_t v_max, const uint8_t* __restrict__ table,
                                                                      uint32_t n_keys, uint8_t* __restrict__ ok_out) {
@@ -172,12 +177,12 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify_keyed(const bsx_v
                     k1.z == pk[6] && k1.w == pk[7];
             decodes = kr[2].x != 0;
         }
-        if (keyed) {
-            const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
-            ok = decodes && ed25519_verify_keyed_core(kt, sr, ss, h);
-        } else {
-            ok = ed25519_verify_core(pk, sr, ss, h);
+        if (!keyed) {
+            ok_out[me] = ED_DEFERRED;   // left to k_ed25519_verify<true>, launched right behind on the same stream
+            return;
         }
+        const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
+        ok = decodes && ed25519_verify_keyed_core(kt, sr, ss, h);
     }
     ok_out[me] = ok ? 1 : 0;
 }
@@ -433,7 +438,7 @@ hipError_t bsxk_sha512_challenge(hipStream_t s, const bsx_validator* vals, uint6
 }
 hipError_t bsxk_ed25519_verify(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint8_t* ok) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_ed25519_verify, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
+    hipLaunchKernelGGL(k_ed25519_verify<false>, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
     return hipGetLastError();
 }
 uint64_t bsxk_keytable_bytes(uint32_t n_keys) { return kt_bytes(n_keys); }
@@ -449,6 +454,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_ed25519_verify_keyed, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n,
                        v_max, table, n_keys, ok);
+    hipLaunchKernelGGL(k_ed25519_verify<true>, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
     return hipGetLastError();
 }
 hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,

@@ -119,9 +119,12 @@ class HeaderRangeEngine:
             self.witness_red_top = torch.zeros(self.n_red_top_el + 2, dtype=torch.int64, device=d)
         self.events = None
         self.side = torch.cuda.Stream(device=d)
-        # which phase the commit side stream starts beside.  Measured (same box, tools/prio_test.py): beside the hashing
-        # 8.0-8.6 ms/step, beside the expansion 8.8-10.6 ms/step, no commit at all 7.2-7.6 ms/step
-        self.commit_with = os.environ.get("BSX_COMMIT_WITH", "hash")
+        # which phase the commit side stream starts beside.  Measured on ONE engine object (same allocations, interleaved
+        # rounds, tools/prio_test.py): no commit 7.59 ms/step; beside the hashing 8.58 (generic P7) / 8.29 (keyed);
+        # beside the expansion 8.05 (generic) / 7.80 (keyed).  The ALU-bound hashing phase has no spare issue slots,
+        # the HBM-bound expansion does — once the field multiplication stopped passing operands through scratch
+        # memory (fe25519.h), which used to queue every multiplication behind the expansion's stores.
+        self.commit_with = os.environ.get("BSX_COMMIT_WITH", "expand")
         # P7 form: "keyed" rebuilds the per-validator tables from range 0's validator slots every step (nothing is carried
         # between steps) and verifies all R commits against them; a slot whose key differs falls back inside the kernel.
         self.ed_path = os.environ.get("BSX_ED_PATH", "keyed" if R >= 8 else "generic")
