@@ -636,7 +636,17 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
     H2D(dv.p, validators, n * sizeof(bsx_validator));
     H2D(dhh.p, header_hashes, (size_t)n_commits * 32);
     HIPCHK(bsxk_sha512_challenge(st, dv.as<bsx_validator>(), n, dh.as<uint8_t>(), nullptr));
-    HIPCHK(bsxk_ed25519_verify(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, dok.as<uint8_t>()));
+    if (n_commits >= 8) {
+        // many commits, (normally) one validator set: per-key tables from the first commit's slots; slots whose key
+        // differs fall back to the generic path inside bsxk_ed25519_verify_keyed
+        DBuf dtab;
+        RET(dtab.alloc(bsxk_keytable_bytes(v_max)));
+        HIPCHK(bsxk_ed25519_keytable(st, dv.as<bsx_validator>(), v_max, dtab.as<uint8_t>()));
+        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dtab.as<uint8_t>(), v_max, dok.as<uint8_t>()));
+        SYNC();   // dtab is released at scope exit
+    } else {
+        HIPCHK(bsxk_ed25519_verify(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, dok.as<uint8_t>()));
+    }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     D2H(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result));
     if (out_sig_ok) D2H(out_sig_ok, dok.p, n);

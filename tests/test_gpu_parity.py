@@ -300,14 +300,15 @@ def test_prove_data_commitment_broken_chain_matches_oracle(builder):
     assert [rec_bytes(r) for r in out["records"]] == [rec_bytes(r) for r in ref["records"]]
 
 
-@pytest.mark.parametrize("v,v_max,absent", [(100, 100, 0), (100, 128, 150), (7, 8, 0), (512, 512, 300), (1, 1, 0)])
-def test_verify_commits_vs_oracle(v, v_max, absent):
-    w = synth.Workload(40 + v, 3, 1, 2, v=v, v_max=v_max, absent_permille=absent)
+@pytest.mark.parametrize("v,v_max,absent,nc", [(100, 100, 0, 3), (100, 128, 150, 3), (7, 8, 0, 3), (512, 512, 300, 3), (1, 1, 0, 3),
+                                                (20, 24, 100, 9), (100, 100, 50, 12)])   # nc >= 8: fixed-key P7 inside the host tier
+def test_verify_commits_vs_oracle(v, v_max, absent, nc):
+    w = synth.Workload(40 + v, nc, 1, 2, v=v, v_max=v_max, absent_permille=absent)
     vals = w.validators.copy()                      # [3, v_max]
     hh = w.commit_hashes.copy()
     rnd = np.random.default_rng(v)
     # tamper: flip a signature bit, a message byte inside the hash, a pubkey bit; make s non-canonical
-    for c in range(3):
+    for c in range(nc):
         signed = np.nonzero(vals[c]["is_signed"])[0]
         if signed.size >= 4:
             a, b, d, e = signed[rnd.permutation(signed.size)[:4]]
@@ -317,7 +318,7 @@ def test_verify_commits_vs_oracle(v, v_max, absent):
             s = int.from_bytes(bytes(vals[c, e]["signature"][32:]), "little") + (2 ** 252 + 27742317777372353535851937790883648493)
             vals[c, e]["signature"][32:] = np.frombuffer((s % 2 ** 256).to_bytes(32, "little"), np.uint8)
     res, ok = verify_commits(vals, hh)
-    for c in range(3):
+    for c in range(nc):
         ref, rok = oracle.verify_commit(vals[c], hh[c].tobytes())
         assert (ok[c] == rok).all(), (c, np.nonzero(ok[c] != rok))
         assert res_bytes(res[c]) == res_bytes(ref), c
