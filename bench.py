@@ -216,7 +216,10 @@ def main():
                        "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": E,
                        "parallelism": f"{world} x ({J // world} of {J} map jobs per range), 1 all-gather of 128-B records" if world > 1 else "1 GPU",
                        "witness_bytes_per_step_per_gpu": int(E * n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
-                       "input_generation_s": round(t_gen, 2)},
+                       "input_generation_s": round(t_gen, 2),
+                       "ed25519_path": e0.ed_path, "commit_beside": e0.commit_with,
+                       # setup-time choice of the witness buffer among a few allocations (engine._place_witness)
+                       "witness_placement_probe": e0.placement_probe},
         }
         if not args.no_witness:
             # the same kernel alone on an idle GPU (after the timed region): what the overlap with the other chunk's hashing costs it

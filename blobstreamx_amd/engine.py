@@ -113,8 +113,9 @@ class HeaderRangeEngine:
         self.n_map_el = RT * jc * int(self.ml["n_elements"])
         self.n_red_local_el = n_local_nodes * int(self.rl["n_elements"])
         self.n_red_top_el = R * max(world - 1, 0) * int(self.rl["n_elements"])
+        self.placement_probe = None
         if with_witness:
-            self.witness_map = torch.zeros(self.n_map_el + 2, dtype=torch.int64, device=d)
+            self.witness_map = self._place_witness(self.n_map_el + 2)
             self.witness_red_local = torch.zeros(self.n_red_local_el + 2, dtype=torch.int64, device=d)
             self.witness_red_top = torch.zeros(self.n_red_top_el + 2, dtype=torch.int64, device=d)
         self.events = None
@@ -131,6 +132,53 @@ class HeaderRangeEngine:
         if self.ed_path not in ("keyed", "generic"):
             raise ValueError(f"BSX_ED_PATH={self.ed_path!r}")
         self.keytable = _u8(int(self.L.bsx_ed25519_keytable_bytes(C.c_uint32(V))), d) if self.ed_path == "keyed" else None
+
+    def _place_witness(self, n_el):
+        """Allocate the expanded-witness buffer of the map jobs (29.5 GB for 256 x header_range_2048).
+
+        Setup-time placement probe.  The store bandwidth of the expansion depends on WHICH physical memory the buffer
+        landed in: on one MI355X, seven 29.5 GB buffers allocated back to back ran the identical launch at 4.72, 5.53,
+        5.27, 5.72, 5.64, 5.09 and 4.84 TB/s, each figure stable for its buffer, and freeing + re-allocating the same
+        virtual address changed it again (tools/placement_test.py) — VRAM fragmentation left behind by earlier
+        processes decides the page-table fragment sizes.  So: allocate up to BSX_PLACEMENT_PROBE candidates while
+        memory allows, time the real expansion launch on each, keep the fastest, release the rest."""
+        d, nbytes = self.dev, n_el * 8
+        first = torch.zeros(n_el, dtype=torch.int64, device=d)
+        k = int(os.environ.get("BSX_PLACEMENT_PROBE", "4"))
+        if k <= 1 or nbytes < (1 << 30):
+            return first
+        cands = [first]
+        for _ in range(k - 1):
+            free, _total = torch.cuda.mem_get_info(d)
+            if free < nbytes + (16 << 30):
+                break
+            try:
+                cands.append(torch.zeros(n_el, dtype=torch.int64, device=d))
+            except RuntimeError:
+                break
+        if len(cands) == 1:
+            return first
+        L, ctx, dp = self.L, self.ctx, _lib.dp
+        st = self._st()
+        times = []
+        for buf in cands:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for it in range(4):
+                if it == 1:
+                    ev[0].record(torch.cuda.current_stream(d))
+                _lib.check(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._ml), C.c_uint32(self.RT * self.jc), dp(self.compact),
+                                                    dp(buf)))
+            ev[1].record(torch.cuda.current_stream(d))
+            torch.cuda.synchronize(d)
+            times.append(ev[0].elapsed_time(ev[1]) / 3)
+        best = min(range(len(cands)), key=lambda i: times[i])
+        self.placement_probe = {"candidates": len(cands), "ms": [round(t, 3) for t in times], "picked": best}
+        keep = cands[best]
+        keep.zero_()
+        del cands, buf, first
+        torch.cuda.synchronize(d)
+        torch.cuda.empty_cache()
+        return keep
 
     # ------------------------------------------------------------------ data
     def upload(self, headers_slice, ranges, latest, skip_headers=None, skip_ranges=None, validators=None, trusted=None):
