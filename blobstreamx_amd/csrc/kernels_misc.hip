@@ -67,12 +67,13 @@ __global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_has
 }
 
 __global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
-                                const uint32_t* target_idx) {
+                                const uint32_t* target_idx, uint8_t* target_out) {
     const uint32_t r = blockIdx.x, t = threadIdx.x;   // 32 lanes
     if (r >= n_ranges) return;
     const uint64_t idx = (uint64_t)r * hpr + (target_idx ? (uint64_t)target_idx[r] : ranges[r].end_block - ranges[r].start_block);
     const uint8_t b = hashes[idx * 32 + t];
     ranges[r].end_header_hash[t] = b;
+    if (target_out) target_out[(uint64_t)r * 32 + t] = b;   // dense copy for the commit tally / finalize
 }
 
 }  // namespace bsx
@@ -89,9 +90,9 @@ hipError_t bsxk_data_commitment(hipStream_t s, const uint8_t* data_hashes, uint3
     return hipGetLastError();
 }
 hipError_t bsxk_fill_end_hash(hipStream_t s, uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
-                              const uint32_t* target_idx) {
+                              const uint32_t* target_idx, uint8_t* target_out) {
     if (!n_ranges) return hipSuccess;
-    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr, target_idx);
+    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr, target_idx, target_out);
     return hipGetLastError();
 }
 }

@@ -220,41 +220,47 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     const uint16_t* lb16 = reinterpret_cast<const uint16_t*>(a.lb_aunts);
     const uint64_t h0 = hbase + (batch_start - S);
     bool bad_leaf = false;
-    for (uint32_t w = threadIdx.x; w < ndw; w += blockDim.x) {
-        uint32_t v = 0;
+    // Branch-free source addressing (an invalid unit reads a dummy location and is masked), AS_UNROLL output dwords
+    // = 2*AS_UNROLL independent loads in flight per lane before the first store: beside the HBM-bound expansion of
+    // the other chunk every load round trip is several times longer, and the gather is pure latency.
+    constexpr int AS_UNROLL = 4;
+    const uint16_t* dummy = reinterpret_cast<const uint16_t*>(a.ranges);
+    auto src = [&](uint32_t u, bool& valid) -> const uint16_t* {
+        const bool is_dh = u < n_dh_units;
+        const uint32_t uu = is_dh ? u : u - n_dh_units;
+        const uint32_t per = is_dh ? (BSX_DH_PROOF_SIZE / 2) : (BSX_LB_PROOF_SIZE / 2);
+        const uint32_t slot = uu / per, k = uu % per;
+        valid = (u < total_units) && !oob && (slot < n_real);
+        const uint64_t hidx = h0 + slot + (is_dh ? 0 : 1);
+        const bsx_header* h = a.headers + hidx;
+        const uint16_t* aunt = (is_dh ? dh16 : lb16) + hidx * 64 + k;
+        const uint16_t* leaf = reinterpret_cast<const uint16_t*>(is_dh ? h->hash[1] : h->last_block_id) + ((int)k - 64);
+        const uint16_t* p = (k < 64) ? aunt : leaf;
+        return valid ? p : dummy;
+    };
+    for (uint32_t w0 = threadIdx.x; w0 < ndw; w0 += blockDim.x * AS_UNROLL) {
+        uint32_t x[2 * AS_UNROLL];
+        bool ok[2 * AS_UNROLL];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const uint32_t u = 2 * w + half;
-            uint32_t x = 0;
-            if (u < total_units && !oob) {
-                if (u < n_dh_units) {
-                    const uint32_t slot = u / (BSX_DH_PROOF_SIZE / 2), k = u % (BSX_DH_PROOF_SIZE / 2);
-                    if (slot < n_real) {
-                        const uint64_t hidx = h0 + slot;
-                        if (k < 64) x = dh16[hidx * 64 + k];
-                        else {
-                            const bsx_header* h = a.headers + hidx;
-                            x = reinterpret_cast<const uint16_t*>(h->hash[1])[k - 64];
-                            if (k == 64 && h->len[BSX_DATA_HASH_INDEX] != BSX_PROTOBUF_HASH_SIZE) bad_leaf = true;   // input.rs:173
-                        }
-                    }
-                } else {
-                    const uint32_t uu = u - n_dh_units;
-                    const uint32_t slot = uu / (BSX_LB_PROOF_SIZE / 2), k = uu % (BSX_LB_PROOF_SIZE / 2);
-                    if (slot < n_real) {
-                        const uint64_t hidx = h0 + slot + 1;
-                        if (k < 64) x = lb16[hidx * 64 + k];
-                        else {
-                            const bsx_header* h = a.headers + hidx;
-                            x = reinterpret_cast<const uint16_t*>(h->last_block_id)[k - 64];
-                            if (k == 64 && h->len[BSX_LAST_BLOCK_ID_INDEX] != BSX_PROTOBUF_BLOCK_ID_SIZE) bad_leaf = true;   // input.rs:190
-                        }
-                    }
-                }
-            }
-            v |= x << (16 * half);
+        for (int j = 0; j < 2 * AS_UNROLL; j++) {
+            const uint32_t w = w0 + (j >> 1) * blockDim.x;
+            x[j] = *src(2 * w + (j & 1), ok[j]);
         }
-        cw32[32 + w] = v;
+#pragma unroll
+        for (int j = 0; j < AS_UNROLL; j++) {
+            const uint32_t w = w0 + j * blockDim.x;
+            if (w < ndw) cw32[32 + w] = (ok[2 * j] ? x[2 * j] : 0u) | ((ok[2 * j + 1] ? x[2 * j + 1] : 0u) << 16);
+        }
+    }
+    // leaf-length rules of the hint (input.rs:173,190): one lane per real proof
+    for (uint32_t s = threadIdx.x; s < 2 * B; s += blockDim.x) {
+        const uint32_t slot = s % B;
+        const bool is_dh = s < B;
+        if (!oob && slot < n_real) {
+            const bsx_header* h = a.headers + h0 + slot + (is_dh ? 0 : 1);
+            if (is_dh ? (h->len[BSX_DATA_HASH_INDEX] != BSX_PROTOBUF_HASH_SIZE) : (h->len[BSX_LAST_BLOCK_ID_INDEX] != BSX_PROTOBUF_BLOCK_ID_SIZE))
+                bad_leaf = true;
+        }
     }
     if (threadIdx.x == 0) {
         uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
@@ -681,10 +687,18 @@ __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
 extern "C" {
 using namespace bsx;
 
+// Occupancy throttle for the two big ALU-bound hashing kernels (experiment knob, default off): BSX_HASH_LDS bytes of
+// unused dynamic LDS per workgroup cap the resident hashing workgroups per CU, leaving registers and wave slots to a
+// co-running HBM-bound expansion on another stream.
+static uint32_t hash_throttle_lds() {
+    static const long v = getenv("BSX_HASH_LDS") ? atol(getenv("BSX_HASH_LDS")) : 0;
+    return (uint32_t)v;
+}
+
 hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint32_t* status) {
     if (!n) return hipSuccess;
     const uint32_t grid = (uint32_t)((n + HM_THREADS - 1) / HM_THREADS);
-    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, status);
+    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), hash_throttle_lds(), s, hdr, n, hashes, dh, lb, status);
     return hipGetLastError();
 }
 hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
@@ -703,7 +717,7 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     const uint32_t n_jobs = n_ranges * job_count;
     SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
     const uint64_t slots = (uint64_t)n_jobs * B;
-    hipLaunchKernelGGL(k_slot_hashes, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_slot_hashes, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), hash_throttle_lds(), s, a);
     uint32_t level_off = 0, level = 1;
     for (uint32_t width = B / 2; width >= 1; width /= 2, level++) {
         a.level = level; a.width = width; a.level_off = level_off;

@@ -79,10 +79,18 @@ class HeaderRangeEngine:
         B, jc, RT, R, V = batch_size, self.jc, self.RT, self.R, v_max
         self.hpr = jc * B + 1                       # headers this rank holds per range: its slice + the next one
         self.hfr = self.jf * B                      # height offset of the first of them (header_first_rel)
-        self.headers = _u8(RT * self.hpr * 512, d)
-        self.hashes = _u8(RT * self.hpr * 32, d)
-        self.dh_aunts = _u8(RT * self.hpr * 128, d)
-        self.lb_aunts = _u8(RT * self.hpr * 128, d)
+        # one header block per pass: this rank's slice of every range, then (owned ranges) the trusted and the target
+        # header of the commit check as a 2-header block per range — hashed by ONE k_header_merkle launch
+        nh_main, nh_skip = RT * self.hpr, (R * 2 if with_commit else 0)
+        self.nh_all = nh_main + nh_skip
+        self.headers_all = _u8(self.nh_all * 512, d)
+        self.hashes_all = _u8(self.nh_all * 32, d)
+        self.headers = self.headers_all[:nh_main * 512]
+        self.hashes = self.hashes_all[:nh_main * 32]
+        self.skip_headers = self.headers_all[nh_main * 512:] if nh_skip else _u8(16, d)
+        self.skip_hashes = self.hashes_all[nh_main * 32:] if nh_skip else _u8(16, d)
+        self.dh_aunts = _u8(self.nh_all * 128, d)
+        self.lb_aunts = _u8(self.nh_all * 128, d)
         self.ranges = _u8(RT * 80, d)
         self.latest = _u8(RT * 8, d)
         self.status = torch.zeros(8, dtype=torch.int32, device=d)       # [0] header, [1] assemble
@@ -98,8 +106,6 @@ class HeaderRangeEngine:
         self.output64 = _u8(R * 64, d)
         self.range_status = torch.zeros(max(R, 1), dtype=torch.int32, device=d)
         # commit (owned ranges): the trusted header and the target header as a 2-header block per range
-        self.skip_headers = _u8(R * 2 * 512, d)
-        self.skip_hashes = _u8(R * 2 * 32, d)
         self.skip_ranges = _u8(R * 80, d)
         self.target_idx = torch.ones(max(R, 1), dtype=torch.int32, device=d)
         self.validators = _u8(R * V * 256, d)
@@ -223,18 +229,21 @@ class HeaderRangeEngine:
         st = self._st()
         ev = self.events if time_kernels else None
         self.status.zero_()
-        if self.with_commit and R:
-            chk(L.bsx_dev_header_merkle(ctx, st, dp(self.skip_headers), C.c_uint64(R * 2), dp(self.skip_hashes), None, None,
-                                        dp(self.status)))
-            self._target_hash_view()
+        commit = self.with_commit and R and self.nh_all > RT * self.hpr
+        if commit and self.commit_with != "hash":
+            # challenges + per-validator tables need nothing from this pass: start them right away beside the hashing
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._commit(self._st(), "prep")
+        chk(L.bsx_dev_header_merkle(ctx, st, dp(self.headers_all), C.c_uint64(self.nh_all if commit else RT * self.hpr),
+                                    dp(self.hashes_all), dp(self.dh_aunts), dp(self.lb_aunts), dp(self.status)))
+        if commit:
             chk(L.bsx_dev_fill_end_hash(ctx, st, C.c_uint32(R), dp(self.skip_ranges), dp(self.skip_hashes), C.c_uint64(2),
-                                        dp(self.target_idx)))
+                                        dp(self.target_idx), dp(self.target_hashes)))
             if self.commit_with == "hash":
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
-                    self._commit(self._st())
-        chk(L.bsx_dev_header_merkle(ctx, st, dp(self.headers), C.c_uint64(RT * self.hpr), dp(self.hashes), dp(self.dh_aunts),
-                                    dp(self.lb_aunts), dp(self.status)))
+                    self._commit(self._st(), "all")
         chk(L.bsx_dev_assemble_inputs(ctx, st, C.c_uint32(RT), C.c_uint32(self.J), C.c_uint32(B), C.c_uint32(self.jf),
                                       C.c_uint32(jc), C.c_uint32(B), dp(self.ranges), dp(self.latest), dp(self.headers),
                                       C.c_uint64(self.hpr), C.c_uint64(self.hfr), dp(self.hashes), dp(self.dh_aunts),
@@ -248,14 +257,21 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_reduce(ctx, st, C.c_uint32(RT), C.c_uint32(jc), dp(self.records), dp(self.partial),
                              dp(self.red_compact_local) if jc > 1 else None))
 
-    def _commit(self, st):
-        """Stage 3 for the owned ranges on stream `st` (builder.skip, header_range.rs:42-48)."""
+    def _commit(self, st, part="all"):
+        """Stage 3 for the owned ranges on stream `st` (builder.skip, header_range.rs:42-48).
+        part "prep": SHA-512 challenges + per-validator tables (small, memory-latency sensitive: 1.5 ms + 1.7 ms when
+        their loads queue behind the expansion's stores, 0.04 + 0.5 ms otherwise) — run beside the hashing;
+        part "verify": the signature checks, tallies and skip conditions (ALU work) — run beside the expansion."""
         L, ctx, dp, chk = self.L, self.ctx, _lib.dp, _lib.check
         R, V = self.R, self.V
         n = R * V
-        chk(L.bsx_dev_sha512_challenge(ctx, st, dp(self.validators), C.c_uint64(n), dp(self.h), None))
+        if part in ("all", "prep"):
+            chk(L.bsx_dev_sha512_challenge(ctx, st, dp(self.validators), C.c_uint64(n), dp(self.h), None))
+            if self.ed_path == "keyed":
+                chk(L.bsx_dev_ed25519_keytable(ctx, st, dp(self.validators), C.c_uint32(V), dp(self.keytable)))
+        if part == "prep":
+            return
         if self.ed_path == "keyed":
-            chk(L.bsx_dev_ed25519_keytable(ctx, st, dp(self.validators), C.c_uint32(V), dp(self.keytable)))
             chk(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(self.validators), dp(self.h), C.c_uint64(n), C.c_uint32(V),
                                                dp(self.keytable), C.c_uint32(V), dp(self.ok)))
         else:
@@ -266,11 +282,6 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges), dp(self.skip_headers), C.c_uint64(2),
                                  dp(self.skip_hashes), dp(self.validators), dp(self.trusted), dp(self.ok), dp(self.commit_res),
                                  dp(self.trusted_res), dp(self.skip_status), None, dp(self.target_idx)))
-
-    def _target_hash_view(self):
-        # device-side strided copy (hipMemcpy2DAsync under torch): rows of 64 bytes, take bytes 32..64
-        src = self.skip_hashes[:self.R * 64].view(self.R, 64)[:, 32:]
-        self.target_hashes[:self.R * 32].view(self.R, 32).copy_(src)
 
     def step_exchange(self, gathered=None):
         """Stage 6: the one collective.  Single GPU: the local fold already is the range result.
@@ -300,7 +311,7 @@ class HeaderRangeEngine:
             main = torch.cuda.current_stream(self.dev)
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
-                self._commit(self._st())
+                self._commit(self._st(), "verify")
         if self.with_witness:
             if ev:
                 ev[2].record(torch.cuda.current_stream(self.dev))
