@@ -212,45 +212,49 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
         else v = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (req_end - S)) * 32)[k] : 0u;
         cw32[t] = v;
     }
-    // proofs: the packed stream [128, 128 + 362*B) in 16-bit units (every proof boundary is 2-byte aligned): unit u of
-    // the stream is unit k of proof `slot`; each lane assembles one output dword from two source units.
-    const uint32_t n_dh_units = (BSX_DH_PROOF_SIZE / 2) * B, total_units = n_dh_units + (BSX_LB_PROOF_SIZE / 2) * B;
-    const uint32_t ndw = (total_units + 1) / 2;
-    const uint16_t* dh16 = reinterpret_cast<const uint16_t*>(a.dh_aunts);
-    const uint16_t* lb16 = reinterpret_cast<const uint16_t*>(a.lb_aunts);
+    // proofs: the packed stream [128, 128 + 362*B) as 24 pieces per slot, 16 bytes each except two tails:
+    //   0..7   data_hash aunts      8..9  data_hash leaf[0..32)     10  leaf[32..34)  (2 bytes)
+    //   11..18 last_block_id aunts  19..22 last_block_id leaf[0..64) 23  leaf[64..72)  (8 bytes)
+    // Proof records are only 2-byte aligned in the packed image; gfx950 serves misaligned global dword / dwordx4
+    // accesses (tools/unaligned_test.hip), so every piece moves as ONE 16-byte load and one store.  All of a lane's
+    // loads are issued before its first store: beside the HBM-bound expansion of the other chunk a load round trip is
+    // several times longer, and this gather is pure latency (the 16-bit-unit version took 1.3-1.8 ms there, 0.12 alone).
     const uint64_t h0 = hbase + (batch_start - S);
     bool bad_leaf = false;
-    // Branch-free source addressing (an invalid unit reads a dummy location and is masked), AS_UNROLL output dwords
-    // = 2*AS_UNROLL independent loads in flight per lane before the first store: beside the HBM-bound expansion of
-    // the other chunk every load round trip is several times longer, and the gather is pure latency.
-    constexpr int AS_UNROLL = 4;
-    const uint16_t* dummy = reinterpret_cast<const uint16_t*>(a.ranges);
-    auto src = [&](uint32_t u, bool& valid) -> const uint16_t* {
-        const bool is_dh = u < n_dh_units;
-        const uint32_t uu = is_dh ? u : u - n_dh_units;
-        const uint32_t per = is_dh ? (BSX_DH_PROOF_SIZE / 2) : (BSX_LB_PROOF_SIZE / 2);
-        const uint32_t slot = uu / per, k = uu % per;
-        valid = (u < total_units) && !oob && (slot < n_real);
+    constexpr uint32_t AS_PIECES = 24, AS_MAX_IT = (AS_PIECES * BSX_MAX_BATCH + 255) / 256;
+    const uint32_t n_items = AS_PIECES * B;
+    uint8_t* dh_dst = cw + 128;
+    uint8_t* lb_dst = cw + 128 + (uint32_t)BSX_DH_PROOF_SIZE * B;
+    const uint8_t* dummy = reinterpret_cast<const uint8_t*>(a.headers);
+    uint4 val[AS_MAX_IT];
+#pragma unroll
+    for (uint32_t it = 0; it < AS_MAX_IT; it++) {
+        if (it * 256u >= n_items) break;                                // block-uniform
+        static_assert(offsetof(bsx_header, hash) + 36 == 236 && offsetof(bsx_header, last_block_id) == 124, "bsx_header offsets");
+        const uint32_t t = threadIdx.x + it * 256u;
+        const uint32_t slot = t / AS_PIECES, pc = t % AS_PIECES;
+        const bool real = (t < n_items) && !oob && (slot < n_real);
+        const bool is_dh = pc < 11;
+        const uint32_t q = is_dh ? pc : pc - 11;                        // 0..7 aunts, 8.. leaf pieces
         const uint64_t hidx = h0 + slot + (is_dh ? 0 : 1);
-        const bsx_header* h = a.headers + hidx;
-        const uint16_t* aunt = (is_dh ? dh16 : lb16) + hidx * 64 + k;
-        const uint16_t* leaf = reinterpret_cast<const uint16_t*>(is_dh ? h->hash[1] : h->last_block_id) + ((int)k - 64);
-        const uint16_t* p = (k < 64) ? aunt : leaf;
-        return valid ? p : dummy;
-    };
-    for (uint32_t w0 = threadIdx.x; w0 < ndw; w0 += blockDim.x * AS_UNROLL) {
-        uint32_t x[2 * AS_UNROLL];
-        bool ok[2 * AS_UNROLL];
+        const uint8_t* hdr = reinterpret_cast<const uint8_t*>(a.headers + hidx);
+        const uint8_t* aunt = (is_dh ? a.dh_aunts : a.lb_aunts) + hidx * 128 + 16 * q;
+        const uint8_t* leaf = hdr + (is_dh ? 236 : 124) + 16 * (q - 8);   // header.hash[1] / header.last_block_id (bsx.h)
+        const uint8_t* p = real ? (q < 8 ? aunt : leaf) : dummy;
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        val[it] = real ? v : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
-        for (int j = 0; j < 2 * AS_UNROLL; j++) {
-            const uint32_t w = w0 + (j >> 1) * blockDim.x;
-            x[j] = *src(2 * w + (j & 1), ok[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < AS_UNROLL; j++) {
-            const uint32_t w = w0 + j * blockDim.x;
-            if (w < ndw) cw32[32 + w] = (ok[2 * j] ? x[2 * j] : 0u) | ((ok[2 * j + 1] ? x[2 * j + 1] : 0u) << 16);
-        }
+    for (uint32_t it = 0; it < AS_MAX_IT; it++) {
+        const uint32_t t = threadIdx.x + it * 256u;
+        if (t >= n_items) break;
+        const uint32_t slot = t / AS_PIECES, pc = t % AS_PIECES;
+        const bool is_dh = pc < 11;
+        const uint32_t q = is_dh ? pc : pc - 11;
+        uint8_t* d = (is_dh ? dh_dst + (uint32_t)BSX_DH_PROOF_SIZE * slot : lb_dst + (uint32_t)BSX_LB_PROOF_SIZE * slot) + 16 * q;
+        if (pc == 10) *reinterpret_cast<uint16_t*>(d) = (uint16_t)val[it].x;
+        else if (pc == 23) *reinterpret_cast<uint2*>(d) = make_uint2(val[it].x, val[it].y);
+        else *reinterpret_cast<uint4*>(d) = val[it];
     }
     // leaf-length rules of the hint (input.rs:173,190): one lane per real proof
     for (uint32_t s = threadIdx.x; s < 2 * B; s += blockDim.x) {
