@@ -70,6 +70,15 @@ __device__ __forceinline__ Digest load_digest_global(const uint8_t* src) {
     return d;
 }
 
+// 16-byte global accesses at ANY byte alignment: gfx950 under ROCm serves misaligned dword / dwordx4 global accesses
+// (checked on the device by tools/unaligned_test.hip); the packed witness sections are only 2-byte aligned.
+__device__ __forceinline__ uint4 ldu4(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stu4(uint8_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ void store_digest_u(uint8_t* dst, const Digest& d) {
+    stu4(dst, make_uint4(bswap32(d.w[0]), bswap32(d.w[1]), bswap32(d.w[2]), bswap32(d.w[3])));
+    stu4(dst + 16, make_uint4(bswap32(d.w[4]), bswap32(d.w[5]), bswap32(d.w[6]), bswap32(d.w[7])));
+}
+
 // ND dwords of a field that starts at a 4-byte aligned global address
 template <int ND>
 __device__ __forceinline__ Digest leaf_from_global(const uint32_t* f, int len) {
@@ -80,24 +89,39 @@ __device__ __forceinline__ Digest leaf_from_global(const uint32_t* f, int len) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_header_merkle
-// One lane per header; each lane streams its own 512-byte record with dword loads (every fetched line is consumed
-// completely by the same lane, so HBM traffic equals the algorithmic 512 B/header) and keeps the 14-leaf tree in
-// registers: 15 leaf blocks + 13 x 2 inner blocks = 41 compressions.
+// One lane per header; the 14-leaf tree stays in registers: 15 leaf blocks + 13 x 2 inner blocks = 41 compressions.
+// Each lane streams its own 512-byte record (every fetched line is consumed completely by the same lane, so HBM traffic
+// equals the algorithmic 512 B/header) in TWO bursts of 16-byte loads — dwords [0,80) for leaves 0..7, dwords [76,128)
+// for leaves 8..13 — and writes its digests in two bursts of stores: every call of the (not inlined) compression
+// function drains the wave's outstanding memory operations, so a load or store between two compressions is a full
+// round trip (3 per lane now, one per leaf before), several times longer beside the other chunk's HBM-bound expansion.
 constexpr int HM_THREADS = 256;
+
+// leaf of a field held in registers: W = dwords [BASE, BASE + N) of the record, field at dword OFF, ND dwords
+template <int ND, int OFF, int BASE, int N>
+__device__ __forceinline__ Digest leaf_from_regs(const uint32_t (&W)[N], int len) {
+    uint32_t d[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) d[j] = (j < ND) ? W[OFF - BASE + j] : 0u;
+    return leaf_hash_1block(d, len);
+}
 
 __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
                                                               uint8_t* __restrict__ lb_aunts, uint32_t* __restrict__ status) {
     const uint64_t me = (uint64_t)blockIdx.x * HM_THREADS + threadIdx.x;
     const bool live = me < n;
-    const uint32_t* my = reinterpret_cast<const uint32_t*>(hdr + (live ? me : 0));
-    int len[14];
-    {
-        const uint4 l = *reinterpret_cast<const uint4*>(my);
-        const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+    const uint8_t* my = reinterpret_cast<const uint8_t*>(hdr + (live ? me : 0));
+    // byte offsets: version 16, chain_id 40, height 92, time 104, last_block_id 124, hash[j] 200+36j, proposer 488
+    uint32_t W1[80];
 #pragma unroll
-        for (int i = 0; i < 14; i++) len[i] = (int)((lw[i >> 2] >> (8 * (i & 3))) & 0xff);
+    for (int k = 0; k < 20; k++) {
+        const uint4 v = ldu4(my + 16 * k);
+        W1[4 * k] = v.x; W1[4 * k + 1] = v.y; W1[4 * k + 2] = v.z; W1[4 * k + 3] = v.w;
     }
+    int len[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) len[i] = (int)((W1[i >> 2] >> (8 * (i & 3))) & 0xff);
     // capacity rules (bsx.h): violations flagged, lengths clamped so nothing reads out of bounds
     bool bad = false;
     {
@@ -107,62 +131,66 @@ __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* 
             if (len[i] > cap[i]) { bad = true; len[i] = cap[i]; }
         }
     }
-    // byte offsets: version 16, chain_id 40, height 92, time 104, last_block_id 124, hash[j] 200+36j, proposer 488
     Digest left, right;
     {
         Digest n0123, n45, n67, L5, L7;
         {
-            const Digest L0 = leaf_from_global<6>(my + 4, len[0]);
-            const Digest L1 = leaf_from_global<13>(my + 10, len[1]);
+            const Digest L0 = leaf_from_regs<6, 4, 0>(W1, len[0]);
+            const Digest L1 = leaf_from_regs<13, 10, 0>(W1, len[1]);
             const Digest n01 = inner_hash(L0, L1);
-            const Digest L2 = leaf_from_global<3>(my + 23, len[2]);
-            const Digest L3 = leaf_from_global<5>(my + 26, len[3]);
+            const Digest L2 = leaf_from_regs<3, 23, 0>(W1, len[2]);
+            const Digest L3 = leaf_from_regs<5, 26, 0>(W1, len[3]);
             n0123 = inner_hash(n01, inner_hash(L2, L3));
         }
         {
-            Digest L4;
             uint32_t d[19];
 #pragma unroll
-            for (int j = 0; j < 19; j++) d[j] = my[31 + j];
-            L4 = (len[4] <= 54) ? leaf_hash_1block(d, len[4]) : leaf_hash_2block(d, len[4]);
-            L5 = leaf_from_global<9>(my + 50, len[5]);
+            for (int j = 0; j < 19; j++) d[j] = W1[31 + j];
+            const Digest L4 = (len[4] <= 54) ? leaf_hash_1block(d, len[4]) : leaf_hash_2block(d, len[4]);
+            L5 = leaf_from_regs<9, 50, 0>(W1, len[5]);
             n45 = inner_hash(L4, L5);
         }
         {
-            const Digest L6 = leaf_from_global<9>(my + 59, len[6]);   // data_hash
-            L7 = leaf_from_global<9>(my + 68, len[7]);
+            const Digest L6 = leaf_from_regs<9, 59, 0>(W1, len[6]);   // data_hash
+            L7 = leaf_from_regs<9, 68, 0>(W1, len[7]);
             n67 = inner_hash(L6, L7);
         }
         left = inner_hash(n0123, inner_hash(n45, n67));
         if (live) {
             if (lb_aunts) {  // index 4: [L5, n67, n0123, right]
-                store_digest_global16(lb_aunts + me * 128, L5);
-                store_digest_global16(lb_aunts + me * 128 + 32, n67);
-                store_digest_global16(lb_aunts + me * 128 + 64, n0123);
+                store_digest_u(lb_aunts + me * 128, L5);
+                store_digest_u(lb_aunts + me * 128 + 32, n67);
+                store_digest_u(lb_aunts + me * 128 + 64, n0123);
             }
             if (dh_aunts) {  // index 6: [L7, n45, n0123, right]
-                store_digest_global16(dh_aunts + me * 128, L7);
-                store_digest_global16(dh_aunts + me * 128 + 32, n45);
-                store_digest_global16(dh_aunts + me * 128 + 64, n0123);
+                store_digest_u(dh_aunts + me * 128, L7);
+                store_digest_u(dh_aunts + me * 128 + 32, n45);
+                store_digest_u(dh_aunts + me * 128 + 64, n0123);
             }
         }
     }
     {
-        const Digest L8 = leaf_from_global<9>(my + 77, len[8]);
-        const Digest L9 = leaf_from_global<9>(my + 86, len[9]);
+        uint32_t W2[52];      // dwords [76, 128)
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const uint4 v = ldu4(my + 304 + 16 * k);
+            W2[4 * k] = v.x; W2[4 * k + 1] = v.y; W2[4 * k + 2] = v.z; W2[4 * k + 3] = v.w;
+        }
+        const Digest L8 = leaf_from_regs<9, 77, 76>(W2, len[8]);
+        const Digest L9 = leaf_from_regs<9, 86, 76>(W2, len[9]);
         const Digest n89 = inner_hash(L8, L9);
-        const Digest L10 = leaf_from_global<9>(my + 95, len[10]);
-        const Digest L11 = leaf_from_global<9>(my + 104, len[11]);
+        const Digest L10 = leaf_from_regs<9, 95, 76>(W2, len[10]);
+        const Digest L11 = leaf_from_regs<9, 104, 76>(W2, len[11]);
         const Digest n8_11 = inner_hash(n89, inner_hash(L10, L11));
-        const Digest L12 = leaf_from_global<9>(my + 113, len[12]);
-        const Digest L13 = leaf_from_global<6>(my + 122, len[13]);
+        const Digest L12 = leaf_from_regs<9, 113, 76>(W2, len[12]);
+        const Digest L13 = leaf_from_regs<6, 122, 76>(W2, len[13]);
         right = inner_hash(n8_11, inner_hash(L12, L13));
     }
     const Digest root = inner_hash(left, right);
     if (live) {
-        if (hashes) store_digest_global16(hashes + me * 32, root);
-        if (lb_aunts) store_digest_global16(lb_aunts + me * 128 + 96, right);
-        if (dh_aunts) store_digest_global16(dh_aunts + me * 128 + 96, right);
+        if (hashes) store_digest_u(hashes + me * 32, root);
+        if (lb_aunts) store_digest_u(lb_aunts + me * 128 + 96, right);
+        if (dh_aunts) store_digest_u(dh_aunts + me * 128 + 96, right);
     }
     // wave-ballot reduction of the "bad header" predicate: one atomic per wave
     const unsigned long long m = __ballot(live && bad);
@@ -310,60 +338,72 @@ __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
     const uint64_t batch_start = (uint64_t)W[BSX_W_BATCH_START] | ((uint64_t)W[BSX_W_BATCH_START + 1] << 32);
     uint8_t* sl = cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i;
 
+    // Every call of the (not inlined) compression function starts by draining the wave's outstanding memory operations
+    // (the callee's prologue s_waitcnt), so a load or a store placed between two compressions costs a full memory round
+    // trip — several times longer while the other chunk's expansion saturates HBM.  Hence two phases, each ONE burst
+    // of 16-byte loads, then all its compressions on registers, then ONE burst of stores (was ~22 round trips per lane).
     uint32_t data_hash_le[8];   // data_hash_proofs[i].leaf[2..34] as LE dwords (builder.rs:250)
     {
         const uint8_t* pr = cw + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * i;
-        uint32_t lf[9];
+        uint4 A[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) lf[k] = gdword_at(pr + 128, k);
-        lf[8] = (uint32_t)reinterpret_cast<const uint16_t*>(pr + 160)[0];
+        for (int k = 0; k < 8; k++) A[k] = ldu4(pr + 16 * k);
+        const uint4 l0 = ldu4(pr + 128), l1 = ldu4(pr + 144);
+        const uint32_t l2 = (uint32_t)reinterpret_cast<const uint16_t*>(pr + 160)[0];
+        const uint32_t lf[9] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2};
 #pragma unroll
         for (int k = 0; k < 8; k++) data_hash_le[k] = funnel_r(lf[k + 1], lf[k], 16);
-        Digest h = leaf_hash_34(lf);
-        store_digest_global(sl, h);
+        Digest d[5];
+        d[0] = leaf_hash_34(lf);
         // path [0,1,1,0] (builder.rs:166-167): h = bit ? inner(aunt, h) : inner(h, aunt)
 #pragma unroll
         for (int lvl = 0; lvl < 4; lvl++) {
-            uint32_t al[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) al[k] = gdword_at(pr + 32 * lvl, k);
+            const uint32_t al[8] = {A[2 * lvl].x, A[2 * lvl].y, A[2 * lvl].z, A[2 * lvl].w,
+                                    A[2 * lvl + 1].x, A[2 * lvl + 1].y, A[2 * lvl + 1].z, A[2 * lvl + 1].w};
             const Digest aunt = digest_from_le(al);
-            h = (lvl == 1 || lvl == 2) ? inner_hash(aunt, h) : inner_hash(h, aunt);
-            store_digest_global(sl + 32 * (lvl + 1), h);
+            d[lvl + 1] = (lvl == 1 || lvl == 2) ? inner_hash(aunt, d[lvl]) : inner_hash(d[lvl], aunt);
         }
+#pragma unroll
+        for (int j = 0; j < 5; j++) store_digest_u(sl + 32 * j, d[j]);
     }
     {
         const uint8_t* pr = cw + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * i;
-        uint32_t lf[18];
+        uint4 A[8], l[4];
 #pragma unroll
-        for (int k = 0; k < 18; k++) lf[k] = gdword_at(pr + 128, k);
-        Digest h = leaf_hash_72(lf);
-        store_digest_global(sl + 160, h);
+        for (int k = 0; k < 8; k++) A[k] = ldu4(pr + 16 * k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) l[k] = ldu4(pr + 128 + 16 * k);
+        const uint2 l4 = *reinterpret_cast<const uint2*>(pr + 192);
+        const uint32_t lf[18] = {l[0].x, l[0].y, l[0].z, l[0].w, l[1].x, l[1].y, l[1].z, l[1].w, l[2].x, l[2].y, l[2].z, l[2].w,
+                                 l[3].x, l[3].y, l[3].z, l[3].w, l4.x, l4.y};
+        Digest d[5];
+        d[0] = leaf_hash_72(lf);
         // path [0,0,1,0] (builder.rs:168-169)
 #pragma unroll
         for (int lvl = 0; lvl < 4; lvl++) {
-            uint32_t al[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) al[k] = gdword_at(pr + 32 * lvl, k);
+            const uint32_t al[8] = {A[2 * lvl].x, A[2 * lvl].y, A[2 * lvl].z, A[2 * lvl].w,
+                                    A[2 * lvl + 1].x, A[2 * lvl + 1].y, A[2 * lvl + 1].z, A[2 * lvl + 1].w};
             const Digest aunt = digest_from_le(al);
-            h = (lvl == 2) ? inner_hash(aunt, h) : inner_hash(h, aunt);
-            store_digest_global(sl + 160 + 32 * (lvl + 1), h);
+            d[lvl + 1] = (lvl == 2) ? inner_hash(aunt, d[lvl]) : inner_hash(d[lvl], aunt);
         }
+        // data-root tuple (builder.rs:82-103,134-137) and its leaf hash
+        const uint64_t curr_idx = batch_start + i;
+        uint32_t t[16];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = 0;
+        t[6] = (uint32_t)(curr_idx >> 32);
+        t[7] = (uint32_t)curr_idx;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[8 + k] = bswap32(data_hash_le[k]);
+        const Digest tleaf = leaf_hash_tuple(t);
+#pragma unroll
+        for (int j = 0; j < 5; j++) store_digest_u(sl + 160 + 32 * j, d[j]);
+        uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            stu4(tp + 16 * k, make_uint4(bswap32(t[4 * k]), bswap32(t[4 * k + 1]), bswap32(t[4 * k + 2]), bswap32(t[4 * k + 3])));
+        store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
     }
-    // data-root tuple (builder.rs:82-103,134-137) and its leaf hash
-    const uint64_t curr_idx = batch_start + i;
-    uint32_t t[16];
-#pragma unroll
-    for (int k = 0; k < 6; k++) t[k] = 0;
-    t[6] = (uint32_t)(curr_idx >> 32);
-    t[7] = (uint32_t)curr_idx;
-#pragma unroll
-    for (int k = 0; k < 8; k++) t[8 + k] = bswap32(data_hash_le[k]);
-    const Digest tleaf = leaf_hash_tuple(t);
-    uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
-#pragma unroll
-    for (int k = 0; k < 16; k++) store_u32_a2(tp + 4 * k, bswap32(t[k]));
-    store_digest_global(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
 }
 
 // batch bounds of a job (builder.rs:235-243) from its compact witness and the global end block
