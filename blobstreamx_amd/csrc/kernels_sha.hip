@@ -230,15 +230,15 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     uint8_t* cw = a.compact + ((uint64_t)r * a.job_count + jl) * a.compact_stride;
     uint32_t* cw32 = reinterpret_cast<uint32_t*>(cw);
 
-    // bytes [0,128): ctx hashes, start/end header
-    for (uint32_t t = threadIdx.x; t < 32; t += blockDim.x) {
-        uint32_t v;
-        const uint32_t k = t & 7;
-        if (t < 8) v = reinterpret_cast<const uint32_t*>(a.ranges[r].start_header_hash)[k];
-        else if (t < 16) v = reinterpret_cast<const uint32_t*>(a.ranges[r].end_header_hash)[k];
-        else if (t < 24) v = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (batch_start - S)) * 32)[k] : 0u;
-        else v = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (req_end - S)) * 32)[k] : 0u;
-        cw32[t] = v;
+    // All loads of the workgroup are issued before its first store (one memory round trip, see below).
+    // bytes [0,128): ctx hashes, start/end header (value loaded here, stored with the rest)
+    uint32_t v_ctx = 0;
+    if (threadIdx.x < 32) {
+        const uint32_t t = threadIdx.x, k = t & 7;
+        if (t < 8) v_ctx = reinterpret_cast<const uint32_t*>(a.ranges[r].start_header_hash)[k];
+        else if (t < 16) v_ctx = reinterpret_cast<const uint32_t*>(a.ranges[r].end_header_hash)[k];
+        else if (t < 24) v_ctx = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (batch_start - S)) * 32)[k] : 0u;
+        else v_ctx = (have_hdrs && !oob) ? reinterpret_cast<const uint32_t*>(a.hashes + (hbase + (req_end - S)) * 32)[k] : 0u;
     }
     // proofs: the packed stream [128, 128 + 362*B) as 24 pieces per slot, 16 bytes each except two tails:
     //   0..7   data_hash aunts      8..9  data_hash leaf[0..32)     10  leaf[32..34)  (2 bytes)
@@ -272,6 +272,17 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
         val[it] = real ? v : make_uint4(0, 0, 0, 0);
     }
+    // leaf-length rules of the hint (input.rs:173,190): one lane per real proof
+    for (uint32_t s = threadIdx.x; s < 2 * B; s += blockDim.x) {
+        const uint32_t slot = s % B;
+        const bool is_dh = s < B;
+        if (!oob && slot < n_real) {
+            const bsx_header* h = a.headers + h0 + slot + (is_dh ? 0 : 1);
+            if (is_dh ? (h->len[BSX_DATA_HASH_INDEX] != BSX_PROTOBUF_HASH_SIZE) : (h->len[BSX_LAST_BLOCK_ID_INDEX] != BSX_PROTOBUF_BLOCK_ID_SIZE))
+                bad_leaf = true;
+        }
+    }
+    if (threadIdx.x < 32) cw32[threadIdx.x] = v_ctx;
 #pragma unroll
     for (uint32_t it = 0; it < AS_MAX_IT; it++) {
         const uint32_t t = threadIdx.x + it * 256u;
@@ -283,16 +294,6 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
         if (pc == 10) *reinterpret_cast<uint16_t*>(d) = (uint16_t)val[it].x;
         else if (pc == 23) *reinterpret_cast<uint2*>(d) = make_uint2(val[it].x, val[it].y);
         else *reinterpret_cast<uint4*>(d) = val[it];
-    }
-    // leaf-length rules of the hint (input.rs:173,190): one lane per real proof
-    for (uint32_t s = threadIdx.x; s < 2 * B; s += blockDim.x) {
-        const uint32_t slot = s % B;
-        const bool is_dh = s < B;
-        if (!oob && slot < n_real) {
-            const bsx_header* h = a.headers + h0 + slot + (is_dh ? 0 : 1);
-            if (is_dh ? (h->len[BSX_DATA_HASH_INDEX] != BSX_PROTOBUF_HASH_SIZE) : (h->len[BSX_LAST_BLOCK_ID_INDEX] != BSX_PROTOBUF_BLOCK_ID_SIZE))
-                bad_leaf = true;
-        }
     }
     if (threadIdx.x == 0) {
         uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
