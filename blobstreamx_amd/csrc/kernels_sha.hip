@@ -796,8 +796,9 @@ hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uin
     ExpandArgs a{*lay, n_jobs, gx, compact, out};
     // BSX_EXPAND_BLOCKS caps the grid (workgroups stride over the items) so that the HBM-bound expansion leaves wave
     // slots for an ALU-bound kernel running beside it on another stream; 0 / unset = one workgroup per item
-    // (measured: 8192 workgroups = 32 per CU keep ~5 TB/s alone and give the best overlapped step time)
-    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 8192;
+    // (measured with 2 pipelined chunks of 4096 jobs: 8192 / 16384 / 32768 / uncapped workgroups give 86-87 / 87-91 / 87 / 77 M
+    // headers/s; fewer than 8192 lose bandwidth: 4096 -> 77, 2048 -> 72)
+    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 16384;
     uint64_t grid = (uint64_t)gx * n_jobs;
     if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
 #define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)
