@@ -135,12 +135,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    # test hooks (tests/test_gpu_engine.py runs the N > 1 code path with two ranks on ONE GPU): device override and a
+    # gloo process group; the driver's multi-GPU runs use neither (one rank per GPU over RCCL)
+    if os.environ.get("BSX_BENCH_DEVICE") is not None:
+        local = int(os.environ["BSX_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("BSX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import synth
     from blobstreamx_amd.engine import PipelinedEngines

@@ -22,7 +22,7 @@ hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint3
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
                                 uint8_t*, uint32_t*);
 hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*);
-hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, bsx_subchain*, uint8_t*);
+hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
 hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_subchain*, const uint8_t*,
                          uint8_t*, uint32_t*);
 hipError_t bsxk_expand_witness(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, uint64_t*);
@@ -196,7 +196,17 @@ int bsx_dev_reduce(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t n, co
     DEV_ENTER();
     if (!pow2(n) || n > 256) return fail(BSX_ERR_BAD_ARG, "reduce fan-in must be a power of two <= 256 (got %u)", n);
     if (!d_records || !d_out) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_reduce(S(ctx, stream), n_ranges, n, d_records, d_out, d_reduce_compact));
+    HIPCHK(bsxk_reduce(S(ctx, stream), n_ranges, n, d_records, n, 1, d_out, d_reduce_compact));
+    return BSX_OK;
+}
+
+int bsx_dev_reduce_strided(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t n, const bsx_subchain* d_records,
+                           uint64_t stride_range, uint64_t stride_record, bsx_subchain* d_out,
+                   uint8_t* d_reduce_compact) {
+    DEV_ENTER();
+    if (!pow2(n) || n > 256) return fail(BSX_ERR_BAD_ARG, "reduce fan-in must be a power of two <= 256 (got %u)", n);
+    if (!d_records || !d_out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_reduce(S(ctx, stream), n_ranges, n, d_records, stride_range, stride_record, d_out, d_reduce_compact));
     return BSX_OK;
 }
 
@@ -507,7 +517,7 @@ int bsx_reduce(bsx_ctx* ctx, const bsx_subchain* records, uint32_t n, bsx_subcha
     DBuf d;
     RET(d.alloc((size_t)(n + 1) * sizeof(bsx_subchain)));
     H2D(d.p, records, (size_t)n * sizeof(bsx_subchain));
-    HIPCHK(bsxk_reduce(st, 1, n, d.as<bsx_subchain>(), d.as<bsx_subchain>() + n, nullptr));
+    HIPCHK(bsxk_reduce(st, 1, n, d.as<bsx_subchain>(), n, 1, d.as<bsx_subchain>() + n, nullptr));
     D2H(out, d.as<bsx_subchain>() + n, sizeof(bsx_subchain));
     SYNC();
     return BSX_OK;
@@ -529,7 +539,7 @@ static int run_data_commitment(hipStream_t st, uint32_t J, uint32_t B, RangeDev&
     HIPCHK(bsxk_assemble_inputs(st, 1, J, B, 0, J, B, rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(), rd.headers.as<bsx_header>(), rd.hpr, 0,
                                 rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(), cw.as<uint8_t>(), rd.astatus.as<uint32_t>()));
     HIPCHK(bsxk_prove_subchain(st, 1, B, J, rd.ranges.as<bsx_shared_ctx>(), cw.as<uint8_t>(), recs.as<bsx_subchain>()));
-    HIPCHK(bsxk_reduce(st, 1, J, recs.as<bsx_subchain>(), res.as<bsx_subchain>(), rcw.as<uint8_t>()));
+    HIPCHK(bsxk_reduce(st, 1, J, recs.as<bsx_subchain>(), J, 1, res.as<bsx_subchain>(), rcw.as<uint8_t>()));
     HIPCHK(bsxk_finalize(st, 1, J, B, rd.ranges.as<bsx_shared_ctx>(), res.as<bsx_subchain>(), d_target_hashes, o64.as<uint8_t>(), stw.as<uint32_t>()));
     if (witness) {
         const size_t nmap = (size_t)J * L.n_elements, nred = (size_t)(J - 1) * R.n_elements;

@@ -564,6 +564,7 @@ __global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
 // One workgroup per range: n (power of two <= 256) records -> 1, level by level in LDS.
 struct ReduceArgs {
     uint32_t n_ranges, n;
+    uint64_t stride_range, stride_record;   // record k of range r = records[r * stride_range + k * stride_record]
     const bsx_subchain* records;
     bsx_subchain* out;
     uint8_t* reduce_compact;       // optional: (n-1) node witnesses per range
@@ -572,10 +573,12 @@ struct ReduceArgs {
 __global__ __launch_bounds__(128) void k_reduce(ReduceArgs a) {
     __shared__ bsx_subchain rec[256];
     const uint32_t r = blockIdx.x, tid = threadIdx.x, n = a.n;
-    {   // coalesced copy in: n * 128 bytes
-        const uint4* src = reinterpret_cast<const uint4*>(a.records + (uint64_t)r * n);
+    {   // copy in: n records of 128 bytes, 8 lanes per record
         uint4* dst = reinterpret_cast<uint4*>(rec);
-        for (uint32_t c = tid; c < n * 8; c += blockDim.x) dst[c] = src[c];
+        for (uint32_t c = tid; c < n * 8; c += blockDim.x) {
+            const uint4* src = reinterpret_cast<const uint4*>(a.records + (uint64_t)r * a.stride_range + (uint64_t)(c >> 3) * a.stride_record);
+            dst[c] = src[c & 7];
+        }
     }
     __syncthreads();
     uint32_t k0 = 0;
@@ -773,10 +776,11 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     hipLaunchKernelGGL(k_batch_finish, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
     return hipGetLastError();
 }
-hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, bsx_subchain* out, uint8_t* reduce_compact) {
+hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, uint64_t stride_range,
+                       uint64_t stride_record, bsx_subchain* out, uint8_t* reduce_compact) {
     if (!n_ranges) return hipSuccess;
     const bsx_witness_layout L = bsx_reduce_layout();
-    ReduceArgs a{n_ranges, n, records, out, reduce_compact, L.compact_stride, L.off_words, L.off_bools};
+    ReduceArgs a{n_ranges, n, stride_range, stride_record, records, out, reduce_compact, L.compact_stride, L.off_words, L.off_bools};
     hipLaunchKernelGGL(k_reduce, dim3(n_ranges), dim3(128), 0, s, a);
     return hipGetLastError();
 }

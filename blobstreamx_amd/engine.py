@@ -43,16 +43,30 @@ def job_slice(nb_map_jobs, rank, world):
     return rank * count, count
 
 
-def gather_partials(partial, rank, world, n_ranges_local, out_gathered=None, out_top=None):
+def all_gather_records(partial, world, n_ranges_total, out_gathered=None):
     """THE collective of the multi-GPU path: all-gather one 128-byte MapReduceSubchainVariable record per
-    (range, rank), then lay the owned ranges out as [range][rank] for the top log2(world) reduce levels.
-    partial: uint8 tensor [world*n_ranges_local*128] (this rank's locally folded record of every range).
+    (range, rank) -> uint8 [world][n_ranges_total][128].  partial: this rank's locally folded record of every range.
     Works on CUDA tensors over RCCL ("nccl") and on CPU tensors over gloo (tests)."""
     import torch.distributed as dist
-    RT = world * n_ranges_local
+    RT = n_ranges_total
     flat = partial[:RT * 128].contiguous()
     gathered = out_gathered[:world * RT * 128] if out_gathered is not None else torch.empty(world * RT * 128, dtype=torch.uint8, device=flat.device)
-    dist.all_gather_into_tensor(gathered, flat)
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        # test-only route (two ranks sharing one GPU, tests/test_gpu_engine.py): gloo moves host memory
+        g_cpu = torch.empty(world * RT * 128, dtype=torch.uint8)
+        dist.all_gather_into_tensor(g_cpu, flat.cpu())
+        gathered.copy_(g_cpu)
+    else:
+        dist.all_gather_into_tensor(gathered, flat)
+    return gathered
+
+
+def gather_partials(partial, rank, world, n_ranges_local, out_gathered=None, out_top=None):
+    """all_gather_records + the owned ranges laid out as [range][rank] (host-side consumers and the CPU tests; the
+    device path folds the gathered layout in place with bsx_dev_reduce_strided)."""
+    RT = world * n_ranges_local
+    gathered = all_gather_records(partial, world, RT, out_gathered)
+    flat = gathered
     g = gathered.view(world, RT, 128)
     own = g[:, rank * n_ranges_local:(rank + 1) * n_ranges_local, :]            # [rank, owned range, 128]
     top = out_top[:n_ranges_local * world * 128] if out_top is not None else torch.empty(n_ranges_local * world * 128, dtype=torch.uint8, device=flat.device)
@@ -290,13 +304,12 @@ class HeaderRangeEngine:
         if self.world == 1:
             return self.partial
         if gathered is None:
-            gather_partials(self.partial, self.rank, self.world, self.R, self.gathered, self.top_in)
-        else:
-            own = gathered.view(self.world, self.RT, 128)[:, self.rank * self.R:(self.rank + 1) * self.R, :]
-            self.top_in[:self.R * self.world * 128].view(self.R, self.world, 128).copy_(own.transpose(0, 1))
+            gathered = all_gather_records(self.partial, self.world, self.RT, self.gathered)
+        # top fold straight from the all-gather layout [rank][range]: record k of owned range r = gathered[k][rank*R + r]
+        own = gathered.view(-1)[self.rank * self.R * 128:]
         L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
-        chk(L.bsx_dev_reduce(ctx, st, C.c_uint32(self.R), C.c_uint32(self.world), dp(self.top_in), dp(self.results),
-                             dp(self.red_compact_top)))
+        chk(L.bsx_dev_reduce_strided(ctx, st, C.c_uint32(self.R), C.c_uint32(self.world), dp(own), C.c_uint64(1),
+                                     C.c_uint64(self.RT), dp(self.results), dp(self.red_compact_top)))
         return self.results
 
     def step_final(self, result_records, time_kernels=False):

@@ -323,6 +323,12 @@ int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32
  * d_reduce_compact (optional) receives n-1 reduce-node compact witnesses per range. */
 int bsx_dev_reduce(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t n,
                    const bsx_subchain* d_records, bsx_subchain* d_out, uint8_t* d_reduce_compact);
+/* Same fold with record k of range r at d_records[r*stride_range + k*stride_record] (strides in records).  The top
+ * fold of the multi-GPU path reads the all-gather result [rank][range] in place: d_records = gathered + first owned
+ * range, stride_range = 1, stride_record = ranges per rank-block — no transposition pass on the data path. */
+int bsx_dev_reduce_strided(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t n, const bsx_subchain* d_records,
+                           uint64_t stride_range, uint64_t stride_record, bsx_subchain* d_out,
+                           uint8_t* d_reduce_compact);
 
 /* Final assertions of prove_data_commitment (builder.rs:292-297,400-406) + the 64-byte public output
  * (header_range.rs:57-58).  d_target_hashes (optional, n_ranges*32): first half of the output; NULL = ctx end hash.

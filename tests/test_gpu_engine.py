@@ -105,3 +105,30 @@ def test_sharded_engines_on_one_gpu(world, J, B, R, n_blocks):
             full = oracle.expand_witness(ml, J, ref["compact"])
             want = full[g * nm:(g + 1) * nm]
             assert (wm[r * nm:(r + 1) * nm] == want).all(), (g, r)
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 code path end to end — RANK/WORLD_SIZE plumbing, job slices, one all-gather per pipelined chunk,
+    strided top fold, barriers, max-over-ranks timing, the correctness gate on every owned range — with two ranks on the
+    ONE GPU of the test box over gloo (the driver's multi-GPU runs use one rank per GPU over RCCL; only the transport
+    differs, see engine.all_gather_records)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BSX_DIST_BACKEND="gloo", BSX_BENCH_DEVICE="0", BSX_PLACEMENT_PROBE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--ranges", "8", "--no-cpu-baseline", "--no-stress"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["ranges_per_gpu"] == 8 and d["config"]["headers_per_step"] == 2 * 8 * 2048
