@@ -1,6 +1,8 @@
 """GPU suite: seeded differential fuzz — random shapes, global-end positions, chain heads (hint clamp / zero padding)
 and random single-byte tampering of headers; the HIP path must agree with the oracle on the status, the assertion
 mask, every per-job record and the full witness, pass or fail."""
+import os
+
 import numpy as np
 import pytest
 
@@ -19,7 +21,7 @@ def _rec(r):
     return r.tobytes()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSX_FUZZ_SEEDS", "12"))))   # BSX_FUZZ_SEEDS=200 for a long soak
 def test_prove_data_commitment_fuzz(seed):
     rnd = np.random.default_rng(1000 + seed)
     J = int(rnd.choice([1, 2, 4, 8, 16]))
