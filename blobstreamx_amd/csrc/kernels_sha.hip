@@ -735,18 +735,10 @@ __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
 extern "C" {
 using namespace bsx;
 
-// Occupancy throttle for the two big ALU-bound hashing kernels (experiment knob, default off): BSX_HASH_LDS bytes of
-// unused dynamic LDS per workgroup cap the resident hashing workgroups per CU, leaving registers and wave slots to a
-// co-running HBM-bound expansion on another stream.
-static uint32_t hash_throttle_lds() {
-    static const long v = getenv("BSX_HASH_LDS") ? atol(getenv("BSX_HASH_LDS")) : 0;
-    return (uint32_t)v;
-}
-
 hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint32_t* status) {
     if (!n) return hipSuccess;
     const uint32_t grid = (uint32_t)((n + HM_THREADS - 1) / HM_THREADS);
-    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), hash_throttle_lds(), s, hdr, n, hashes, dh, lb, status);
+    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, status);
     return hipGetLastError();
 }
 hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
@@ -765,7 +757,7 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     const uint32_t n_jobs = n_ranges * job_count;
     SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
     const uint64_t slots = (uint64_t)n_jobs * B;
-    hipLaunchKernelGGL(k_slot_hashes, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), hash_throttle_lds(), s, a);
+    hipLaunchKernelGGL(k_slot_hashes, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
     uint32_t level_off = 0, level = 1;
     for (uint32_t width = B / 2; width >= 1; width /= 2, level++) {
         a.level = level; a.width = width; a.level_off = level_off;
