@@ -28,6 +28,7 @@ SYMBOLS = [
     "bsx_dev_expand_witness", "bsx_dev_fill_end_hash", "bsx_dev_sha512_challenge", "bsx_dev_ed25519_verify",
     "bsx_dev_commit_tally", "bsx_dev_skip_check",
     "bsx_ed25519_keytable_bytes", "bsx_dev_ed25519_keytable", "bsx_dev_ed25519_verify_keyed",
+    "bsx_dev_skip_eval", "bsx_find_block_to_request",
     "bsx_ingest_last_error", "bsx_ingest_header_json", "bsx_ingest_signed_block_json", "bsx_ingest_data_commitment_json",
 ]
 

@@ -166,6 +166,31 @@ def verify_commits(validators, header_hashes, device=0):
     return res, ok
 
 
+def find_block_to_request(start_block, max_end_block, start_validators, candidate_heights, candidate_validators, device=0):
+    """The operator's skip-target search (circuits/fetcher.rs:60-87 `find_block_to_request`, called at
+    bin/blobstreamx.rs:221-225) over pre-fetched candidates: returns (block, evals).  candidate_heights must contain
+    every height of the halving sequence max_end, (max_end+start)/2, ... that the loop visits; `halving_sequence`
+    lists them.  is_valid_skip is [UPSTREAM] (see include/bsx.h): parity unpinned."""
+    sv = np.ascontiguousarray(start_validators, T.VALIDATOR).reshape(-1)
+    hs = np.ascontiguousarray(candidate_heights, np.uint64)
+    cv = np.ascontiguousarray(candidate_validators, T.VALIDATOR).reshape(hs.size, sv.size)
+    ev = np.zeros(hs.size, T.SKIP_EVAL)
+    out = C.c_uint64(0)
+    _lib.check(_lib.lib().bsx_find_block_to_request(_lib.context(device), C.c_uint64(start_block), C.c_uint64(max_end_block),
+                                                    _lib.p(sv), C.c_uint32(hs.size), _lib.p(hs), _lib.p(cv), C.c_uint32(sv.size),
+                                                    C.byref(out), _lib.p(ev)))
+    return int(out.value), ev
+
+
+def halving_sequence(start_block, max_end_block):
+    """Heights find_block_to_request can visit, in order (fetcher.rs:61-85)."""
+    out, c = [], max_end_block
+    while c - start_block > 1:
+        out.append(c)
+        c = (c + start_block) // 2
+    return out
+
+
 class CombinedSkipCircuit:
     """CombinedSkipCircuit<MAX_VALIDATOR_SET_SIZE, CHAIN_ID_SIZE, C, NB_MAP_JOBS, BATCH_SIZE>
     (circuits/header_range.rs:13-59; instantiated 100/32/32 and 100/32/64 by bin/header_range_{1024,2048}.rs:6-17)."""

@@ -39,6 +39,7 @@ hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
 hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
 hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*, uint8_t*);
 int bsxk_tally_vmax(void);
+hipError_t bsxk_skip_eval(hipStream_t, const bsx_validator*, const bsx_validator*, uint32_t, uint32_t, bsx_skip_eval*);
 }
 
 static_assert(sizeof(bsx_header) == 512, "bsx_header");
@@ -46,6 +47,7 @@ static_assert(sizeof(bsx_data_hash_proof) == 162 && sizeof(bsx_last_block_id_pro
 static_assert(sizeof(bsx_shared_ctx) == 80 && sizeof(bsx_subchain) == 128, "records");
 static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "commit");
 static_assert(sizeof(bsx_witness_layout) == 40, "layout");
+static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
 
 struct bsx_ctx {
     int device;
@@ -267,6 +269,15 @@ int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator
     if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
     HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, d_ok));
+    return BSX_OK;
+}
+
+int bsx_dev_skip_eval(bsx_ctx* ctx, void* stream, const bsx_validator* d_start_validators, const bsx_validator* d_candidate_validators,
+                      uint32_t n_candidates, uint32_t v_max, bsx_skip_eval* d_out) {
+    DEV_ENTER();
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+    if (n_candidates && (!d_start_validators || !d_candidate_validators || !d_out)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    HIPCHK(bsxk_skip_eval(S(ctx, stream), d_start_validators, d_candidate_validators, n_candidates, v_max, d_out));
     return BSX_OK;
 }
 
@@ -626,6 +637,45 @@ int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_numb
     memcpy(out_data_commitment, img.data() + bsx_off_leaf_hashes(1), 32);
     if (memcmp(img.data() + bsx_off_slots(1) + 128, prev_header_hash, 32) != 0)   // :434 (A10)
         return fail(BSX_ERR_ASSERT, "prove_next_header_data_commitment: data_hash proof root != prev_header_hash (A10, builder.rs:434)");
+    return BSX_OK;
+}
+
+// fetcher.rs:60-87 find_block_to_request over pre-fetched candidates: every is_valid_skip of the halving sequence in
+// one launch, then the reference's loop on the host
+int bsx_find_block_to_request(bsx_ctx* ctx, uint64_t start_block, uint64_t max_end_block, const bsx_validator* start_validators,
+                              uint32_t n_candidates, const uint64_t* candidate_heights, const bsx_validator* candidate_validators,
+                              uint32_t v_max, uint64_t* out_block, bsx_skip_eval* out_evals) {
+    DEV_ENTER();
+    if (!out_block || !start_validators || (n_candidates && (!candidate_heights || !candidate_validators)))
+        return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (max_end_block <= start_block) return fail(BSX_ERR_BAD_ARG, "max_end_block must be above start_block");
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+    hipStream_t st = ctx->stream;
+    std::vector<bsx_skip_eval> ev(n_candidates);
+    if (n_candidates) {
+        DBuf ds, dc, de;
+        RET(ds.alloc((size_t)v_max * sizeof(bsx_validator)));
+        RET(dc.alloc((size_t)n_candidates * v_max * sizeof(bsx_validator)));
+        RET(de.alloc((size_t)n_candidates * sizeof(bsx_skip_eval)));
+        H2D(ds.p, start_validators, (size_t)v_max * sizeof(bsx_validator));
+        H2D(dc.p, candidate_validators, (size_t)n_candidates * v_max * sizeof(bsx_validator));
+        HIPCHK(bsxk_skip_eval(st, ds.as<bsx_validator>(), dc.as<bsx_validator>(), n_candidates, v_max, de.as<bsx_skip_eval>()));
+        D2H(ev.data(), de.p, (size_t)n_candidates * sizeof(bsx_skip_eval));
+        SYNC();
+    }
+    if (out_evals) memcpy(out_evals, ev.data(), (size_t)n_candidates * sizeof(bsx_skip_eval));
+    uint64_t curr_end_block = max_end_block;                                  // :61
+    for (;;) {                                                                // :62
+        if (curr_end_block - start_block == 1) break;                         // :63-65
+        uint32_t c = 0;
+        while (c < n_candidates && candidate_heights[c] != curr_end_block) c++;
+        if (c == n_candidates)
+            return fail(BSX_ERR_BAD_ARG, "find_block_to_request visits height %llu, which is not among the candidates",
+                        (unsigned long long)curr_end_block);
+        if (ev[c].valid) break;                                               // :76-82
+        curr_end_block = (curr_end_block + start_block) / 2;                  // :84-85
+    }
+    *out_block = curr_end_block;
     return BSX_OK;
 }
 

@@ -427,6 +427,66 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ k_skip_eval
+// Operator skip-target search (fetcher.rs:60-87): one workgroup per candidate target evaluates is_valid_skip — the
+// start-set power of the validators that signed the candidate's commit against 1/3 of the start set ([UPSTREAM]
+// predicate, see bsx.h).  Candidate keys are staged in LDS; each lane owns start validators and scans them.
+__global__ __launch_bounds__(256) void k_skip_eval(const bsx_validator* __restrict__ start, const bsx_validator* __restrict__ cand,
+                                                   uint32_t v_max, bsx_skip_eval* __restrict__ out) {
+    __shared__ uint32_t tpk[TL_VMAX * 8];
+    __shared__ uint8_t tsig[TL_VMAX];
+    __shared__ unsigned long long acc[4];          // overlap, start total, signed, target total
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, V = v_max;
+    const bsx_validator* tv = cand + (uint64_t)c * V;
+    if (tid < 4) acc[tid] = 0;
+    uint64_t signed_p = 0, target_total = 0;
+    for (uint32_t k = tid; k < V; k += 256) {
+        uint32_t pk[8];
+        load_pk(tv + k, pk);
+#pragma unroll
+        for (int q = 0; q < 8; q++) tpk[k * 8 + q] = pk[q];
+        const uint4 flags = reinterpret_cast<const uint4*>(tv + k)[14];      // voting_power (8), enabled, is_signed, ...
+        const bool en = (flags.z & 0xffu) != 0, sg = ((flags.z >> 8) & 0xffu) != 0;
+        const uint64_t power = (uint64_t)flags.x | ((uint64_t)flags.y << 32);
+        tsig[k] = (en && sg) ? 1 : 0;
+        if (en) target_total += power;
+        if (en && sg) signed_p += power;
+    }
+    __syncthreads();
+    uint64_t ov = 0, start_total = 0;
+    for (uint32_t i = tid; i < V; i += 256) {
+        const uint4 flags = reinterpret_cast<const uint4*>(start + i)[14];
+        if ((flags.z & 0xffu) == 0) continue;
+        const uint64_t power = (uint64_t)flags.x | ((uint64_t)flags.y << 32);
+        start_total += power;
+        uint32_t pk[8];
+        load_pk(start + i, pk);
+        bool found = false;
+        for (uint32_t k = 0; k < V && !found; k++) {
+            if (!tsig[k]) continue;
+            uint32_t d = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) d |= tpk[k * 8 + q] ^ pk[q];
+            found = d == 0;
+        }
+        if (found) ov += power;
+    }
+    ov = wave_sum_u64(ov); start_total = wave_sum_u64(start_total);
+    signed_p = wave_sum_u64(signed_p); target_total = wave_sum_u64(target_total);
+    if ((tid & 63) == 0) {
+        atomicAdd(&acc[0], (unsigned long long)ov); atomicAdd(&acc[1], (unsigned long long)start_total);
+        atomicAdd(&acc[2], (unsigned long long)signed_p); atomicAdd(&acc[3], (unsigned long long)target_total);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bsx_skip_eval e;
+        e.overlap_power = acc[0]; e.start_total_power = acc[1]; e.signed_power = acc[2]; e.target_total_power = acc[3];
+        e.valid = ((unsigned __int128)acc[0] * 3 > (unsigned __int128)acc[1]) ? 1u : 0u;
+        e._pad = 0;
+        out[c] = e;
+    }
+}
+
 }  // namespace bsx
 
 extern "C" {
@@ -473,4 +533,9 @@ hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, con
     return hipGetLastError();
 }
 int bsxk_tally_vmax(void) { return TL_VMAX; }
+hipError_t bsxk_skip_eval(hipStream_t s, const bsx_validator* start, const bsx_validator* cand, uint32_t n_cand, uint32_t v_max, bsx_skip_eval* out) {
+    if (!n_cand) return hipSuccess;
+    hipLaunchKernelGGL(k_skip_eval, dim3(n_cand), dim3(256), 0, s, start, cand, v_max, out);
+    return hipGetLastError();
+}
 }

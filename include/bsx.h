@@ -367,6 +367,34 @@ int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_
                              void* d_table);
 int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
                                  uint64_t n, uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok);
+/* ------------------------------------------------------------------ operator skip-target search
+ * circuits/fetcher.rs:60-87 find_block_to_request: starting at max_end_block, return the first candidate c with
+ * is_valid_skip(start set, c's set, c's commit); otherwise halve the distance to start_block; c - start_block == 1 is
+ * returned unconditionally.  The reference fetches one candidate per iteration over HTTP; here the caller hands over the
+ * commits of the whole halving sequence and all predicates are evaluated in ONE launch (one workgroup per candidate),
+ * the walk itself is the reference's loop.  is_valid_skip is [UPSTREAM] tendermintx v1.0.0 (PARITY UNPINNED): evaluated
+ * as "start-set validators that signed the candidate's commit (flag is_signed, signatures not verified — the operator
+ * does not verify them either) hold > 1/3 of the start set's power", the rule builder.skip enforces in circuit. */
+typedef struct bsx_skip_eval {
+    uint64_t overlap_power;       /* start-set power of validators that signed the candidate */
+    uint64_t start_total_power;
+    uint64_t signed_power;        /* candidate-set power that signed */
+    uint64_t target_total_power;
+    uint32_t valid;               /* overlap_power * 3 > start_total_power */
+    uint32_t _pad;
+} bsx_skip_eval;                  /* sizeof == 40 */
+/* d_start_validators: v_max records (pubkey, voting_power, enabled); d_candidate_validators: n_candidates * v_max
+ * records (pubkey, voting_power, enabled, is_signed). */
+int bsx_dev_skip_eval(bsx_ctx* ctx, void* stream, const bsx_validator* d_start_validators,
+                      const bsx_validator* d_candidate_validators, uint32_t n_candidates, uint32_t v_max,
+                      bsx_skip_eval* d_out);
+/* Host tier.  candidate_heights must contain every height the loop visits (BSX_ERR_BAD_ARG otherwise);
+ * out_evals (optional) receives the n_candidates evaluations. */
+int bsx_find_block_to_request(bsx_ctx* ctx, uint64_t start_block, uint64_t max_end_block,
+                              const bsx_validator* start_validators, uint32_t n_candidates,
+                              const uint64_t* candidate_heights, const bsx_validator* candidate_validators,
+                              uint32_t v_max, uint64_t* out_block, bsx_skip_eval* out_evals);
+
 /* P8+P9: validator-set hash, voting-power tallies and message checks; one workgroup per commit; v_max <= 512.
  * d_header_hashes / d_ok may be NULL (then only validators_hash, total_power, n_enabled are meaningful). */
 int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits,

@@ -251,6 +251,23 @@ def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest
     return rc, out.tobytes(), res[0], compact
 
 
+SKIP_EVAL = np.dtype([("overlap_power", "<u8"), ("start_total_power", "<u8"), ("signed_power", "<u8"),
+                      ("target_total_power", "<u8"), ("valid", "<u4"), ("_pad", "<u4")])
+
+
+def find_block_to_request(start_block, max_end_block, start_validators, candidate_heights, candidate_validators):
+    """fetcher.rs:60-87 over pre-fetched candidates -> (rc, block, evals[n_candidates])."""
+    sv = np.ascontiguousarray(start_validators, T.VALIDATOR).reshape(-1)
+    cv = np.ascontiguousarray(candidate_validators, T.VALIDATOR).reshape(-1, sv.size)
+    hs = np.ascontiguousarray(candidate_heights, np.uint64)
+    assert cv.shape[0] == hs.size
+    ev = np.zeros(hs.size, SKIP_EVAL)
+    out = C.c_uint64(0)
+    rc = lib().orc_find_block_to_request(C.c_uint64(start_block), C.c_uint64(max_end_block), _p(sv), C.c_uint32(hs.size), _p(hs),
+                                         _p(cv), C.c_uint32(sv.size), C.byref(out), _p(ev))
+    return rc, int(out.value), ev
+
+
 def bench_header_range(nb_map_jobs, batch_size, ranges, headers, headers_per_range, latest, target, trusted, v_max,
                        with_witness, n_threads, reps=1):
     ranges = np.ascontiguousarray(ranges, T.SHARED_CTX).reshape(-1)

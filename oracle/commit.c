@@ -265,3 +265,53 @@ int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t J, uint32_
     free(th);
     return rc;
 }
+
+
+/* ---------------------------------------------------------------- skip-target search (fetcher.rs:60-87) */
+/* is_valid_skip(start set, target set, target commit): [UPSTREAM] tendermintx v1.0.0 — PARITY UNPINNED.  Restated as:
+ * the start-set validators that also signed the target commit hold more than 1/3 of the start set's voting power
+ * (the rule builder.skip enforces in circuit).  Signatures are counted by presence (BlockIDFlag
+ * commit), not verified: the operator's search does not verify them either (fetcher.rs:76-80 passes the bare commit). */
+void orc_is_valid_skip(const bsx_validator* sv, const bsx_validator* tv, uint32_t v_max, orc_skip_eval* out) {
+    unsigned __int128 start_total = 0, overlap = 0, signed_p = 0, target_total = 0;
+    for (uint32_t k = 0; k < v_max; k++) {
+        if (!tv[k].enabled) continue;
+        target_total += tv[k].voting_power;
+        if (tv[k].is_signed) signed_p += tv[k].voting_power;
+    }
+    for (uint32_t i = 0; i < v_max; i++) {
+        if (!sv[i].enabled) continue;
+        start_total += sv[i].voting_power;
+        for (uint32_t k = 0; k < v_max; k++)
+            if (tv[k].enabled && tv[k].is_signed && memcmp(tv[k].pubkey, sv[i].pubkey, 32) == 0) {
+                overlap += sv[i].voting_power;
+                break;
+            }
+    }
+    out->overlap_power = (uint64_t)overlap;
+    out->start_total_power = (uint64_t)start_total;
+    out->signed_power = (uint64_t)signed_p;
+    out->target_total_power = (uint64_t)target_total;
+    out->valid = (overlap * 3 > start_total) ? 1u : 0u;
+    out->_pad = 0;
+}
+
+/* fetcher.rs:60-87, line by line; candidates must contain every height the loop visits */
+int orc_find_block_to_request(uint64_t start_block, uint64_t max_end_block, const bsx_validator* start_validators,
+                              uint32_t n_candidates, const uint64_t* heights, const bsx_validator* cand, uint32_t v_max,
+                              uint64_t* out_block, orc_skip_eval* out_evals) {
+    if (max_end_block <= start_block) return BSX_ERR_BAD_ARG;
+    if (out_evals)
+        for (uint32_t c = 0; c < n_candidates; c++) orc_is_valid_skip(start_validators, cand + (size_t)c * v_max, v_max, out_evals + c);
+    uint64_t curr_end_block = max_end_block;                                   /* :61 */
+    for (;;) {                                                                 /* :62 */
+        if (curr_end_block - start_block == 1) { *out_block = curr_end_block; return BSX_OK; }   /* :63-65 */
+        uint32_t c = 0;
+        while (c < n_candidates && heights[c] != curr_end_block) c++;
+        if (c == n_candidates) return BSX_ERR_BAD_ARG;                         /* the caller did not supply this height */
+        orc_skip_eval e;
+        orc_is_valid_skip(start_validators, cand + (size_t)c * v_max, v_max, &e);               /* :76-80 */
+        if (e.valid) { *out_block = curr_end_block; return BSX_OK; }           /* :81 */
+        curr_end_block = (curr_end_block + start_block) / 2;                   /* :84-85 */
+    }
+}

@@ -93,6 +93,20 @@ int orc_header_range(uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t in
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact);
 
+/* ---- operator skip-target search (circuits/fetcher.rs:60-87 find_block_to_request).  The loop is
+ * the reference's; the predicate is_valid_skip is [UPSTREAM] tendermintx v1.0.0 (not under /root/reference): restated
+ * as the > 1/3 trusted-power overlap rule the circuit enforces -> PARITY UNPINNED for the predicate. */
+typedef struct orc_skip_eval {
+    uint64_t overlap_power, start_total_power, signed_power, target_total_power;
+    uint32_t valid, _pad;
+} orc_skip_eval;
+void orc_is_valid_skip(const bsx_validator* start_validators, const bsx_validator* target_validators, uint32_t v_max,
+                       orc_skip_eval* out);
+int orc_find_block_to_request(uint64_t start_block, uint64_t max_end_block, const bsx_validator* start_validators,
+                              uint32_t n_candidates, const uint64_t* candidate_heights,
+                              const bsx_validator* candidate_validators, uint32_t v_max, uint64_t* out_block,
+                              orc_skip_eval* out_evals /* optional, n_candidates */);
+
 /* ---- batch drivers for the cpu_baseline leg (pthread pool, n_threads >= 1) */
 int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t nb_map_jobs, uint32_t batch_size,
                            const bsx_shared_ctx* ranges, const bsx_header* headers, uint64_t headers_per_range,

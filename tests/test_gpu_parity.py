@@ -464,3 +464,37 @@ def test_expand_witness_property_full_size():
     got = dw.cpu().numpy().view(np.uint64)
     want = oracle.expand_witness(lay, J, compact)
     assert (got == want).all()
+
+
+# ------------------------------------------------------------------ §8(f) row 3: operator skip-target search
+@pytest.mark.parametrize("seed,v,v_max", [(1, 9, 9), (2, 100, 100), (3, 37, 64), (4, 512, 512)])
+def test_find_block_to_request_vs_oracle(seed, v, v_max):
+    """bsx_find_block_to_request (one launch evaluating every candidate of the halving sequence, then the reference's
+    loop, fetcher.rs:60-87) against the oracle: block chosen and every per-candidate tally.  Candidates drift away from
+    the start set the further they are (validators replaced, signers dropping out), so the search really descends."""
+    from blobstreamx_amd.builder import find_block_to_request, halving_sequence
+    rnd = np.random.default_rng(seed)
+    start = synth.ValidatorSet(100 + seed, v).as_validators(v_max)
+    S = 5000
+    for M in (S + 1, S + 2, S + 777, S + 2048):
+        heights = halving_sequence(S, M)
+        cands = []
+        for h in heights:
+            c = start.copy()
+            far = (h - S) / 2048.0                                  # 0 near the start block, 1 at the far end
+            for i in range(v):
+                if rnd.random() < 0.9 * far:                        # replaced by a stranger
+                    c[i]["pubkey"] = rnd.integers(0, 256, 32, dtype=np.uint8)
+                c[i]["is_signed"] = 1 if rnd.random() < 0.8 else 0
+                if rnd.random() < 0.1:
+                    c[i]["voting_power"] = int(rnd.integers(1, 10 ** 9))   # the candidate's own power, never used for the overlap
+            cands.append(c)
+        cands = np.stack(cands) if cands else np.zeros((0, v_max), T.VALIDATOR)
+        rc, want, wev = oracle.find_block_to_request(S, M, start, heights, cands)
+        blk, ev = find_block_to_request(S, M, start, heights, cands)
+        assert rc == T.OK and blk == want, (M, blk, want)
+        for f in ("overlap_power", "start_total_power", "signed_power", "target_total_power", "valid"):
+            assert (ev[f] == wev[f]).all(), (M, f)
+    with pytest.raises(_lib.BsxError) as ei:                       # a visited height is missing
+        find_block_to_request(S, S + 100, start, [S + 100], np.stack([np.zeros(v_max, T.VALIDATOR)]))
+    assert ei.value.status == T.ERR_BAD_ARG

@@ -129,3 +129,55 @@ def test_synthetic_chain_is_consistent():
                                            w.validators[1], w.trusted[1])
     assert rc == T.OK and out[:32] == w.hashes[1, 32].tobytes()
     assert cres["two_thirds_ok"] == 1 and cres["trusted_signed_power"] == cres["total_power"]
+
+
+def _skip_search_case():
+    """Start set of 9 validators (total power 100) and commits with chosen signers."""
+    V = 9
+    start = synth.ValidatorSet(5, V).as_validators(V)
+    start["voting_power"] = [10, 10, 10, 10, 10, 10, 10, 10, 20]
+
+    def commit(signers, strangers=()):
+        c = start.copy()
+        c["is_signed"] = 0
+        for i in signers:
+            c[i]["is_signed"] = 1
+        for i in strangers:                       # slot taken over by a key that is not in the start set, and signs
+            c[i]["pubkey"] = np.frombuffer(bytes([i + 1]) * 32, np.uint8)
+            c[i]["is_signed"] = 1
+        return c
+    return start, commit
+
+
+def test_find_block_to_request_follows_the_reference_loop():
+    """fetcher.rs:60-87: first valid candidate of the halving sequence, distance 1 accepted unconditionally.  The
+    predicate is [UPSTREAM] (parity unpinned): > 1/3 of the start set's power among the validators that signed."""
+    start, commit = _skip_search_case()
+    S, M = 1000, 1100
+    heights, c = [], M
+    while c - S > 1:
+        heights.append(c)
+        c = (c + S) // 2
+    assert heights == [1100, 1050, 1025, 1012, 1006, 1003]
+    # overlap 30 (no), 30 with 50 of stranger power signing (no), 40 (yes), 100 (yes, never reached)
+    cands = [commit([0, 1, 2]), commit([0, 1, 2], strangers=[3, 4, 5, 6, 7]), commit([0, 1, 8]), commit(range(9)),
+             commit(range(9)), commit(range(9))]
+    rc, blk, ev = oracle.find_block_to_request(S, M, start, heights, np.stack(cands))
+    assert rc == 0 and blk == 1025
+    assert list(ev["overlap_power"][:4]) == [30, 30, 40, 100] and list(ev["valid"][:4]) == [0, 0, 1, 1]
+    assert ev["signed_power"][1] == 80 and ev["start_total_power"][0] == 100 and ev["target_total_power"][0] == 100
+    # nothing valid: the loop ends at start + 1 without evaluating it
+    none = np.stack([commit([0])] * len(heights))
+    rc, blk, _ = oracle.find_block_to_request(S, M, start, heights, none)
+    assert rc == 0 and blk == S + 1
+    # a visited height missing from the candidates is an argument error
+    rc, _, _ = oracle.find_block_to_request(S, M, start, heights[:1], none[:1])
+    assert rc == T.ERR_BAD_ARG
+    # exactly one third is NOT enough (strict inequality)
+    start3 = start.copy()
+    start3["voting_power"] = 10
+    third = start3.copy()
+    third["is_signed"] = 0
+    third["is_signed"][:3] = 1
+    rc, blk, ev = oracle.find_block_to_request(S, S + 2, start3, [S + 2], third[None])
+    assert blk == S + 1 and ev["valid"][0] == 0 and ev["overlap_power"][0] * 3 == ev["start_total_power"][0]
