@@ -160,42 +160,49 @@ class HeaderRangeEngine:
         landed in: on one MI355X, seven 29.5 GB buffers allocated back to back ran the identical launch at 4.72, 5.53,
         5.27, 5.72, 5.64, 5.09 and 4.84 TB/s, each figure stable for its buffer, and freeing + re-allocating the same
         virtual address changed it again (tools/placement_test.py) — VRAM fragmentation left behind by earlier
-        processes decides the page-table fragment sizes.  So: allocate up to BSX_PLACEMENT_PROBE candidates while
-        memory allows, time the real expansion launch on each, keep the fastest, release the rest."""
+        processes decides the page-table fragment sizes.  On another box 3 of 4 candidates ran at 4.8 TB/s and one at
+        6.0 TB/s.  So: allocate candidates one by one (up to BSX_PLACEMENT_PROBE, while memory allows), time the real
+        expansion launch on each, stop at the first one that reaches the part's store ceiling, keep the fastest, release
+        the rest."""
         d, nbytes = self.dev, n_el * 8
         first = torch.zeros(n_el, dtype=torch.int64, device=d)
-        k = int(os.environ.get("BSX_PLACEMENT_PROBE", "4"))
+        k = int(os.environ.get("BSX_PLACEMENT_PROBE", "8"))
         if k <= 1 or nbytes < (1 << 30):
             return first
-        cands = [first]
-        for _ in range(k - 1):
-            free, _total = torch.cuda.mem_get_info(d)
-            if free < nbytes + (16 << 30):
-                break
-            try:
-                cands.append(torch.zeros(n_el, dtype=torch.int64, device=d))
-            except RuntimeError:
-                break
-        if len(cands) == 1:
-            return first
+        # stop early at a placement that runs at the store ceiling of the part (5.9 TB/s measured, tools/microbench)
+        good_gbps = float(os.environ.get("BSX_PLACEMENT_GOOD_GBPS", "5850"))
         L, ctx, dp = self.L, self.ctx, _lib.dp
         st = self._st()
-        times = []
-        for buf in cands:
+        n_jobs = self.RT * self.jc
+        job_bytes = int(self.ml["n_bytes"]) + 4 * int(self.ml["n_words"]) + int(self.ml["n_bools"]) + 8 * int(self.ml["n_elements"])
+
+        def launch_ms(buf):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             for it in range(4):
                 if it == 1:
                     ev[0].record(torch.cuda.current_stream(d))
-                _lib.check(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._ml), C.c_uint32(self.RT * self.jc), dp(self.compact),
-                                                    dp(buf)))
+                _lib.check(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._ml), C.c_uint32(n_jobs), dp(self.compact), dp(buf)))
             ev[1].record(torch.cuda.current_stream(d))
             torch.cuda.synchronize(d)
-            times.append(ev[0].elapsed_time(ev[1]) / 3)
+            return ev[0].elapsed_time(ev[1]) / 3
+
+        cands, times = [first], [launch_ms(first)]
+        while len(cands) < k and n_jobs * job_bytes / times[-1] / 1e6 < good_gbps:
+            free, _total = torch.cuda.mem_get_info(d)
+            if free < nbytes + (16 << 30):
+                break
+            try:
+                buf = torch.zeros(n_el, dtype=torch.int64, device=d)      # held until the end: a freed buffer's pages come back
+            except RuntimeError:
+                break
+            cands.append(buf)
+            times.append(launch_ms(buf))
         best = min(range(len(cands)), key=lambda i: times[i])
-        self.placement_probe = {"candidates": len(cands), "ms": [round(t, 3) for t in times], "picked": best}
+        self.placement_probe = {"candidates": len(cands), "ms": [round(t, 3) for t in times], "picked": best,
+                                "GBps": round(n_jobs * job_bytes / times[best] / 1e6)}
         keep = cands[best]
         keep.zero_()
-        del cands, buf, first
+        cands = buf = first = None
         torch.cuda.synchronize(d)
         torch.cuda.empty_cache()
         return keep
