@@ -785,8 +785,12 @@ hipError_t bsxk_finalize(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t 
 hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uint32_t n_jobs, const uint8_t* compact, uint64_t* out) {
     if (!n_jobs) return hipSuccess;
     const uint64_t npairs = (lay->n_elements + 2) / 2;
-    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 2048;
-    static const long nt = getenv("BSX_EXPAND_NT") ? atol(getenv("BSX_EXPAND_NT")) : 0;
+    // Staging chunk and store flavour.  Alone on the GPU plain stores with 2 KiB chunks are fastest (5.9-6.1 TB/s vs
+    // 5.3-5.4 with non-temporal stores); in the pipelined step the non-temporal 512-byte variant does not slow down
+    // beside the other chunk's hashing (5.30-5.46 TB/s in-region vs 5.19-5.31) and disturbs it less:
+    // 5 alternating runs 90.0-92.5 vs 88.0-89.9 M headers/s.  The product path is the pipelined one.
+    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 512;
+    static const long nt = getenv("BSX_EXPAND_NT") ? atol(getenv("BSX_EXPAND_NT")) : 1;
     const uint32_t ppb = (uint32_t)chunk * 4;
     const uint32_t gx = (uint32_t)((npairs + ppb - 1) / ppb);
     ExpandArgs a{*lay, n_jobs, gx, compact, out};

@@ -169,8 +169,10 @@ class HeaderRangeEngine:
         k = int(os.environ.get("BSX_PLACEMENT_PROBE", "8"))
         if k <= 1 or nbytes < (1 << 30):
             return first
-        # stop early at a placement that runs at the store ceiling of the part (5.9 TB/s measured, tools/microbench)
-        good_gbps = float(os.environ.get("BSX_PLACEMENT_GOOD_GBPS", "5850"))
+        # stop early at a placement that runs at the ceiling of the launch: 5.9 TB/s for plain stores (tools/microbench),
+        # 5.4 TB/s for the non-temporal variant the library launches by default (csrc/kernels_sha.hip)
+        nt = os.environ.get("BSX_EXPAND_NT", "1") != "0"
+        good_gbps = float(os.environ.get("BSX_PLACEMENT_GOOD_GBPS", "5350" if nt else "5850"))
         L, ctx, dp = self.L, self.ctx, _lib.dp
         st = self._st()
         n_jobs = self.RT * self.jc
