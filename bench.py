@@ -7,7 +7,8 @@ instances (32 map jobs x 64 headers, 100 validators, mode F = one commit per ran
 does) whose inputs are already resident in HBM.  value = N * R * 2048 headers / step time, all ranks, max over ranks.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): every rank computes its 32/N-job slice of all
-N*R ranges, ONE all-gather of 128-byte records, the owner finishes its R ranges — weak scaling (blobstreamx_amd/engine.py).
+N*R ranges, one all-gather of 128-byte records per pipelined chunk, the owner finishes its R ranges — weak scaling
+(blobstreamx_amd/engine.py).
 
 Extra objects on the JSON line: `roofline` (dominant kernel = witness expansion, HBM-write bound), `kernels` (the SHA
 kernels' compact-byte rates, never mixed with the expanded figure), `cpu_baseline` (the C oracle timed on this box's

@@ -5,7 +5,12 @@
 //
 //   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, records staged via LDS
 //   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
-//   k_commit_tally      P8+P9 validator-set hash (masked Merkle tree), voting-power sums, message checks;
+//   k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed
+//                       P7, fixed-key form: per-validator tables of j*(-A), j*(-2^128 A) (j = 1..128) built once per
+//                           pass, signatures checked with 8-bit windows over split scalars; slots whose key is not the
+//                           table row's key are deferred to k_ed25519_verify<true> (same accept set)
+//   k_skip_eval         operator skip-target search (fetcher.rs:60-87): is_valid_skip of every candidate in one launch
+//   k_commit_tally     P8+P9 validator-set hash (masked Merkle tree), voting-power sums, message checks;
 //                           one workgroup per commit, wave-shuffle + LDS reductions
 //   k_skip_check        skip conditions of CombinedSkipCircuit (header_range.rs:42-48): header/validator-hash links,
 //                           2/3 of the target set, > 1/3 of the trusted set
