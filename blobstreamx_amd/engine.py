@@ -321,7 +321,10 @@ class HeaderRangeEngine:
                                      C.c_uint64(self.RT), dp(self.results), dp(self.red_compact_top)))
         return self.results
 
-    def step_final(self, result_records, time_kernels=False):
+    def step_final(self, result_records, time_kernels=False, before_expand=None):
+        """finalize + (commit verification on the side stream) + witness expansion.  before_expand: hook called right
+        before the expansion is enqueued (PipelinedEngines waits for the other chunk's expansion there, so that the tiny
+        finalize kernel and the side-stream launch do not sit between two expansions)."""
         L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
         ev = self.events if time_kernels else None
         own_ranges = self.skip_ranges if self.with_commit else self.ranges[self.rank * self.R * 80:]
@@ -334,6 +337,8 @@ class HeaderRangeEngine:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 self._commit(self._st(), "verify")
+        if before_expand is not None:
+            before_expand()
         if self.with_witness:
             if ev:
                 ev[2].record(torch.cuda.current_stream(self.dev))
@@ -418,9 +423,8 @@ class PipelinedEngines:
                 if self.E > 1:
                     self._hash_token = torch.cuda.Event()
                     self._hash_token.record(s)
-                    if self._expand_token is not None:
-                        s.wait_event(self._expand_token)
-                eng.step_final(res, time_kernels)
+                tok = self._expand_token if self.E > 1 else None
+                eng.step_final(res, time_kernels, before_expand=(lambda s=s, tok=tok: s.wait_event(tok)) if tok is not None else None)
                 if self.E > 1:
                     self._expand_token = torch.cuda.Event()
                     self._expand_token.record(s)
