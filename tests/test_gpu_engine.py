@@ -46,8 +46,13 @@ def test_engine_batch_vs_oracle(J, B, V, R, n_blocks):
         assert (wrl[r * nr:(r + 1) * nr] == ref[nm:]).all(), r
 
 
-def test_engine_reports_failures_per_range():
+@pytest.mark.parametrize("ed_path,commit_with", [("generic", "expand"), ("keyed", "expand"), ("keyed", "hash"), ("generic", "hash")])
+def test_engine_reports_failures_per_range(ed_path, commit_with, monkeypatch):
+    """Both forms of the signature check (per-signature / per-validator tables) and both placements of the commit
+    side stream must report the same per-range verdicts as the oracle."""
     from blobstreamx_amd.engine import HeaderRangeEngine
+    monkeypatch.setenv("BSX_ED_PATH", ed_path)
+    monkeypatch.setenv("BSX_COMMIT_WITH", commit_with)
     J, B, V, R = 4, 8, 12, 4
     w = synth.Workload(6, R, J, B, v=V)
     w.headers[1, 9]["hash"][1][5] ^= 1            # range 1: chain breaks at header 9
@@ -132,3 +137,39 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["ranges_per_gpu"] == 8 and d["config"]["headers_per_step"] == 2 * 8 * 2048
+
+
+def test_expansion_kernel_variants_agree():
+    """k_expand_witness has eight instantiations (staging chunk 512/1024/2048/4096 x plain / non-temporal stores, chosen
+    by BSX_EXPAND_CHUNK / BSX_EXPAND_NT when the library is loaded).  Every one of them, and a capped grid, must emit
+    the oracle's witness bit for bit; each runs in its own process because the choice is read once."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    J, B, V, R = 8, 32, 10, 3
+    w = synth.Workload(9, R, J, B, v=V, n_blocks=200)
+    ml, rl = T.map_layout(B), T.reduce_layout()
+    want = hashlib.sha256()
+    for r in range(R):
+        rc, _, _, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
+                                           w.validators[r], w.trusted[r], want_witness=True)
+        assert rc == T.OK
+        want.update(oracle.expand_range_witness(J, B, cw)[:J * int(ml["n_elements"])].tobytes())
+    snippet = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "import synth\n"
+        "from blobstreamx_amd.engine import HeaderRangeEngine\n"
+        "w = synth.Workload(9, %d, %d, %d, v=%d, n_blocks=200)\n"
+        "e = HeaderRangeEngine(%d, %d, %d, %d); e.upload_workload(w); e.step()\n"
+        "m, _, _ = e.witness_numpy(); print('WITNESS', hashlib.sha256(m.tobytes()).hexdigest())\n" % (root, R, J, B, V, J, B, V, R))
+    variants = [(c, nt, "") for c in (512, 1024, 2048, 4096) for nt in (0, 1)] + [(512, 1, "7"), (2048, 0, "1")]
+    for chunk, nt, cap in variants:
+        env = dict(os.environ, BSX_EXPAND_CHUNK=str(chunk), BSX_EXPAND_NT=str(nt))
+        if cap:
+            env["BSX_EXPAND_BLOCKS"] = cap
+        out = subprocess.run([sys.executable, "-c", snippet], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (chunk, nt, cap, out.stderr[-2000:])
+        got = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("WITNESS")]
+        assert got == [want.hexdigest()], (chunk, nt, cap)
