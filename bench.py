@@ -129,6 +129,22 @@ def stress(args, dev):
             "tally_validator_hash_ms": t_tally}
 
 
+def secondary_1024(args):
+    """The metric's other production shape, header_range_1024 (32 map jobs x 32 headers, bin/header_range_1024.rs:6-17),
+    through the same code path: this script again with --batch 32 in a fresh process (streams, hardware queues and the
+    allocator start clean), same ranges per step, half the slots.  Reported beside the headline, N = 1 only."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--jobs", "32", "--batch", "32", "--validators", str(args.validators),
+           "--ranges", str(args.ranges), "--engines", str(args.engines), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-cpu-baseline", "--no-stress"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        return {"error": out.stderr[-500:]}
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    return {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+            "steps": d["steps"], "roofline_frac": d["roofline"]["frac"]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -264,6 +280,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, J, B, V, args.cpu_seconds, gpu_out64)
         if world == 1 and not args.no_stress:
             out["stress"] = stress(args, dev)
+            out["header_range_1024"] = secondary_1024(args)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -37,7 +37,7 @@ hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx
                            uint32_t*, uint8_t*, const uint32_t*);
 hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
 hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
-hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*, uint8_t*);
+hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*, uint8_t*, uint8_t*);
 int bsxk_tally_vmax(void);
 hipError_t bsxk_skip_eval(hipStream_t, const bsx_validator*, const bsx_validator*, uint32_t, uint32_t, bsx_skip_eval*);
 }
@@ -231,10 +231,10 @@ int bsx_dev_expand_witness(bsx_ctx* ctx, void* stream, const bsx_witness_layout*
 }
 
 int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_shared_ctx* d_ranges, const uint8_t* d_hashes,
-                          uint64_t headers_per_range, const uint32_t* d_target_index, uint8_t* d_target_hashes) {
+                          uint64_t headers_per_range, const uint32_t* d_target_index, uint8_t* d_target_hashes, uint8_t* d_hashes_copy) {
     DEV_ENTER();
     if (!d_ranges || !d_hashes) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_fill_end_hash(S(ctx, stream), n_ranges, d_ranges, d_hashes, headers_per_range, d_target_index, d_target_hashes));
+    HIPCHK(bsxk_fill_end_hash(S(ctx, stream), n_ranges, d_ranges, d_hashes, headers_per_range, d_target_index, d_target_hashes, d_hashes_copy));
     return BSX_OK;
 }
 
@@ -738,7 +738,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     RangeDev rd;
     RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd));
     // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash
-    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, nullptr));
+    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, nullptr, nullptr));
     DBuf dv, dtv, dh, dok, dres, dtres, dskip, dth;
     RET(dv.alloc((size_t)v_max * sizeof(bsx_validator)));
     RET(dtv.alloc((size_t)v_max * sizeof(bsx_validator)));

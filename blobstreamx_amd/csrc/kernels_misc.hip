@@ -67,13 +67,15 @@ __global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_has
 }
 
 __global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
-                                const uint32_t* target_idx, uint8_t* target_out) {
+                                const uint32_t* target_idx, uint8_t* target_out, uint8_t* hashes_copy) {
     const uint32_t r = blockIdx.x, t = threadIdx.x;   // 32 lanes
     if (r >= n_ranges) return;
     const uint64_t idx = (uint64_t)r * hpr + (target_idx ? (uint64_t)target_idx[r] : ranges[r].end_block - ranges[r].start_block);
     const uint8_t b = hashes[idx * 32 + t];
     ranges[r].end_header_hash[t] = b;
     if (target_out) target_out[(uint64_t)r * 32 + t] = b;   // dense copy for the commit tally / finalize
+    if (hashes_copy)                                        // private copy of the range's hashes for a consumer on another stream
+        for (uint64_t k = 0; k < hpr; k++) hashes_copy[((uint64_t)r * hpr + k) * 32 + t] = hashes[((uint64_t)r * hpr + k) * 32 + t];
 }
 
 }  // namespace bsx
@@ -90,9 +92,9 @@ hipError_t bsxk_data_commitment(hipStream_t s, const uint8_t* data_hashes, uint3
     return hipGetLastError();
 }
 hipError_t bsxk_fill_end_hash(hipStream_t s, uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
-                              const uint32_t* target_idx, uint8_t* target_out) {
+                              const uint32_t* target_idx, uint8_t* target_out, uint8_t* hashes_copy) {
     if (!n_ranges) return hipSuccess;
-    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr, target_idx, target_out);
+    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr, target_idx, target_out, hashes_copy);
     return hipGetLastError();
 }
 }

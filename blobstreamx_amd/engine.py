@@ -129,7 +129,15 @@ class HeaderRangeEngine:
         self.commit_res = _u8(R * 96, d)
         self.trusted_res = _u8(R * 96, d)
         self.skip_status = torch.zeros(max(R, 1), dtype=torch.int32, device=d)
-        self.target_hashes = _u8(R * 32, d)
+        # Commit-check inputs that the main stream produces are double-buffered by pass parity, so that the check of
+        # pass i (side stream) may still be running while pass i+1 hashes: target hashes, the (trusted, target) header
+        # hashes, and a never-rewritten copy of the owned ranges' contexts.
+        self._parity = 0
+        self._target_hashes_pp = [_u8(R * 32, d), _u8(R * 32, d)]
+        self._skip_hashes_pp = [_u8(R * 2 * 32, d), _u8(R * 2 * 32, d)]
+        self._commit_done = [None, None]           # event per parity: the side stream finished the check that used it
+        self.skip_ranges_side = _u8(R * 80, d)
+        self.defer_commit_wait = False             # PipelinedEngines: do not join the side stream at the end of a pass
         self.n_map_el = RT * jc * int(self.ml["n_elements"])
         self.n_red_local_el = n_local_nodes * int(self.rl["n_elements"])
         self.n_red_top_el = R * max(world - 1, 0) * int(self.rl["n_elements"])
@@ -224,6 +232,7 @@ class HeaderRangeEngine:
         if self.with_commit:
             put(self.skip_headers, skip_headers)
             put(self.skip_ranges, skip_ranges)
+            put(self.skip_ranges_side, skip_ranges)
             put(self.validators, validators)
             put(self.trusted, trusted)
         torch.cuda.synchronize(self.dev)
@@ -261,8 +270,12 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_header_merkle(ctx, st, dp(self.headers_all), C.c_uint64(self.nh_all if commit else RT * self.hpr),
                                     dp(self.hashes_all), dp(self.dh_aunts), dp(self.lb_aunts), dp(self.status)))
         if commit:
+            self._parity ^= 1
+            done = self._commit_done[self._parity]
+            if done is not None:                   # the check two passes ago read this parity's buffers
+                main.wait_event(done)
             chk(L.bsx_dev_fill_end_hash(ctx, st, C.c_uint32(R), dp(self.skip_ranges), dp(self.skip_hashes), C.c_uint64(2),
-                                        dp(self.target_idx), dp(self.target_hashes)))
+                                        dp(self.target_idx), dp(self.target_hashes), dp(self._skip_hashes_pp[self._parity])))
             if self.commit_with == "hash":
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
@@ -302,9 +315,17 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.trusted), C.c_uint32(R), C.c_uint32(V), None, None, dp(self.trusted_res)))
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.validators), C.c_uint32(R), C.c_uint32(V), dp(self.target_hashes), dp(self.ok),
                                    dp(self.commit_res)))
-        chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges), dp(self.skip_headers), C.c_uint64(2),
-                                 dp(self.skip_hashes), dp(self.validators), dp(self.trusted), dp(self.ok), dp(self.commit_res),
-                                 dp(self.trusted_res), dp(self.skip_status), None, dp(self.target_idx)))
+        chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges_side), dp(self.skip_headers),
+                                 C.c_uint64(2), dp(self._skip_hashes_pp[self._parity]), dp(self.validators), dp(self.trusted),
+                                 dp(self.ok), dp(self.commit_res), dp(self.trusted_res), dp(self.skip_status), None,
+                                 dp(self.target_idx)))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._commit_done[self._parity] = ev
+
+    @property
+    def target_hashes(self):
+        return self._target_hashes_pp[self._parity]
 
     def step_exchange(self, gathered=None):
         """Stage 6: the one collective.  Single GPU: the local fold already is the range result.
@@ -357,6 +378,10 @@ class HeaderRangeEngine:
         self.step_local(time_kernels)
         res = self.step_exchange()
         self.step_final(res, time_kernels)
+        self.join_commit()
+
+    def join_commit(self):
+        """Make the current stream wait for the commit check on the side stream."""
         if self.with_commit and self.R:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
@@ -428,13 +453,15 @@ class PipelinedEngines:
                 if self.E > 1:
                     self._expand_token = torch.cuda.Event()
                     self._expand_token.record(s)
-                if eng.with_commit and eng.R:
-                    s.wait_stream(eng.side)
+                # the commit check is NOT joined here: its inputs are double-buffered by pass parity (HeaderRangeEngine), so
+                # it may run on into the chunk's next pass; join() / download() wait for it
 
     def join(self):
         cur = torch.cuda.current_stream(self.dev)
-        for s in self.streams:
+        for s, eng in zip(self.streams, self.engines):
             cur.wait_stream(s)
+            if eng.with_commit and eng.R:
+                cur.wait_stream(eng.side)
 
     def download(self):
         self.join()

@@ -344,10 +344,12 @@ int bsx_dev_expand_witness(bsx_ctx* ctx, void* stream, const bsx_witness_layout*
 /* d_ranges[r].end_header_hash := d_hashes[r*headers_per_range + (end_block - start_block)] (the target header hash
  * builder.skip returns and prove_data_commitment consumes, header_range.rs:42-55).  d_target_index (optional,
  * n_ranges u32) overrides the position of the target header inside the range's header block.  d_target_hashes
- * (optional, n_ranges*32) receives the same hashes densely, the layout bsx_dev_commit_tally / bsx_dev_finalize take. */
+ * (optional, n_ranges*32) receives the same hashes densely, the layout bsx_dev_commit_tally / bsx_dev_finalize take.
+ * d_hashes_copy (optional, n_ranges*headers_per_range*32) receives a copy of the ranges' hashes: a consumer on another
+ * stream (the commit check) can then keep reading them while d_hashes is rewritten by the next pass. */
 int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_shared_ctx* d_ranges,
                           const uint8_t* d_hashes, uint64_t headers_per_range, const uint32_t* d_target_index,
-                          uint8_t* d_target_hashes);
+                          uint8_t* d_target_hashes, uint8_t* d_hashes_copy);
 
 /* P6: h = SHA512(R ‖ A ‖ M) mod L per validator slot. d_h: n*32 (LE scalar), d_digest (optional) n*64. */
 int bsx_dev_sha512_challenge(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n,
