@@ -24,9 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Two pipelined chunks need four independent hardware queues (2 main + 2 commit side streams); HIP's default of 4
-# maps the second chunk's main stream onto the first chunk's side-stream queue and serialises them (profiles/README.md).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Two pipelined chunks need four independent hardware queues (2 main + 2 commit side streams) beside the default stream,
+# the library's own stream and — at N > 1 — RCCL's; HIP's default of 4 maps the second chunk's main stream onto the first
+# chunk's side-stream queue and serialises them.  8 and 16 measure the same at N = 1 (91.8 / 91.3 M headers/s); 16 leaves
+# headroom for the collective's streams.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -46,7 +48,7 @@ def parse():
     ap.add_argument("--engines", type=int, default=2, help="chunks of the step pipelined on separate HIP streams (the ALU-bound hashing "
                     "of one chunk beside the HBM-bound expansion of the other; phase tokens keep the chunks in complementary "
                     "phases).  Measured on MI355X with GPU_MAX_HW_QUEUES=8: 72.8 / 80.5-81.3 / ~52 M headers/s at 1 / 2 / 4 chunks "
-                    "(4 chunks x 2 streams exceed the hardware queues).  At N > 1 every chunk does its own all-gather")
+                    "(4 chunks: the co-running chunks starve each other; more hardware queues do not help: 67 M at 16 queues).  At N > 1 every chunk does its own all-gather")
     ap.add_argument("--event-every", type=int, default=1, help="record the per-kernel HIP events on every n-th timed step")
     ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
