@@ -269,6 +269,8 @@ class HeaderRangeEngine:
                 self._commit(self._st(), "prep")
         chk(L.bsx_dev_header_merkle(ctx, st, dp(self.headers_all), C.c_uint64(self.nh_all if commit else RT * self.hpr),
                                     dp(self.hashes_all), dp(self.dh_aunts), dp(self.lb_aunts), dp(self.status)))
+        self.merkle_done = torch.cuda.Event()
+        self.merkle_done.record(main)
         if commit:
             self._parity ^= 1
             done = self._commit_done[self._parity]
@@ -276,6 +278,8 @@ class HeaderRangeEngine:
                 main.wait_event(done)
             chk(L.bsx_dev_fill_end_hash(ctx, st, C.c_uint32(R), dp(self.skip_ranges), dp(self.skip_hashes), C.c_uint64(2),
                                         dp(self.target_idx), dp(self.target_hashes), dp(self._skip_hashes_pp[self._parity])))
+            self.fill_done = torch.cuda.Event()
+            self.fill_done.record(main)
             if self.commit_with == "hash":
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
@@ -342,7 +346,20 @@ class HeaderRangeEngine:
                                      C.c_uint64(self.RT), dp(self.results), dp(self.red_compact_top)))
         return self.results
 
-    def step_final(self, result_records, time_kernels=False, before_expand=None):
+    def launch_verify(self, after_event=None):
+        """Signature checks, tallies and skip conditions of the current pass on the side stream ("expand" placement).
+        They need the target hashes (fill_end_hash) and the prep part already queued on the side stream; after_event
+        (optional) delays them further — PipelinedEngines passes the other chunk's header-hashing event, so that this
+        ALU work runs beside that chunk's memory-leaning kernels instead of beside its k_header_merkle."""
+        if not (self.with_commit and self.R and self.commit_with == "expand"):
+            return
+        self.side.wait_event(self.fill_done)
+        if after_event is not None:
+            self.side.wait_event(after_event)
+        with torch.cuda.stream(self.side):
+            self._commit(self._st(), "verify")
+
+    def step_final(self, result_records, time_kernels=False, before_expand=None, launch_verify=True):
         """finalize + (commit verification on the side stream) + witness expansion.  before_expand: hook called right
         before the expansion is enqueued (PipelinedEngines waits for the other chunk's expansion there, so that the tiny
         finalize kernel and the side-stream launch do not sit between two expansions)."""
@@ -352,12 +369,11 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_finalize(ctx, st, C.c_uint32(self.R), C.c_uint32(self.J), C.c_uint32(self.B), dp(own_ranges),
                                dp(result_records), dp(self.target_hashes) if self.with_commit else None, dp(self.output64),
                                dp(self.range_status)))
-        if self.with_commit and self.R and self.commit_with == "expand":
-            # the commit verification is integer-ALU work: start it beside the HBM-bound expansion, not beside the hashing
-            main = torch.cuda.current_stream(self.dev)
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                self._commit(self._st(), "verify")
+        if launch_verify:
+            # integer-ALU work: start it beside the HBM-bound expansion (i.e. once finalize is done), not beside the hashing
+            fin = torch.cuda.Event()
+            fin.record(torch.cuda.current_stream(self.dev))
+            self.launch_verify(after_event=fin)
         if before_expand is not None:
             before_expand()
         if self.with_witness:
@@ -424,6 +440,8 @@ class PipelinedEngines:
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_engines)]
         self._hash_token = None
         self._expand_token = None
+        self._pending_verify = None
+        self.verify_after_merkle = os.environ.get("BSX_VERIFY_AFTER_MERKLE", "1") == "1"
 
     def sel(self, e):
         return np.concatenate([np.arange(g * self.R + e * self.Rc, g * self.R + (e + 1) * self.Rc) for g in range(self.world)])
@@ -444,12 +462,21 @@ class PipelinedEngines:
                 if self.E > 1 and self._hash_token is not None:
                     s.wait_event(self._hash_token)
                 eng.step_local(time_kernels)
+                if self._pending_verify is not None:
+                    # the previous chunk's signature checks: enqueued now so that they can wait for THIS chunk's
+                    # k_header_merkle (both are integer-ALU bound; the rest of this chunk's hashing phase leans on memory)
+                    self._pending_verify.launch_verify(after_event=eng.merkle_done)
+                    self._pending_verify = None
                 res = eng.step_exchange()
                 if self.E > 1:
                     self._hash_token = torch.cuda.Event()
                     self._hash_token.record(s)
                 tok = self._expand_token if self.E > 1 else None
-                eng.step_final(res, time_kernels, before_expand=(lambda s=s, tok=tok: s.wait_event(tok)) if tok is not None else None)
+                defer = self.verify_after_merkle and self.E > 1
+                eng.step_final(res, time_kernels, before_expand=(lambda s=s, tok=tok: s.wait_event(tok)) if tok is not None else None,
+                               launch_verify=not defer)
+                if defer:
+                    self._pending_verify = eng
                 if self.E > 1:
                     self._expand_token = torch.cuda.Event()
                     self._expand_token.record(s)
@@ -457,6 +484,9 @@ class PipelinedEngines:
                 # it may run on into the chunk's next pass; join() / download() wait for it
 
     def join(self):
+        if self._pending_verify is not None:          # no later chunk to wait for: launch the deferred checks now
+            self._pending_verify.launch_verify()
+            self._pending_verify = None
         cur = torch.cuda.current_stream(self.dev)
         for s, eng in zip(self.streams, self.engines):
             cur.wait_stream(s)
