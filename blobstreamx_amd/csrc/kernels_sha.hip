@@ -211,6 +211,10 @@ struct AssembleArgs {
     uint32_t* status;
 };
 
+// AS_IT = 16-byte pieces per lane = ceil(24 * B / 256): a template parameter so that the in-flight buffer (and with it
+// the register footprint: 96 VGPRs for the general case, 24 at B = 64) matches the batch size — more resident waves
+// = more loads in flight when the kernel runs beside the expansion.
+template <uint32_t AS_IT>
 __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     const uint32_t r = blockIdx.x / a.job_count, jl = blockIdx.x % a.job_count, j = a.job_first + jl;
     const uint32_t B = a.batch;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     // several times longer, and this gather is pure latency (the 16-bit-unit version took 1.3-1.8 ms there, 0.12 alone).
     const uint64_t h0 = hbase + (batch_start - S);
     bool bad_leaf = false;
-    constexpr uint32_t AS_PIECES = 24, AS_MAX_IT = (AS_PIECES * BSX_MAX_BATCH + 255) / 256;
+    constexpr uint32_t AS_PIECES = 24, AS_MAX_IT = AS_IT;
     const uint32_t n_items = AS_PIECES * B;
     uint8_t* dh_dst = cw + 128;
     uint8_t* lb_dst = cw + 128 + (uint32_t)BSX_DH_PROOF_SIZE * B;
@@ -747,7 +751,15 @@ hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, ui
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hfr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status};
-    hipLaunchKernelGGL(k_assemble_inputs, dim3(n_ranges * job_count), dim3(256), 0, s, a);
+    const uint32_t it = (24u * B + 255u) / 256u;
+#define BSX_AS_LAUNCH(N) hipLaunchKernelGGL(k_assemble_inputs<N>, dim3(n_ranges * job_count), dim3(256), 0, s, a)
+    if (it <= 1) BSX_AS_LAUNCH(1);
+    else if (it <= 2) BSX_AS_LAUNCH(2);
+    else if (it <= 3) BSX_AS_LAUNCH(3);
+    else if (it <= 6) BSX_AS_LAUNCH(6);
+    else if (it <= 12) BSX_AS_LAUNCH(12);
+    else BSX_AS_LAUNCH(24);
+#undef BSX_AS_LAUNCH
     return hipGetLastError();
 }
 hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_t job_count, const bsx_shared_ctx* ranges,
