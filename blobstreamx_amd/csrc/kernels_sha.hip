@@ -26,6 +26,11 @@
 
 namespace bsx {
 
+// Kernels of the hashing chain (the critical path of a pipelined chunk) raise their wave priority above the commit
+// check's kernels, which share the integer ALUs but have a whole pass of slack (engine.py); the HBM-bound expansion
+// runs at priority 3.
+#define BSX_CHAIN_PRIO() __builtin_amdgcn_s_setprio(1)
+
 // ------------------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ void store_u32_a2(uint8_t* dst, uint32_t v) {  // dst 2-byte aligned (odd batch sizes only)
     if (reinterpret_cast<uintptr_t>(dst) & 2) {
@@ -109,6 +114,7 @@ __device__ __forceinline__ Digest leaf_from_regs(const uint32_t (&W)[N], int len
 __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
                                                               uint8_t* __restrict__ lb_aunts, uint32_t* __restrict__ status) {
+    BSX_CHAIN_PRIO();
     const uint64_t me = (uint64_t)blockIdx.x * HM_THREADS + threadIdx.x;
     const bool live = me < n;
     const uint8_t* my = reinterpret_cast<const uint8_t*>(hdr + (live ? me : 0));
@@ -216,6 +222,7 @@ struct AssembleArgs {
 // = more loads in flight when the kernel runs beside the expansion.
 template <uint32_t AS_IT>
 __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
+    BSX_CHAIN_PRIO();
     const uint32_t r = blockIdx.x / a.job_count, jl = blockIdx.x % a.job_count, j = a.job_first + jl;
     const uint32_t B = a.batch;
     const bsx_shared_ctx rg = a.ranges[r];
@@ -334,6 +341,7 @@ __device__ __forceinline__ uint32_t gdword_at(const uint8_t* p, int k) {
 // ---- stage 1: one lane per slot, no communication (builder.rs:180-199, 134-137 + leaf hashes of :144-147)
 constexpr int SH_THREADS = 256;
 __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
+    BSX_CHAIN_PRIO();
     const uint32_t B = a.batch;
     const uint64_t gs = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x;     // global slot index
     if (gs >= (uint64_t)a.n_jobs * B) return;
@@ -424,6 +432,7 @@ __device__ __forceinline__ void batch_bounds(const uint32_t* W, uint64_t E, uint
 // inner = inner_hash(l, r) always; node = both children enabled ? inner : l; enabled = l || r (prefix mask).
 constexpr int TR_THREADS = 256;
 __global__ __launch_bounds__(TR_THREADS) void k_tree_level(SubchainArgs a) {
+    BSX_CHAIN_PRIO();
     const uint32_t B = a.batch, width = a.width;
     const uint64_t g = (uint64_t)blockIdx.x * TR_THREADS + threadIdx.x;
     if (g >= (uint64_t)a.n_jobs * width) return;
@@ -451,6 +460,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tree_level(SubchainArgs a) {
 // per-slot assertion bits are reduced with a wave ballot and at most one LDS atomic per failing lane.
 constexpr int BF_THREADS = 256;
 __global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
+    BSX_CHAIN_PRIO();
     __shared__ uint32_t job_fail[BF_THREADS];
     __shared__ uint32_t job_first_bad[BF_THREADS];
     const uint32_t B = a.batch, tid = threadIdx.x;
