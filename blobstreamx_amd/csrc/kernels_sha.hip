@@ -818,9 +818,10 @@ hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uin
     ExpandArgs a{*lay, n_jobs, gx, compact, out};
     // BSX_EXPAND_BLOCKS caps the grid (workgroups stride over the items) so that the HBM-bound expansion leaves wave
     // slots for an ALU-bound kernel running beside it on another stream; 0 / unset = one workgroup per item
-    // (measured with 2 pipelined chunks of 4096 jobs: 8192 / 16384 / 32768 / uncapped workgroups give 86-87 / 87-91 / 87 / 77 M
-    // headers/s; fewer than 8192 lose bandwidth: 4096 -> 77, 2048 -> 72)
-    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 16384;
+    // (measured with 2 pipelined chunks of 4096 jobs and the default non-temporal 512-byte variant, 450 k items per
+    // launch: 16384 / 32768 / 65536 / 131072 / 262144 / uncapped workgroups give 91.5-93.8 / 93.9-95.3 / 93.1-95.1 / 94.1-95.2 /
+    // 92.6-93.1 / 80 M headers/s; the plain-store 2 KiB variant preferred 16384, and fewer than 8192 lose bandwidth)
+    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 131072;
     uint64_t grid = (uint64_t)gx * n_jobs;
     if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
 #define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)
