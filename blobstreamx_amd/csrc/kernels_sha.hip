@@ -807,25 +807,28 @@ hipError_t bsxk_finalize(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t 
 hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uint32_t n_jobs, const uint8_t* compact, uint64_t* out) {
     if (!n_jobs) return hipSuccess;
     const uint64_t npairs = (lay->n_elements + 2) / 2;
-    // Staging chunk and store flavour.  Alone on the GPU plain stores with 2 KiB chunks are fastest (5.9-6.1 TB/s vs
-    // 5.3-5.4 with non-temporal stores); in the pipelined step the non-temporal 512-byte variant does not slow down
-    // beside the other chunk's hashing (5.30-5.46 TB/s in-region vs 5.19-5.31) and disturbs it less:
-    // 5 alternating runs 90.0-92.5 vs 88.0-89.9 M headers/s.  The product path is the pipelined one.
-    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 512;
+    // Staging chunk and store flavour.  Alone on the GPU plain stores with 2 KiB chunks are fastest (5.9-6.1 TB/s);
+    // in the pipelined step non-temporal stores with SMALL chunks do not slow down beside the other chunk's hashing and
+    // disturb it less.  Non-temporal, grid cap scaled with the item count (~3.4 items per workgroup): 2 KiB 87 M
+    // headers/s, 1 KiB 91, 512 B 93-95, 256 B 98-100 (5.7-5.8 TB/s in-region), 128 B 87-89; plain stores 87.5-90.
+    // The product path is the pipelined one.
+    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 256;
     static const long nt = getenv("BSX_EXPAND_NT") ? atol(getenv("BSX_EXPAND_NT")) : 1;
     const uint32_t ppb = (uint32_t)chunk * 4;
     const uint32_t gx = (uint32_t)((npairs + ppb - 1) / ppb);
     ExpandArgs a{*lay, n_jobs, gx, compact, out};
     // BSX_EXPAND_BLOCKS caps the grid (workgroups stride over the items) so that the HBM-bound expansion leaves wave
     // slots for an ALU-bound kernel running beside it on another stream; 0 / unset = one workgroup per item
-    // (measured with 2 pipelined chunks of 4096 jobs and the default non-temporal 512-byte variant, 450 k items per
-    // launch: 16384 / 32768 / 65536 / 131072 / 262144 / uncapped workgroups give 91.5-93.8 / 93.9-95.3 / 93.1-95.1 / 94.1-95.2 /
-    // 92.6-93.1 / 80 M headers/s; the plain-store 2 KiB variant preferred 16384, and fewer than 8192 lose bandwidth)
-    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 131072;
+    // (measured with 2 pipelined chunks of 4096 jobs: the non-temporal 512-byte variant, 450 k items per launch, gives
+    // 91.5-93.8 / 93.9-95.3 / 93.1-95.1 / 94.1-95.2 / 92.6-93.1 / 80 M headers/s at 16384 / 32768 / 65536 / 131072 / 262144 /
+    // uncapped workgroups; the default 256-byte variant, 901 k items, 94.5-96.9 / 98.1-100 / 94.3 / 82 M at 131072 /
+    // 262144 / 524288 / uncapped; the plain-store 2 KiB variant preferred 16384, and fewer than 8192 lose bandwidth)
+    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 262144;
     uint64_t grid = (uint64_t)gx * n_jobs;
     if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
 #define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)
-    if (chunk == 512) { if (nt) BSX_EX_LAUNCH(512, true); else BSX_EX_LAUNCH(512, false); }
+    if (chunk == 256) { if (nt) BSX_EX_LAUNCH(256, true); else BSX_EX_LAUNCH(256, false); }
+    else if (chunk == 512) { if (nt) BSX_EX_LAUNCH(512, true); else BSX_EX_LAUNCH(512, false); }
     else if (chunk == 2048) { if (nt) BSX_EX_LAUNCH(2048, true); else BSX_EX_LAUNCH(2048, false); }
     else if (chunk == 4096) { if (nt) BSX_EX_LAUNCH(4096, true); else BSX_EX_LAUNCH(4096, false); }
     else { if (nt) BSX_EX_LAUNCH(1024, true); else BSX_EX_LAUNCH(1024, false); }

@@ -178,9 +178,9 @@ class HeaderRangeEngine:
         if k <= 1 or nbytes < (1 << 30):
             return first
         # stop early at a placement that runs at the ceiling of the launch: 5.9 TB/s for plain stores (tools/microbench),
-        # 5.5-5.6 TB/s for the non-temporal variant the library launches by default (csrc/kernels_sha.hip)
+        # 5.7-5.8 TB/s for the non-temporal 256-byte variant the library launches by default (csrc/kernels_sha.hip)
         nt = os.environ.get("BSX_EXPAND_NT", "1") != "0"
-        good_gbps = float(os.environ.get("BSX_PLACEMENT_GOOD_GBPS", "5500" if nt else "5850"))
+        good_gbps = float(os.environ.get("BSX_PLACEMENT_GOOD_GBPS", "5700" if nt else "5850"))
         L, ctx, dp = self.L, self.ctx, _lib.dp
         st = self._st()
         n_jobs = self.RT * self.jc

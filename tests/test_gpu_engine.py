@@ -140,7 +140,7 @@ def test_bench_two_ranks_share_one_gpu():
 
 
 def test_expansion_kernel_variants_agree():
-    """k_expand_witness has eight instantiations (staging chunk 512/1024/2048/4096 x plain / non-temporal stores, chosen
+    """k_expand_witness has ten instantiations (staging chunk 256/512/1024/2048/4096 x plain / non-temporal stores, chosen
     by BSX_EXPAND_CHUNK / BSX_EXPAND_NT when the library is loaded).  Every one of them, and a capped grid, must emit
     the oracle's witness bit for bit; each runs in its own process because the choice is read once."""
     import hashlib
@@ -164,7 +164,7 @@ def test_expansion_kernel_variants_agree():
         "w = synth.Workload(9, %d, %d, %d, v=%d, n_blocks=200)\n"
         "e = HeaderRangeEngine(%d, %d, %d, %d); e.upload_workload(w); e.step()\n"
         "m, _, _ = e.witness_numpy(); print('WITNESS', hashlib.sha256(m.tobytes()).hexdigest())\n" % (root, R, J, B, V, J, B, V, R))
-    variants = [(c, nt, "") for c in (512, 1024, 2048, 4096) for nt in (0, 1)] + [(512, 1, "7"), (2048, 0, "1")]
+    variants = [(c, nt, "") for c in (256, 512, 1024, 2048, 4096) for nt in (0, 1)] + [(256, 1, "7"), (2048, 0, "1")]
     for chunk, nt, cap in variants:
         env = dict(os.environ, BSX_EXPAND_CHUNK=str(chunk), BSX_EXPAND_NT=str(nt))
         if cap:
