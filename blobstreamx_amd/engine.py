@@ -43,22 +43,24 @@ def job_slice(nb_map_jobs, rank, world):
     return rank * count, count
 
 
-def all_gather_records(partial, world, n_ranges_total, out_gathered=None):
+def all_gather_records(partial, world, n_ranges_total, out_gathered=None, async_op=False):
     """THE collective of the multi-GPU path: all-gather one 128-byte MapReduceSubchainVariable record per
     (range, rank) -> uint8 [world][n_ranges_total][128].  partial: this rank's locally folded record of every range.
-    Works on CUDA tensors over RCCL ("nccl") and on CPU tensors over gloo (tests)."""
+    Works on CUDA tensors over RCCL ("nccl") and on CPU tensors over gloo (tests).
+    async_op: return (gathered, work) without waiting; work.wait() orders the caller's stream behind the collective."""
     import torch.distributed as dist
     RT = n_ranges_total
     flat = partial[:RT * 128].contiguous()
     gathered = out_gathered[:world * RT * 128] if out_gathered is not None else torch.empty(world * RT * 128, dtype=torch.uint8, device=flat.device)
+    work = None
     if flat.is_cuda and dist.get_backend() == "gloo":
         # test-only route (two ranks sharing one GPU, tests/test_gpu_engine.py): gloo moves host memory
         g_cpu = torch.empty(world * RT * 128, dtype=torch.uint8)
         dist.all_gather_into_tensor(g_cpu, flat.cpu())
         gathered.copy_(g_cpu)
     else:
-        dist.all_gather_into_tensor(gathered, flat)
-    return gathered
+        work = dist.all_gather_into_tensor(gathered, flat, async_op=async_op)
+    return (gathered, work) if async_op else gathered
 
 
 def gather_partials(partial, rank, world, n_ranges_local, out_gathered=None, out_top=None):
@@ -339,12 +341,33 @@ class HeaderRangeEngine:
             return self.partial
         if gathered is None:
             gathered = all_gather_records(self.partial, self.world, self.RT, self.gathered)
+        return self._top_fold(gathered)
+
+    def _top_fold(self, gathered):
         # top fold straight from the all-gather layout [rank][range]: record k of owned range r = gathered[k][rank*R + r]
         own = gathered.view(-1)[self.rank * self.R * 128:]
         L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
         chk(L.bsx_dev_reduce_strided(ctx, st, C.c_uint32(self.R), C.c_uint32(self.world), dp(own), C.c_uint64(1),
                                      C.c_uint64(self.RT), dp(self.results), dp(self.red_compact_top)))
         return self.results
+
+    def step_exchange_begin(self):
+        """Start the collective without waiting for it (N > 1): the map-job expansion needs nothing from it, so
+        PipelinedEngines enqueues that expansion next and finishes the exchange (top fold, finalize) behind it —
+        the all-gather's latency, inflated while every GPU's HBM is saturated, then hides beside this chunk's own
+        expansion instead of delaying it."""
+        self._gather_pending = None
+        if self.world > 1:
+            self._gather_pending = all_gather_records(self.partial, self.world, self.RT, self.gathered, async_op=True)
+
+    def step_exchange_end(self):
+        if self.world == 1:
+            return self.partial
+        gathered, work = self._gather_pending
+        if work is not None:
+            work.wait()                 # stream-level wait on the collective (the host does not block for NCCL)
+        self._gather_pending = None
+        return self._top_fold(gathered)
 
     def launch_verify(self, after_event=None):
         """Signature checks, tallies and skip conditions of the current pass on the side stream ("expand" placement).
@@ -359,16 +382,24 @@ class HeaderRangeEngine:
         with torch.cuda.stream(self.side):
             self._commit(self._st(), "verify")
 
-    def step_final(self, result_records, time_kernels=False, before_expand=None, launch_verify=True):
+    def step_final(self, result_records, time_kernels=False, before_expand=None, launch_verify=True, after_expand=None):
         """finalize + (commit verification on the side stream) + witness expansion.  before_expand: hook called right
         before the expansion is enqueued (PipelinedEngines waits for the other chunk's expansion there, so that the tiny
-        finalize kernel and the side-stream launch do not sit between two expansions)."""
+        finalize kernel and the side-stream launch do not sit between two expansions); after_expand: hook called right
+        behind the map-job expansion (PipelinedEngines releases the other chunk's expansion there).
+        result_records None = the exchange was only begun (step_exchange_begin): top fold, finalize and the top
+        reduce nodes' expansion then run behind the map-job expansion."""
         L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
         ev = self.events if time_kernels else None
         own_ranges = self.skip_ranges if self.with_commit else self.ranges[self.rank * self.R * 80:]
-        chk(L.bsx_dev_finalize(ctx, st, C.c_uint32(self.R), C.c_uint32(self.J), C.c_uint32(self.B), dp(own_ranges),
-                               dp(result_records), dp(self.target_hashes) if self.with_commit else None, dp(self.output64),
-                               dp(self.range_status)))
+
+        def finalize(records):
+            chk(L.bsx_dev_finalize(ctx, st, C.c_uint32(self.R), C.c_uint32(self.J), C.c_uint32(self.B), dp(own_ranges),
+                                   dp(records), dp(self.target_hashes) if self.with_commit else None, dp(self.output64),
+                                   dp(self.range_status)))
+        late = result_records is None          # exchange still in flight (step_exchange_begin): finish it behind the expansion
+        if not late:
+            finalize(result_records)
         if launch_verify:
             # integer-ALU work: start it beside the HBM-bound expansion (i.e. once finalize is done), not beside the hashing
             fin = torch.cuda.Event()
@@ -386,6 +417,11 @@ class HeaderRangeEngine:
             if self.jc > 1:
                 chk(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._rl), C.c_uint32(self.RT * (self.jc - 1)),
                                              dp(self.red_compact_local), dp(self.witness_red_local)))
+        if after_expand is not None:
+            after_expand()
+        if late:
+            finalize(self.step_exchange_end())
+        if self.with_witness:
             if self.world > 1:
                 chk(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._rl), C.c_uint32(self.R * (self.world - 1)),
                                              dp(self.red_compact_top), dp(self.witness_red_top)))
@@ -467,19 +503,24 @@ class PipelinedEngines:
                     # k_header_merkle (both are integer-ALU bound; the rest of this chunk's hashing phase leans on memory)
                     self._pending_verify.launch_verify(after_event=eng.merkle_done)
                     self._pending_verify = None
-                res = eng.step_exchange()
+                if self.world > 1:
+                    eng.step_exchange_begin()      # collective in flight; finished behind this chunk's expansion
+                    res = None
+                else:
+                    res = eng.step_exchange()
                 if self.E > 1:
                     self._hash_token = torch.cuda.Event()
                     self._hash_token.record(s)
                 tok = self._expand_token if self.E > 1 else None
                 defer = self.verify_after_merkle and self.E > 1
+                def release(s=s):
+                    if self.E > 1:
+                        self._expand_token = torch.cuda.Event()
+                        self._expand_token.record(s)
                 eng.step_final(res, time_kernels, before_expand=(lambda s=s, tok=tok: s.wait_event(tok)) if tok is not None else None,
-                               launch_verify=not defer)
+                               launch_verify=not defer, after_expand=release)
                 if defer:
                     self._pending_verify = eng
-                if self.E > 1:
-                    self._expand_token = torch.cuda.Event()
-                    self._expand_token.record(s)
                 # the commit check is NOT joined here: its inputs are double-buffered by pass parity (HeaderRangeEngine), so
                 # it may run on into the chunk's next pass; join() / download() wait for it
 

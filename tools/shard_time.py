@@ -8,11 +8,11 @@ import torch, synth
 import blobstreamx_amd.engine as E
 J, B, V, R = 32, 64, 100, int(os.environ.get("R", "256"))
 for world in [int(x) for x in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
-    def fake_gather(partial, w_, rt, out):
+    def fake_gather(partial, w_, rt, out, async_op=False):
         flat = partial[:rt * 128]
         g = out[:w_ * rt * 128].view(w_, rt * 128)
         g.copy_(flat.unsqueeze(0).expand(w_, rt * 128))      # every "rank" contributes this rank's records: shapes and traffic as in the real gather
-        return out[:w_ * rt * 128]
+        return (out[:w_ * rt * 128], None) if async_op else out[:w_ * rt * 128]
     E.all_gather_records = fake_gather
     w = synth.Workload(4, R * world, J, B, v=V)
     eng = E.PipelinedEngines(J, B, V, R, n_engines=2, rank=0, world=world)
