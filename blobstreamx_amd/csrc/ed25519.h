@@ -162,14 +162,17 @@ BSX_HDI bool ed25519_verify_core(const uint32_t pk[8], const uint32_t sig_r[8], 
 
 // ------------------------------------------------------------------------------------------------ fixed-key path
 // A validator set signs every commit of a range batch with the same keys, so the per-key work (decompression and
-// the multiples table) is hoisted out of the per-signature lane: per key we keep j*(-A) and j*(-2^128 A), j = 1..128
-// (cached form, 40 int32 each), and the 253-bit scalars h and s are split at bit 128 and recoded into signed
-// radix-256 digits.  One signature then costs 128 doublings + 64 additions instead of 256 + 128 and no decompression.
-#include "ed25519_btab8.h"   // ge_b8_limb: j*B and j*2^128*B, j = 1..128 (generated)
+// the multiples table) is hoisted out of the per-signature lane: per key we keep j*(-2^(64k) A), k = 0..3, j = 1..128
+// (cached form, 40 int32 each), and the 253-bit scalars h and s are split into four 64-bit parts and recoded into
+// signed radix-256 digits.  One signature then costs 64 doublings + 64 additions instead of 256 + 128 and no
+// decompression (two parts of 128 bits, the first version: 128 + 64).
+#include "ed25519_btab8.h"   // ge_b8_limb: j * 2^(64k) * B, k = 0..3, j = 1..128 (generated)
 
 constexpr int KT_ENTRY_I32 = 40;          // one cached point
-constexpr int KT_HALF_ENTRIES = 128;      // j = 1..128
-constexpr int KT_KEY_I32 = 2 * KT_HALF_ENTRIES * KT_ENTRY_I32;
+constexpr int KT_HALF_ENTRIES = 128;      // j = 1..128 per part
+constexpr int KT_PARTS = 4;               // scalar parts of 64 bits = 8 radix-256 digits each
+constexpr int KT_PART_DIGITS = 32 / KT_PARTS;
+constexpr int KT_KEY_I32 = KT_PARTS * KT_HALF_ENTRIES * KT_ENTRY_I32;
 
 // r = x + 0x8080...80 (x < 2^253, so no carry out); digit_i = byte_i(r) - 128 in [-128, 127]
 BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
@@ -183,16 +186,18 @@ BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
 }
 BSX_HDI int sc_digit8(const uint32_t r[8], int i) { return (int)((pick8(r, i >> 2) >> (8 * (i & 3))) & 255) - 128; }
 
-// per key: base[0] = -A, base[1] = 2^128 * (-A); false when the key does not decode (RFC 8032 strict)
-BSX_HDI bool ge_keytable_bases(const uint32_t pk[8], ge_p3& negA, ge_p3& hi) {
-    const bool ok = ge_frombytes_negate(negA, pk);
-    ge_p2 q{negA.X, negA.Y, negA.Z};
-    ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
-    for (int i = 1; i < 128; i++) {
-        q = p1p1_to_p2(t);
-        t = ge_dbl(q.X, q.Y, q.Z);
+// per key: base[0] = -A, base[k] = 2^64 * base[k-1]; false when the key does not decode (RFC 8032 strict)
+BSX_HDI bool ge_keytable_bases(const uint32_t pk[8], ge_p3 (&base)[KT_PARTS]) {
+    const bool ok = ge_frombytes_negate(base[0], pk);
+    for (int k = 1; k < KT_PARTS; k++) {
+        ge_p2 q{base[k - 1].X, base[k - 1].Y, base[k - 1].Z};
+        ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
+        for (int i = 1; i < 8 * KT_PART_DIGITS; i++) {
+            q = p1p1_to_p2(t);
+            t = ge_dbl(q.X, q.Y, q.Z);
+        }
+        base[k] = p1p1_to_p3(t);
     }
-    hi = p1p1_to_p3(t);
     return ok;
 }
 // j * base, j in 1..128, by an 8-step double-and-add that is uniform across lanes (the addition is selected, not branched)
@@ -231,7 +236,7 @@ BSX_HDI ge_cached cached_load(const int32_t* src_) {
     }
     return c;
 }
-BSX_HDI ge_precomp ge_b8_entry(int half, int k) {  // (k+1) * 2^(128*half) * B
+BSX_HDI ge_precomp ge_b8_entry(int half, int k) {  // (k+1) * 2^(64*part) * B
     ge_precomp e;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
@@ -257,28 +262,29 @@ BSX_HDI ge_precomp b8_pick(int half, int d) {
 }
 
 // Same accept set as ed25519_verify_core for a key whose table was built by ge_keytable_bases/entry
-// (key_tab: KT_KEY_I32 int32: [half][j-1][40]); the caller has already established that the key decodes.
+// (key_tab: KT_KEY_I32 int32: [part][j-1][40]); the caller has already established that the key decodes.
 BSX_HDI bool ed25519_verify_keyed_core(const int32_t* key_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
                                        const uint32_t h[8]) {
     const bool ok = sc_is_canonical(sig_s);
     uint32_t hr[8], sr[8];
     sc_recode8(h, hr);
     sc_recode8(sig_s, sr);
-    const int32_t* lo = key_tab;
-    const int32_t* hi = key_tab + KT_HALF_ENTRIES * KT_ENTRY_I32;
-
     ge_p2 q{fe_zero(), fe_one(), fe_one()};
-    for (int i = 15; i >= 0; i--) {
+    for (int i = KT_PART_DIGITS - 1; i >= 0; i--) {
         ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
         for (int d = 0; d < 7; d++) {
             q = p1p1_to_p2(t);
             t = ge_dbl(q.X, q.Y, q.Z);
         }
         ge_p3 p = p1p1_to_p3(t);
-        p = p1p1_to_p3(ge_add(p, keytable_pick(lo, sc_digit8(hr, i))));
-        p = p1p1_to_p3(ge_add(p, keytable_pick(hi, sc_digit8(hr, 16 + i))));
-        p = p1p1_to_p3(ge_madd(p, b8_pick(0, sc_digit8(sr, i))));
-        q = p1p1_to_p2(ge_madd(p, b8_pick(1, sc_digit8(sr, 16 + i))));
+        // not unrolled on the device: four table entries (160 registers) prefetched at once would spill
+#pragma unroll 1
+        for (int k = 0; k < KT_PARTS; k++)
+            p = p1p1_to_p3(ge_add(p, keytable_pick(key_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(hr, KT_PART_DIGITS * k + i))));
+#pragma unroll 1
+        for (int k = 0; k < KT_PARTS - 1; k++)
+            p = p1p1_to_p3(ge_madd(p, b8_pick(k, sc_digit8(sr, KT_PART_DIGITS * k + i))));
+        q = p1p1_to_p2(ge_madd(p, b8_pick(KT_PARTS - 1, sc_digit8(sr, KT_PART_DIGITS * (KT_PARTS - 1) + i))));
     }
     uint32_t enc[8];
     ge_tobytes(enc, q.X, q.Y, q.Z);

@@ -6,8 +6,8 @@
 //   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, records staged via LDS
 //   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
 //   k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed
-//                       P7, fixed-key form: per-validator tables of j*(-A), j*(-2^128 A) (j = 1..128) built once per
-//                           pass, signatures checked with 8-bit windows over split scalars; slots whose key is not the
+//                       P7, fixed-key form: per-validator tables of j*(-2^(64k) A) (k = 0..3, j = 1..128) built once per
+//                           pass, signatures checked with 8-bit windows over scalars split in four; slots whose key is not the
 //                           table row's key are deferred to k_ed25519_verify<true> (same accept set)
 //   k_skip_eval         operator skip-target search (fetcher.rs:60-87): is_valid_skip of every candidate in one launch
 //   k_commit_tally     P8+P9 validator-set hash (masked Merkle tree), voting-power sums, message checks;
@@ -93,9 +93,9 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validat
 
 // ------------------------------------------------------------------------------------------------ fixed-key tables
 // Key table in HBM (bsx_ed25519_keytable_bytes): [n_keys x 64 B key records: pubkey, decodes flag]
-//                                                [n_keys x 2 x 40 i32 base points -A, -2^128 A (X, Y, Z, T)]
-//                                                [n_keys x 2 x 128 x 40 i32 cached multiples]
-constexpr uint64_t KT_REC_BYTES = 64, KT_BASE_I32 = 80;
+//                                                [n_keys x KT_PARTS x 40 i32 base points -2^(64k) A (X, Y, Z, T)]
+//                                                [n_keys x KT_PARTS x 128 x 40 i32 cached multiples]
+constexpr uint64_t KT_REC_BYTES = 64, KT_BASE_I32 = 40 * KT_PARTS;
 __host__ __device__ inline uint64_t kt_bases_off(uint64_t n_keys) { return n_keys * KT_REC_BYTES; }
 __host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys) { return n_keys * (KT_REC_BYTES + KT_BASE_I32 * 4); }
 __host__ __device__ inline uint64_t kt_bytes(uint64_t n_keys) { return kt_entries_off(n_keys) + n_keys * (uint64_t)KT_KEY_I32 * 4; }
@@ -106,15 +106,15 @@ __device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) 
     pk[0] = p0.x; pk[1] = p0.y; pk[2] = p0.z; pk[3] = p0.w; pk[4] = p1.x; pk[5] = p1.y; pk[6] = p1.z; pk[7] = p1.w;
 }
 
-// one lane per key: decode, negate, and run the 128 doublings that give the high-half base point
+// one lane per key: decode, negate, and run the 3 x 64 doublings that give the base points of the upper scalar parts
 __global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validator* __restrict__ vals, uint32_t n_keys,
                                                                uint8_t* __restrict__ table) {
     const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
     if (k >= n_keys) return;
     uint32_t pk[8];
     load_pk(vals + k, pk);
-    ge_p3 b[2];
-    const bool ok = ge_keytable_bases(pk, b[0], b[1]);
+    ge_p3 b[KT_PARTS];
+    const bool ok = ge_keytable_bases(pk, b);
     uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
     rec[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     rec[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validat
     rec[3] = make_uint4(0u, 0u, 0u, 0u);
     int32_t* dst = reinterpret_cast<int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)k * KT_BASE_I32;
 #pragma unroll
-    for (int half = 0; half < 2; half++)
+    for (int half = 0; half < KT_PARTS; half++)
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             dst[half * 40 + i] = b[half].X.v[i];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validat
 // one lane per (key, half, j): j * base in cached form
 __global__ __launch_bounds__(ED_THREADS) void k_keytable_entries(uint32_t n_keys, uint8_t* __restrict__ table) {
     const uint32_t idx = blockIdx.x * ED_THREADS + threadIdx.x;
-    if (idx >= n_keys * 2u * KT_HALF_ENTRIES) return;
+    if (idx >= n_keys * (uint32_t)KT_PARTS * KT_HALF_ENTRIES) return;
     const uint32_t kh = idx / KT_HALF_ENTRIES, j = idx % KT_HALF_ENTRIES + 1;
     const int32_t* src = reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)kh * 40;
     ge_p3 base;
@@ -528,7 +528,7 @@ uint64_t bsxk_keytable_bytes(uint32_t n_keys) { return kt_bytes(n_keys); }
 hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint32_t n_keys, uint8_t* table) {
     if (n_keys == 0) return hipSuccess;
     hipLaunchKernelGGL(k_keytable_bases, dim3((n_keys + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, vals, n_keys, table);
-    const uint32_t n_entries = n_keys * 2u * KT_HALF_ENTRIES;
+    const uint32_t n_entries = n_keys * (uint32_t)KT_PARTS * KT_HALF_ENTRIES;
     hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, n_keys, table);
     return hipGetLastError();
 }

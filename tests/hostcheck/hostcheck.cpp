@@ -91,10 +91,10 @@ void hc_fe_invert(const uint8_t* a, uint8_t out[32]) {
 int hc_ed25519_verify_keyed(const uint8_t* pk, const uint8_t* sig, const uint8_t* h) {
     uint32_t p[8], r[8], s[8], hh[8];
     load_le(p, pk, 32, 8); load_le(r, sig, 32, 8); load_le(s, sig + 32, 32, 8); load_le(hh, h, 32, 8);
-    ge_p3 base[2];
-    if (!ge_keytable_bases(p, base[0], base[1])) return 0;
+    ge_p3 base[KT_PARTS];
+    if (!ge_keytable_bases(p, base)) return 0;
     static thread_local int32_t tab[KT_KEY_I32];
-    for (int half = 0; half < 2; half++)
+    for (int half = 0; half < KT_PARTS; half++)
         for (int j = 1; j <= KT_HALF_ENTRIES; j++)
             cached_store(tab + (half * KT_HALF_ENTRIES + (j - 1)) * KT_ENTRY_I32, ge_keytable_entry(base[half], j));
     return ed25519_verify_keyed_core(tab, r, s, hh) ? 1 : 0;
