@@ -261,10 +261,10 @@ def main():
                 iso[1].record()
                 torch.cuda.synchronize(dev)
                 t_iso += iso[0].elapsed_time(iso[1]) / 5
-            # HBM bytes per map job from the PMC passes in profiles/r1_pmc_hbm_traffic.csv (WRITE_SIZE 14,924,132 KB +
-            # FETCH_SIZE 200,231 KB for a launch of 4096 jobs = one pipelined chunk; rocprofv3 units are KB; FETCH_SIZE not
+            # HBM bytes per map job from the PMC passes in profiles/r1_pmc_hbm_traffic.csv (WRITE_SIZE 14,925,404 KB +
+            # FETCH_SIZE 200,228 KB for a launch of 4096 jobs = one pipelined chunk; rocprofv3 units are KB; FETCH_SIZE not
             # doubled: the kernel reads its source with dword loads)
-            pmc_bytes_per_job = (14924132 + 200231) * 1024 / 4096
+            pmc_bytes_per_job = (14925404 + 200228) * 1024 / 4096
             out["roofline"] = {"kernel": "k_expand_witness (map-job section)", "bound": "hbm", "achieved": exp_bytes / t_exp / 1e6,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exp_bytes / t_exp / 1e6 / HBM_PEAK_GBS,
                                "traffic": pmc_bytes_per_job * n_jobs,
