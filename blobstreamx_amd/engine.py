@@ -68,10 +68,9 @@ def gather_partials(partial, rank, world, n_ranges_local, out_gathered=None, out
     device path folds the gathered layout in place with bsx_dev_reduce_strided)."""
     RT = world * n_ranges_local
     gathered = all_gather_records(partial, world, RT, out_gathered)
-    flat = gathered
     g = gathered.view(world, RT, 128)
     own = g[:, rank * n_ranges_local:(rank + 1) * n_ranges_local, :]            # [rank, owned range, 128]
-    top = out_top[:n_ranges_local * world * 128] if out_top is not None else torch.empty(n_ranges_local * world * 128, dtype=torch.uint8, device=flat.device)
+    top = out_top[:n_ranges_local * world * 128] if out_top is not None else torch.empty(n_ranges_local * world * 128, dtype=torch.uint8, device=gathered.device)
     top.view(n_ranges_local, world, 128).copy_(own.transpose(0, 1))
     return top
 
@@ -116,7 +115,6 @@ class HeaderRangeEngine:
         n_local_nodes = RT * max(jc - 1, 0)
         self.red_compact_local = _u8(n_local_nodes * int(self.rl["compact_stride"]), d)
         self.gathered = _u8(world * RT * 128, d)     # all-gather output [rank][range]
-        self.top_in = _u8(R * world * 128, d)        # owned ranges, [range][rank]
         self.red_compact_top = _u8(R * max(world - 1, 0) * int(self.rl["compact_stride"]), d)
         self.results = _u8(R * 128, d)
         self.output64 = _u8(R * 64, d)
