@@ -166,6 +166,30 @@ def verify_commits(validators, header_hashes, device=0):
     return res, ok
 
 
+class CombinedStepCircuit:
+    """CombinedStepCircuit<MAX_VALIDATOR_SET_SIZE, CHAIN_ID_SIZE, C> (circuits/next_header.rs:11-46; instantiated with 100
+    validators by bin/next_header{,_mocha}.rs:5-8)."""
+
+    def __init__(self, max_validator_set_size, device=0):
+        self.V, self.device = max_validator_set_size, device
+
+    def prove(self, input40, prev_header, next_header, latest_block, next_validators):
+        """40-byte EVM-packed input (prev_block_number ‖ prev_header_hash) -> (64-byte output, commit result)."""
+        if len(input40) != 40:
+            raise ValueError("input must be 40 bytes: uint64 prev_block_number ‖ bytes32 prev_header_hash")
+        ph = np.ascontiguousarray(prev_header, T.HEADER).reshape(1)
+        nh = np.ascontiguousarray(next_header, T.HEADER).reshape(1)
+        nv = np.ascontiguousarray(next_validators, T.VALIDATOR).reshape(-1)
+        if nv.size != self.V:
+            raise ValueError(f"validator array must have MAX_VALIDATOR_SET_SIZE = {self.V} slots")
+        inp = np.frombuffer(bytes(input40), np.uint8).copy()
+        out = np.zeros(64, np.uint8)
+        res = np.zeros(1, T.COMMIT_RESULT)
+        _lib.check(_lib.lib().bsx_next_header(_lib.context(self.device), _lib.p(inp), _lib.p(ph), _lib.p(nh), C.c_uint64(latest_block),
+                                              _lib.p(nv), C.c_uint32(self.V), _lib.p(out), _lib.p(res)))
+        return out.tobytes(), res[0]
+
+
 def find_block_to_request(start_block, max_end_block, start_validators, candidate_heights, candidate_validators, device=0):
     """The operator's skip-target search (circuits/fetcher.rs:60-87 `find_block_to_request`, called at
     bin/blobstreamx.rs:221-225) over pre-fetched candidates: returns (block, evals).  candidate_heights must contain

@@ -65,7 +65,7 @@ def main(argv=None):
         return 0
     if not a.input or not a.fixtures:
         ap.error("prove needs input.json and --fixtures")
-    from .builder import CombinedSkipCircuit, DataCommitmentBuilder, InputDataFetcher, verify_commits
+    from .builder import CombinedStepCircuit, CombinedSkipCircuit, DataCommitmentBuilder, InputDataFetcher, verify_commits
     inp = _read_input(a.input)
     fx = ingest.FixtureFetcher(a.fixtures, v_max=V)
     if a.circuit.startswith("header_range"):
@@ -85,17 +85,10 @@ def main(argv=None):
         prev = int.from_bytes(inp[:8], "big")
         blocks = {h: fx.signed_block(h) for h in (prev, prev + 1)}
         headers = np.array([blocks[prev]["header"], blocks[prev + 1]["header"]], dtype=T.HEADER)
-        fetcher = InputDataFetcher(headers, prev, a.latest or prev + 3)
-        hashes = fetcher.header_hashes()
-        # builder.step (circuits/next_header.rs:32-36) [UPSTREAM]: commit of prev+1 verified against its validator set,
-        # last_block_id linkage to prev_header_hash
-        res, _ = verify_commits(blocks[prev + 1]["validators"].reshape(1, -1), hashes[1:2])
-        if res[0]["n_bad_signature"] or res[0]["n_bad_message"] or not res[0]["two_thirds_ok"]:
-            raise SystemExit("step: commit of the next header does not verify")
-        if bytes(blocks[prev + 1]["header"]["last_block_id"][2:34]) != inp[8:40] or hashes[0].tobytes() != inp[8:40]:
-            raise SystemExit("step: next header does not link to prev_header_hash")
-        dc = DataCommitmentBuilder().prove_next_header_data_commitment(fetcher, prev, inp[8:40], prev + 1)   # :38-42
-        out, wit = hashes[1].tobytes() + dc, None
+        # CombinedStepCircuit::define (circuits/next_header.rs:25-46) behind the C ABI (bsx_next_header)
+        out, _ = CombinedStepCircuit(blocks[prev + 1]["validators"].size).prove(inp, headers[0], headers[1], a.latest or prev + 3,
+                                                                               blocks[prev + 1]["validators"])
+        wit = None
     json.dump({"type": "res_bytes", "data": {"output": "0x" + out.hex()}}, open(a.output, "w"))
     if a.witness and wit is not None:
         wit.astype("<u8").tofile(a.witness)

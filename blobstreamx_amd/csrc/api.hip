@@ -775,4 +775,54 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     return rc;
 }
 
+// CombinedStepCircuit::define (circuits/next_header.rs:25-46): built from the host tier above — every hash, signature
+// check and tally runs in the kernels those calls launch; the host only compares 32-byte values and decodes statuses.
+int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
+                    bsx_commit_result* out_commit) {
+    DEV_ENTER();
+    if (!input40 || !prev_header || !next_header || !next_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    uint64_t prev_block = 0;                                                    // next_header.rs:26 evm_read u64 (big endian)
+    for (int i = 0; i < 8; i++) prev_block = prev_block << 8 | input40[i];
+    const uint8_t* prev_hash = input40 + 8;                                     // :27
+    const uint64_t next_block = prev_block + 1;                                 // :29-30
+    bsx_header two[2] = {*prev_header, *next_header};
+    uint8_t hashes[64];
+    RET(bsx_header_hashes(ctx, two, 2, hashes, nullptr, nullptr));
+    // builder.step (:32-36) [UPSTREAM tendermintx v1.0.0]
+    bsx_commit_result cr;
+    std::vector<uint8_t> sig_ok(v_max);
+    RET(bsx_verify_commits(ctx, next_validators, 1, v_max, hashes + 32, &cr, sig_ok.data()));
+    if (out_commit) *out_commit = cr;
+    int st = BSX_OK;
+    const char* why = "";
+    if (memcmp(hashes, prev_hash, 32) != 0) { st = BSX_ERR_ASSERT; why = "prev header does not hash to prev_header_hash"; }
+    uint8_t hf[12];                                                             // height leaf of the next header: 08 varint(prev + 1)
+    int hn = 0;
+    hf[hn++] = 0x08;
+    for (uint64_t hv = next_block;; hv >>= 7) { if (hv >= 0x80) hf[hn++] = (uint8_t)(hv | 0x80); else { hf[hn++] = (uint8_t)hv; break; } }
+    if (!st && (next_header->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(next_header->height, hf, (size_t)hn) != 0)) {
+        st = BSX_ERR_ASSERT; why = "next header's height is not prev_block_number + 1";
+    }
+    if (!st && (cr.n_bad_signature || cr.n_bad_message)) { st = BSX_ERR_BAD_SIGNATURE; why = "a signed validator's signature or message is bad"; }
+    if (!st && (next_header->len[7] != 34 || memcmp(next_header->hash[2] + 2, cr.validators_hash, 32) != 0)) {
+        st = BSX_ERR_ASSERT; why = "validator set does not hash to the next header's validators_hash";
+    }
+    if (!st && (prev_header->len[8] != 34 || memcmp(prev_header->hash[3] + 2, cr.validators_hash, 32) != 0)) {
+        st = BSX_ERR_ASSERT; why = "validator set does not hash to the prev header's next_validators_hash";
+    }
+    if (!st && (next_header->len[BSX_LAST_BLOCK_ID_INDEX] < 34 || memcmp(next_header->last_block_id + 2, hashes, 32) != 0)) {
+        st = BSX_ERR_ASSERT; why = "next header's last_block_id does not point at the prev header";
+    }
+    if (!st && !cr.two_thirds_ok) { st = BSX_ERR_VOTING_POWER; why = "less than 2/3 of the voting power signed"; }
+    // prove_next_header_data_commitment (:38-42) and the public output (:44-45)
+    uint8_t dc[32];
+    const int rc = bsx_prove_next_header_data_commitment(ctx, prev_block, prev_hash, next_block, prev_header, latest_block, dc);
+    if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
+    memcpy(output64, hashes + 32, 32);
+    memcpy(output64 + 32, dc, 32);
+    if (st) return fail(st, "step verification failed: %s", why);
+    return rc;
+}
+
 }  // extern "C"

@@ -369,6 +369,17 @@ int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_
                              void* d_table);
 int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
                                  uint64_t n, uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok);
+/* CombinedStepCircuit::define — circuits/next_header.rs:25-46 (bin/next_header{,_mocha}.rs).  input40 =
+ * prev_block_number (u64 big endian) ‖ prev_header_hash; output64 = next_header_hash ‖ data_commitment.
+ * builder.step (:32-36) is [UPSTREAM] tendermintx v1.0.0; checked here: prev_header hashes to
+ * prev_header_hash; next_header's height is prev + 1 and its last_block_id points at prev_header; the supplied
+ * validator set hashes to next_header.validators_hash and to prev_header.next_validators_hash; every signed
+ * validator's Ed25519 signature verifies over a message carrying the next header hash; signed power > 2/3.
+ * The data commitment is prove_next_header_data_commitment (builder.rs:411-443).  Failure codes as bsx_header_range. */
+int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
+                    bsx_commit_result* out_commit);
+
 /* ------------------------------------------------------------------ operator skip-target search
  * circuits/fetcher.rs:60-87 find_block_to_request: starting at max_end_block, return the first candidate c with
  * is_valid_skip(start set, c's set, c's commit); otherwise halve the distance to start_block; c - start_block == 1 is

@@ -251,6 +251,18 @@ def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest
     return rc, out.tobytes(), res[0], compact
 
 
+def next_header(input40, prev_header, next_header_, latest_block, next_validators):
+    """CombinedStepCircuit::define (circuits/next_header.rs:25-46) -> (rc, output64, commit_result)."""
+    ph = np.ascontiguousarray(prev_header, T.HEADER).reshape(1)
+    nh = np.ascontiguousarray(next_header_, T.HEADER).reshape(1)
+    nv = np.ascontiguousarray(next_validators, T.VALIDATOR).reshape(-1)
+    out = np.zeros(64, np.uint8)
+    res = np.zeros(1, T.COMMIT_RESULT)
+    rc = lib().orc_next_header(_p(_b(input40, 40)), _p(ph), _p(nh), C.c_uint64(latest_block), _p(nv), C.c_uint32(nv.size), _p(out),
+                               _p(res))
+    return rc, out.tobytes(), res[0]
+
+
 SKIP_EVAL = np.dtype([("overlap_power", "<u8"), ("start_total_power", "<u8"), ("signed_power", "<u8"),
                       ("target_total_power", "<u8"), ("valid", "<u4"), ("_pad", "<u4")])
 

@@ -315,3 +315,42 @@ int orc_find_block_to_request(uint64_t start_block, uint64_t max_end_block, cons
         curr_end_block = (curr_end_block + start_block) / 2;                   /* :84-85 */
     }
 }
+
+
+/* ---------------------------------------------------------------- next_header (circuits/next_header.rs:25-46) */
+int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
+                    bsx_commit_result* out_commit) {
+    uint64_t prev_block = 0;                                       /* :26 */
+    for (int i = 0; i < 8; i++) prev_block = prev_block << 8 | input40[i];
+    const uint8_t* prev_hash = input40 + 8;                        /* :27 */
+    const uint64_t next_block = prev_block + 1;                    /* :29-30 */
+    uint8_t hp[32], hn_[32];
+    if (orc_header_check(prev_header) || orc_header_check(next_header)) return BSX_ERR_BAD_HEADER;
+    orc_header_hash(prev_header, hp, NULL, NULL);
+    orc_header_hash(next_header, hn_, NULL, NULL);
+    /* builder.step :32-36 [UPSTREAM] */
+    bsx_commit_result cr;
+    uint8_t* ok = (uint8_t*)malloc(v_max ? v_max : 1);
+    orc_verify_commit(next_validators, v_max, hn_, &cr, ok);
+    free(ok);
+    if (out_commit) *out_commit = cr;
+    int st = BSX_OK;
+    if (memcmp(hp, prev_hash, 32) != 0) st = BSX_ERR_ASSERT;
+    uint8_t hf[12];
+    int hl = 0;
+    hf[hl++] = 0x08;
+    for (uint64_t hv = next_block;; hv >>= 7) { if (hv >= 0x80) hf[hl++] = (uint8_t)(hv | 0x80); else { hf[hl++] = (uint8_t)hv; break; } }
+    if (!st && (next_header->len[BSX_BLOCK_HEIGHT_INDEX] != hl || memcmp(next_header->height, hf, (size_t)hl) != 0)) st = BSX_ERR_ASSERT;
+    if (!st && (cr.n_bad_signature || cr.n_bad_message)) st = BSX_ERR_BAD_SIGNATURE;
+    if (!st && (next_header->len[7] != 34 || memcmp(next_header->hash[2] + 2, cr.validators_hash, 32) != 0)) st = BSX_ERR_ASSERT;
+    if (!st && (prev_header->len[8] != 34 || memcmp(prev_header->hash[3] + 2, cr.validators_hash, 32) != 0)) st = BSX_ERR_ASSERT;
+    if (!st && (next_header->len[BSX_LAST_BLOCK_ID_INDEX] < 34 || memcmp(next_header->last_block_id + 2, hp, 32) != 0)) st = BSX_ERR_ASSERT;
+    if (!st && !cr.two_thirds_ok) st = BSX_ERR_VOTING_POWER;
+    uint8_t dc[32];
+    const int rc = orc_prove_next_header_data_commitment(prev_block, prev_hash, next_block, prev_header, latest_block, dc);   /* :38-42 */
+    if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
+    memcpy(output64, hn_, 32);                                     /* :44 */
+    memcpy(output64 + 32, dc, 32);                                 /* :45 */
+    return st ? st : rc;
+}

@@ -93,6 +93,12 @@ int orc_header_range(uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t in
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact);
 
+/* CombinedStepCircuit::define (circuits/next_header.rs:25-46); builder.step is [UPSTREAM] (checks restated from
+ * SURVEY App. B, same list as include/bsx.h bsx_next_header) */
+int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
+                    bsx_commit_result* out_commit);
+
 /* ---- operator skip-target search (circuits/fetcher.rs:60-87 find_block_to_request).  The loop is
  * the reference's; the predicate is_valid_skip is [UPSTREAM] tendermintx v1.0.0 (not under /root/reference): restated
  * as the > 1/3 trusted-power overlap rule the circuit enforces -> PARITY UNPINNED for the predicate. */

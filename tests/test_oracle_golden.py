@@ -134,3 +134,28 @@ def test_witness_expansion_matches_layout(mocha):
     # words: ctx.start_block limbs lo, hi
     words = w[8 * int(ml["n_bytes"]):8 * int(ml["n_bytes"]) + int(ml["n_words"])]
     assert words[0] == 10000 and words[1] == 0 and words[2] == 10004
+
+
+def test_next_header_reproduces_the_fixture_chain(golden, mocha):
+    """CombinedStepCircuit::define (circuits/next_header.rs:25-46) over the mocha-4 fixture blocks: every step
+    10000 -> 10001 ... 10003 -> 10004 verifies (two real signatures per commit) and yields next header hash ‖ the
+    reference's own data commitment for [h, h+1) where the fixtures hold one (tests/golden/mocha4.json)."""
+    for k in range(4):
+        h = 10000 + k
+        inp = h.to_bytes(8, "big") + mocha["hashes"][k]
+        rc, out, cr = oracle.next_header(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1])
+        assert rc == 0, (h, rc)
+        assert out[:32] == mocha["hashes"][k + 1]
+        want = golden["data_commitments"].get(f"{h}-{h + 1}")
+        if want:
+            assert out[32:].hex() == want
+        assert cr["n_signed"] == 2 and cr["two_thirds_ok"] == 1
+    # wrong public input, a commit for the wrong block, a broken signature
+    bad = (10000).to_bytes(8, "big") + mocha["hashes"][1]
+    assert oracle.next_header(bad, mocha["headers"][0], mocha["headers"][1], mocha["latest"], mocha["commits"][1])[0] == T.ERR_ASSERT
+    inp = (10000).to_bytes(8, "big") + mocha["hashes"][0]
+    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][1], mocha["latest"], mocha["commits"][2])[0] == T.ERR_BAD_SIGNATURE
+    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][2], mocha["latest"], mocha["commits"][2])[0] == T.ERR_ASSERT
+    v = mocha["commits"][1].copy()
+    v[0]["signature"][5] ^= 1
+    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][1], mocha["latest"], v)[0] == T.ERR_BAD_SIGNATURE
