@@ -1,8 +1,9 @@
 """Device-resident batched header_range pipeline (the throughput path bench.py times).
 
-R independent header_range instances per pass, inputs already in HBM, every kernel enqueued on one HIP stream through
-the device tier of the C ABI (include/bsx.h, bsx_dev_*).  PyTorch only owns the device buffers, the stream and — across
-GPUs — the one collective; no torch op touches the data path.
+R independent header_range instances per pass, inputs already in HBM, every kernel enqueued through the device tier of
+the C ABI (include/bsx.h, bsx_dev_*) on a main HIP stream plus a side stream for the commit check.  PyTorch only owns
+the device buffers, the streams/events and — across GPUs — the one collective; no torch kernel runs on the data path.
+PipelinedEngines splits a pass into two chunks whose hashing and expansion phases alternate.
 
 Pass over R ranges of J map jobs x B headers (reference shapes 32x32 / 32x64, bin/header_range_{1024,2048}.rs:6-17):
 
@@ -254,7 +255,8 @@ class HeaderRangeEngine:
 
     def step_local(self, time_kernels=False):
         """Stages 1-5 + local fold: everything before the cross-GPU exchange.  The commit verification of the owned
-        ranges (stage 3, ~1 ms of latency-bound Ed25519) runs on a side stream beside the SHA/witness stream."""
+        ranges (stage 3) runs on a side stream: challenges + per-validator tables from here (beside the hashing), the
+        signature checks, tallies and skip conditions from launch_verify (beside an expansion)."""
         L, ctx, dp, chk = self.L, self.ctx, _lib.dp, _lib.check
         B, jc, RT, R, V = self.B, self.jc, self.RT, self.R, self.V
         main = torch.cuda.current_stream(self.dev)
