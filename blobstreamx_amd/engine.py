@@ -150,7 +150,7 @@ class HeaderRangeEngine:
         self.events = None
         self.side = torch.cuda.Stream(device=d)
         # which phase the commit side stream starts beside.  Measured on ONE engine object (same allocations, interleaved
-        # rounds, tools/prio_test.py): no commit 7.59 ms/step; beside the hashing 8.58 (generic P7) / 8.29 (keyed);
+        # rounds, tools/exp_prio.py): no commit 7.59 ms/step; beside the hashing 8.58 (generic P7) / 8.29 (keyed);
         # beside the expansion 8.05 (generic) / 7.80 (keyed).  The ALU-bound hashing phase has no spare issue slots,
         # the HBM-bound expansion does — once the field multiplication stopped passing operands through scratch
         # memory (fe25519.h), which used to queue every multiplication behind the expansion's stores.
@@ -168,7 +168,7 @@ class HeaderRangeEngine:
         Setup-time placement probe.  The store bandwidth of the expansion depends on WHICH physical memory the buffer
         landed in: on one MI355X, seven 29.5 GB buffers allocated back to back ran the identical launch at 4.72, 5.53,
         5.27, 5.72, 5.64, 5.09 and 4.84 TB/s, each figure stable for its buffer, and freeing + re-allocating the same
-        virtual address changed it again (tools/placement_test.py) — VRAM fragmentation left behind by earlier
+        virtual address changed it again (tools/exp_placement.py) — VRAM fragmentation left behind by earlier
         processes decides the page-table fragment sizes.  On another box 3 of 4 candidates ran at 4.8 TB/s and one at
         6.0 TB/s.  So: allocate candidates one by one (up to BSX_PLACEMENT_PROBE, while memory allows), time the real
         expansion launch on each, stop at the first one that reaches the part's store ceiling, keep the fastest, release
