@@ -46,6 +46,65 @@ def test_engine_batch_vs_oracle(J, B, V, R, n_blocks):
         assert (wrl[r * nr:(r + 1) * nr] == ref[nm:]).all(), r
 
 
+def _check_pipelined_against_oracle(pe, w, J, B):
+    """Every range of a PipelinedEngines batch vs the oracle: public output, statuses, commit result, per-job records and
+    the complete map + reduce Goldilocks witness (the same assertions as test_engine_batch_vs_oracle, plus records and
+    the failure verdicts of test_engine_reports_failures_per_range)."""
+    res = pe.download()
+    ml, rl = T.map_layout(B), T.reduce_layout()
+    nm, nr = J * int(ml["n_elements"]), (J - 1) * int(rl["n_elements"])
+    assert res["header_status"] == 0 and res["assemble_status"] == 0
+    wits = [eng.witness_numpy() for eng in pe.engines]
+    for r in range(pe.R):
+        e, k = divmod(r, pe.Rc)
+        rc, out, cres, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
+                                                w.validators[r], w.trusted[r], want_witness=True)
+        mine = res["skip_status"][r] if res["skip_status"][r] else (T.ERR_ASSERT if res["range_status"][r] else T.OK)
+        assert mine == rc, (r, mine, rc)
+        assert res["output64"][r].tobytes() == out, r
+        got = np.array(res["commit"][r]).copy(); got["_pad"] = 0
+        want = np.array(cres).copy(); want["_pad"] = 0
+        assert got.tobytes() == want.tobytes(), r
+        ctx = w.ranges[r:r + 1].copy()
+        ctx["end_header_hash"][0] = np.frombuffer(out[:32], np.uint8)
+        _, ref = oracle.prove_data_commitment(J, B, ctx, w.headers[r], int(w.first_height[r]), int(w.latest[r]))
+        assert [_rec(x) for x in res["records"][r]] == [_rec(x) for x in ref["records"]], r
+        full = oracle.expand_range_witness(J, B, cw)
+        wm, wrl, _ = wits[e]
+        assert (wm[k * nm:(k + 1) * nm] == full[:nm]).all(), r
+        assert (wrl[k * nr:(k + 1) * nr] == full[nm:]).all(), r
+    return res
+
+
+@pytest.mark.parametrize("J,B,V,R,n_blocks", [(32, 64, 100, 4, 2048), (32, 32, 100, 4, 1024), (8, 32, 20, 6, 131)])
+def test_pipelined_engines_multi_step_vs_oracle(J, B, V, R, n_blocks, monkeypatch):
+    """THE object bench.py times: PipelinedEngines with two chunks on separate streams, event tokens, the commit check
+    deferred onto side streams and double-buffered by pass parity.  Three consecutive step()s WITHOUT a join in between
+    (cross-step races — step i+1's hint / header hashing vs step i's side-stream commit check or expansion — would
+    corrupt a status, a record or the witness), then every range is diffed against the oracle.  One tampered range per
+    chunk: the per-range verdicts must be the oracle's and must not leak into the neighbours."""
+    from blobstreamx_amd.engine import PipelinedEngines
+    monkeypatch.setenv("BSX_PLACEMENT_PROBE", "1")
+    w = synth.Workload(4, R, J, B, v=V, n_blocks=n_blocks)
+    w.headers[1, 9]["hash"][1][5] ^= 1                     # chunk 0: range 1's chain breaks at header 9
+    w.validators[R - 1, 3]["signature"][0] ^= 2            # chunk 1: the last range carries one bad signature
+    pe = PipelinedEngines(J, B, V, R, n_engines=2)
+    pe.upload_workload(w)
+    for _ in range(3):
+        pe.step()
+    res = _check_pipelined_against_oracle(pe, w, J, B)
+    assert res["range_status"][1] != 0 and res["skip_status"][R - 1] == T.ERR_BAD_SIGNATURE
+    assert not res["range_status"][[r for r in range(R) if r != 1]].any()
+    # new inputs into the same buffers, again without draining the pipeline first: nothing of the old batch may survive
+    w2 = synth.Workload(5, R, J, B, v=V, n_blocks=n_blocks)
+    pe.step()
+    pe.upload_workload(w2)          # upload synchronises the device
+    for _ in range(2):
+        pe.step()
+    res = _check_pipelined_against_oracle(pe, w2, J, B)
+    assert not res["range_status"].any() and not res["skip_status"].any()
+
+
 @pytest.mark.parametrize("ed_path,commit_with", [("generic", "expand"), ("keyed", "expand"), ("keyed", "hash"), ("generic", "hash")])
 def test_engine_reports_failures_per_range(ed_path, commit_with, monkeypatch):
     """Both forms of the signature check (per-signature / per-validator tables) and both placements of the commit
