@@ -29,6 +29,9 @@ SYMBOLS = [
     "bsx_dev_commit_tally", "bsx_dev_skip_check",
     "bsx_ed25519_keytable_bytes", "bsx_dev_ed25519_keytable", "bsx_dev_ed25519_verify_keyed",
     "bsx_dev_skip_eval", "bsx_find_block_to_request",
+    "bsx_poseidon_permute", "bsx_poseidon_hash_no_pad", "bsx_poseidon_two_to_one", "bsx_poseidon_tree_digests",
+    "bsx_witness_leaf_count", "bsx_poseidon_merkle_tree", "bsx_witness_merkle_caps",
+    "bsx_dev_poseidon_permute", "bsx_dev_poseidon_leaf_hashes", "bsx_dev_witness_leaf_hashes", "bsx_dev_poseidon_merkle_caps",
     "bsx_ingest_last_error", "bsx_ingest_header_json", "bsx_ingest_signed_block_json", "bsx_ingest_data_commitment_json",
 ]
 
@@ -65,6 +68,8 @@ def lib():
             L = C.CDLL(_SO)
             L.bsx_version.restype = C.c_uint32
             L.bsx_ed25519_keytable_bytes.restype = C.c_uint64
+            L.bsx_poseidon_tree_digests.restype = C.c_uint64
+            L.bsx_witness_leaf_count.restype = C.c_uint32
             L.bsx_last_error.restype = C.c_char_p
             L.bsx_status_str.restype = C.c_char_p
             L.bsx_ingest_last_error.restype = C.c_char_p

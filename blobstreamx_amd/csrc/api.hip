@@ -15,6 +15,7 @@
 
 #include "../../include/bsx.h"
 #include "../../include/bsx_layout.h"
+#include "api_internal.h"
 
 extern "C" {
 hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*);
@@ -49,14 +50,8 @@ static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "
 static_assert(sizeof(bsx_witness_layout) == 40, "layout");
 static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
 
-struct bsx_ctx {
-    int device;
-    hipStream_t stream;
-};
-
-namespace {
+namespace bsxapi {
 thread_local std::string g_err;
-
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -66,41 +61,24 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(BSX_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-#define RET(expr)                 \
-    do {                          \
-        int rc_ = (expr);         \
-        if (rc_ != BSX_OK) return rc_; \
-    } while (0)
-
-bool pow2(uint32_t x) { return x && !(x & (x - 1)); }
-
-// device buffer with the lifetime of one host-tier call
-struct DBuf {
-    void* p = nullptr;
-    ~DBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) {
-        if (n == 0) n = 16;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) return fail(BSX_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
-        return BSX_OK;
-    }
-    template <typename T> T* as() const { return static_cast<T*>(p); }
-};
-
-// device tier: the caller's stream exactly as given (NULL = the HIP default stream, which is what PyTorch's default
-// stream is), so bsx_dev_* calls are ordered with the caller's own work on that stream
-hipStream_t S(bsx_ctx*, void* s) { return static_cast<hipStream_t>(s); }
-
 int use(bsx_ctx* ctx) {
     if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");
     HIPCHK(hipSetDevice(ctx->device));
     return BSX_OK;
 }
+}  // namespace bsxapi
+
+namespace {
+using bsxapi::DBuf;
+using bsxapi::fail;
+using bsxapi::g_err;
+using bsxapi::pow2;
+using bsxapi::use;
+
+// device tier: the caller's stream exactly as given (NULL = the HIP default stream, which is what PyTorch's default
+// stream is), so bsx_dev_* calls are ordered with the caller's own work on that stream
+hipStream_t S(bsx_ctx*, void* s) { return static_cast<hipStream_t>(s); }
+
 }  // namespace
 
 extern "C" {

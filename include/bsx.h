@@ -423,6 +423,53 @@ int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v
                        bsx_commit_result* d_target_res, const bsx_commit_result* d_trusted_res,
                        uint32_t* d_skip_status, uint8_t* d_target_hashes, const uint32_t* d_target_index);
 
+/* ------------------------------------------------------------------ Poseidon over Goldilocks
+ * plonky2's `PoseidonGoldilocksConfig` — the hash config of every reference binary (plonky2x DefaultParameters,
+ * bin/header_range_2048.rs:1-17); reached from builder.build()/prove and the recursion inside mapreduce
+ * (circuits/builder.rs:301-302).  Implementation [UPSTREAM] plonky2 53c5bc3e (Cargo.lock:3110-3112): width 12, rate 8,
+ * 4 + 22 + 4 rounds, x^7, circulant + diagonal MDS; constants regenerated (tools/gen_poseidon_constants.py).
+ * Field elements are u64; inputs are reduced mod p = 2^64 - 2^32 + 1 on the way in, outputs are canonical.
+ * PARITY: the reference tree holds no Poseidon value -> pinned to plonky2's public test vectors only. */
+#define BSX_POSEIDON_WIDTH 12
+#define BSX_POSEIDON_DIGEST 4              /* HashOut<F>: 4 field elements */
+#define BSX_GOLDILOCKS_ORDER 0xFFFFFFFF00000001ull
+
+/* Poseidon::poseidon — n independent 12-element states (in and out may alias). */
+int bsx_poseidon_permute(bsx_ctx* ctx, const uint64_t* states, uint64_t n, uint64_t* out);
+/* hash_n_to_hash_no_pad::<F, PoseidonPermutation> of n_inputs vectors of `len` elements each (row major) -> n_inputs x 4. */
+int bsx_poseidon_hash_no_pad(bsx_ctx* ctx, const uint64_t* elements, uint64_t n_inputs, uint32_t len, uint64_t* out_digests);
+/* PoseidonHash::two_to_one — n (left, right) digest pairs -> n digests. */
+int bsx_poseidon_two_to_one(bsx_ctx* ctx, const uint64_t* left, const uint64_t* right, uint64_t n, uint64_t* out_digests);
+/* Digests a tree stores: all levels from the n_leaves leaf digests up to the 2^cap_height cap nodes, bottom-up,
+ * = 2*n_leaves - 2^cap_height (the cap is the LAST 2^cap_height digests).  0 on invalid arguments. */
+uint64_t bsx_poseidon_tree_digests(uint32_t n_leaves, uint32_t cap_height);
+/* Rows (Merkle leaves) of a witness of n_elements in rows of leaf_len, rounded up to a power of two (MerkleTree::new
+ * needs one; plonky2 pads circuits to a power-of-two degree): the padding rows are all-zero elements. */
+uint32_t bsx_witness_leaf_count(uint64_t n_elements, uint32_t leaf_len);
+/* MerkleTree::<F, PoseidonHash>::new(leaves, cap_height): leaves = rows of leaf_len consecutive elements of `elements`
+ * (zero padded to n_leaves rows; leaf digest = hash_or_noop).  out_tree: bsx_poseidon_tree_digests() x 4 u64. */
+int bsx_poseidon_merkle_tree(bsx_ctx* ctx, const uint64_t* elements, uint64_t n_elements, uint32_t leaf_len,
+                             uint32_t n_leaves, uint32_t cap_height, uint64_t* out_tree);
+/* The witness-column commitment of n_jobs witnesses (layout->n_elements u64 each, as bsx_header_range /
+ * bsx_prove_data_commitment return them): one Merkle cap per job, out_caps n_jobs x 2^cap_height x 4. */
+int bsx_witness_merkle_caps(bsx_ctx* ctx, const bsx_witness_layout* layout, const uint64_t* witness, uint32_t n_jobs,
+                            uint32_t leaf_len, uint32_t cap_height, uint64_t* out_caps);
+
+/* device tier */
+int bsx_dev_poseidon_permute(bsx_ctx* ctx, void* stream, const uint64_t* d_states, uint64_t n, uint64_t* d_out);
+/* Leaf digests of n_trees MATERIALISED witnesses (d_elements: n_trees x n_elements u64) into
+ * d_trees[t*tree_stride + 4*j], j < n_leaves (tree_stride in u64 words, >= 4*bsx_poseidon_tree_digests()). */
+int bsx_dev_poseidon_leaf_hashes(bsx_ctx* ctx, void* stream, const uint64_t* d_elements, uint32_t n_trees, uint64_t n_elements,
+                                 uint32_t leaf_len, uint32_t n_leaves, uint64_t tree_stride, uint64_t* d_trees);
+/* FUSED form: the same digests straight from the COMPACT witnesses (what bsx_dev_prove_subchain / bsx_dev_reduce leave in
+ * d_compact): elements are produced on the fly, the 64x expanded image is never materialised. */
+int bsx_dev_witness_leaf_hashes(bsx_ctx* ctx, void* stream, const bsx_witness_layout* layout, uint32_t n_jobs,
+                                const uint8_t* d_compact, uint32_t leaf_len, uint32_t n_leaves, uint64_t tree_stride,
+                                uint64_t* d_trees);
+/* Upper levels of n_trees trees whose leaf digests are in place, down to the cap (2^cap_height nodes). */
+int bsx_dev_poseidon_merkle_caps(bsx_ctx* ctx, void* stream, uint64_t* d_trees, uint32_t n_trees, uint64_t tree_stride,
+                                 uint32_t n_leaves, uint32_t cap_height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -292,3 +292,50 @@ def bench_header_range(nb_map_jobs, batch_size, ranges, headers, headers_per_ran
                                       C.c_uint32(v_max), C.c_int(int(with_witness)), C.c_int(n_threads), _p(out64),
                                       C.byref(cs))
     return rc, out64, cs.value
+
+
+# ---------------------------------------------------------------- Poseidon over Goldilocks (oracle/poseidon.c)
+def poseidon_round_constants():
+    lib().orc_poseidon_round_constants.restype = C.POINTER(C.c_uint64)
+    ptr = lib().orc_poseidon_round_constants()
+    return np.ctypeslib.as_array(ptr, shape=(360,)).copy()
+
+
+def poseidon_permute(state):
+    s = np.ascontiguousarray(state, np.uint64).reshape(12).copy()
+    lib().orc_poseidon_permute(_p(s))
+    return s
+
+
+def poseidon_hash_no_pad(elems):
+    e = np.ascontiguousarray(elems, np.uint64).reshape(-1)
+    out = np.zeros(4, np.uint64)
+    lib().orc_poseidon_hash_no_pad(_p(e if e.size else np.zeros(1, np.uint64)), C.c_uint64(e.size), _p(out))
+    return out
+
+
+def poseidon_hash_or_noop(elems):
+    e = np.ascontiguousarray(elems, np.uint64).reshape(-1)
+    out = np.zeros(4, np.uint64)
+    lib().orc_poseidon_hash_or_noop(_p(e if e.size else np.zeros(1, np.uint64)), C.c_uint64(e.size), _p(out))
+    return out
+
+
+def poseidon_two_to_one(l, r):
+    out = np.zeros(4, np.uint64)
+    lib().orc_poseidon_two_to_one(_p(np.ascontiguousarray(l, np.uint64)), _p(np.ascontiguousarray(r, np.uint64)), _p(out))
+    return out
+
+
+def poseidon_tree_digests(n_leaves, cap_height):
+    return 2 * n_leaves - (1 << cap_height)
+
+
+def poseidon_merkle_tree(elements, leaf_len, n_leaves, cap_height):
+    """MerkleTree::new over rows of leaf_len elements (zero padded to n_leaves rows) -> (tree [digests, 4], cap)."""
+    e = np.ascontiguousarray(elements, np.uint64).reshape(-1)
+    tree = np.zeros((poseidon_tree_digests(n_leaves, cap_height), 4), np.uint64)
+    rc = lib().orc_poseidon_merkle_tree(_p(e), C.c_uint64(e.size), C.c_uint32(leaf_len), C.c_uint32(n_leaves),
+                                        C.c_uint32(cap_height), _p(tree))
+    assert rc == 0, rc
+    return tree, tree[-(1 << cap_height):]

@@ -113,6 +113,16 @@ int orc_find_block_to_request(uint64_t start_block, uint64_t max_end_block, cons
                               const bsx_validator* candidate_validators, uint32_t v_max, uint64_t* out_block,
                               orc_skip_eval* out_evals /* optional, n_candidates */);
 
+/* ---- Poseidon over Goldilocks (plonky2 PoseidonGoldilocksConfig [UPSTREAM, Cargo.lock:3110-3112]; oracle/poseidon.c).
+ * Pinned to plonky2's public known answers only — the reference tree holds none. */
+const uint64_t* orc_poseidon_round_constants(void);            /* 360, regenerated (ChaCha8Rng::seed_from_u64(0)) */
+void orc_poseidon_permute(uint64_t state[12]);
+void orc_poseidon_hash_no_pad(const uint64_t* in, uint64_t n, uint64_t out[4]);
+void orc_poseidon_hash_or_noop(const uint64_t* in, uint64_t n, uint64_t out[4]);
+void orc_poseidon_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+int orc_poseidon_merkle_tree(const uint64_t* elements, uint64_t n_elements, uint32_t leaf_len, uint32_t n_leaves,
+                             uint32_t cap_height, uint64_t* tree /* (2*n_leaves - 2^cap_height) * 4 */);
+
 /* ---- batch drivers for the cpu_baseline leg (pthread pool, n_threads >= 1) */
 int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t nb_map_jobs, uint32_t batch_size,
                            const bsx_shared_ctx* ranges, const bsx_header* headers, uint64_t headers_per_range,

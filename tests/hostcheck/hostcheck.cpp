@@ -7,6 +7,8 @@
 #include "../../blobstreamx_amd/csrc/sha256.h"
 #include "../../blobstreamx_amd/csrc/sha512.h"
 #include "../../blobstreamx_amd/csrc/ed25519.h"
+#include "../../blobstreamx_amd/csrc/poseidon.h"
+#include "../../blobstreamx_amd/csrc/poseidon_consts.h"
 
 using namespace bsx;
 
@@ -99,4 +101,22 @@ int hc_ed25519_verify_keyed(const uint8_t* pk, const uint8_t* sig, const uint8_t
             cached_store(tab + (half * KT_HALF_ENTRIES + (j - 1)) * KT_ENTRY_I32, ge_keytable_entry(base[half], j));
     return ed25519_verify_keyed_core(tab, r, s, hh) ? 1 : 0;
 }
+
+// ---- Goldilocks / Poseidon (goldilocks.h, poseidon.h): the device source on the host
+uint64_t hc_gl_add(uint64_t a, uint64_t b) { return gl_add(a, b); }
+uint64_t hc_gl_add_canon(uint64_t a, uint64_t c) { return gl_add_canon(a, c); }
+uint64_t hc_gl_sub(uint64_t a, uint64_t b) { return gl_sub(a, b); }
+uint64_t hc_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a, b); }
+uint64_t hc_gl_pow7(uint64_t a) { return gl_pow7(a); }
+uint64_t hc_gl_reduce128(uint64_t lo, uint64_t hi) { return gl_reduce128(lo, hi); }
+uint64_t hc_gl_canonical(uint64_t a) { return gl_canonical(a); }
+static const uint64_t HC_RC[BSX_POSEIDON_N_CONSTANTS] = {BSX_POSEIDON_RC_TABLE};
+const uint64_t* hc_poseidon_rc(void) { return HC_RC; }
+void hc_poseidon_mds(uint64_t s[12]) { poseidon_mds(s); }
+void hc_poseidon_permute(uint64_t s[12]) { poseidon_permute(s, HC_RC); for (int i = 0; i < 12; i++) s[i] = gl_canonical(s[i]); }
+void hc_poseidon_hash(const uint64_t* in, uint64_t n, int noop, uint64_t out[4]) {
+    auto get = [&](uint64_t k) -> uint64_t { return in[k]; };
+    if (noop) poseidon_hash_or_noop(get, n, HC_RC, out); else poseidon_hash_no_pad(get, n, HC_RC, out);
+}
+void hc_poseidon_two_to_one(const uint64_t* l, const uint64_t* r, uint64_t out[4]) { poseidon_two_to_one(l, r, HC_RC, out); }
 }
