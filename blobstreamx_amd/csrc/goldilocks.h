@@ -16,24 +16,27 @@ constexpr uint64_t GL_EPS = 0xFFFFFFFFull;   // 2^64 mod p
 BSX_HDI uint64_t gl_canonical(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
 
 // a + b for arbitrary representatives
+// EPS if `carry` else 0, without a 64-bit compare/select: the carry-out of the preceding add/sub becomes a 32-bit mask
+BSX_HDI uint64_t gl_eps_if(bool carry) { return (uint64_t)(0u - (uint32_t)carry); }
+
+// a + b for arbitrary representatives
 BSX_HDI uint64_t gl_add(uint64_t a, uint64_t b) {
-    uint64_t s = a + b;
-    if (s < a) {                 // wrapped: 2^64 = EPS
-        s += GL_EPS;
-        if (s < GL_EPS) s += GL_EPS;   // second wrap (only when both inputs were >= p)
-    }
-    return s;
+    uint64_t s, t;
+    const bool c1 = __builtin_add_overflow(a, b, &s);                  // wrapped: 2^64 = EPS
+    const bool c2 = __builtin_add_overflow(s, gl_eps_if(c1), &t);      // second wrap (only when both inputs were >= p)
+    return t + gl_eps_if(c2);
 }
 // a + c with c canonical (round constants): one correction suffices
 BSX_HDI uint64_t gl_add_canon(uint64_t a, uint64_t c) {
-    const uint64_t s = a + c;
-    return s < a ? s + GL_EPS : s;
+    uint64_t s;
+    const bool cy = __builtin_add_overflow(a, c, &s);
+    return s + gl_eps_if(cy);
 }
 BSX_HDI uint64_t gl_sub(uint64_t a, uint64_t b) {
     b = gl_canonical(b);
-    uint64_t d = a - b;
-    if (a < b) d -= GL_EPS;      // borrowed 2^64 = p + EPS: give EPS back
-    return d;
+    uint64_t d;
+    const bool bw = __builtin_sub_overflow(a, b, &d);
+    return d - gl_eps_if(bw);    // borrowed 2^64 = p + EPS: give EPS back
 }
 
 // full 128-bit product from 32-bit halves
@@ -49,12 +52,12 @@ BSX_HDI void gl_mul128(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
 // (lo + 2^64 hi) mod p, result any u64 representative
 BSX_HDI uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
     const uint64_t hi_hi = hi >> 32, hi_lo = (uint32_t)hi;
-    uint64_t t0 = lo - hi_hi;                        // 2^96 = -1
-    if (lo < hi_hi) t0 -= GL_EPS;
-    const uint64_t t1 = (hi_lo << 32) - hi_lo;       // hi_lo * EPS
-    uint64_t t2 = t0 + t1;
-    if (t2 < t1) t2 += GL_EPS;
-    return t2;
+    uint64_t t0, t2;
+    const bool bw = __builtin_sub_overflow(lo, hi_hi, &t0);      // 2^96 = -1
+    t0 -= gl_eps_if(bw);
+    const uint64_t t1 = (hi_lo << 32) - hi_lo;                   // hi_lo * EPS
+    const bool cy = __builtin_add_overflow(t0, t1, &t2);
+    return t2 + gl_eps_if(cy);
 }
 
 BSX_HDI uint64_t gl_mul(uint64_t a, uint64_t b) {

@@ -12,8 +12,8 @@
 // /root/reference holds a Poseidon value; pinned to plonky2's public test vectors (tests/test_oracle_poseidon.py).
 //
 // MDS on gfx950: every state word is split into 22/22/20-bit limbs; a limb times a coefficient (< 2^6) summed over a
-// row (coefficients add to 284 < 2^9) stays below 2^31, so the 3 x 144 products are full-rate 24-bit multiply-adds
-// (v_mad_u32_u24) instead of quarter-rate 32 x 32 -> 64 ones, and a row is recombined and reduced once.
+// row (coefficients add to 284 < 2^9) stays below 2^31, so each limb set is an exact 32-bit integer problem, solved
+// without multiplications (poseidon_mds_limbs below); a row is recombined and reduced mod p once.
 #pragma once
 #include "goldilocks.h"
 
@@ -21,31 +21,66 @@ namespace bsx {
 
 constexpr int POSEIDON_WIDTH = 12, POSEIDON_RATE = 8, POSEIDON_FULL_HALF = 4, POSEIDON_PARTIAL = 22, POSEIDON_ROUNDS = 30;
 
+// The circulant part is a length-12 cyclic convolution: out = s (*) c' with c'[m] = C[-m mod 12].  By the CRT over
+// x^12 - 1 = prod_{w^4 = 1} (x^3 - w) it splits into a 4-point DFT over the stride-3 sub-sequences (twiddles 1, i, -1, -i:
+// additions only), three 3 x 3 products modulo x^3 - w, and the inverse DFT.  For THIS matrix the transformed
+// coefficients are (after moving the inverse transform's 1/4 into them)
+//     w =  1: (16, 32, 16)        w = -1: (-1, -8, 2)        w = i: (2 + i, -4 - i, 16 - i)
+// — all +-2^k, so one limb set costs ~100 shift/add/sub operations in 32-bit wrap-around arithmetic instead of 144
+// multiply-adds (the idea of plonky2's mds_multiply_freq, re-derived here from the matrix; checked against the
+// definition in tests/test_oracle_poseidon.py::test_mds_layer_vs_definition).  Exact because every true output is < 284 * 2^22 < 2^31.
+BSX_HDI void poseidon_mds_limbs(const uint32_t l[12], uint32_t out[12]) {
+    constexpr int32_t K1[3] = {16, 32, 16}, KM[3] = {-1, -8, 2}, KR[3] = {2, -4, 16}, KI[3] = {1, -1, -1};
+    uint32_t f1[3], fm[3], fr[3], fi[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t t0 = l[k] + l[k + 6], t1 = l[k + 3] + l[k + 9];
+        f1[k] = t0 + t1; fm[k] = t0 - t1; fr[k] = l[k] - l[k + 6]; fi[k] = l[k + 3] - l[k + 9];
+    }
+    uint32_t o1[3] = {0, 0, 0}, om[3] = {0, 0, 0}, orr[3] = {0, 0, 0}, oi[3] = {0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int k = (a + b) % 3;
+            const bool wrap = a + b >= 3;                 // x^3 = w
+            o1[k] += f1[a] * (uint32_t)K1[b];
+            const uint32_t pm = fm[a] * (uint32_t)KM[b];
+            om[k] += wrap ? 0u - pm : pm;
+            const uint32_t pr = fr[a] * (uint32_t)KR[b] - fi[a] * (uint32_t)KI[b];
+            const uint32_t pi = fr[a] * (uint32_t)KI[b] + fi[a] * (uint32_t)KR[b];
+            orr[k] += wrap ? 0u - pi : pr;                // times i: (pr, pi) -> (-pi, pr)
+            oi[k] += wrap ? pr : pi;
+        }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t p = o1[k] + om[k], q = o1[k] - om[k];
+        out[k] = p + orr[k]; out[k + 3] = q + oi[k]; out[k + 6] = p - orr[k]; out[k + 9] = q - oi[k];
+    }
+    out[0] += l[0] * 8u;                                  // diagonal
+}
+
 BSX_HDI void poseidon_mds(uint64_t s[12]) {
-    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    uint32_t l0[12], l1[12], l2[12];
+    uint32_t l0[12], l1[12], l2[12], a0[12], a1[12], a2[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         l0[i] = (uint32_t)s[i] & 0x3fffffu;
         l1[i] = (uint32_t)(s[i] >> 22) & 0x3fffffu;
         l2[i] = (uint32_t)(s[i] >> 44);
     }
+    poseidon_mds_limbs(l0, a0);
+    poseidon_mds_limbs(l1, a1);
+    poseidon_mds_limbs(l2, a2);
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        uint32_t a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int j = (i + r) % 12;
-            a0 += l0[j] * C[i]; a1 += l1[j] * C[i]; a2 += l2[j] * C[i];
-        }
-        if (r == 0) { a0 += l0[0] * 8u; a1 += l1[0] * 8u; a2 += l2[0] * 8u; }      // diagonal
         // a0 + 2^22 a1 + 2^44 a2, a_k < 2^31: the part of a2 above bit 20 has weight 2^64 = EPS
-        const uint64_t x = (uint64_t)a0 + ((uint64_t)a1 << 22);
-        const uint64_t y = (uint64_t)(a2 & 0xfffffu) << 44;
-        const uint64_t lo = x + y;
-        const uint64_t hi = (uint64_t)(a2 >> 20) + (lo < y ? 1u : 0u);                 // < 2^12
-        const uint64_t t = lo + ((hi << 32) - hi);
-        s[r] = t < lo ? t + GL_EPS : t;
+        const uint64_t x = (uint64_t)a0[r] + ((uint64_t)a1[r] << 22);
+        const uint64_t y = (uint64_t)(a2[r] & 0xfffffu) << 44;
+        uint64_t lo, t;
+        const bool c1 = __builtin_add_overflow(x, y, &lo);
+        const uint64_t hi = (uint64_t)(a2[r] >> 20) + (c1 ? 1u : 0u);                     // < 2^12
+        const bool c2 = __builtin_add_overflow(lo, (hi << 32) - hi, &t);
+        s[r] = t + gl_eps_if(c2);
     }
 }
 

@@ -84,3 +84,57 @@ def witness_merkle_caps(layout, witness, n_jobs, leaf_len, cap_height, device=0)
     _lib.check(_lib.lib().bsx_witness_merkle_caps(_lib.context(device), _lib.p(lay), _lib.p(w), C.c_uint32(n_jobs), C.c_uint32(leaf_len),
                                                   C.c_uint32(cap_height), _lib.p(out)))
     return out
+
+
+class WitnessCommitter:
+    """Device-resident witness-column commitment of n_jobs witnesses of one layout: per job a Poseidon Merkle tree over
+    rows of `leaf_len` elements (plonky2 standard_recursion_config has 135 wires per row; cap_height 4), kept in HBM
+    as [n_jobs][tree_digests][4] u64.  commit_compact() is the fused path (elements generated on the fly from the
+    compact witness — nothing 64x-expanded is ever written); commit_materialised() hashes an expanded witness buffer.
+    PyTorch only owns the buffer and the stream."""
+
+    def __init__(self, layout, n_jobs, leaf_len=135, cap_height=4, device=None):
+        import torch
+        self.lay = np.array(layout).reshape(1)
+        self.n_jobs, self.leaf_len = int(n_jobs), int(leaf_len)
+        self.nel = int(self.lay["n_elements"][0])
+        self.n_leaves = witness_leaf_count(self.nel, leaf_len)
+        self.cap_height = min(int(cap_height), self.n_leaves.bit_length() - 1)
+        self.nd = tree_digests(self.n_leaves, self.cap_height)
+        self.dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.ctx = _lib.context(self.dev.index if self.dev.index is not None else 0)
+        self.trees = torch.zeros(max(self.n_jobs * self.nd * 4, 4), dtype=torch.int64, device=self.dev)
+        self.n_rows = -(-self.nel // leaf_len)
+        # permutations per job: ceil(leaf_len / 8) per real row (the zero rows share one digest) + the tree above
+        self.perms_per_job = self.n_rows * (-(-leaf_len // 8) if leaf_len > 4 else 0) + (self.n_leaves - (1 << self.cap_height))
+
+    def _st(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _caps(self):
+        _lib.check(_lib.lib().bsx_dev_poseidon_merkle_caps(self.ctx, self._st(), _lib.dp(self.trees), C.c_uint32(self.n_jobs),
+                                                           C.c_uint64(4 * self.nd), C.c_uint32(self.n_leaves), C.c_uint32(self.cap_height)))
+
+    def commit_compact(self, d_compact):
+        _lib.check(_lib.lib().bsx_dev_witness_leaf_hashes(self.ctx, self._st(), _lib.p(self.lay), C.c_uint32(self.n_jobs), _lib.dp(d_compact),
+                                                          C.c_uint32(self.leaf_len), C.c_uint32(self.n_leaves), C.c_uint64(4 * self.nd),
+                                                          _lib.dp(self.trees)))
+        self._caps()
+
+    def commit_materialised(self, d_witness):
+        _lib.check(_lib.lib().bsx_dev_poseidon_leaf_hashes(self.ctx, self._st(), _lib.dp(d_witness), C.c_uint32(self.n_jobs), C.c_uint64(self.nel),
+                                                           C.c_uint32(self.leaf_len), C.c_uint32(self.n_leaves), C.c_uint64(4 * self.nd),
+                                                           _lib.dp(self.trees)))
+        self._caps()
+
+    def caps_numpy(self):
+        import torch
+        torch.cuda.synchronize(self.dev)
+        t = self.trees[:self.n_jobs * self.nd * 4].cpu().numpy().view(np.uint64).reshape(self.n_jobs, self.nd, 4)
+        return t[:, self.nd - (1 << self.cap_height):, :]
+
+    def trees_numpy(self):
+        import torch
+        torch.cuda.synchronize(self.dev)
+        return self.trees[:self.n_jobs * self.nd * 4].cpu().numpy().view(np.uint64).reshape(self.n_jobs, self.nd, 4)
