@@ -170,8 +170,10 @@ class CombinedStepCircuit:
     """CombinedStepCircuit<MAX_VALIDATOR_SET_SIZE, CHAIN_ID_SIZE, C> (circuits/next_header.rs:11-46; instantiated with 100
     validators by bin/next_header{,_mocha}.rs:5-8)."""
 
-    def __init__(self, max_validator_set_size, device=0):
-        self.V, self.device = max_validator_set_size, device
+    def __init__(self, max_validator_set_size, device=0, chain_id=b"celestia"):
+        """chain_id = C::CHAIN_ID_BYTES, the circuit constant builder.step is called with (next_header.rs:32-33;
+        circuits/config.rs:6-28: celestia / mocha-4)."""
+        self.V, self.device, self.chain_id = max_validator_set_size, device, bytes(chain_id)
 
     def prove(self, input40, prev_header, next_header, latest_block, next_validators):
         """40-byte EVM-packed input (prev_block_number ‖ prev_header_hash) -> (64-byte output, commit result)."""
@@ -185,8 +187,10 @@ class CombinedStepCircuit:
         inp = np.frombuffer(bytes(input40), np.uint8).copy()
         out = np.zeros(64, np.uint8)
         res = np.zeros(1, T.COMMIT_RESULT)
+        cid = np.frombuffer(self.chain_id, np.uint8).copy() if self.chain_id else None
         _lib.check(_lib.lib().bsx_next_header(_lib.context(self.device), _lib.p(inp), _lib.p(ph), _lib.p(nh), C.c_uint64(latest_block),
-                                              _lib.p(nv), C.c_uint32(self.V), _lib.p(out), _lib.p(res)))
+                                              _lib.p(nv), C.c_uint32(self.V), _lib.p(cid), C.c_uint32(len(self.chain_id)), _lib.p(out),
+                                              _lib.p(res)))
         return out.tobytes(), res[0]
 
 
@@ -219,8 +223,11 @@ class CombinedSkipCircuit:
     """CombinedSkipCircuit<MAX_VALIDATOR_SET_SIZE, CHAIN_ID_SIZE, C, NB_MAP_JOBS, BATCH_SIZE>
     (circuits/header_range.rs:13-59; instantiated 100/32/32 and 100/32/64 by bin/header_range_{1024,2048}.rs:6-17)."""
 
-    def __init__(self, max_validator_set_size, nb_map_jobs, batch_size, skip_max=None, device=0):
+    def __init__(self, max_validator_set_size, nb_map_jobs, batch_size, skip_max=None, device=0, chain_id=b"celestia"):
+        """chain_id = C::CHAIN_ID_BYTES, the circuit constant builder.skip is called with (header_range.rs:42-43;
+        circuits/config.rs:6-28: celestia / mocha-4)."""
         self.V, self.J, self.B = max_validator_set_size, nb_map_jobs, batch_size
+        self.chain_id = bytes(chain_id)
         skip_max = skip_max if skip_max is not None else nb_map_jobs * batch_size
         # header_range.rs:37-40 (build-time assert)
         assert nb_map_jobs * batch_size <= skip_max, "NB_MAP_JOBS * BATCH_SIZE must be <= than SKIP_MAX"
@@ -241,5 +248,6 @@ class CombinedSkipCircuit:
         _lib.check(_lib.lib().bsx_header_range(
             _lib.context(self.device), C.c_uint32(self.J), C.c_uint32(self.B), _lib.p(_b(input48, 48)), _lib.p(fetcher.headers),
             C.c_uint64(fetcher.first_height), C.c_uint64(fetcher.headers.size), C.c_uint64(fetcher.latest_block), _lib.p(tv),
-            _lib.p(rv), C.c_uint32(self.V), _lib.p(out), _lib.p(res), _lib.p(wit)))
+            _lib.p(rv), C.c_uint32(self.V), _lib.p(np.frombuffer(self.chain_id, np.uint8).copy()) if self.chain_id else None,
+            C.c_uint32(len(self.chain_id)), _lib.p(out), _lib.p(res), _lib.p(wit)))
         return out.tobytes(), res[0], wit

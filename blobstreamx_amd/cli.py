@@ -54,7 +54,9 @@ def main(argv=None):
     ap.add_argument("--validators", type=int)
     ap.add_argument("--output", default="output.json")
     ap.add_argument("--witness")
+    ap.add_argument("--chain-id", help="C::CHAIN_ID_BYTES (default: mocha-4 for the *_mocha circuits, celestia otherwise; config.rs:6-28)")
     a = ap.parse_args(argv)
+    chain_id = (a.chain_id or ("mocha-4" if a.circuit.endswith("_mocha") else "celestia")).encode()
     V, J, B = CIRCUITS[a.circuit]
     V, J, B = a.validators or V, a.jobs or J, a.batch or B
     if a.command == "build":
@@ -77,7 +79,7 @@ def main(argv=None):
         fetcher = InputDataFetcher(headers, trusted, a.latest or target + 2)
         tr = blocks[trusted]["validators"].copy()
         tr["is_signed"] = 0
-        out, commit, wit = CombinedSkipCircuit(V, J, B).prove(inp, fetcher, blocks[target]["validators"], tr,
+        out, commit, wit = CombinedSkipCircuit(V, J, B, chain_id=chain_id).prove(inp, fetcher, blocks[target]["validators"], tr,
                                                               want_witness=bool(a.witness))
     else:
         if len(inp) != 40:
@@ -86,7 +88,7 @@ def main(argv=None):
         blocks = {h: fx.signed_block(h) for h in (prev, prev + 1)}
         headers = np.array([blocks[prev]["header"], blocks[prev + 1]["header"]], dtype=T.HEADER)
         # CombinedStepCircuit::define (circuits/next_header.rs:25-46) behind the C ABI (bsx_next_header)
-        out, _ = CombinedStepCircuit(blocks[prev + 1]["validators"].size).prove(inp, headers[0], headers[1], a.latest or prev + 3,
+        out, _ = CombinedStepCircuit(blocks[prev + 1]["validators"].size, chain_id=chain_id).prove(inp, headers[0], headers[1], a.latest or prev + 3,
                                                                                blocks[prev + 1]["validators"])
         wit = None
     json.dump({"type": "res_bytes", "data": {"output": "0x" + out.hex()}}, open(a.output, "w"))

@@ -35,7 +35,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const ui
 hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
                            const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
-                           uint32_t*, uint8_t*, const uint32_t*);
+                           uint32_t*, uint8_t*, const uint32_t*, const uint8_t*, uint32_t);
 hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
 hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
 hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*, uint8_t*, uint8_t*);
@@ -272,13 +272,14 @@ int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v
                        const bsx_header* d_headers, uint64_t headers_per_range, const uint8_t* d_hashes, const bsx_validator* d_target,
                        const bsx_validator* d_trusted, const uint8_t* d_target_ok, bsx_commit_result* d_target_res,
                        const bsx_commit_result* d_trusted_res, uint32_t* d_skip_status, uint8_t* d_target_hashes,
-                       const uint32_t* d_target_index) {
+                       const uint32_t* d_target_index, const uint8_t* chain_id, uint32_t chain_id_len) {
     DEV_ENTER();
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
     if (!d_ranges || !d_headers || !d_hashes || !d_target || !d_trusted || !d_target_ok || !d_target_res || !d_trusted_res || !d_skip_status)
         return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     HIPCHK(bsxk_skip_check(S(ctx, stream), n_ranges, v_max, d_ranges, d_headers, headers_per_range, d_hashes, d_target, d_trusted,
-                           d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes, d_target_index));
+                           d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes, d_target_index, chain_id, chain_id_len));
     return BSX_OK;
 }
 
@@ -694,10 +695,11 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
 
 int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const bsx_header* headers,
                      uint64_t first_height, uint64_t n_headers, uint64_t latest_block, const bsx_validator* target_validators,
-                     const bsx_validator* trusted_validators, uint32_t v_max, uint8_t output64[64], bsx_commit_result* out_commit,
-                     uint64_t* witness) {
+                     const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len,
+                     uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness) {
     DEV_ENTER();
     if (!input48 || !headers || !target_validators || !trusted_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     if (!pow2(nb_map_jobs) || nb_map_jobs > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
@@ -735,7 +737,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     HIPCHK(bsxk_commit_tally(st, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
     HIPCHK(bsxk_skip_check(st, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
-                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth.as<uint8_t>(), nullptr));
+                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth.as<uint8_t>(), nullptr, chain_id, chain_id_len));
     // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58)
     int rc = run_data_commitment(st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, output64, nullptr, nullptr, witness, nullptr);
     if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
@@ -756,10 +758,11 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
 // CombinedStepCircuit::define (circuits/next_header.rs:25-46): built from the host tier above — every hash, signature
 // check and tally runs in the kernels those calls launch; the host only compares 32-byte values and decodes statuses.
 int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
-                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
-                    bsx_commit_result* out_commit) {
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
+                    uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit) {
     DEV_ENTER();
     if (!input40 || !prev_header || !next_header || !next_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     uint64_t prev_block = 0;                                                    // next_header.rs:26 evm_read u64 (big endian)
     for (int i = 0; i < 8; i++) prev_block = prev_block << 8 | input40[i];
     const uint8_t* prev_hash = input40 + 8;                                     // :27
@@ -781,6 +784,10 @@ int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* p
     for (uint64_t hv = next_block;; hv >>= 7) { if (hv >= 0x80) hf[hn++] = (uint8_t)(hv | 0x80); else { hf[hn++] = (uint8_t)hv; break; } }
     if (!st && (next_header->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(next_header->height, hf, (size_t)hn) != 0)) {
         st = BSX_ERR_ASSERT; why = "next header's height is not prev_block_number + 1";
+    }
+    if (!st && (next_header->len[1] != chain_id_len + 2 || next_header->chain_id[0] != 0x0a || next_header->chain_id[1] != chain_id_len ||
+                memcmp(next_header->chain_id + 2, chain_id, chain_id_len) != 0)) {
+        st = BSX_ERR_ASSERT; why = "next header's chain id is not the circuit's CHAIN_ID_BYTES";
     }
     if (!st && (cr.n_bad_signature || cr.n_bad_message)) { st = BSX_ERR_BAD_SIGNATURE; why = "a signed validator's signature or message is bad"; }
     if (!st && (next_header->len[7] != 34 || memcmp(next_header->hash[2] + 2, cr.validators_hash, 32) != 0)) {

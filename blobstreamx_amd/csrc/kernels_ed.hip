@@ -355,6 +355,8 @@ struct SkipArgs {
     uint32_t* skip_status;              // n_ranges
     uint8_t* target_hashes;             // n_ranges * 32 (out): hash of the target header
     const uint32_t* target_idx;         // optional: index of the target header inside the range's header block (default E - S)
+    uint32_t chain_id_len;              // C::CHAIN_ID_BYTES (header_range.rs:42-43): the target header's field 1 must be 0a len bytes
+    uint8_t chain_id[52];
 };
 __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
     __shared__ uint32_t tpk[TL_VMAX * 8];
@@ -410,6 +412,8 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
         const uint8_t b_tvh = th->hash[2][2 + q], b_rvh = tr->hash[2][2 + q];
         const uint8_t b_cvh = cr->validators_hash[q], b_tcvh = trc->validators_hash[q];
         const uint8_t b_height = th->height[q < 12 ? q : 0];
+        const uint8_t b_chain = th->chain_id[tid < 52 ? tid : 0];          // all 64 lanes: the leaf is up to 52 bytes
+        const uint8_t l_chain = th->len[1];
         const uint8_t l_height = th->len[BSX_BLOCK_HEIGHT_INDEX], l_tv = th->len[7], l_rv = tr->len[7];
         const uint32_t n_bad_sig = cr->n_bad_signature, n_bad_msg = cr->n_bad_message, two_thirds = cr->two_thirds_ok;
         const uint64_t ttotal64 = trc->total_power;
@@ -431,6 +435,10 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
         }
         const bool eq_trusted = __ballot(b_trhash != rg.start_header_hash[q]) == 0;     // trusted header hash is the public input
         const bool heq = (l_height == hn) && __ballot((int)q < hn && b_height != want) == 0;
+        // chain-id leaf = 0a len bytes
+        const uint32_t cl = a.chain_id_len;
+        const uint8_t want_c = tid == 0 ? 0x0a : tid == 1 ? (uint8_t)cl : a.chain_id[tid >= 2 && tid < 52 ? tid - 2 : 0];
+        const bool ceq = (l_chain == cl + 2) && __ballot(tid < cl + 2 && b_chain != want_c) == 0;
         const bool veq = (l_tv == 34) && __ballot(b_tvh != b_cvh) == 0;
         const bool treq = (l_rv == 34) && __ballot(b_rvh != b_tcvh) == 0;
         if (a.target_hashes && tid < 32) a.target_hashes[32 * (uint64_t)r + q] = b_thash;
@@ -438,6 +446,7 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
             uint32_t st = BSX_OK;
             if (!eq_trusted) st = BSX_ERR_ASSERT;
             if (!st && !heq) st = BSX_ERR_ASSERT;
+            if (!st && !ceq) st = BSX_ERR_ASSERT;
             if (!st && (n_bad_sig || n_bad_msg)) st = BSX_ERR_BAD_SIGNATURE;
             if (!st && !veq) st = BSX_ERR_ASSERT;
             if (!st && !treq) st = BSX_ERR_ASSERT;
@@ -549,9 +558,12 @@ hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t 
 hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* ranges, const bsx_header* headers,
                            uint64_t hpr, const uint8_t* hashes, const bsx_validator* target, const bsx_validator* trusted,
                            const uint8_t* target_ok, bsx_commit_result* target_res, const bsx_commit_result* trusted_res,
-                           uint32_t* skip_status, uint8_t* target_hashes, const uint32_t* target_idx) {
+                           uint32_t* skip_status, uint8_t* target_hashes, const uint32_t* target_idx, const uint8_t* chain_id,
+                           uint32_t chain_id_len) {
     if (!n_ranges) return hipSuccess;
-    SkipArgs a{n_ranges, v_max, ranges, headers, hpr, hashes, target, trusted, target_ok, target_res, trusted_res, skip_status, target_hashes, target_idx};
+    SkipArgs a{n_ranges, v_max, ranges, headers, hpr, hashes, target, trusted, target_ok, target_res, trusted_res, skip_status, target_hashes, target_idx,
+               chain_id_len, {0}};
+    for (uint32_t i = 0; i < chain_id_len && i < 50; i++) a.chain_id[i] = chain_id[i];
     hipLaunchKernelGGL(k_skip_check, dim3(n_ranges), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -78,8 +78,9 @@ def gather_partials(partial, rank, world, n_ranges_local, out_gathered=None, out
 
 class HeaderRangeEngine:
     def __init__(self, nb_map_jobs, batch_size, v_max, n_ranges_local, rank=0, world=1, device=None, with_witness=True,
-                 with_commit=True):
+                 with_commit=True, chain_id=b"celestia"):
         self.J, self.B, self.V = nb_map_jobs, batch_size, v_max
+        self.chain_id = np.frombuffer(bytes(chain_id), np.uint8).copy()       # C::CHAIN_ID_BYTES (header_range.rs:42-43)
         self.rank, self.world = rank, world
         self.R = n_ranges_local                     # ranges owned by this rank (commit + final reduce)
         self.RT = n_ranges_local * world            # ranges whose job slice this rank computes
@@ -324,7 +325,8 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges_side), dp(self.skip_headers),
                                  C.c_uint64(2), dp(self._skip_hashes_pp[self._parity]), dp(self.validators), dp(self.trusted),
                                  dp(self.ok), dp(self.commit_res), dp(self.trusted_res), dp(self.skip_status), None,
-                                 dp(self.target_idx)))
+                                 dp(self.target_idx), _lib.p(self.chain_id) if self.chain_id.size else None,
+                                 C.c_uint32(self.chain_id.size)))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
         self._commit_done[self._parity] = ev

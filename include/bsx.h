@@ -266,10 +266,13 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
  * trusted_validators (pubkey, voting_power, enabled used).  Checks skip conditions
  * [UPSTREAM tendermintx skip]: trusted < target <= trusted + nb_map_jobs*batch_size, signatures,
  * validators_hash of both sets against the headers' field 7, 2/3 of target power signed, more
- * than 1/3 of trusted power signed. */
+ * than 1/3 of trusted power signed; the target header's chain-id leaf (field 1: 0a len bytes) equals chain_id — the
+ * circuit constant C::CHAIN_ID_BYTES that builder.skip is called with (header_range.rs:42-43; config.rs:6-28),
+ * chain_id_len <= 50.  A header of another chain signed by the same keys fails with BSX_ERR_ASSERT. */
 int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48],
                      const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
+                     const uint8_t* chain_id, uint32_t chain_id_len,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness);
 
 /* ------------------------------------------------------------------ wire-format ingest
@@ -374,11 +377,12 @@ int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator
  * builder.step (:32-36) is [UPSTREAM] tendermintx v1.0.0; checked here: prev_header hashes to
  * prev_header_hash; next_header's height is prev + 1 and its last_block_id points at prev_header; the supplied
  * validator set hashes to next_header.validators_hash and to prev_header.next_validators_hash; every signed
- * validator's Ed25519 signature verifies over a message carrying the next header hash; signed power > 2/3.
+ * validator's Ed25519 signature verifies over a message carrying the next header hash; signed power > 2/3; the next
+ * header's chain-id leaf equals chain_id (C::CHAIN_ID_BYTES, next_header.rs:32-33).
  * The data commitment is prove_next_header_data_commitment (builder.rs:411-443).  Failure codes as bsx_header_range. */
 int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
-                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
-                    bsx_commit_result* out_commit);
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max,
+                    const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit);
 
 /* ------------------------------------------------------------------ operator skip-target search
  * circuits/fetcher.rs:60-87 find_block_to_request: starting at max_end_block, return the first candidate c with
@@ -414,14 +418,15 @@ int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_vali
                          uint32_t v_max, const uint8_t* d_header_hashes, const uint8_t* d_ok,
                          bsx_commit_result* d_results);
 /* Skip conditions of CombinedSkipCircuit per range ([UPSTREAM] tendermintx skip; fetcher.rs:76-80): trusted header
- * hash == public input, target height leaf, signatures, both validator-set hashes against the headers' field 7,
+ * hash == public input, target height leaf, target chain-id leaf == chain_id, signatures, both validator-set hashes against the headers' field 7,
  * 2/3 of the target power, > 1/3 of the trusted power.  d_skip_status[r] = bsx_status; d_target_hashes (optional)
  * receives the target header hashes; d_target_res[r].trusted_signed_power := trusted-set overlap. */
 int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* d_ranges,
                        const bsx_header* d_headers, uint64_t headers_per_range, const uint8_t* d_hashes,
                        const bsx_validator* d_target, const bsx_validator* d_trusted, const uint8_t* d_target_ok,
                        bsx_commit_result* d_target_res, const bsx_commit_result* d_trusted_res,
-                       uint32_t* d_skip_status, uint8_t* d_target_hashes, const uint32_t* d_target_index);
+                       uint32_t* d_skip_status, uint8_t* d_target_hashes, const uint32_t* d_target_index,
+                       const uint8_t* chain_id /* HOST pointer, copied into the launch */, uint32_t chain_id_len);
 
 /* ------------------------------------------------------------------ Poseidon over Goldilocks
  * plonky2's `PoseidonGoldilocksConfig` — the hash config of every reference binary (plonky2x DefaultParameters,

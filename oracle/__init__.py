@@ -234,8 +234,11 @@ def verify_commit(validators, header_hash):
     return res[0], ok
 
 
+CHAIN_ID = b"celestia"      # the synthetic workload's chain (synth.CHAIN_ID); the mocha-4 fixtures pass b"mocha-4"
+
+
 def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest_block, target_validators,
-                 trusted_validators, want_witness=False):
+                 trusted_validators, want_witness=False, chain_id=CHAIN_ID):
     headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
     tv = np.ascontiguousarray(target_validators, T.VALIDATOR).reshape(-1)
     rv = np.ascontiguousarray(trusted_validators, T.VALIDATOR).reshape(-1)
@@ -247,19 +250,19 @@ def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest
     res = np.zeros(1, T.COMMIT_RESULT)
     rc = lib().orc_header_range(C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(_b(input48, 48)), _p(headers),
                                 C.c_uint64(first_height), C.c_uint64(headers.size), C.c_uint64(latest_block), _p(tv), _p(rv),
-                                C.c_uint32(tv.size), _p(out), _p(res), _p(compact))
+                                C.c_uint32(tv.size), _p(_b(chain_id)), C.c_uint32(len(chain_id)), _p(out), _p(res), _p(compact))
     return rc, out.tobytes(), res[0], compact
 
 
-def next_header(input40, prev_header, next_header_, latest_block, next_validators):
+def next_header(input40, prev_header, next_header_, latest_block, next_validators, chain_id=CHAIN_ID):
     """CombinedStepCircuit::define (circuits/next_header.rs:25-46) -> (rc, output64, commit_result)."""
     ph = np.ascontiguousarray(prev_header, T.HEADER).reshape(1)
     nh = np.ascontiguousarray(next_header_, T.HEADER).reshape(1)
     nv = np.ascontiguousarray(next_validators, T.VALIDATOR).reshape(-1)
     out = np.zeros(64, np.uint8)
     res = np.zeros(1, T.COMMIT_RESULT)
-    rc = lib().orc_next_header(_p(_b(input40, 40)), _p(ph), _p(nh), C.c_uint64(latest_block), _p(nv), C.c_uint32(nv.size), _p(out),
-                               _p(res))
+    rc = lib().orc_next_header(_p(_b(input40, 40)), _p(ph), _p(nh), C.c_uint64(latest_block), _p(nv), C.c_uint32(nv.size),
+                               _p(_b(chain_id)), C.c_uint32(len(chain_id)), _p(out), _p(res))
     return rc, out.tobytes(), res[0]
 
 
@@ -281,7 +284,7 @@ def find_block_to_request(start_block, max_end_block, start_validators, candidat
 
 
 def bench_header_range(nb_map_jobs, batch_size, ranges, headers, headers_per_range, latest, target, trusted, v_max,
-                       with_witness, n_threads, reps=1):
+                       with_witness, n_threads, reps=1, chain_id=CHAIN_ID):
     ranges = np.ascontiguousarray(ranges, T.SHARED_CTX).reshape(-1)
     n = ranges.size
     out64 = np.zeros((n, 64), np.uint8)
@@ -289,8 +292,8 @@ def bench_header_range(nb_map_jobs, batch_size, ranges, headers, headers_per_ran
     latest = np.ascontiguousarray(latest, np.uint64)
     rc = lib().orc_bench_header_range(C.c_uint32(n), C.c_uint32(reps), C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(ranges),
                                       _p(headers), C.c_uint64(headers_per_range), _p(latest), _p(target), _p(trusted),
-                                      C.c_uint32(v_max), C.c_int(int(with_witness)), C.c_int(n_threads), _p(out64),
-                                      C.byref(cs))
+                                      C.c_uint32(v_max), _p(_b(chain_id)), C.c_uint32(len(chain_id)), C.c_int(int(with_witness)),
+                                      C.c_int(n_threads), _p(out64), C.byref(cs))
     return rc, out64, cs.value
 
 

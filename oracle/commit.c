@@ -120,8 +120,8 @@ static int varint_height_field(uint64_t h, uint8_t out[12]) {
 /* circuits/header_range.rs:32-59 */
 int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height,
                      uint64_t n_headers, uint64_t latest_block, const bsx_validator* target_validators,
-                     const bsx_validator* trusted_validators, uint32_t v_max, uint8_t output64[64],
-                     bsx_commit_result* out_commit, uint8_t* compact) {
+                     const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len,
+                     uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact) {
     uint64_t trusted_block = 0, target_block = 0;
     for (int i = 0; i < 8; i++) trusted_block = trusted_block << 8 | input48[i];      /* :33 evm_read U64 = big endian */
     const uint8_t* trusted_header_hash = input48 + 8;                                /* :34 */
@@ -139,6 +139,9 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
     uint8_t hf[12];
     int hn = varint_height_field(target_block, hf);
     if (th->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(th->height, hf, (size_t)hn) != 0) return BSX_ERR_ASSERT;
+    /* builder.skip is called with C::CHAIN_ID_BYTES (:42-43): the target header's chain-id leaf is 0a len bytes */
+    if (chain_id_len > 50 || th->len[1] != chain_id_len + 2 || th->chain_id[0] != 0x0a || th->chain_id[1] != chain_id_len ||
+        memcmp(th->chain_id + 2, chain_id, chain_id_len) != 0) return BSX_ERR_ASSERT;
     bsx_commit_result cr, trc;
     uint8_t* ok = malloc(v_max);
     orc_verify_commit(target_validators, v_max, target_hash, &cr, ok);
@@ -191,6 +194,8 @@ typedef struct {
     const uint64_t* latest;
     const bsx_validator *target, *trusted;
     int with_witness, n_threads, tid;
+    const uint8_t* chain_id;
+    uint32_t chain_id_len;
     uint8_t* out64;
     uint64_t checksum;
     int rc;
@@ -216,7 +221,7 @@ static void* worker(void* arg) {
         for (int i = 0; i < 8; i++) in48[40 + i] = (uint8_t)(rg->end_block >> (56 - 8 * i));
         int rc = orc_header_range(jb->J, jb->B, in48, jb->headers + (size_t)r * jb->headers_per_range, rg->start_block,
                                   jb->headers_per_range, jb->latest[r], jb->target + (size_t)r * jb->v_max,
-                                  jb->trusted + (size_t)r * jb->v_max, jb->v_max, o64, NULL, compact);
+                                  jb->trusted + (size_t)r * jb->v_max, jb->v_max, jb->chain_id, jb->chain_id_len, o64, NULL, compact);
         if (rc) jb->rc = rc;
         if (t < jb->n_ranges) memcpy(jb->out64 + 64 * (size_t)r, o64, 64);
         if (compact) {
@@ -241,7 +246,8 @@ static void* worker(void* arg) {
 int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t J, uint32_t B, const bsx_shared_ctx* ranges,
                            const bsx_header* headers, uint64_t headers_per_range, const uint64_t* latest_block,
                            const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
-                           int with_witness, int n_threads, uint8_t* out64, uint64_t* checksum) {
+                           const uint8_t* chain_id, uint32_t chain_id_len, int with_witness, int n_threads, uint8_t* out64,
+                           uint64_t* checksum) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
     if (reps < 1) reps = 1;
@@ -249,7 +255,7 @@ int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t J, uint32_
     pthread_t* th = calloc((size_t)n_threads, sizeof *th);
     for (int t = 0; t < n_threads; t++) {
         job_t j = {n_ranges, J, B, v_max, reps, ranges, headers, headers_per_range, latest_block, target_validators,
-                   trusted_validators, with_witness, n_threads, t, out64, 0, 0};
+                   trusted_validators, with_witness, n_threads, t, chain_id, chain_id_len, out64, 0, 0};
         jobs[t] = j;
         pthread_create(&th[t], NULL, worker, &jobs[t]);
     }
@@ -319,8 +325,8 @@ int orc_find_block_to_request(uint64_t start_block, uint64_t max_end_block, cons
 
 /* ---------------------------------------------------------------- next_header (circuits/next_header.rs:25-46) */
 int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
-                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
-                    bsx_commit_result* out_commit) {
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
+                    uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit) {
     uint64_t prev_block = 0;                                       /* :26 */
     for (int i = 0; i < 8; i++) prev_block = prev_block << 8 | input40[i];
     const uint8_t* prev_hash = input40 + 8;                        /* :27 */
@@ -342,6 +348,9 @@ int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, co
     hf[hl++] = 0x08;
     for (uint64_t hv = next_block;; hv >>= 7) { if (hv >= 0x80) hf[hl++] = (uint8_t)(hv | 0x80); else { hf[hl++] = (uint8_t)hv; break; } }
     if (!st && (next_header->len[BSX_BLOCK_HEIGHT_INDEX] != hl || memcmp(next_header->height, hf, (size_t)hl) != 0)) st = BSX_ERR_ASSERT;
+    if (!st && (chain_id_len > 50 || next_header->len[1] != chain_id_len + 2 || next_header->chain_id[0] != 0x0a ||
+                next_header->chain_id[1] != chain_id_len || memcmp(next_header->chain_id + 2, chain_id, chain_id_len) != 0))
+        st = BSX_ERR_ASSERT;   /* builder.step is called with C::CHAIN_ID_BYTES (next_header.rs:32-33) */
     if (!st && (cr.n_bad_signature || cr.n_bad_message)) st = BSX_ERR_BAD_SIGNATURE;
     if (!st && (next_header->len[7] != 34 || memcmp(next_header->hash[2] + 2, cr.validators_hash, 32) != 0)) st = BSX_ERR_ASSERT;
     if (!st && (prev_header->len[8] != 34 || memcmp(prev_header->hash[3] + 2, cr.validators_hash, 32) != 0)) st = BSX_ERR_ASSERT;

@@ -91,13 +91,14 @@ void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t 
 int orc_header_range(uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const bsx_header* headers,
                      uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
+                     const uint8_t* chain_id, uint32_t chain_id_len,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact);
 
 /* CombinedStepCircuit::define (circuits/next_header.rs:25-46); builder.step is [UPSTREAM] (checks restated from
  * SURVEY App. B, same list as include/bsx.h bsx_next_header) */
 int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
-                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, uint8_t output64[64],
-                    bsx_commit_result* out_commit);
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
+                    uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit);
 
 /* ---- operator skip-target search (circuits/fetcher.rs:60-87 find_block_to_request).  The loop is
  * the reference's; the predicate is_valid_skip is [UPSTREAM] tendermintx v1.0.0 (not under /root/reference): restated
@@ -127,8 +128,8 @@ int orc_poseidon_merkle_tree(const uint64_t* elements, uint64_t n_elements, uint
 int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t nb_map_jobs, uint32_t batch_size,
                            const bsx_shared_ctx* ranges, const bsx_header* headers, uint64_t headers_per_range,
                            const uint64_t* latest_block, const bsx_validator* target_validators,
-                           const bsx_validator* trusted_validators, uint32_t v_max, int with_witness, int n_threads,
-                           uint8_t* out64, uint64_t* checksum);
+                           const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id,
+                           uint32_t chain_id_len, int with_witness, int n_threads, uint8_t* out64, uint64_t* checksum);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import oracle
 import synth
 from blobstreamx_amd import _lib
 from blobstreamx_amd import types as T
-from blobstreamx_amd.builder import CombinedSkipCircuit, DataCommitmentBuilder, InputDataFetcher, verify_commits
+from blobstreamx_amd.builder import CombinedSkipCircuit, CombinedStepCircuit, DataCommitmentBuilder, InputDataFetcher, verify_commits
 
 pytestmark = pytest.mark.gpu
 
@@ -410,6 +410,41 @@ def test_header_range_vs_oracle(J, B, v, n_blocks):
     assert (wit == oracle.expand_range_witness(J, B, cw)).all()
 
 
+def test_chain_id_is_checked_on_gpu_like_the_oracle():
+    """a header of another chain signed by the same validator keys must not get BSX_OK (builder.skip / step are
+    called with C::CHAIN_ID_BYTES, header_range.rs:42-43, next_header.rs:32-33) — host tier, step circuit and the batched
+    engine, every verdict equal to the oracle's."""
+    from blobstreamx_amd.engine import HeaderRangeEngine
+    for fork_id in ("celestiaX", "celestib", "mocha-4", "c"):
+        w = synth.Workload(98, 1, 2, 4, v=4, chain_id=fork_id)
+        S = int(w.first_height[0])
+        f = InputDataFetcher(w.headers[0], S, int(w.latest[0]))
+        for cid in (fork_id.encode(), b"celestia"):
+            want = oracle.header_range(2, 4, w.input48(0), w.headers[0], S, int(w.latest[0]), w.validators[0], w.trusted[0], chain_id=cid)[0]
+            assert want == (T.OK if cid == fork_id.encode() else T.ERR_ASSERT)
+            try:
+                CombinedSkipCircuit(4, 2, 4, chain_id=cid).prove(w.input48(0), f, w.validators[0], w.trusted[0])
+                rc = T.OK
+            except _lib.BsxError as e:
+                rc = e.status
+            assert rc == want, (fork_id, cid, rc)
+            eng = HeaderRangeEngine(2, 4, 4, 1, chain_id=cid)
+            eng.upload_workload(w)
+            eng.step()
+            assert eng.download()["skip_status"][0] == want
+        wS = synth.Workload(98, 1, 2, 4, v=4, chain_id=fork_id, mode="S")
+        inp = int(wS.first_height[0]).to_bytes(8, "big") + wS.hashes[0, 0].tobytes()
+        vals = wS.validators[0].reshape(-1, 4)[0]
+        for cid in (fork_id.encode(), b"celestia"):
+            want = oracle.next_header(inp, wS.headers[0, 0], wS.headers[0, 1], int(wS.latest[0]), vals, chain_id=cid)[0]
+            try:
+                CombinedStepCircuit(4, chain_id=cid).prove(inp, wS.headers[0, 0], wS.headers[0, 1], int(wS.latest[0]), vals)
+                rc = T.OK
+            except _lib.BsxError as e:
+                rc = e.status
+            assert rc == want == (T.OK if cid == fork_id.encode() else T.ERR_ASSERT)
+
+
 def test_header_range_failure_codes_match_oracle():
     J, B, v = 2, 4, 10
     circ = CombinedSkipCircuit(v, J, B)
@@ -505,12 +540,12 @@ def test_golden_next_header_circuit(golden, mocha):
     """bsx_next_header over the fixture chain: next header hash ‖ data commitment, equal to the oracle and to the
     reference's fixture commitments; reject paths return the oracle's codes."""
     from blobstreamx_amd.builder import CombinedStepCircuit
-    circ = CombinedStepCircuit(4)
+    circ = CombinedStepCircuit(4, chain_id=b"mocha-4")
     for k in range(4):
         h = 10000 + k
         inp = h.to_bytes(8, "big") + mocha["hashes"][k]
-        out, cr = circ.prove(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1])
-        rc, want, wcr = oracle.next_header(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1])
+        out, cr = circ.prove(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1], chain_id=b"mocha-4")
+        rc, want, wcr = oracle.next_header(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1], chain_id=b"mocha-4")
         assert rc == T.OK and out == want and res_bytes(cr) == res_bytes(wcr)
         assert out[:32] == mocha["hashes"][k + 1]
         if f"{h}-{h + 1}" in golden["data_commitments"]:
@@ -518,7 +553,7 @@ def test_golden_next_header_circuit(golden, mocha):
     inp = (10000).to_bytes(8, "big") + mocha["hashes"][0]
     cases = [((10000).to_bytes(8, "big") + mocha["hashes"][1], 0, 1, 1), (inp, 0, 1, 2), (inp, 0, 2, 2), ((10001).to_bytes(8, "big") + mocha["hashes"][0], 0, 1, 1)]
     for i, a, b, c in cases:
-        rc = oracle.next_header(i, mocha["headers"][a], mocha["headers"][b], mocha["latest"], mocha["commits"][c])[0]
+        rc = oracle.next_header(i, mocha["headers"][a], mocha["headers"][b], mocha["latest"], mocha["commits"][c], chain_id=b"mocha-4")[0]
         assert rc != T.OK
         with pytest.raises(_lib.BsxError) as ei:
             circ.prove(i, mocha["headers"][a], mocha["headers"][b], mocha["latest"], mocha["commits"][c])

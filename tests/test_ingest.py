@@ -101,7 +101,7 @@ def test_fixture_json_to_gpu_end_to_end(golden):
     assert inp.hex() == golden["kats"]["header_range_input_10000_10004"]
     trusted = blocks[0]["validators"].copy()
     trusted["is_signed"] = 0
-    out, cres, _ = CombinedSkipCircuit(4, 2, 2).prove(inp, fetcher, blocks[4]["validators"], trusted)
+    out, cres, _ = CombinedSkipCircuit(4, 2, 2, chain_id=b"mocha-4").prove(inp, fetcher, blocks[4]["validators"], trusted)
     assert out[:32] == hashes[4].tobytes() and out[32:] == f.get_data_commitment(10000, 10004)
     assert cres["trusted_signed_power"] == 50_000_000
 

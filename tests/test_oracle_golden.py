@@ -143,7 +143,7 @@ def test_next_header_reproduces_the_fixture_chain(golden, mocha):
     for k in range(4):
         h = 10000 + k
         inp = h.to_bytes(8, "big") + mocha["hashes"][k]
-        rc, out, cr = oracle.next_header(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1])
+        rc, out, cr = oracle.next_header(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1], chain_id=b"mocha-4")
         assert rc == 0, (h, rc)
         assert out[:32] == mocha["hashes"][k + 1]
         want = golden["data_commitments"].get(f"{h}-{h + 1}")
@@ -152,10 +152,10 @@ def test_next_header_reproduces_the_fixture_chain(golden, mocha):
         assert cr["n_signed"] == 2 and cr["two_thirds_ok"] == 1
     # wrong public input, a commit for the wrong block, a broken signature
     bad = (10000).to_bytes(8, "big") + mocha["hashes"][1]
-    assert oracle.next_header(bad, mocha["headers"][0], mocha["headers"][1], mocha["latest"], mocha["commits"][1])[0] == T.ERR_ASSERT
+    assert oracle.next_header(bad, mocha["headers"][0], mocha["headers"][1], mocha["latest"], mocha["commits"][1], chain_id=b"mocha-4")[0] == T.ERR_ASSERT
     inp = (10000).to_bytes(8, "big") + mocha["hashes"][0]
-    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][1], mocha["latest"], mocha["commits"][2])[0] == T.ERR_BAD_SIGNATURE
-    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][2], mocha["latest"], mocha["commits"][2])[0] == T.ERR_ASSERT
+    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][1], mocha["latest"], mocha["commits"][2], chain_id=b"mocha-4")[0] == T.ERR_BAD_SIGNATURE
+    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][2], mocha["latest"], mocha["commits"][2], chain_id=b"mocha-4")[0] == T.ERR_ASSERT
     v = mocha["commits"][1].copy()
     v[0]["signature"][5] ^= 1
-    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][1], mocha["latest"], v)[0] == T.ERR_BAD_SIGNATURE
+    assert oracle.next_header(inp, mocha["headers"][0], mocha["headers"][1], mocha["latest"], v, chain_id=b"mocha-4")[0] == T.ERR_BAD_SIGNATURE

@@ -131,6 +131,22 @@ def test_synthetic_chain_is_consistent():
     assert cres["two_thirds_ok"] == 1 and cres["trusted_signed_power"] == cres["total_power"]
 
 
+def test_chain_id_is_checked_by_skip_and_step():
+    """builder.skip / builder.step take C::CHAIN_ID_BYTES (header_range.rs:42-43, next_header.rs:32-33): a fork that
+    carries another chain id — same heights, same validator keys, validly signed — must be rejected, also when the
+    other id merely has the circuit's id as a prefix or differs in its last byte."""
+    for fork_id in ("celestiaX", "celestib", "mocha-4", "c"):
+        w = synth.Workload(98, 1, 2, 4, v=4, chain_id=fork_id)
+        args = (2, 4, w.input48(0), w.headers[0], int(w.first_height[0]), int(w.latest[0]), w.validators[0], w.trusted[0])
+        assert oracle.header_range(*args, chain_id=fork_id.encode())[0] == T.OK
+        assert oracle.header_range(*args)[0] == T.ERR_ASSERT                      # circuit constant b"celestia"
+        wS = synth.Workload(98, 1, 2, 4, v=4, chain_id=fork_id, mode="S")
+        inp = int(wS.first_height[0]).to_bytes(8, "big") + wS.hashes[0, 0].tobytes()
+        step = (inp, wS.headers[0, 0], wS.headers[0, 1], int(wS.latest[0]), wS.validators[0].reshape(-1, 4)[0])
+        assert oracle.next_header(*step, chain_id=fork_id.encode())[0] == T.OK
+        assert oracle.next_header(*step)[0] == T.ERR_ASSERT
+
+
 def _skip_search_case():
     """Start set of 9 validators (total power 100) and commits with chosen signers."""
     V = 9
