@@ -680,6 +680,7 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
         // differs fall back to the generic path inside bsxk_ed25519_verify_keyed
         DBuf dtab;
         RET(dtab.alloc(bsxk_keytable_bytes(v_max)));
+        HIPCHK(hipMemsetAsync(dtab.p, 0, (size_t)v_max * 64, st));        // key records: nothing to reuse in a fresh buffer
         HIPCHK(bsxk_ed25519_keytable(st, dv.as<bsx_validator>(), v_max, dtab.as<uint8_t>()));
         HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dtab.as<uint8_t>(), v_max, dok.as<uint8_t>()));
         SYNC();   // dtab is released at scope exit

@@ -162,15 +162,16 @@ BSX_HDI bool ed25519_verify_core(const uint32_t pk[8], const uint32_t sig_r[8], 
 
 // ------------------------------------------------------------------------------------------------ fixed-key path
 // A validator set signs every commit of a range batch with the same keys, so the per-key work (decompression and
-// the multiples table) is hoisted out of the per-signature lane: per key we keep j*(-2^(64k) A), k = 0..3, j = 1..128
-// (cached form, 40 int32 each), and the 253-bit scalars h and s are split into four 64-bit parts and recoded into
-// signed radix-256 digits.  One signature then costs 64 doublings + 64 additions instead of 256 + 128 and no
-// decompression (two parts of 128 bits, the first version: 128 + 64).
-#include "ed25519_btab8.h"   // ge_b8_limb: j * 2^(64k) * B, k = 0..3, j = 1..128 (generated)
+// the multiples table) is hoisted out of the per-signature lane: per key we keep j*(-2^(32k) A), k = 0..7, j = 1..128
+// (cached form, 40 int32 each), and the 253-bit scalars h and s are split into KT_PARTS parts and recoded into signed
+// radix-256 digits.  With eight 32-bit parts one signature costs 32 doublings + 64 additions instead of 256 + 128 and no
+// decompression (two parts of 128 bits, the first version: 128 + 64; four parts of 64 bits: 64 + 64).
+#include "ed25519_btab8.h"   // ge_b8_limb: j * 2^(32k) * B, k = 0..7, j = 1..128 (generated)
 
 constexpr int KT_ENTRY_I32 = 40;          // one cached point
 constexpr int KT_HALF_ENTRIES = 128;      // j = 1..128 per part
-constexpr int KT_PARTS = 4;               // scalar parts of 64 bits = 8 radix-256 digits each
+constexpr int KT_PARTS = GE_B8_PARTS;     // scalar parts of 256 / KT_PARTS bits (8 parts of 32 bits = 4 radix-256 digits each)
+static_assert(GE_B8_PARTS * GE_B8_PART_BITS == 256, "the generated B table must cover 256 scalar bits");
 constexpr int KT_PART_DIGITS = 32 / KT_PARTS;
 constexpr int KT_KEY_I32 = KT_PARTS * KT_HALF_ENTRIES * KT_ENTRY_I32;
 
@@ -186,18 +187,20 @@ BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
 }
 BSX_HDI int sc_digit8(const uint32_t r[8], int i) { return (int)((pick8(r, i >> 2) >> (8 * (i & 3))) & 255) - 128; }
 
-// per key: base[0] = -A, base[k] = 2^64 * base[k-1]; false when the key does not decode (RFC 8032 strict)
-BSX_HDI bool ge_keytable_bases(const uint32_t pk[8], ge_p3 (&base)[KT_PARTS]) {
-    const bool ok = ge_frombytes_negate(base[0], pk);
-    for (int k = 1; k < KT_PARTS; k++) {
-        ge_p2 q{base[k - 1].X, base[k - 1].Y, base[k - 1].Z};
-        ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
-        for (int i = 1; i < 8 * KT_PART_DIGITS; i++) {
-            q = p1p1_to_p2(t);
-            t = ge_dbl(q.X, q.Y, q.Z);
-        }
-        base[k] = p1p1_to_p3(t);
+// per key: base[0] = -A (false when the key does not decode, RFC 8032 strict), base[k] = 2^(part bits) * base[k-1]
+BSX_HDI ge_p3 ge_keytable_next_base(const ge_p3& prev) {
+    ge_p2 q{prev.X, prev.Y, prev.Z};
+    ge_p1p1 t = ge_dbl_inl(q.X, q.Y, q.Z);
+#pragma unroll 1
+    for (int i = 1; i < 8 * KT_PART_DIGITS; i++) {
+        q = p1p1_to_p2_inl(t);
+        t = ge_dbl_inl(q.X, q.Y, q.Z);
     }
+    return p1p1_to_p3_inl(t);
+}
+BSX_HDI bool ge_keytable_bases(const uint32_t pk[8], ge_p3 (&base)[KT_PARTS]) {      // host check / small uses
+    const bool ok = ge_frombytes_negate(base[0], pk);
+    for (int k = 1; k < KT_PARTS; k++) base[k] = ge_keytable_next_base(base[k - 1]);
     return ok;
 }
 // j * base, j in 1..128, by an 8-step double-and-add that is uniform across lanes (the addition is selected, not branched)
@@ -236,7 +239,7 @@ BSX_HDI ge_cached cached_load(const int32_t* src_) {
     }
     return c;
 }
-BSX_HDI ge_precomp ge_b8_entry(int half, int k) {  // (k+1) * 2^(64*part) * B
+BSX_HDI ge_precomp ge_b8_entry(int half, int k) {  // (k+1) * 2^(32*part) * B
     ge_precomp e;
 #pragma unroll
     for (int i = 0; i < 10; i++) {

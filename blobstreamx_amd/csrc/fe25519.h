@@ -61,8 +61,10 @@ BSX_HDI fe fe_from_v(i32x8 a, i32x2 b) {
 BSX_HDI i32x8 fe_lo8(const fe& f) { return i32x8{f.v[0], f.v[1], f.v[2], f.v[3], f.v[4], f.v[5], f.v[6], f.v[7]}; }
 BSX_HDI i32x2 fe_hi2(const fe& f) { return i32x2{f.v[8], f.v[9]}; }
 
-BSX_HD_NOINLINE fe fe_mul_v(i32x8 fa, i32x2 fb, i32x8 ga, i32x2 gb) {
-    const fe f = fe_from_v(fa, fb), g = fe_from_v(ga, gb);
+// the schoolbook body; fe_mul_inl inlines it at the call site (used only by the one-lane-per-key doubling chain of the
+// fixed-key table build, which is pure dependent-issue latency: inlined, the three / four independent field operations of
+// a point doubling interleave instead of running back to back behind call boundaries)
+BSX_HDI fe fe_mul_inl(const fe& f, const fe& g) {
     int32_t g19[10], f2[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) { g19[i] = 19 * g.v[i]; f2[i] = 2 * f.v[i]; }
@@ -81,6 +83,7 @@ BSX_HD_NOINLINE fe fe_mul_v(i32x8 fa, i32x2 fb, i32x8 ga, i32x2 gb) {
     }
     return fe_carry64(h);
 }
+BSX_HD_NOINLINE fe fe_mul_v(i32x8 fa, i32x2 fb, i32x8 ga, i32x2 gb) { return fe_mul_inl(fe_from_v(fa, fb), fe_from_v(ga, gb)); }
 BSX_HDI fe fe_mul(const fe& f, const fe& g) { return fe_mul_v(fe_lo8(f), fe_hi2(f), fe_lo8(g), fe_hi2(g)); }
 
 // h = f^2 (DBL == false) or 2 f^2 (DBL == true)
@@ -223,6 +226,21 @@ BSX_HDI ge_p1p1 ge_dbl(const fe& X, const fe& Y, const fe& Z) {
     ge_p1p1 r;
     fe xx = fe_sq(X), yy = fe_sq(Y), zz2 = fe_sq2(Z);
     fe t0 = fe_sq(fe_add(X, Y));
+    r.Y = fe_add(yy, xx);
+    r.Z = fe_sub(yy, xx);
+    r.X = fe_sub(t0, r.Y);
+    r.T = fe_sub(zz2, r.Z);
+    return r;
+}
+// inlined forms for latency-bound single-chain code (see fe_mul_inl)
+BSX_HDI ge_p2 p1p1_to_p2_inl(const ge_p1p1& p) { return ge_p2{fe_mul_inl(p.X, p.T), fe_mul_inl(p.Y, p.Z), fe_mul_inl(p.Z, p.T)}; }
+BSX_HDI ge_p3 p1p1_to_p3_inl(const ge_p1p1& p) {
+    return ge_p3{fe_mul_inl(p.X, p.T), fe_mul_inl(p.Y, p.Z), fe_mul_inl(p.Z, p.T), fe_mul_inl(p.X, p.Y)};
+}
+BSX_HDI ge_p1p1 ge_dbl_inl(const fe& X, const fe& Y, const fe& Z) {
+    ge_p1p1 r;
+    fe xx = fe_sq_impl<false>(X), yy = fe_sq_impl<false>(Y), zz2 = fe_sq_impl<true>(Z);
+    fe t0 = fe_sq_impl<false>(fe_add(X, Y));
     r.Y = fe_add(yy, xx);
     r.Z = fe_sub(yy, xx);
     r.X = fe_sub(t0, r.Y);

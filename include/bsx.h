@@ -366,7 +366,11 @@ int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
  * aligned); bsx_dev_ed25519_verify_keyed then checks n = n_commits*v_max slots, slot i of every commit against
  * table row i.  A slot whose public key differs from its table row (validator-set change inside the batch, or
  * i >= n_keys) is verified by the generic per-signature path inside the same kernel, so the accept set is
- * exactly bsx_dev_ed25519_verify's for any input. */
+ * exactly bsx_dev_ed25519_verify's for any input.
+ * d_table persists between calls: its first n_keys * 64 bytes (the key records) must be ZERO before the first call;
+ * afterwards bsx_dev_ed25519_keytable rebuilds only the rows whose public key (or n_keys) changed since the previous call
+ * on the same buffer — a validator set is stable for hours, so steady-state calls cost one key compare per row.  Zero the
+ * key records again (or set BSX_KEYTABLE_REUSE=0) to force a rebuild. */
 uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys);
 int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys,
                              void* d_table);

@@ -372,6 +372,61 @@ def test_ed25519_fixed_key_path_matches_generic_and_oracle(n_keys):
     assert ok_k.sum() > n_commits * v // 2
 
 
+def test_ed25519_key_table_reuse_across_calls_and_validator_set_changes():
+    """bsx_dev_ed25519_keytable keeps rows whose key is unchanged (one compare per row) and rebuilds exactly the rows that
+    changed: the same table buffer is driven through set A, set A again (pure reuse), set A with three slots re-keyed, a
+    different n_keys (layout change) and back; after every call the keyed verdicts must equal the oracle's, and the
+    stale-row hazard (a reused row must never serve another key) is probed by swapping two validators' slots."""
+    import ctypes as C
+    import torch
+    v = 20
+    L, ctx, dp = _lib.lib(), _lib.context(0), _lib.dp
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tab = torch.zeros(int(L.bsx_ed25519_keytable_bytes(C.c_uint32(v))), dtype=torch.uint8, device="cuda")
+    wA = synth.Workload(70, 3, 1, 2, v=v)
+    wB = synth.Workload(71, 3, 1, 2, v=v)              # a different validator set
+
+    def run(vals, hashes, n_keys):
+        flat = np.ascontiguousarray(vals).reshape(-1)
+        n = flat.size
+        dv = torch.from_numpy(flat.view(np.uint8).copy()).cuda()
+        dh = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+        ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(dv), C.c_uint64(n), dp(dh), None))
+        _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab)))
+        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v), dp(tab), C.c_uint32(n_keys), dp(ok)))
+        torch.cuda.synchronize()
+        ok = ok.cpu().numpy().reshape(vals.shape[0], v)
+        for c in range(vals.shape[0]):
+            _, rok = oracle.verify_commit(vals[c], hashes[c].tobytes())
+            assert (ok[c] == rok).all(), c
+        dirty = tab[:n_keys * 64].cpu().numpy().view(np.uint32).reshape(n_keys, 16)[:, 14]
+        return ok, dirty
+
+    ok, dirty = run(wA.validators, wA.commit_hashes, v)
+    assert ok.all() and dirty.all()                                   # cold: every row built
+    ok, dirty = run(wA.validators, wA.commit_hashes, v)
+    assert ok.all() and not dirty.any()                               # warm: nothing rebuilt, same verdicts
+    mixed = wA.validators.copy()
+    for slot in (2, 7, 19):
+        mixed[:, slot] = wB.validators[:, slot]                       # three validators replaced (their own valid signatures
+    hh = wA.commit_hashes                                             # are over wB's hashes: message check is the tally's job)
+    ok, dirty = run(mixed, hh, v)
+    assert list(np.nonzero(dirty)[0]) == [2, 7, 19] and ok.all()
+    swapped = wA.validators.copy()
+    swapped[:, [4, 5]] = swapped[:, [5, 4]]                            # same keys, other rows: both rows must be rebuilt
+    ok, dirty = run(swapped, wA.commit_hashes, v)
+    assert set(np.nonzero(dirty)[0]) == {2, 4, 5, 7, 19} and ok.all()
+    ok, dirty = run(wA.validators[:, :], wA.commit_hashes, 12)         # fewer table rows: layout changes, slots >= 12 fall back
+    assert dirty.all() and ok.all()
+    ok, dirty = run(wA.validators, wA.commit_hashes, v)
+    assert dirty.all() and ok.all()
+    bad = wA.validators.copy()
+    bad[1, 3]["signature"][3] ^= 1
+    ok, dirty = run(bad, wA.commit_hashes, v)
+    assert not dirty.any() and ok[1, 3] == 0 and ok.sum() == ok.size - 1
+
+
 def test_sha512_challenge_vs_oracle():
     import ctypes as C
     import torch
@@ -544,7 +599,7 @@ def test_golden_next_header_circuit(golden, mocha):
     for k in range(4):
         h = 10000 + k
         inp = h.to_bytes(8, "big") + mocha["hashes"][k]
-        out, cr = circ.prove(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1], chain_id=b"mocha-4")
+        out, cr = circ.prove(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1])
         rc, want, wcr = oracle.next_header(inp, mocha["headers"][k], mocha["headers"][k + 1], mocha["latest"], mocha["commits"][k + 1], chain_id=b"mocha-4")
         assert rc == T.OK and out == want and res_bytes(cr) == res_bytes(wcr)
         assert out[:32] == mocha["hashes"][k + 1]
