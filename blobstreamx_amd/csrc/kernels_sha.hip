@@ -431,6 +431,19 @@ __device__ __forceinline__ void batch_bounds(const uint32_t* W, uint64_t E, uint
 // ---- stage 2: one level of compute_root_from_leaves [UPSTREAM plonky2x; SURVEY App. B] for all jobs at once:
 // inner = inner_hash(l, r) always; node = both children enabled ? inner : l; enabled = l || r (prefix mask).
 constexpr int TR_THREADS = 256;
+// node t of tree level `level` (width nodes, stored at level_off) of the job whose compact witness is cw, from its two
+// children l, r; nb = nb_enabled_leaves (builder.rs:119,124, low limb).  Returns the selected node.
+__device__ __forceinline__ Digest tree_node(uint8_t* cw, uint32_t off_bools, uint32_t B, uint32_t level, uint32_t level_off, uint32_t t,
+                                            uint32_t nb, const Digest& l, const Digest& r) {
+    const uint32_t span = 1u << level;                   // leaves under a node of this level
+    const Digest in = inner_hash(l, r);
+    const bool en_l = t * span < nb, en_r = t * span + span / 2 < nb;
+    const Digest node = (en_l && en_r) ? in : l;
+    store_digest_global(cw + bsx_off_inner(B) + 32 * (level_off + t), in);
+    store_digest_global(cw + bsx_off_nodes(B) + 32 * (level_off + t), node);
+    cw[off_bools + bsx_b_node_enabled(B) + level_off + t] = en_l || en_r;
+    return node;
+}
 __global__ __launch_bounds__(TR_THREADS) void k_tree_level(SubchainArgs a) {
     BSX_CHAIN_PRIO();
     const uint32_t B = a.batch, width = a.width;
@@ -442,27 +455,25 @@ __global__ __launch_bounds__(TR_THREADS) void k_tree_level(SubchainArgs a) {
     const uint64_t E = a.ranges[q / a.job_count].end_block;
     uint64_t bs, be, te, ebn;
     batch_bounds(W, E, bs, be, te, ebn);
-    const uint32_t nb = (uint32_t)(ebn - bs);           // builder.rs:119,124 nb_enabled_leaves (low limb)
-    const uint32_t span = 1u << a.level;                 // leaves under a node of this level
+    const uint32_t nb = (uint32_t)(ebn - bs);
     // children: level 1 reads the leaf hashes, upper levels the previous level's selected nodes
     const uint8_t* ch = (a.level == 1) ? cw + bsx_off_leaf_hashes(B) + 64 * t
                                        : cw + bsx_off_nodes(B) + 32 * (a.level_off - 2 * width + 2 * t);
     const Digest l = load_digest_global(ch), r = load_digest_global(ch + 32);
-    const Digest in = inner_hash(l, r);
-    const bool en_l = t * span < nb, en_r = t * span + span / 2 < nb;
-    const Digest node = (en_l && en_r) ? in : l;
-    store_digest_global(cw + bsx_off_inner(B) + 32 * (a.level_off + t), in);
-    store_digest_global(cw + bsx_off_nodes(B) + 32 * (a.level_off + t), node);
-    cw[a.off_bools + bsx_b_node_enabled(B) + a.level_off + t] = en_l || en_r;
+    tree_node(cw, a.off_bools, B, a.level, a.level_off, t, nb, l, r);
 }
 
 // ---- stage 3: predicates + batch tail (builder.rs:174-270), no hashing.  256 consecutive slots per workgroup;
 // per-slot assertion bits are reduced with a wave ballot and at most one LDS atomic per failing lane.
 constexpr int BF_THREADS = 256;
+constexpr uint32_t BF_TOP_WIDTH = 8;
 __global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
     BSX_CHAIN_PRIO();
     __shared__ uint32_t job_fail[BF_THREADS];
     __shared__ uint32_t job_first_bad[BF_THREADS];
+    // the top of every job's commitment tree (levels of width <= BF_TOP_WIDTH) is folded here instead of by one
+    // k_tree_level launch per level: those launches held 4 .. 32 nodes per job and cost ~28 us each, mostly launch gap
+    __shared__ uint32_t top_nodes[2][BF_THREADS / 2 * 8];
     const uint32_t B = a.batch, tid = threadIdx.x;
     const uint64_t total = (uint64_t)a.n_jobs * B;
     const uint64_t gs0 = (uint64_t)blockIdx.x * BF_THREADS;
@@ -531,9 +542,37 @@ __global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
         }
     }
     __syncthreads();
+    // top tree levels: level a.level (width a.width, at a.level_off) reads what the last k_tree_level launch (or, for
+    // B <= 2 * BF_TOP_WIDTH, k_slot_hashes) left in global memory; the levels above hand over through LDS
+    Digest root = start_header;
+    if (B > 1) {
+        uint32_t level = a.level, level_off = a.level_off, cur = 0;
+        for (uint32_t width = a.width; width >= 1; width /= 2, level++) {
+            if (live && i < width) {
+                Digest l, r;
+                if (width == a.width) {
+                    const uint8_t* ch = (level == 1) ? cw + bsx_off_leaf_hashes(B) + 64 * i
+                                                     : cw + bsx_off_nodes(B) + 32 * (level_off - 2 * width + 2 * i);
+                    l = load_digest_global(ch); r = load_digest_global(ch + 32);
+                } else {
+                    const uint32_t* s = &top_nodes[cur][(jl * a.width + 2 * i) * 8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { l.w[k] = s[k]; r.w[k] = s[8 + k]; }
+                }
+                const Digest node = tree_node(cw, a.off_bools, B, level, level_off, i, nb_enabled, l, r);
+                uint32_t* d = &top_nodes[cur ^ 1][(jl * a.width + i) * 8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = node.w[k];
+                if (width == 1) root = node;
+            }
+            __syncthreads();
+            cur ^= 1;
+            level_off += width;
+        }
+    }
     // batch tail + record (builder.rs:229-270): one lane per job
     if (live && i == 0) {
-        const Digest root = load_digest_global(B > 1 ? cw + bsx_off_nodes(B) + 32 * (B - 2) : cw + bsx_off_leaf_hashes(B));
+        if (B == 1) root = load_digest_global(cw + bsx_off_leaf_hashes(B));
         const bool curr_enabled_end = batch_enabled && !(jstar < (uint64_t)B);   // enabled after the last slot
         const Digest curr_final = (m > 0) ? load_digest_global(slots + BSX_SLOT_BYTES * (m - 1) + 160 + 128) : start_header;
         const Digest end_header = load_digest_global(cw + bsx_off_end_header());
@@ -781,12 +820,14 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     const uint64_t slots = (uint64_t)n_jobs * B;
     hipLaunchKernelGGL(k_slot_hashes, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
     uint32_t level_off = 0, level = 1;
-    for (uint32_t width = B / 2; width >= 1; width /= 2, level++) {
+    for (uint32_t width = B / 2; width > BF_TOP_WIDTH; width /= 2, level++) {
         a.level = level; a.width = width; a.level_off = level_off;
         const uint64_t nodes = (uint64_t)n_jobs * width;
         hipLaunchKernelGGL(k_tree_level, dim3((uint32_t)((nodes + TR_THREADS - 1) / TR_THREADS)), dim3(TR_THREADS), 0, s, a);
         level_off += width;
     }
+    // the remaining levels (width <= BF_TOP_WIDTH) run inside k_batch_finish
+    a.level = level; a.width = B / 2 < BF_TOP_WIDTH ? B / 2 : BF_TOP_WIDTH; a.level_off = level_off;
     hipLaunchKernelGGL(k_batch_finish, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
     return hipGetLastError();
 }
