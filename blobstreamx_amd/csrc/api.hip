@@ -52,6 +52,7 @@ static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
 
 namespace bsxapi {
 thread_local std::string g_err;
+thread_local bsx_arena* tl_arena = nullptr;
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -100,7 +101,8 @@ int bsx_init(int device, bsx_ctx** out) {
         return fail(BSX_ERR_NO_DEVICE, "no HIP device visible (%s); libbsx has no CPU fallback", e == hipSuccess ? "count == 0" : hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(BSX_ERR_BAD_ARG, "device %d out of range (0..%d)", device, n - 1);
     if (hipSetDevice(device) != hipSuccess) return fail(BSX_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
-    bsx_ctx* c = new bsx_ctx{device, nullptr};
+    bsx_ctx* c = new bsx_ctx{};
+    c->device = device;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -114,6 +116,7 @@ void bsx_shutdown(bsx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     delete ctx;
 }
 
@@ -138,6 +141,9 @@ int bsx_reduce_witness_layout(bsx_witness_layout* out) {
 
 // ------------------------------------------------------------------------------------------------ device tier
 #define DEV_ENTER() RET(use(ctx))
+#define HOST_ENTER()  \
+    RET(use(ctx));    \
+    bsxapi::ArenaScope arena_scope_(ctx)
 
 int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n, uint8_t* d_hashes,
                           uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint32_t* d_status) {
@@ -296,7 +302,7 @@ static int header_status_to_rc(uint32_t hs, uint32_t as) {
 }
 
 int bsx_encode_data_root_tuple(bsx_ctx* ctx, const uint8_t data_hash[32], uint64_t height, uint8_t out[64]) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!data_hash || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
     hipStream_t st = ctx->stream;
     DBuf d;
@@ -310,7 +316,7 @@ int bsx_encode_data_root_tuple(bsx_ctx* ctx, const uint8_t data_hash[32], uint64
 
 int bsx_get_data_commitment(bsx_ctx* ctx, const uint8_t* data_hashes, uint32_t max_leaves, uint64_t start_block, uint64_t end_block,
                             uint8_t out_root[32]) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!data_hashes || !out_root) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!pow2(max_leaves) || max_leaves > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "MAX_LEAVES must be a power of two <= %d", BSX_MAX_BATCH);
     hipStream_t st = ctx->stream;
@@ -331,7 +337,7 @@ int bsx_get_data_commitment(bsx_ctx* ctx, const uint8_t* data_hashes, uint32_t m
 
 int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8_t* out_hashes, bsx_data_hash_proof* out_dh,
                       bsx_last_block_id_proof* out_lb) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (n && !headers) return fail(BSX_ERR_BAD_ARG, "null headers");
     if (!n) return BSX_OK;
     hipStream_t st = ctx->stream;
@@ -402,7 +408,7 @@ int bsx_data_commitment_inputs(bsx_ctx* ctx, const bsx_header* headers, uint64_t
                                uint64_t start_block, uint64_t end_block, uint32_t max_leaves, uint8_t out_start_header[32],
                                uint8_t out_end_header[32], bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb,
                                uint8_t out_expected_data_commitment[32]) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!out_start_header || !out_end_header || !out_dh || !out_lb) return fail(BSX_ERR_BAD_ARG, "null output");
     if (!max_leaves || max_leaves > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "MAX_LEAVES must be in 1..%d", BSX_MAX_BATCH);
     if (end_block - start_block > (uint64_t)max_leaves) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start > MAX_LEAVES (circuits/input.rs:154)");
@@ -462,7 +468,7 @@ int bsx_prove_subchain(bsx_ctx* ctx, uint32_t batch_size, const uint8_t start_he
                        const bsx_data_hash_proof* dh, const bsx_last_block_id_proof* lb, uint64_t batch_start_block,
                        uint64_t batch_end_block, uint64_t global_end_block, const uint8_t global_end_header_hash[32],
                        bsx_subchain* out_record, uint64_t* witness) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!start_header || !end_header || !dh || !lb || !global_end_header_hash || !out_record) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
     const uint32_t B = batch_size;
@@ -500,7 +506,7 @@ int bsx_prove_subchain(bsx_ctx* ctx, uint32_t batch_size, const uint8_t start_he
 }
 
 int bsx_reduce(bsx_ctx* ctx, const bsx_subchain* records, uint32_t n, bsx_subchain* out) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!records || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!pow2(n) || n > 256) return fail(BSX_ERR_BAD_ARG, "reduce fan-in must be a power of two <= 256 (got %u)", n);
     hipStream_t st = ctx->stream;
@@ -568,7 +574,7 @@ static int run_data_commitment(hipStream_t st, uint32_t J, uint32_t B, RangeDev&
 int bsx_prove_data_commitment(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const bsx_shared_ctx* range, const bsx_header* headers,
                               uint64_t first_height, uint64_t n_headers, uint64_t latest_block, uint8_t out_data_commitment[32],
                               bsx_subchain* out_result, bsx_subchain* records, uint64_t* witness) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!range || !out_data_commitment) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!pow2(nb_map_jobs) || nb_map_jobs > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
@@ -581,7 +587,7 @@ int bsx_prove_data_commitment(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch
 int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_number, const uint8_t prev_header_hash[32],
                                           uint64_t next_block_number, const bsx_header* header, uint64_t latest_block,
                                           uint8_t out_data_commitment[32]) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!prev_header_hash || !header || !out_data_commitment) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (next_block_number - prev_block_number > 1) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start > MAX_LEAVES = 1 (circuits/input.rs:154)");
     if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
@@ -624,7 +630,7 @@ int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_numb
 int bsx_find_block_to_request(bsx_ctx* ctx, uint64_t start_block, uint64_t max_end_block, const bsx_validator* start_validators,
                               uint32_t n_candidates, const uint64_t* candidate_heights, const bsx_validator* candidate_validators,
                               uint32_t v_max, uint64_t* out_block, bsx_skip_eval* out_evals) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!out_block || !start_validators || (n_candidates && (!candidate_heights || !candidate_validators)))
         return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (max_end_block <= start_block) return fail(BSX_ERR_BAD_ARG, "max_end_block must be above start_block");
@@ -660,7 +666,7 @@ int bsx_find_block_to_request(bsx_ctx* ctx, uint64_t start_block, uint64_t max_e
 
 int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,
                        bsx_commit_result* out_results, uint8_t* out_sig_ok) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!validators || !header_hashes || !out_results) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
     if (!n_commits) return BSX_OK;
@@ -698,7 +704,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                      uint64_t first_height, uint64_t n_headers, uint64_t latest_block, const bsx_validator* target_validators,
                      const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!input48 || !headers || !target_validators || !trusted_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     if (!pow2(nb_map_jobs) || nb_map_jobs > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
@@ -761,7 +767,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
 int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
                     uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
                     uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit) {
-    DEV_ENTER();
+    HOST_ENTER();
     if (!input40 || !prev_header || !next_header || !next_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     uint64_t prev_block = 0;                                                    // next_header.rs:26 evm_read u64 (big endian)

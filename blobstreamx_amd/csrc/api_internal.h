@@ -8,9 +8,22 @@
 
 #include "../../include/bsx.h"
 
+#include <vector>
+
+// Scratch arena of the host tier: one device allocation per context, bump-allocated by the DBufs of a host-tier call
+// and rewound when the outermost call returns — a hipMalloc/hipFree pair per buffer per call cost more than the
+// kernels of a single header_range (bench.py `latency`).  A call that needs more than the arena holds takes overflow
+// chunks for its duration; the arena is then regrown once to that call's total.
+struct bsx_arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, need = 0;
+    int depth = 0;
+    std::vector<void*> overflow;
+};
 struct bsx_ctx {
     int device;
     hipStream_t stream;
+    bsx_arena arena;
 };
 
 namespace bsxapi {
@@ -31,14 +44,53 @@ int use(bsx_ctx* ctx);                       // hipSetDevice(ctx->device)
 
 inline bool pow2(uint32_t x) { return x && !(x & (x - 1)); }
 
+extern thread_local bsx_arena* tl_arena;      // arena of the host-tier call running on this thread (null: plain hipMalloc)
+
+// RAII of one host-tier entry point (nested entry points share the outermost scope)
+struct ArenaScope {
+    bsx_arena* a;
+    bsx_arena* prev;
+    explicit ArenaScope(bsx_ctx* ctx) : a(&ctx->arena), prev(tl_arena) {
+        tl_arena = a;
+        a->depth++;
+    }
+    ~ArenaScope() {
+        if (--a->depth == 0) {
+            if (!a->overflow.empty()) {                       // grow once to what this call needed
+                for (void* q : a->overflow) (void)hipFree(q);
+                a->overflow.clear();
+                if (a->base) (void)hipFree(a->base);
+                a->base = nullptr;
+                a->cap = a->need + a->need / 4 + (1u << 20);
+                if (hipMalloc(reinterpret_cast<void**>(&a->base), a->cap) != hipSuccess) { a->base = nullptr; a->cap = 0; }
+            }
+            a->off = 0;
+            a->need = 0;
+        }
+        tl_arena = prev;
+    }
+};
+
 // device buffer with the lifetime of one host-tier call
 struct DBuf {
     void* p = nullptr;
-    ~DBuf() { if (p) (void)hipFree(p); }
+    bool owned = false;
+    ~DBuf() { if (p && owned) (void)hipFree(p); }
     int alloc(size_t n) {
         if (n == 0) n = 16;
+        n = (n + 255) & ~(size_t)255;
+        bsx_arena* a = tl_arena;
+        if (a) {
+            a->need += n;
+            if (a->off + n <= a->cap) {
+                p = a->base + a->off;
+                a->off += n;
+                return BSX_OK;
+            }
+        }
         hipError_t e = hipMalloc(&p, n);
         if (e != hipSuccess) return fail(BSX_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+        if (a) a->overflow.push_back(p); else owned = true;
         return BSX_OK;
     }
     template <typename T> T* as() const { return static_cast<T*>(p); }

@@ -88,6 +88,7 @@ int bsx_dev_poseidon_merkle_caps(bsx_ctx* ctx, void* stream, uint64_t* d_trees, 
 // ------------------------------------------------------------------------------------------------ host tier
 int bsx_poseidon_permute(bsx_ctx* ctx, const uint64_t* states, uint64_t n, uint64_t* out) {
     RET(use(ctx));
+    bsxapi::ArenaScope arena_scope_(ctx);
     if (n && (!states || !out)) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!n) return BSX_OK;
     hipStream_t st = ctx->stream;
@@ -102,6 +103,7 @@ int bsx_poseidon_permute(bsx_ctx* ctx, const uint64_t* states, uint64_t n, uint6
 
 int bsx_poseidon_hash_no_pad(bsx_ctx* ctx, const uint64_t* elements, uint64_t n_inputs, uint32_t len, uint64_t* out_digests) {
     RET(use(ctx));
+    bsxapi::ArenaScope arena_scope_(ctx);
     if (n_inputs && (!out_digests || (len && !elements))) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!n_inputs) return BSX_OK;
     if (n_inputs > 0x7fffffffull) return fail(BSX_ERR_BAD_ARG, "too many inputs");
@@ -124,6 +126,7 @@ int bsx_poseidon_hash_no_pad(bsx_ctx* ctx, const uint64_t* elements, uint64_t n_
 
 int bsx_poseidon_two_to_one(bsx_ctx* ctx, const uint64_t* left, const uint64_t* right, uint64_t n, uint64_t* out_digests) {
     RET(use(ctx));
+    bsxapi::ArenaScope arena_scope_(ctx);
     if (n && (!left || !right || !out_digests)) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!n) return BSX_OK;
     if (n > 0x3fffffffull) return fail(BSX_ERR_BAD_ARG, "too many pairs");
@@ -144,6 +147,7 @@ int bsx_poseidon_two_to_one(bsx_ctx* ctx, const uint64_t* left, const uint64_t* 
 int bsx_poseidon_merkle_tree(bsx_ctx* ctx, const uint64_t* elements, uint64_t n_elements, uint32_t leaf_len, uint32_t n_leaves,
                              uint32_t cap_height, uint64_t* out_tree) {
     RET(use(ctx));
+    bsxapi::ArenaScope arena_scope_(ctx);
     if (!elements || !out_tree) return fail(BSX_ERR_BAD_ARG, "null pointer");
     RET(tree_args_ok(leaf_len, n_leaves, cap_height));
     if ((n_elements + leaf_len - 1) / leaf_len > n_leaves) return fail(BSX_ERR_BAD_ARG, "n_leaves rows of leaf_len do not cover n_elements");
@@ -165,6 +169,7 @@ int bsx_poseidon_merkle_tree(bsx_ctx* ctx, const uint64_t* elements, uint64_t n_
 int bsx_witness_merkle_caps(bsx_ctx* ctx, const bsx_witness_layout* layout, const uint64_t* witness, uint32_t n_jobs, uint32_t leaf_len,
                             uint32_t cap_height, uint64_t* out_caps) {
     RET(use(ctx));
+    bsxapi::ArenaScope arena_scope_(ctx);
     if (!layout || !witness || !out_caps) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!n_jobs) return BSX_OK;
     const uint32_t n_leaves = bsx_witness_leaf_count(layout->n_elements, leaf_len);

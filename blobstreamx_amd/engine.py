@@ -137,6 +137,10 @@ class HeaderRangeEngine:
         self._parity = 0
         self._target_hashes_pp = [_u8(R * 32, d), _u8(R * 32, d)]
         self._skip_hashes_pp = [_u8(R * 2 * 32, d), _u8(R * 2 * 32, d)]
+        self._skip_headers_pp = [_u8(R * 2 * 512, d), _u8(R * 2 * 512, d)]   # the (trusted, target) headers the check reads
+        self.inputs_consumed = None                # event: this pass no longer reads headers_all (input streaming)
+        self._h2d = None                           # (copy stream, pinned host image of headers_all) when inputs are streamed
+        self._h2d_done = None
         self._commit_done = [None, None]           # event per parity: the side stream finished the check that used it
         self.skip_ranges_side = _u8(R * 80, d)
         self.defer_commit_wait = False             # PipelinedEngines: do not join the side stream at the end of a pass
@@ -250,6 +254,29 @@ class HeaderRangeEngine:
         sk = np.stack([w.headers[own, 0], w.headers[own, w.n_blocks]], axis=1)
         self.upload(hs, w.ranges[sel], w.latest[sel], sk, w.ranges[own], w.validators[own], w.trusted[own])
 
+    def enable_input_streaming(self, host_image=None):
+        """Stream the NEXT pass's headers from pinned host memory while this pass computes (what a caller that does not
+        keep its inputs in HBM sees): stream_inputs() enqueues one H2D copy of the whole header block on a copy stream
+        as soon as the current pass has consumed the buffer (header hashing + hint assembly, early in the pass), the
+        next step_local waits for it.  host_image: pinned uint8 tensor, default = a pinned copy of the resident block."""
+        if host_image is None:
+            host_image = torch.empty(self.headers_all.numel(), dtype=torch.uint8, pin_memory=True)
+            host_image.copy_(self.headers_all)
+            torch.cuda.synchronize(self.dev)
+        assert host_image.is_pinned() and host_image.numel() == self.headers_all.numel()
+        self._h2d = (torch.cuda.Stream(device=self.dev), host_image)
+
+    def stream_inputs(self):
+        if self._h2d is None:
+            return
+        s, img = self._h2d
+        if self.inputs_consumed is not None:
+            s.wait_event(self.inputs_consumed)
+        with torch.cuda.stream(s):
+            self.headers_all.copy_(img, non_blocking=True)
+            self._h2d_done = torch.cuda.Event()
+            self._h2d_done.record(s)
+
     # ------------------------------------------------------------------ one pass
     def _st(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -263,6 +290,9 @@ class HeaderRangeEngine:
         main = torch.cuda.current_stream(self.dev)
         st = self._st()
         ev = self.events if time_kernels else None
+        if self._h2d_done is not None:             # streamed inputs: this pass's headers arrive on the copy stream
+            main.wait_event(self._h2d_done)
+            self._h2d_done = None
         self.status.zero_()
         commit = self.with_commit and R and self.nh_all > RT * self.hpr
         if commit and self.commit_with != "hash":
@@ -281,6 +311,8 @@ class HeaderRangeEngine:
                 main.wait_event(done)
             chk(L.bsx_dev_fill_end_hash(ctx, st, C.c_uint32(R), dp(self.skip_ranges), dp(self.skip_hashes), C.c_uint64(2),
                                         dp(self.target_idx), dp(self.target_hashes), dp(self._skip_hashes_pp[self._parity])))
+            if self.nh_all > RT * self.hpr:
+                self._skip_headers_pp[self._parity][:R * 1024].copy_(self.skip_headers[:R * 1024], non_blocking=True)   # 1 KB per range, d2d
             self.fill_done = torch.cuda.Event()
             self.fill_done.record(main)
             if self.commit_with == "hash":
@@ -291,6 +323,8 @@ class HeaderRangeEngine:
                                       C.c_uint32(jc), C.c_uint32(B), dp(self.ranges), dp(self.latest), dp(self.headers),
                                       C.c_uint64(self.hpr), C.c_uint64(self.hfr), dp(self.hashes), dp(self.dh_aunts),
                                       dp(self.lb_aunts), dp(self.compact), dp(self.status[1:])))
+        self.inputs_consumed = torch.cuda.Event()
+        self.inputs_consumed.record(main)          # headers_all may be overwritten from here on (stream_inputs)
         if ev:
             ev[0].record(main)
         chk(L.bsx_dev_prove_subchain(ctx, st, C.c_uint32(RT), C.c_uint32(B), C.c_uint32(jc), dp(self.ranges), dp(self.compact),
@@ -322,7 +356,7 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.trusted), C.c_uint32(R), C.c_uint32(V), None, None, dp(self.trusted_res)))
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.validators), C.c_uint32(R), C.c_uint32(V), dp(self.target_hashes), dp(self.ok),
                                    dp(self.commit_res)))
-        chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges_side), dp(self.skip_headers),
+        chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges_side), dp(self._skip_headers_pp[self._parity]),
                                  C.c_uint64(2), dp(self._skip_hashes_pp[self._parity]), dp(self.validators), dp(self.trusted),
                                  dp(self.ok), dp(self.commit_res), dp(self.trusted_res), dp(self.skip_status), None,
                                  dp(self.target_idx), _lib.p(self.chain_id) if self.chain_id.size else None,
@@ -430,6 +464,7 @@ class HeaderRangeEngine:
 
     def step(self, time_kernels=False):
         self.step_local(time_kernels)
+        self.stream_inputs()
         res = self.step_exchange()
         self.step_final(res, time_kernels)
         self.join_commit()
@@ -500,6 +535,7 @@ class PipelinedEngines:
                 if self.E > 1 and self._hash_token is not None:
                     s.wait_event(self._hash_token)
                 eng.step_local(time_kernels)
+                eng.stream_inputs()                # no-op unless enable_input_streaming(): next pass's headers, H2D
                 if self._pending_verify is not None:
                     # the previous chunk's signature checks: enqueued now so that they can wait for THIS chunk's
                     # k_header_merkle (both are integer-ALU bound; the rest of this chunk's hashing phase leans on memory)

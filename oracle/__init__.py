@@ -342,3 +342,15 @@ def poseidon_merkle_tree(elements, leaf_len, n_leaves, cap_height):
                                         C.c_uint32(cap_height), _p(tree))
     assert rc == 0, rc
     return tree, tree[-(1 << cap_height):]
+
+
+def bench_verify_commits(validators, header_hashes, n_threads, reps=1):
+    """mode S driver: validators [n_commits, v_max] VALIDATOR, header_hashes [n_commits, 32] -> (results, sig_ok)."""
+    v = np.ascontiguousarray(validators, T.VALIDATOR)
+    n, vmax = v.shape
+    hh = np.ascontiguousarray(header_hashes, np.uint8).reshape(n, 32)
+    res = np.zeros(n, T.COMMIT_RESULT)
+    ok = np.zeros((n, vmax), np.uint8)
+    rc = lib().orc_bench_verify_commits(C.c_uint32(n), C.c_uint32(reps), C.c_uint32(vmax), _p(v), _p(hh), C.c_int(n_threads), _p(res), _p(ok))
+    assert rc == 0
+    return res, ok

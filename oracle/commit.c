@@ -272,6 +272,50 @@ int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t J, uint32_
     return rc;
 }
 
+/* mode S (one commit per header; BASELINE configs #4/#5, next_header.rs:25-47 per header): n_commits * reps
+ * orc_verify_commit tasks over n_threads threads; results / sig_ok of the first repetition are returned */
+typedef struct {
+    uint32_t n_commits, v_max, reps;
+    const bsx_validator* vals;
+    const uint8_t* hashes;
+    bsx_commit_result* res;
+    uint8_t* ok;
+    int n_threads, tid;
+} sjob_t;
+static void* sworker(void* arg) {
+    sjob_t* jb = arg;
+    uint8_t* tmp_ok = malloc(jb->v_max);
+    const uint32_t n_tasks = jb->n_commits * jb->reps;
+    for (uint32_t t = (uint32_t)jb->tid; t < n_tasks; t += (uint32_t)jb->n_threads) {
+        const uint32_t c = t % jb->n_commits;
+        bsx_commit_result r;
+        orc_verify_commit(jb->vals + (size_t)c * jb->v_max, jb->v_max, jb->hashes + 32 * (size_t)c, &r, tmp_ok);
+        if (t < jb->n_commits) {
+            jb->res[c] = r;
+            if (jb->ok) memcpy(jb->ok + (size_t)c * jb->v_max, tmp_ok, jb->v_max);
+        }
+    }
+    free(tmp_ok);
+    return NULL;
+}
+int orc_bench_verify_commits(uint32_t n_commits, uint32_t reps, uint32_t v_max, const bsx_validator* validators,
+                             const uint8_t* header_hashes, int n_threads, bsx_commit_result* out_results, uint8_t* out_sig_ok) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    if (reps < 1) reps = 1;
+    sjob_t* jobs = calloc((size_t)n_threads, sizeof *jobs);
+    pthread_t* th = calloc((size_t)n_threads, sizeof *th);
+    for (int t = 0; t < n_threads; t++) {
+        sjob_t j = {n_commits, v_max, reps, validators, header_hashes, out_results, out_sig_ok, n_threads, t};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, sworker, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    free(jobs);
+    free(th);
+    return BSX_OK;
+}
+
 
 /* ---------------------------------------------------------------- skip-target search (fetcher.rs:60-87) */
 /* is_valid_skip(start set, target set, target commit): [UPSTREAM] tendermintx v1.0.0 — PARITY UNPINNED.  Restated as:

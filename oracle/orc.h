@@ -131,6 +131,9 @@ int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t nb_map_job
                            const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id,
                            uint32_t chain_id_len, int with_witness, int n_threads, uint8_t* out64, uint64_t* checksum);
 
+int orc_bench_verify_commits(uint32_t n_commits, uint32_t reps, uint32_t v_max, const bsx_validator* validators,
+                             const uint8_t* header_hashes, int n_threads, bsx_commit_result* out_results, uint8_t* out_sig_ok);
+
 #ifdef __cplusplus
 }
 #endif
