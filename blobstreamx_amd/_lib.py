@@ -24,7 +24,7 @@ SYMBOLS = [
     "bsx_encode_data_root_tuple", "bsx_get_data_commitment", "bsx_header_hashes", "bsx_data_commitment_inputs",
     "bsx_prove_subchain", "bsx_reduce", "bsx_prove_data_commitment", "bsx_prove_next_header_data_commitment",
     "bsx_verify_commits", "bsx_header_range", "bsx_next_header",
-    "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_reduce_strided", "bsx_dev_finalize",
+    "bsx_dev_alloc", "bsx_dev_free", "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_reduce_strided", "bsx_dev_finalize",
     "bsx_dev_expand_witness", "bsx_dev_fill_end_hash", "bsx_dev_sha512_challenge", "bsx_dev_ed25519_verify",
     "bsx_dev_commit_tally", "bsx_dev_skip_check",
     "bsx_ed25519_keytable_bytes", "bsx_dev_ed25519_keytable", "bsx_dev_ed25519_verify_keyed",
@@ -117,3 +117,26 @@ def dp(t):
     if isinstance(t, int):
         return C.c_void_p(t)
     return C.c_void_p(t.data_ptr())
+
+
+class DeviceBuffer:
+    """A bsx_dev_alloc block (VMM-backed device memory for the large streaming buffers) seen as a torch int64 tensor
+    through __cuda_array_interface__ — zero copy; the block is released when the last tensor view is gone."""
+
+    def __init__(self, n_int64, device=0):
+        self.device, self.n = device, int(n_int64)
+        self.ptr = C.c_void_p()
+        check(lib().bsx_dev_alloc(context(device), C.c_uint64(self.n * 8), C.byref(self.ptr)))
+        self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "<i8", "data": (int(self.ptr.value), False), "version": 2}
+
+    def tensor(self):
+        import torch
+        return torch.as_tensor(self, device=f"cuda:{self.device}")
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ptr.value:
+                lib().bsx_dev_free(context(self.device), self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass

@@ -117,6 +117,7 @@ void bsx_shutdown(bsx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    for (auto& b : ctx->vmm) { (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size); }
     delete ctx;
 }
 
@@ -144,6 +145,53 @@ int bsx_reduce_witness_layout(bsx_witness_layout* out) {
 #define HOST_ENTER()  \
     RET(use(ctx));    \
     bsxapi::ArenaScope arena_scope_(ctx)
+
+int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr) {
+    DEV_ENTER();
+    if (!out_ptr || !bytes) return fail(BSX_ERR_BAD_ARG, "bsx_dev_alloc: null out / zero size");
+    *out_ptr = nullptr;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    size_t gran = 0;
+    HIPCHK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (gran < (2u << 20)) gran = 2u << 20;
+    const size_t size = (bytes + gran - 1) / gran * gran;
+    bsx_vmm_block b{nullptr, size, {}};
+    HIPCHK(hipMemCreate(&b.handle, size, &prop, 0));
+    hipError_t e = hipMemAddressReserve(&b.va, size, 1ull << 30, nullptr, 0);
+    if (e == hipSuccess) e = hipMemMap(b.va, size, 0, b.handle, 0);
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (e == hipSuccess) e = hipMemSetAccess(b.va, size, &acc, 1);
+    if (e == hipSuccess) e = hipMemsetAsync(b.va, 0, size, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipMemRelease(b.handle);
+        if (b.va) (void)hipMemAddressFree(b.va, size);
+        return fail(BSX_ERR_HIP, "bsx_dev_alloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    }
+    ctx->vmm.push_back(b);
+    *out_ptr = b.va;
+    return BSX_OK;
+}
+
+int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
+    DEV_ENTER();
+    for (size_t i = 0; i < ctx->vmm.size(); i++)
+        if (ctx->vmm[i].va == ptr) {
+            const bsx_vmm_block b = ctx->vmm[i];
+            ctx->vmm.erase(ctx->vmm.begin() + (long)i);
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemUnmap(b.va, b.size));
+            HIPCHK(hipMemRelease(b.handle));
+            HIPCHK(hipMemAddressFree(b.va, b.size));
+            return BSX_OK;
+        }
+    return fail(BSX_ERR_BAD_ARG, "bsx_dev_free: pointer was not returned by bsx_dev_alloc on this context");
+}
 
 int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n, uint8_t* d_hashes,
                           uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint32_t* d_status) {

@@ -20,10 +20,16 @@ struct bsx_arena {
     int depth = 0;
     std::vector<void*> overflow;
 };
+struct bsx_vmm_block {
+    void* va;
+    size_t size;
+    hipMemGenericAllocationHandle_t handle;
+};
 struct bsx_ctx {
     int device;
     hipStream_t stream;
     bsx_arena arena;
+    std::vector<bsx_vmm_block> vmm;      // bsx_dev_alloc blocks still alive
 };
 
 namespace bsxapi {

@@ -705,8 +705,8 @@ __global__ void k_finalize(uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t bat
 
 // ------------------------------------------------------------------------------------------------ k_expand_witness
 // HBM-write bound: every lane emits 16 bytes (two Goldilocks elements) per store, lane-contiguous (1 KiB per wave
-// store).  grid.y = job; a job's expanded image starts at job * n_elements * 8 bytes (8-byte aligned only), so lanes
-// are aligned to GLOBAL 16-byte pairs and the (at most two) straddling elements fall back to 8-byte stores.
+// store).  A job's expanded image starts at job * n_elements * 8 bytes (8-byte aligned only), so lanes are aligned to
+// GLOBAL 128-byte lines and the elements of a pair that belong to a neighbouring job are left to that job's lanes.
 struct ExpandArgs {
     bsx_witness_layout lay;
     uint32_t n_jobs, blocks_per_job;
@@ -738,34 +738,38 @@ __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
     const uint8_t* c = a.compact + (uint64_t)job * a.lay.compact_stride;
     const uint64_t nel = a.lay.n_elements;
     const uint64_t g0 = (uint64_t)job * nel;                 // global element index of this job's first element
-    const uint32_t odd = (uint32_t)(g0 & 1);
+    // Lanes are aligned to GLOBAL 128-byte lines: local pair p covers local elements 2p - sh, 2p - sh + 1 with
+    // sh = g0 mod 16, so that every wave-store (64 lanes x 16 B) is eight whole 128-byte lines wherever the job's image
+    // starts (a job is 449,755 elements: its base is only 8-byte aligned).  With 16-byte alignment only, every wave-store
+    // straddled two lines that a neighbouring wave completed later: non-temporal stores then reached HBM as partial
+    // lines (WRITE_SIZE 1.03x the algorithmic bytes) at a rate that depended on the buffer's placement.
+    const uint32_t sh = (uint32_t)(g0 & 15);
     const uint32_t nbits = 8u * a.lay.n_bytes;
-    // local pair p covers local elements 2p - odd, 2p - odd + 1
-    const uint32_t npairs = (uint32_t)((nel + odd + 1) / 2);
+    const uint32_t npairs = (uint32_t)((nel + sh + 1) / 2);
     const uint32_t pbase = bx * EX_PAIRS_PER_BLOCK;
-    const int32_t byte0 = (int32_t)(pbase / 4) - 4;          // staged window starts one dword early (odd jobs look back one bit)
+    const int32_t byte0 = (int32_t)(pbase / 4) - 4;          // staged window starts one dword early (pairs look back up to 15 bits)
     for (uint32_t t = tid; t < EX_CHUNK / 4 + 2; t += EX_THREADS) {
         const int32_t bi = byte0 + 4 * (int32_t)t;
         lds[t] = (bi >= 0 && (uint32_t)bi < a.lay.compact_stride) ? reinterpret_cast<const uint32_t*>(c)[bi >> 2] : 0u;
     }
     __syncthreads();
     const uint8_t* lb = reinterpret_cast<const uint8_t*>(lds);
-    uint64_t* base = a.out + g0 - odd;                       // 16-byte aligned
+    uint64_t* base = a.out + g0 - sh;                        // 128-byte aligned
 #pragma unroll 4
     for (int u = 0; u < EX_PAIRS_PER_BLOCK / EX_THREADS; u++) {
         const uint32_t p = pbase + (uint32_t)u * EX_THREADS + tid;
         if (p >= npairs) break;
-        const uint32_t e1 = 2 * p + 1 - odd;                 // local index of the pair's second element (>= 0)
-        const bool in0 = (2 * p >= odd), in1 = e1 < nel;
+        const int64_t e0 = 2ll * p - sh, e1 = e0 + 1;        // local element indices of the pair (negative: previous job's)
+        const bool in0 = e0 >= 0 && e0 < (int64_t)nel, in1 = e1 >= 0 && e1 < (int64_t)nel;
         uint64_t v0, v1;
-        if (in0 && e1 < nbits) {                             // both elements are bits (the overwhelmingly common case)
-            const uint32_t e0 = e1 - 1;
-            const uint32_t by0 = lb[(int32_t)(e0 >> 3) - byte0], by1 = lb[(int32_t)(e1 >> 3) - byte0];
-            v0 = (by0 >> (7 - (e0 & 7))) & 1u;
-            v1 = (by1 >> (7 - (e1 & 7))) & 1u;
+        if (in0 && e1 < (int64_t)nbits) {                    // both elements are bits (the overwhelmingly common case)
+            const uint32_t b0 = (uint32_t)e0, b1 = (uint32_t)e1;
+            const uint32_t by0 = lb[(int32_t)(b0 >> 3) - byte0], by1 = lb[(int32_t)(b1 >> 3) - byte0];
+            v0 = (by0 >> (7 - (b0 & 7))) & 1u;
+            v1 = (by1 >> (7 - (b1 & 7))) & 1u;
         } else {
-            v0 = in0 ? expand_elem(a, c, (int64_t)e1 - 1) : 0;
-            v1 = in1 ? expand_elem(a, c, (int64_t)e1) : 0;
+            v0 = in0 ? expand_elem(a, c, e0) : 0;
+            v1 = in1 ? expand_elem(a, c, e1) : 0;
         }
         uint64_t* dst = base + 2 * (uint64_t)p;
         if (in0 && in1) {
@@ -847,24 +851,19 @@ hipError_t bsxk_finalize(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t 
 }
 hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uint32_t n_jobs, const uint8_t* compact, uint64_t* out) {
     if (!n_jobs) return hipSuccess;
-    const uint64_t npairs = (lay->n_elements + 2) / 2;
-    // Staging chunk and store flavour.  Alone on the GPU plain stores with 2 KiB chunks are fastest (5.9-6.1 TB/s);
-    // in the pipelined step non-temporal stores with SMALL chunks do not slow down beside the other chunk's hashing and
-    // disturb it less.  Non-temporal, grid cap scaled with the item count (~3.4 items per workgroup): 2 KiB 87 M
-    // headers/s, 1 KiB 91, 512 B 93-95, 256 B 98-100 (5.7-5.8 TB/s in-region), 128 B 87-89; plain stores 87.5-90.
-    // The product path is the pipelined one.
+    const uint64_t npairs = (lay->n_elements + 16) / 2;      // a job's pair grid may start up to 15 elements before its first element
+    // Staging chunk and store flavour (tools/exp_expand_sweep.sh, tools/exp_alloc_variants.sh; round 2, after the stores became
+    // 128-byte-line aligned): non-temporal stores with 256-byte chunks, one workgroup per item.  Alone the launch runs at
+    // 2.1-2.6 ms (14.97 GB: 5.8-7.1 TB/s) depending on the box; plain stores 2.6-2.8 ms.  In the pipelined step, beside the
+    // other chunk's hashing: 256 B uncapped 89.0-89.4 / 93.2-93.8 M headers/s on two boxes, 512 B 85.0-85.3 / 92.9-94.0, 256 B
+    // capped at 262,144 workgroups (the round-1 choice) 79.9-85.1, plain stores 74-81.
     static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 256;
     static const long nt = getenv("BSX_EXPAND_NT") ? atol(getenv("BSX_EXPAND_NT")) : 1;
     const uint32_t ppb = (uint32_t)chunk * 4;
     const uint32_t gx = (uint32_t)((npairs + ppb - 1) / ppb);
     ExpandArgs a{*lay, n_jobs, gx, compact, out};
-    // BSX_EXPAND_BLOCKS caps the grid (workgroups stride over the items) so that the HBM-bound expansion leaves wave
-    // slots for an ALU-bound kernel running beside it on another stream; 0 / unset = one workgroup per item
-    // (measured with 2 pipelined chunks of 4096 jobs: the non-temporal 512-byte variant, 450 k items per launch, gives
-    // 91.5-93.8 / 93.9-95.3 / 93.1-95.1 / 94.1-95.2 / 92.6-93.1 / 80 M headers/s at 16384 / 32768 / 65536 / 131072 / 262144 /
-    // uncapped workgroups; the default 256-byte variant, 901 k items, 94.5-96.9 / 98.1-100 / 94.3 / 82 M at 131072 /
-    // 262144 / 524288 / uncapped; the plain-store 2 KiB variant preferred 16384, and fewer than 8192 lose bandwidth)
-    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 262144;
+    // BSX_EXPAND_BLOCKS > 0 caps the grid (workgroups then stride over the items); default: one workgroup per item
+    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 0;
     uint64_t grid = (uint64_t)gx * n_jobs;
     if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
 #define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)

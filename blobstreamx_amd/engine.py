@@ -168,60 +168,18 @@ class HeaderRangeEngine:
         self.keytable = _u8(int(self.L.bsx_ed25519_keytable_bytes(C.c_uint32(V))), d) if self.ed_path == "keyed" else None
 
     def _place_witness(self, n_el):
-        """Allocate the expanded-witness buffer of the map jobs (29.5 GB for 256 x header_range_2048).
-
-        Setup-time placement probe.  The store bandwidth of the expansion depends on WHICH physical memory the buffer
-        landed in: on one MI355X, seven 29.5 GB buffers allocated back to back ran the identical launch at 4.72, 5.53,
-        5.27, 5.72, 5.64, 5.09 and 4.84 TB/s, each figure stable for its buffer, and freeing + re-allocating the same
-        virtual address changed it again (tools/exp_placement.py) — VRAM fragmentation left behind by earlier
-        processes decides the page-table fragment sizes.  On another box 3 of 4 candidates ran at 4.8 TB/s and one at
-        6.0 TB/s.  So: allocate candidates one by one (up to BSX_PLACEMENT_PROBE, while memory allows), time the real
-        expansion launch on each, stop at the first one that reaches the part's store ceiling, keep the fastest, release
-        the rest."""
-        d, nbytes = self.dev, n_el * 8
-        first = torch.zeros(n_el, dtype=torch.int64, device=d)
-        k = int(os.environ.get("BSX_PLACEMENT_PROBE", "8"))
-        if k <= 1 or nbytes < (1 << 30):
-            return first
-        # stop early at a placement that runs at the ceiling of the launch: 5.9 TB/s for plain stores (tools/microbench),
-        # 5.7-5.8 TB/s for the non-temporal 256-byte variant the library launches by default (csrc/kernels_sha.hip)
-        nt = os.environ.get("BSX_EXPAND_NT", "1") != "0"
-        good_gbps = float(os.environ.get("BSX_PLACEMENT_GOOD_GBPS", "5700" if nt else "5850"))
-        L, ctx, dp = self.L, self.ctx, _lib.dp
-        st = self._st()
-        n_jobs = self.RT * self.jc
-        job_bytes = int(self.ml["n_bytes"]) + 4 * int(self.ml["n_words"]) + int(self.ml["n_bools"]) + 8 * int(self.ml["n_elements"])
-
-        def launch_ms(buf):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            for it in range(4):
-                if it == 1:
-                    ev[0].record(torch.cuda.current_stream(d))
-                _lib.check(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._ml), C.c_uint32(n_jobs), dp(self.compact), dp(buf)))
-            ev[1].record(torch.cuda.current_stream(d))
-            torch.cuda.synchronize(d)
-            return ev[0].elapsed_time(ev[1]) / 3
-
-        cands, times = [first], [launch_ms(first)]
-        while len(cands) < k and n_jobs * job_bytes / times[-1] / 1e6 < good_gbps:
-            free, _total = torch.cuda.mem_get_info(d)
-            if free < nbytes + (16 << 30):
-                break
-            try:
-                buf = torch.zeros(n_el, dtype=torch.int64, device=d)      # held until the end: a freed buffer's pages come back
-            except RuntimeError:
-                break
-            cands.append(buf)
-            times.append(launch_ms(buf))
-        best = min(range(len(cands)), key=lambda i: times[i])
-        self.placement_probe = {"candidates": len(cands), "ms": [round(t, 3) for t in times], "picked": best,
-                                "GBps": round(n_jobs * job_bytes / times[best] / 1e6)}
-        keep = cands[best]
-        keep.zero_()
-        cands = buf = first = None
-        torch.cuda.synchronize(d)
-        torch.cuda.empty_cache()
-        return keep
+        """Allocate the expanded-witness buffer of the map jobs (29.5 GB for 256 x header_range_2048): ONE allocation through
+        bsx_dev_alloc (HIP virtual-memory API).  Root cause of round 1's "placement" spread: the store bandwidth of a
+        multi-GB buffer depends on where its physical pages lie — hipMalloc'ed buffers of one process ran the same store
+        sweep at 5.5-6.6 TB/s, slices of one big arena at 5.4-6.2 TB/s reproducibly by offset, hipMemCreate-backed ones at
+        6.0-6.25 TB/s every time (tools/exp_vmm.hip).  BSX_WITNESS_ALLOC=torch falls back to the caching allocator."""
+        mode = os.environ.get("BSX_WITNESS_ALLOC", "vmm")
+        if mode == "vmm" and n_el * 8 >= (64 << 20):
+            self._witness_block = _lib.DeviceBuffer(n_el, self.dev.index if self.dev.index is not None else 0)
+            self.placement_probe = {"allocator": "bsx_dev_alloc (hipMemCreate + hipMemMap, one handle)", "candidates": 1}
+            return self._witness_block.tensor()
+        self.placement_probe = {"allocator": "torch caching allocator (hipMalloc)", "candidates": 1}
+        return torch.zeros(n_el, dtype=torch.int64, device=self.dev)
 
     # ------------------------------------------------------------------ data
     def upload(self, headers_slice, ranges, latest, skip_headers=None, skip_ranges=None, validators=None, trusted=None):

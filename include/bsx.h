@@ -296,6 +296,15 @@ int bsx_ingest_data_commitment_json(const char* json, size_t len, uint8_t out[32
  * default stream) and returns, so calls are ordered with the caller's own work on that stream.
  * Device status words are ORed into, never cleared: the caller zeroes them (hipMemsetAsync) before a pass. */
 
+/* Device memory for the LARGE streaming buffers of the device tier (the expanded witness: tens of GB written once per
+ * pass).  Backed by the HIP virtual-memory API (hipMemCreate + hipMemMap of one physical handle): on MI355X the store
+ * bandwidth of a multi-GB buffer depends on where its physical pages lie — hipMalloc'ed buffers of one process ran the
+ * same store sweep at 5.5 .. 6.6 TB/s, slices of one big hipMalloc arena at 5.4 .. 6.2 TB/s by offset, VMM-backed buffers
+ * at 6.0 .. 6.25 TB/s every time (tools/exp_vmm.hip) — so this replaces the round-1 "allocate candidates and
+ * time them" probe with one deterministic allocation.  Zero-filled.  Free with bsx_dev_free (or bsx_shutdown). */
+int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr);
+int bsx_dev_free(bsx_ctx* ctx, void* ptr);
+
 /* P5: one lane per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be
  * NULL.  d_status (1 u32, optional): bit0 = a header violates the field-size rules. */
 int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n,
