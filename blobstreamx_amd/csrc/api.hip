@@ -18,11 +18,12 @@
 #include "api_internal.h"
 
 extern "C" {
-hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*);
+hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*);
+hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
 hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
-                                uint8_t*, uint32_t*);
-hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*);
+                                uint8_t*, uint32_t*, const uint8_t*, const uint8_t*);
+hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*, uint32_t);
 hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
 hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_subchain*, const uint8_t*,
                          uint8_t*, uint32_t*);
@@ -108,6 +109,15 @@ int bsx_init(int device, bsx_ctx** out) {
         delete c;
         return fail(BSX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    // constants of the hint's zero-padded proofs (kernels_sha.hip k_zero_paths)
+    e = hipMalloc(reinterpret_cast<void**>(&c->zero_paths), 320);
+    if (e == hipSuccess) e = bsxk_zero_paths(c->stream, c->zero_paths);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(BSX_ERR_HIP, "bsx_init: %s", hipGetErrorString(e));
+    }
     *out = c;
     return BSX_OK;
 }
@@ -117,6 +127,7 @@ void bsx_shutdown(bsx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    if (ctx->zero_paths) (void)hipFree(ctx->zero_paths);
     for (auto& b : ctx->vmm) { (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size); }
     delete ctx;
 }
@@ -194,10 +205,10 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
 }
 
 int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n, uint8_t* d_hashes,
-                          uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint32_t* d_status) {
+                          uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint8_t* d_paths, uint32_t* d_status) {
     DEV_ENTER();
     if (n && !d_headers) return fail(BSX_ERR_BAD_ARG, "null headers");
-    HIPCHK(bsxk_header_merkle(S(ctx, stream), d_headers, n, d_hashes, d_dh_aunts, d_lb_aunts, d_status));
+    HIPCHK(bsxk_header_merkle(S(ctx, stream), d_headers, n, d_hashes, d_dh_aunts, d_lb_aunts, d_paths, d_status));
     return BSX_OK;
 }
 
@@ -205,23 +216,25 @@ int bsx_dev_assemble_inputs(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint3
                             uint32_t job_first, uint32_t job_count, uint32_t span, const bsx_shared_ctx* d_ranges,
                             const uint64_t* d_latest, const bsx_header* d_headers, uint64_t headers_per_range,
                             uint64_t header_first_rel, const uint8_t* d_hashes, const uint8_t* d_dh_aunts,
-                            const uint8_t* d_lb_aunts, uint8_t* d_compact, uint32_t* d_status) {
+                            const uint8_t* d_lb_aunts, uint8_t* d_compact, uint32_t* d_status, const uint8_t* d_paths) {
     DEV_ENTER();
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "batch_size must be a power of two <= %d", BSX_MAX_BATCH);
     if (span > batch_size) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start = %u > MAX_LEAVES = %u (input.rs:154)", span, batch_size);
     if (job_first + job_count > nb_map_jobs) return fail(BSX_ERR_BAD_ARG, "job slice [%u,%u) exceeds nb_map_jobs %u", job_first, job_first + job_count, nb_map_jobs);
     if (!d_ranges || !d_latest || !d_headers || !d_hashes || !d_dh_aunts || !d_lb_aunts || !d_compact) return fail(BSX_ERR_BAD_ARG, "null pointer");
     HIPCHK(bsxk_assemble_inputs(S(ctx, stream), n_ranges, nb_map_jobs, batch_size, job_first, job_count, span, d_ranges, d_latest,
-                                d_headers, headers_per_range, header_first_rel, d_hashes, d_dh_aunts, d_lb_aunts, d_compact, d_status));
+                                d_headers, headers_per_range, header_first_rel, d_hashes, d_dh_aunts, d_lb_aunts, d_compact, d_status,
+                                d_paths, ctx->zero_paths));
     return BSX_OK;
 }
 
 int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t batch_size, uint32_t job_count,
-                           const bsx_shared_ctx* d_ranges, uint8_t* d_compact, bsx_subchain* d_records) {
+                           const bsx_shared_ctx* d_ranges, uint8_t* d_compact, bsx_subchain* d_records, uint32_t flags) {
     DEV_ENTER();
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "batch_size must be a power of two <= %d", BSX_MAX_BATCH);
     if (!d_ranges || !d_compact || !d_records) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_prove_subchain(S(ctx, stream), n_ranges, batch_size, job_count, d_ranges, d_compact, d_records));
+    if (flags & ~BSX_SUBCHAIN_PATHS_FROM_HINT) return fail(BSX_ERR_BAD_ARG, "unknown flags 0x%x", flags);
+    HIPCHK(bsxk_prove_subchain(S(ctx, stream), n_ranges, batch_size, job_count, d_ranges, d_compact, d_records, flags));
     return BSX_OK;
 }
 
@@ -398,7 +411,7 @@ int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8
     uint8_t* d_lb = d_dh + n * 128;
     H2D(dh.p, headers, n * sizeof(bsx_header));
     HIPCHK(hipMemsetAsync(dst.p, 0, 4, st));
-    HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, dst.as<uint32_t>()));
+    HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, nullptr, dst.as<uint32_t>()));
     std::vector<uint8_t> tmp(n * 288);
     uint32_t hs = 0;
     D2H(tmp.data(), d_hash, n * 288);
@@ -423,7 +436,7 @@ int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8
 
 // Shared by the hint-level entry points: uploads headers [S .. ) of one range and runs P5.
 struct RangeDev {
-    DBuf headers, hashes, dh, lb, ranges, latest, hstatus, astatus;
+    DBuf headers, hashes, dh, lb, paths, ranges, latest, hstatus, astatus;
     uint64_t hpr = 0;
 };
 static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
@@ -437,6 +450,7 @@ static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers,
     RET(rd.hashes.alloc(rd.hpr * 32));
     RET(rd.dh.alloc(rd.hpr * 128));
     RET(rd.lb.alloc(rd.hpr * 128));
+    RET(rd.paths.alloc(rd.hpr * BSX_HEADER_PATH_BYTES));
     RET(rd.ranges.alloc(sizeof(bsx_shared_ctx)));
     RET(rd.latest.alloc(8));
     RET(rd.hstatus.alloc(4));
@@ -447,7 +461,7 @@ static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers,
     HIPCHK(hipMemsetAsync(rd.hstatus.p, 0, 4, st));
     HIPCHK(hipMemsetAsync(rd.astatus.p, 0, 4, st));
     HIPCHK(bsxk_header_merkle(st, rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
-                              rd.hstatus.as<uint32_t>()));
+                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>()));
     (void)ctx;
     return BSX_OK;
 }
@@ -475,7 +489,7 @@ int bsx_data_commitment_inputs(bsx_ctx* ctx, const bsx_header* headers, uint64_t
     HIPCHK(hipMemsetAsync(cw.p, 0, L.compact_stride, st));
     HIPCHK(bsxk_assemble_inputs(st, 1, 1, P, 0, 1, (uint32_t)(end_block - start_block), rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(),
                                 rd.headers.as<bsx_header>(), rd.hpr, 0, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
-                                cw.as<uint8_t>(), rd.astatus.as<uint32_t>()));
+                                cw.as<uint8_t>(), rd.astatus.as<uint32_t>(), nullptr, nullptr));
     std::vector<uint8_t> img(L.compact_stride);
     uint32_t hs = 0, as = 0;
     D2H(img.data(), cw.p, L.compact_stride);
@@ -542,7 +556,7 @@ int bsx_prove_subchain(bsx_ctx* ctx, uint32_t batch_size, const uint8_t start_he
     RET(rec.alloc(sizeof(bsx_subchain)));
     H2D(cw.p, img.data(), L.compact_stride);
     H2D(rg.p, &range, sizeof range);
-    HIPCHK(bsxk_prove_subchain(st, 1, B, 1, rg.as<bsx_shared_ctx>(), cw.as<uint8_t>(), rec.as<bsx_subchain>()));
+    HIPCHK(bsxk_prove_subchain(st, 1, B, 1, rg.as<bsx_shared_ctx>(), cw.as<uint8_t>(), rec.as<bsx_subchain>(), 0));   // caller's proofs
     if (witness) {
         RET(wit.alloc(L.n_elements * 8));
         HIPCHK(bsxk_expand_witness(st, &L, 1, cw.as<uint8_t>(), wit.as<uint64_t>()));
@@ -568,7 +582,7 @@ int bsx_reduce(bsx_ctx* ctx, const bsx_subchain* records, uint32_t n, bsx_subcha
 }
 
 // prove_data_commitment on one range whose device state (headers hashed) is in rd.  d_target_hashes optional.
-static int run_data_commitment(hipStream_t st, uint32_t J, uint32_t B, RangeDev& rd, const uint8_t* d_target_hashes,
+static int run_data_commitment(bsx_ctx* ctx, hipStream_t st, uint32_t J, uint32_t B, RangeDev& rd, const uint8_t* d_target_hashes,
                                uint8_t out_commitment[32], uint8_t output64[64], bsx_subchain* out_result, bsx_subchain* records,
                                uint64_t* witness, uint32_t* out_status) {
     const bsx_witness_layout L = bsx_map_layout(B), R = bsx_reduce_layout();
@@ -581,8 +595,11 @@ static int run_data_commitment(hipStream_t st, uint32_t J, uint32_t B, RangeDev&
     RET(stw.alloc(4));
     HIPCHK(hipMemsetAsync(cw.p, 0, (size_t)J * L.compact_stride, st));
     HIPCHK(bsxk_assemble_inputs(st, 1, J, B, 0, J, B, rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(), rd.headers.as<bsx_header>(), rd.hpr, 0,
-                                rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(), cw.as<uint8_t>(), rd.astatus.as<uint32_t>()));
-    HIPCHK(bsxk_prove_subchain(st, 1, B, J, rd.ranges.as<bsx_shared_ctx>(), cw.as<uint8_t>(), recs.as<bsx_subchain>()));
+                                rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(), cw.as<uint8_t>(), rd.astatus.as<uint32_t>(),
+                                rd.paths.as<uint8_t>(), ctx->zero_paths));
+    // the proofs are the hint's own (nodes of the header trees hashed above): their path digests are already in place
+    HIPCHK(bsxk_prove_subchain(st, 1, B, J, rd.ranges.as<bsx_shared_ctx>(), cw.as<uint8_t>(), recs.as<bsx_subchain>(),
+                               BSX_SUBCHAIN_PATHS_FROM_HINT));
     HIPCHK(bsxk_reduce(st, 1, J, recs.as<bsx_subchain>(), J, 1, res.as<bsx_subchain>(), rcw.as<uint8_t>()));
     HIPCHK(bsxk_finalize(st, 1, J, B, rd.ranges.as<bsx_shared_ctx>(), res.as<bsx_subchain>(), d_target_hashes, o64.as<uint8_t>(), stw.as<uint32_t>()));
     if (witness) {
@@ -629,7 +646,7 @@ int bsx_prove_data_commitment(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch
     hipStream_t st = ctx->stream;
     RangeDev rd;
     RET(upload_range(ctx, st, headers, first_height, n_headers, range->start_block, *range, latest_block, rd));
-    return run_data_commitment(st, nb_map_jobs, batch_size, rd, nullptr, out_data_commitment, nullptr, out_result, records, witness, nullptr);
+    return run_data_commitment(ctx, st, nb_map_jobs, batch_size, rd, nullptr, out_data_commitment, nullptr, out_result, records, witness, nullptr);
 }
 
 int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_number, const uint8_t prev_header_hash[32],
@@ -664,7 +681,7 @@ int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_numb
     RET(rec.alloc(sizeof(bsx_subchain)));
     H2D(cw.p, img.data(), L.compact_stride);
     H2D(rg.p, &range, sizeof range);
-    HIPCHK(bsxk_prove_subchain(st, 1, 1, 1, rg.as<bsx_shared_ctx>(), cw.as<uint8_t>(), rec.as<bsx_subchain>()));
+    HIPCHK(bsxk_prove_subchain(st, 1, 1, 1, rg.as<bsx_shared_ctx>(), cw.as<uint8_t>(), rec.as<bsx_subchain>(), 0));
     D2H(img.data(), cw.p, L.compact_stride);
     SYNC();
     memcpy(out_data_commitment, img.data() + bsx_off_leaf_hashes(1), 32);
@@ -794,7 +811,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
                            dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth.as<uint8_t>(), nullptr, chain_id, chain_id_len));
     // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58)
-    int rc = run_data_commitment(st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, output64, nullptr, nullptr, witness, nullptr);
+    int rc = run_data_commitment(ctx, st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, output64, nullptr, nullptr, witness, nullptr);
     if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
     const std::string dc_err = g_err;
     uint32_t skip = 0;

@@ -30,6 +30,7 @@ struct bsx_ctx {
     hipStream_t stream;
     bsx_arena arena;
     std::vector<bsx_vmm_block> vmm;      // bsx_dev_alloc blocks still alive
+    uint8_t* zero_paths = nullptr;       // 320 B: path digests of the hint's zero-padded proofs (k_zero_paths)
 };
 
 namespace bsxapi {

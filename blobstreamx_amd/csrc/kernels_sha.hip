@@ -111,9 +111,15 @@ __device__ __forceinline__ Digest leaf_from_regs(const uint32_t (&W)[N], int len
     return leaf_hash_1block(d, len);
 }
 
+// paths (optional): per header the 7 distinct digests of the two inclusion-proof PATHS prove_subchain materialises for it
+// (builder.rs:189-199) — [L6, n67, L4, n45, n4567, left, root]: data_hash path = L6, n67, n4567, left, root; last_block_id path
+// = L4, n45, n4567, left, root.  They are nodes of the tree hashed here anyway; handing them to the hint (k_assemble_inputs)
+// lets prove_subchain skip re-deriving them from the proofs (19 of its 21 compressions per slot).
+constexpr uint32_t HM_PATH_BYTES = 7 * 32;
 __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
-                                                              uint8_t* __restrict__ lb_aunts, uint32_t* __restrict__ status) {
+                                                              uint8_t* __restrict__ lb_aunts, uint8_t* __restrict__ paths,
+                                                              uint32_t* __restrict__ status) {
     BSX_CHAIN_PRIO();
     const uint64_t me = (uint64_t)blockIdx.x * HM_THREADS + threadIdx.x;
     const bool live = me < n;
@@ -155,13 +161,22 @@ __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* 
             const Digest L4 = (len[4] <= 54) ? leaf_hash_1block(d, len[4]) : leaf_hash_2block(d, len[4]);
             L5 = leaf_from_regs<9, 50, 0>(W1, len[5]);
             n45 = inner_hash(L4, L5);
+            if (live && paths) store_digest_u(paths + me * HM_PATH_BYTES + 64, L4);
         }
         {
             const Digest L6 = leaf_from_regs<9, 59, 0>(W1, len[6]);   // data_hash
             L7 = leaf_from_regs<9, 68, 0>(W1, len[7]);
             n67 = inner_hash(L6, L7);
+            if (live && paths) store_digest_u(paths + me * HM_PATH_BYTES, L6);
         }
-        left = inner_hash(n0123, inner_hash(n45, n67));
+        const Digest n4567 = inner_hash(n45, n67);
+        left = inner_hash(n0123, n4567);
+        if (live && paths) {
+            store_digest_u(paths + me * HM_PATH_BYTES + 32, n67);
+            store_digest_u(paths + me * HM_PATH_BYTES + 96, n45);
+            store_digest_u(paths + me * HM_PATH_BYTES + 128, n4567);
+            store_digest_u(paths + me * HM_PATH_BYTES + 160, left);
+        }
         if (live) {
             if (lb_aunts) {  // index 4: [L5, n67, n0123, right]
                 store_digest_u(lb_aunts + me * 128, L5);
@@ -195,6 +210,7 @@ __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* 
     const Digest root = inner_hash(left, right);
     if (live) {
         if (hashes) store_digest_u(hashes + me * 32, root);
+        if (paths) store_digest_u(paths + me * HM_PATH_BYTES + 192, root);
         if (lb_aunts) store_digest_u(lb_aunts + me * 128 + 96, right);
         if (dh_aunts) store_digest_u(dh_aunts + me * 128 + 96, right);
     }
@@ -215,6 +231,8 @@ struct AssembleArgs {
     uint8_t* compact;
     uint32_t compact_stride, off_words;
     uint32_t* status;
+    const uint8_t* paths;        // optional (k_header_merkle): the slots' path digests are gathered too
+    const uint8_t* zero_paths;   // path digests of the all-zero proofs (padding slots): dh[5] then lb[5]
 };
 
 // AS_IT = 16-byte pieces per lane = ceil(24 * B / 256): a template parameter so that the in-flight buffer (and with it
@@ -306,6 +324,36 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
         else if (pc == 23) *reinterpret_cast<uint2*>(d) = make_uint2(val[it].x, val[it].y);
         else *reinterpret_cast<uint4*>(d) = val[it];
     }
+    // The slots' path digests (builder.rs:189-199): dh_path[5] = nodes of header h's tree, lb_path[5] = nodes of header h+1's —
+    // 20 pieces of 16 bytes per slot, gathered like the proofs (second burst); padding slots take the zero-proof constants.
+    if (a.paths) {
+        constexpr uint32_t P_PIECES = 20, P_IT = (P_PIECES * BSX_MAX_BATCH + 255) / 256;
+        const uint32_t n_p = P_PIECES * B;
+        uint8_t* slots = cw + bsx_off_slots(B);
+        for (uint32_t it0 = 0; it0 < P_IT; it0 += 4) {
+            uint4 pv[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t t = threadIdx.x + (it0 + u) * 256u;
+                const uint32_t slot = t / P_PIECES, pc = t % P_PIECES;
+                const bool is_dh = pc < 10;
+                const uint32_t j = (is_dh ? pc : pc - 10) >> 1, half = pc & 1;
+                const uint32_t node = j >= 2 ? j + 2 : (is_dh ? j : j + 2);        // [L6, n67, L4, n45, n4567, left, root]
+                const bool real = (t < n_p) && !oob && (slot < n_real);
+                const uint8_t* src = real ? a.paths + (h0 + slot + (is_dh ? 0 : 1)) * HM_PATH_BYTES + 32 * node + 16 * half
+                                          : a.zero_paths + (is_dh ? 0 : 160) + 32 * j + 16 * half;
+                pv[u] = (t < n_p) ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t t = threadIdx.x + (it0 + u) * 256u;
+                if (t >= n_p) break;
+                const uint32_t slot = t / P_PIECES, pc = t % P_PIECES;
+                stu4(slots + BSX_SLOT_BYTES * slot + 16 * pc, pv[u]);              // dh_path at +0, lb_path at +160
+            }
+            if ((it0 + 4) * 256u >= n_p) break;
+        }
+    }
     if (threadIdx.x == 0) {
         uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
         W[BSX_W_CTX_START] = (uint32_t)rg.start_block; W[BSX_W_CTX_START + 1] = (uint32_t)(rg.start_block >> 32);
@@ -340,6 +388,9 @@ __device__ __forceinline__ uint32_t gdword_at(const uint8_t* p, int k) {
 
 // ---- stage 1: one lane per slot, no communication (builder.rs:180-199, 134-137 + leaf hashes of :144-147)
 constexpr int SH_THREADS = 256;
+// PATHS = false: the path digests are already in the slot section (written by the hint from the header trees,
+// k_assemble_inputs with `paths`): only the data-root tuple and its leaf hash remain (2 compressions instead of 21)
+template <bool PATHS>
 __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
     BSX_CHAIN_PRIO();
     const uint32_t B = a.batch;
@@ -359,13 +410,16 @@ __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
     {
         const uint8_t* pr = cw + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * i;
         uint4 A[8];
+        if (PATHS) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) A[k] = ldu4(pr + 16 * k);
+            for (int k = 0; k < 8; k++) A[k] = ldu4(pr + 16 * k);
+        }
         const uint4 l0 = ldu4(pr + 128), l1 = ldu4(pr + 144);
         const uint32_t l2 = (uint32_t)reinterpret_cast<const uint16_t*>(pr + 160)[0];
         const uint32_t lf[9] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2};
 #pragma unroll
         for (int k = 0; k < 8; k++) data_hash_le[k] = funnel_r(lf[k + 1], lf[k], 16);
+        if (PATHS) {
         Digest d[5];
         d[0] = leaf_hash_34(lf);
         // path [0,1,1,0] (builder.rs:166-167): h = bit ? inner(aunt, h) : inner(h, aunt)
@@ -378,8 +432,9 @@ __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 5; j++) store_digest_u(sl + 32 * j, d[j]);
+        }
     }
-    {
+    if (PATHS) {
         const uint8_t* pr = cw + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * i;
         uint4 A[8], l[4];
 #pragma unroll
@@ -399,6 +454,10 @@ __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
             const Digest aunt = digest_from_le(al);
             d[lvl + 1] = (lvl == 2) ? inner_hash(aunt, d[lvl]) : inner_hash(d[lvl], aunt);
         }
+#pragma unroll
+        for (int j = 0; j < 5; j++) store_digest_u(sl + 160 + 32 * j, d[j]);
+    }
+    {
         // data-root tuple (builder.rs:82-103,134-137) and its leaf hash
         const uint64_t curr_idx = batch_start + i;
         uint32_t t[16];
@@ -409,14 +468,27 @@ __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; k++) t[8 + k] = bswap32(data_hash_le[k]);
         const Digest tleaf = leaf_hash_tuple(t);
-#pragma unroll
-        for (int j = 0; j < 5; j++) store_digest_u(sl + 160 + 32 * j, d[j]);
         uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
 #pragma unroll
         for (int k = 0; k < 4; k++)
             stu4(tp + 16 * k, make_uint4(bswap32(t[4 * k]), bswap32(t[4 * k + 1]), bswap32(t[4 * k + 2]), bswap32(t[4 * k + 3])));
         store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
     }
+}
+
+// path digests of the ALL-ZERO proofs (the hint's padding slots, input.rs:220-239): dh[5] then lb[5], 320 bytes; computed
+// once per context (bsx_init) with the same operations k_slot_hashes<true> applies to a zero proof
+__global__ void k_zero_paths(uint8_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t z[18] = {0};
+    const Digest zero = digest_from_le(z);
+    Digest d[5];
+    d[0] = leaf_hash_34(z);
+    for (int lvl = 0; lvl < 4; lvl++) d[lvl + 1] = (lvl == 1 || lvl == 2) ? inner_hash(zero, d[lvl]) : inner_hash(d[lvl], zero);
+    for (int j = 0; j < 5; j++) store_digest_u(out + 32 * j, d[j]);
+    d[0] = leaf_hash_72(z);
+    for (int lvl = 0; lvl < 4; lvl++) d[lvl + 1] = (lvl == 2) ? inner_hash(zero, d[lvl]) : inner_hash(d[lvl], zero);
+    for (int j = 0; j < 5; j++) store_digest_u(out + 160 + 32 * j, d[j]);
 }
 
 // batch bounds of a job (builder.rs:235-243) from its compact witness and the global end block
@@ -792,18 +864,25 @@ __global__ __launch_bounds__(EX_THREADS) void k_expand_witness(ExpandArgs a) {
 extern "C" {
 using namespace bsx;
 
-hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint32_t* status) {
+hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint8_t* paths,
+                              uint32_t* status) {
     if (!n) return hipSuccess;
     const uint32_t grid = (uint32_t)((n + HM_THREADS - 1) / HM_THREADS);
-    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, status);
+    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status);
+    return hipGetLastError();
+}
+hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {
+    hipLaunchKernelGGL(k_zero_paths, dim3(1), dim3(64), 0, s, out);
     return hipGetLastError();
 }
 hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
                                 const bsx_shared_ctx* ranges, const uint64_t* latest, const bsx_header* headers, uint64_t hpr, uint64_t hfr,
-                                const uint8_t* hashes, const uint8_t* dh, const uint8_t* lb, uint8_t* compact, uint32_t* status) {
+                                const uint8_t* hashes, const uint8_t* dh, const uint8_t* lb, uint8_t* compact, uint32_t* status,
+                                const uint8_t* paths, const uint8_t* zero_paths) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
-    AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hfr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status};
+    AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hfr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status,
+                   paths, zero_paths};
     const uint32_t it = (24u * B + 255u) / 256u;
 #define BSX_AS_LAUNCH(N) hipLaunchKernelGGL(k_assemble_inputs<N>, dim3(n_ranges * job_count), dim3(256), 0, s, a)
     if (it <= 1) BSX_AS_LAUNCH(1);
@@ -816,13 +895,16 @@ hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, ui
     return hipGetLastError();
 }
 hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_t job_count, const bsx_shared_ctx* ranges,
-                               uint8_t* compact, bsx_subchain* records) {
+                               uint8_t* compact, bsx_subchain* records, uint32_t flags) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     const uint32_t n_jobs = n_ranges * job_count;
     SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
     const uint64_t slots = (uint64_t)n_jobs * B;
-    hipLaunchKernelGGL(k_slot_hashes, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
+    if (flags & BSX_SUBCHAIN_PATHS_FROM_HINT)
+        hipLaunchKernelGGL(k_slot_hashes<false>, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_slot_hashes<true>, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
     uint32_t level_off = 0, level = 1;
     for (uint32_t width = B / 2; width > BF_TOP_WIDTH; width /= 2, level++) {
         a.level = level; a.width = width; a.level_off = level_off;

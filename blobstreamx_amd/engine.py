@@ -108,6 +108,11 @@ class HeaderRangeEngine:
         self.skip_hashes = self.hashes_all[nh_main * 32:] if nh_skip else _u8(16, d)
         self.dh_aunts = _u8(self.nh_all * 128, d)
         self.lb_aunts = _u8(self.nh_all * 128, d)
+        # "fused hint" (default): k_header_merkle also hands over the 7 path digests per header, the hint copies them into
+        # the slots and prove_subchain does not re-derive them (19 of its 21 compressions per slot); BSX_FUSED_HINT=0 keeps
+        # the proofs-only hand-over
+        self.fused_hint = os.environ.get("BSX_FUSED_HINT", "1") != "0"
+        self.paths = _u8(self.nh_all * 224, d) if self.fused_hint else None
         self.ranges = _u8(RT * 80, d)
         self.latest = _u8(RT * 8, d)
         self.status = torch.zeros(8, dtype=torch.int32, device=d)       # [0] header, [1] assemble
@@ -259,7 +264,7 @@ class HeaderRangeEngine:
             with torch.cuda.stream(self.side):
                 self._commit(self._st(), "prep")
         chk(L.bsx_dev_header_merkle(ctx, st, dp(self.headers_all), C.c_uint64(self.nh_all if commit else RT * self.hpr),
-                                    dp(self.hashes_all), dp(self.dh_aunts), dp(self.lb_aunts), dp(self.status)))
+                                    dp(self.hashes_all), dp(self.dh_aunts), dp(self.lb_aunts), dp(self.paths), dp(self.status)))
         self.merkle_done = torch.cuda.Event()
         self.merkle_done.record(main)
         if commit:
@@ -280,13 +285,13 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_assemble_inputs(ctx, st, C.c_uint32(RT), C.c_uint32(self.J), C.c_uint32(B), C.c_uint32(self.jf),
                                       C.c_uint32(jc), C.c_uint32(B), dp(self.ranges), dp(self.latest), dp(self.headers),
                                       C.c_uint64(self.hpr), C.c_uint64(self.hfr), dp(self.hashes), dp(self.dh_aunts),
-                                      dp(self.lb_aunts), dp(self.compact), dp(self.status[1:])))
+                                      dp(self.lb_aunts), dp(self.compact), dp(self.status[1:]), dp(self.paths)))
         self.inputs_consumed = torch.cuda.Event()
         self.inputs_consumed.record(main)          # headers_all may be overwritten from here on (stream_inputs)
         if ev:
             ev[0].record(main)
         chk(L.bsx_dev_prove_subchain(ctx, st, C.c_uint32(RT), C.c_uint32(B), C.c_uint32(jc), dp(self.ranges), dp(self.compact),
-                                     dp(self.records)))
+                                     dp(self.records), C.c_uint32(1 if self.fused_hint else 0)))
         if ev:
             ev[1].record(main)
         chk(L.bsx_dev_reduce(ctx, st, C.c_uint32(RT), C.c_uint32(jc), dp(self.records), dp(self.partial),

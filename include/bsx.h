@@ -306,9 +306,13 @@ int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr);
 int bsx_dev_free(bsx_ctx* ctx, void* ptr);
 
 /* P5: one lane per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be
- * NULL.  d_status (1 u32, optional): bit0 = a header violates the field-size rules. */
+ * NULL.  d_status (1 u32, optional): bit0 = a header violates the field-size rules.
+ * d_paths (optional, n * BSX_HEADER_PATH_BYTES): the 7 distinct digests of the two inclusion-proof paths of each header
+ * [L6, n67, L4, n45, n4567, left, root] — what prove_subchain's get_root_from_merkle_proof calls (builder.rs:189-199)
+ * materialise for a proof taken from this header; give them to bsx_dev_assemble_inputs to save re-deriving them. */
+#define BSX_HEADER_PATH_BYTES 224
 int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n,
-                          uint8_t* d_hashes, uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint32_t* d_status);
+                          uint8_t* d_hashes, uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint8_t* d_paths, uint32_t* d_status);
 
 /* The hint for many map jobs at once (input.rs:149-271): job j of range r covers
  * [S_r + j*B, S_r + j*B + span) (span == B for map jobs, input.rs:154 requires span <= B).  Headers of range r start
@@ -317,19 +321,27 @@ int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_header
  * (input.rs:160-162).  Only jobs [job_first, job_first+job_count) are written (multi-GPU sharding); compact witnesses
  * are indexed [range][job - job_first] with stride bsx_map_witness_layout(B).compact_stride.  Writes the
  * DataCommitmentProofVariable part, the ctx and the batch bounds of each job's compact witness.
- * d_status bits: 1 = inclusion-proof leaf is not 34/72 bytes (input.rs:173,190), 2 = headers not supplied / latest < 2. */
+ * d_status bits: 1 = inclusion-proof leaf is not 34/72 bytes (input.rs:173,190), 2 = headers not supplied / latest < 2.
+ * d_paths (optional, from bsx_dev_header_merkle over the same headers): also writes every slot's dh_path / lb_path
+ * digests (padding slots: the digests of the all-zero proof), after which bsx_dev_prove_subchain may be called with
+ * BSX_SUBCHAIN_PATHS_FROM_HINT. */
 int bsx_dev_assemble_inputs(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch_size,
                             uint32_t job_first, uint32_t job_count, uint32_t span,
                             const bsx_shared_ctx* d_ranges, const uint64_t* d_latest,
                             const bsx_header* d_headers, uint64_t headers_per_range, uint64_t header_first_rel,
                             const uint8_t* d_hashes, const uint8_t* d_dh_aunts, const uint8_t* d_lb_aunts,
-                            uint8_t* d_compact, uint32_t* d_status);
+                            uint8_t* d_compact, uint32_t* d_status, const uint8_t* d_paths);
 
 /* prove_subchain for n_ranges*job_count map jobs (builder.rs:150-271 incl. get_data_commitment :105-148).  Reads the
  * proofs, start/end header and batch bounds from each compact witness, global end block/hash from d_ranges[r];
- * completes the compact witness and writes d_records[range][job]. */
+ * completes the compact witness and writes d_records[range][job].  flags: see below. */
 int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t batch_size, uint32_t job_count,
-                           const bsx_shared_ctx* d_ranges, uint8_t* d_compact, bsx_subchain* d_records);
+                           const bsx_shared_ctx* d_ranges, uint8_t* d_compact, bsx_subchain* d_records, uint32_t flags);
+/* flags: the proofs in d_compact were produced by bsx_dev_assemble_inputs WITH d_paths, i.e. their path digests are nodes
+ * of header trees this library hashed itself and already sit in the slot section: get_root_from_merkle_proof's 19
+ * compressions per slot are not repeated (the witness is bit-identical; every link assertion A3-A6 is still evaluated on
+ * those digests).  Never set it for proofs that came from a caller. */
+#define BSX_SUBCHAIN_PATHS_FROM_HINT 1u
 
 /* Binary reduce (builder.rs:337-395) of `n` consecutive records per range -> 1, n a power of two <= 256.
  * d_reduce_compact (optional) receives n-1 reduce-node compact witnesses per range. */
