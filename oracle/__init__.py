@@ -12,7 +12,7 @@ import numpy as np
 from blobstreamx_amd import types as T
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_DIR, "liboracle.so")
+_SO = os.environ.get("ORACLE_SO_OVERRIDE") or os.path.join(_DIR, "liboracle.so")   # override: the sanitizer build
 _lib = None
 
 

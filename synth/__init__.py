@@ -13,7 +13,7 @@ import numpy as np
 from blobstreamx_amd import types as T
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_DIR, "libsynth.so")
+_SO = os.environ.get("SYNTH_SO_OVERRIDE") or os.path.join(_DIR, "libsynth.so")   # override: the sanitizer build
 _lib = None
 
 BASE_SEED = 0xB10B57
@@ -73,7 +73,8 @@ def chain(seed, n_headers, valset_hash, start_height=START_HEIGHT, chain_id=CHAI
     return headers, hashes
 
 
-def commits(seed, valset, v_max, heights, block_hashes, time_secs, chain_id=CHAIN_ID, absent_permille=0, n_threads=None):
+def commits(seed, valset, v_max, heights, block_hashes, time_secs, chain_id=CHAIN_ID, absent_permille=0, n_threads=None, round=0,
+            nil_permille=0):
     """One signed commit per (height, block_hash) -> ndarray[n_commits, v_max] of VALIDATOR"""
     heights = np.ascontiguousarray(heights, np.uint64).reshape(-1)
     n = heights.size
@@ -84,7 +85,8 @@ def commits(seed, valset, v_max, heights, block_hashes, time_secs, chain_id=CHAI
         n_threads = os.cpu_count() or 1
     rc = lib().synth_commits(C.c_uint64(seed), chain_id.encode(), C.c_uint32(n), _p(heights), _p(bh), _p(ts),
                              C.c_uint32(valset.v), C.c_uint32(v_max), _p(valset.sk_seeds), _p(valset.pubkeys),
-                             _p(valset.powers), C.c_uint32(absent_permille), C.c_int(n_threads), _p(out))
+                             _p(valset.powers), C.c_uint32(absent_permille), C.c_int(n_threads), _p(out), C.c_uint64(round),
+                             C.c_uint32(nil_permille))
     assert rc == 0
     return out
 
@@ -128,7 +130,7 @@ class Workload:
     """
 
     def __init__(self, config_index, n_ranges, nb_map_jobs, batch_size, v, v_max=None, n_blocks=None, mode="F",
-                 absent_permille=0, chain_id=CHAIN_ID):
+                 absent_permille=0, chain_id=CHAIN_ID, round=0, nil_permille=0):
         J, B = nb_map_jobs, batch_size
         self.J, self.B, self.R, self.v = J, B, n_ranges, v
         self.v_max = v_max or v
@@ -169,7 +171,7 @@ class Workload:
         ts = (TIME0 + 12 * idx).astype(np.uint64).reshape(-1)
         self.commit_hashes = bh.copy()
         self.validators = commits(seed ^ 0xC0FFEE, self.valset, self.v_max, heights, bh, ts, chain_id=chain_id,
-                                  absent_permille=absent_permille)
+                                  absent_permille=absent_permille, round=round, nil_permille=nil_permille)
         self.trusted = np.tile(self.valset.as_validators(self.v_max), (n_ranges, 1))
 
     def input48(self, r):

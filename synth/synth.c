@@ -131,7 +131,7 @@ static void car25519(gf o) {
         o[i] += (1LL << 16);
         c = o[i] >> 16;
         o[(i + 1) * (i < 15)] += c - 1 + 37 * (c - 1) * (i == 15);
-        o[i] -= c << 16;
+        o[i] -= c * 65536; /* not `c << 16`: c may be negative (UBSan) */
     }
 }
 static void sel25519(gf p, gf q, int b) {
@@ -211,7 +211,7 @@ static void modL(u8* r, i64 x[64]) {
         for (j = i - 32; j < i - 12; ++j) {
             x[j] += carry - 16 * x[i] * (i64)LL[j - (i - 32)];
             carry = (x[j] + 128) >> 8;
-            x[j] -= carry << 8;
+            x[j] -= carry * 256; /* carry may be negative: no `<<` (UBSan) */
         }
         x[j] += carry;
         x[i] = 0;
@@ -406,6 +406,9 @@ typedef struct {
     const uint64_t* powers;
     uint32_t absent_permille;
     bsx_validator* out;
+    uint64_t round;            /* commit round: != 0 adds the CanonicalVote round field (block hash then sits at offset 25) */
+    uint32_t nil_permille;     /* validators that voted NIL (BlockIDFlagNil): a valid signature over a vote WITHOUT block id,
+                                  is_signed = 0 — the slot carries bytes that must not be counted */
 } cjob_t;
 
 static void* commit_worker(void* arg) {
@@ -430,17 +433,24 @@ static void* commit_worker(void* arg) {
             memcpy(o->pubkey, j->pubkeys + 32 * i, 32);
             int absent = (rng_next(&r) % 1000) < j->absent_permille;
             if (absent) continue;
-            o->is_signed = 1;
+            const int nil = j->nil_permille && (rng_next(&r) % 1000) < j->nil_permille;
+            o->is_signed = nil ? 0 : 1;
             /* CanonicalVote sign-bytes */
             u8 body[160], ts[16];
             int n = 0, tn = 0;
             body[n++] = 0x08; body[n++] = 0x02;
             body[n++] = 0x11;
             for (int b = 0; b < 8; b++) body[n++] = (u8)(j->heights[c] >> (8 * b));
-            body[n++] = 0x22; body[n++] = 0x48; body[n++] = 0x0a; body[n++] = 0x20;
-            memcpy(body + n, j->block_hashes + 32 * c, 32); n += 32;
-            body[n++] = 0x12; body[n++] = 0x24; body[n++] = 0x08; body[n++] = 0x01; body[n++] = 0x12; body[n++] = 0x20;
-            memcpy(body + n, parts_hash, 32); n += 32;
+            if (j->round) {
+                body[n++] = 0x19;
+                for (int b = 0; b < 8; b++) body[n++] = (u8)(j->round >> (8 * b));
+            }
+            if (!nil) {
+                body[n++] = 0x22; body[n++] = 0x48; body[n++] = 0x0a; body[n++] = 0x20;
+                memcpy(body + n, j->block_hashes + 32 * c, 32); n += 32;
+                body[n++] = 0x12; body[n++] = 0x24; body[n++] = 0x08; body[n++] = 0x01; body[n++] = 0x12; body[n++] = 0x20;
+                memcpy(body + n, parts_hash, 32); n += 32;
+            }
             u64 secs = j->time_secs[c] + 10 + rng_next(&r) % 2, nanos = rng_next(&r) % 1000000000ULL;
             ts[tn++] = 0x08; tn += put_varint(ts + tn, secs);
             if (nanos) { ts[tn++] = 0x10; tn += put_varint(ts + tn, nanos); }
@@ -463,8 +473,8 @@ static void* commit_worker(void* arg) {
 int synth_commits(uint64_t seed, const char* chain_id, uint32_t n_commits, const uint64_t* heights,
                   const uint8_t* block_hashes, const uint64_t* time_secs, uint32_t v, uint32_t v_max,
                   const uint8_t* sk_seeds, const uint8_t* pubkeys, const uint64_t* powers, uint32_t absent_permille,
-                  int n_threads, bsx_validator* out) {
-    if (strlen(chain_id) > 40 || v > v_max) return 1; /* keeps the sign-bytes <= 124 */
+                  int n_threads, bsx_validator* out, uint64_t round, uint32_t nil_permille) {
+    if (strlen(chain_id) > (round ? 31 : 40) || v > v_max) return 1; /* keeps the sign-bytes <= 124 */
     init_tables();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
@@ -472,7 +482,7 @@ int synth_commits(uint64_t seed, const char* chain_id, uint32_t n_commits, const
     cjob_t jobs[64];
     for (int t = 0; t < n_threads; t++) {
         cjob_t j = {seed, chain_id, n_commits, v, v_max, (uint32_t)t, (uint32_t)n_threads, heights, block_hashes, time_secs,
-                    sk_seeds, pubkeys, powers, absent_permille, out};
+                    sk_seeds, pubkeys, powers, absent_permille, out, round, nil_permille};
         jobs[t] = j;
         pthread_create(&th[t], NULL, commit_worker, &jobs[t]);
     }

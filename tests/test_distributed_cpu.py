@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 import oracle
 import synth
 from blobstreamx_amd import types as T
-from blobstreamx_amd.engine import gather_partials, job_slice
+from blobstreamx_amd.engine import all_gather_records, gather_partials, job_slice
 
 
 def _free_port():
@@ -50,7 +50,16 @@ def _worker(rank, world, port, J, B, R, n_blocks, q):
                                                    bytes(w.ranges[r]["end_header_hash"]))
                 recs.append(rec)
             _, partial[r], _ = oracle.reduce(np.array(recs, T.SUBCHAIN))
-        top = gather_partials(torch.from_numpy(partial.view(np.uint8).reshape(-1).copy()), rank, world, R)
+        flat = torch.from_numpy(partial.view(np.uint8).reshape(-1).copy())
+        top = gather_partials(flat, rank, world, R)
+        # the branch the GPU engine takes at N > 1 (engine.step_exchange_begin / _end): the collective issued with
+        # async_op=True into a preallocated buffer, finished by work.wait() — must deliver the same [rank][range] image
+        g_sync = all_gather_records(flat, world, RT)
+        g_async, work = all_gather_records(flat, world, RT, out_gathered=torch.full((world * RT * 128,), 0xEE, dtype=torch.uint8), async_op=True)
+        assert work is not None
+        work.wait()
+        assert torch.equal(g_sync, g_async)
+        assert torch.equal(g_async.view(world, RT, 128)[rank], flat.view(RT, 128))
         top = top.numpy().view(T.SUBCHAIN).reshape(R, world)
         res = []
         for k in range(R):

@@ -500,6 +500,40 @@ def test_chain_id_is_checked_on_gpu_like_the_oracle():
             assert rc == want == (T.OK if cid == fork_id.encode() else T.ERR_ASSERT)
 
 
+@pytest.mark.parametrize("rnd,nil,absent", [(3, 250, 150), (1 << 40, 0, 0), (0, 400, 0), (9, 0, 600)])
+def test_commit_round_nonzero_nil_and_absent_votes_on_gpu(rnd, nil, absent):
+    """round != 0 sign-bytes (block hash at offset 25), BlockIDFlag Nil and Absent validators — per
+    signature ok bits, commit results and the header_range verdict (which may be BSX_ERR_VOTING_POWER when too few signed)
+    equal the oracle's, through both Ed25519 paths (8 commits -> fixed-key tables, 1 commit -> generic)."""
+    V = 24
+    w = synth.Workload(35, 8, 2, 4, v=V, round=rnd, nil_permille=nil, absent_permille=absent)
+    res, ok = verify_commits(w.validators, w.commit_hashes)
+    for c in range(8):
+        want, wok = oracle.verify_commit(w.validators[c], w.commit_hashes[c].tobytes())
+        assert (ok[c] == wok).all() and res_bytes(res[c]) == res_bytes(want), c
+        signed = w.validators[c]["is_signed"] != 0
+        assert (ok[c] == signed).all() and want["n_bad_message"] == 0
+    res1, ok1 = verify_commits(w.validators[:1], w.commit_hashes[:1])
+    assert (ok1[0] == ok[0]).all() and res_bytes(res1[0]) == res_bytes(res[0])
+    bad = w.validators[:1].copy()
+    k = int(np.nonzero(bad[0]["is_signed"])[0][0])
+    off = 25 if rnd else 16
+    bad[0, k]["message"][off + 3] ^= 0x10                         # the carried block hash no longer matches
+    r2, o2 = verify_commits(bad, w.commit_hashes[:1])
+    want, wok = oracle.verify_commit(bad[0], w.commit_hashes[0].tobytes())
+    assert res_bytes(r2[0]) == res_bytes(want) and (o2[0] == wok).all() and want["n_bad_message"] == 1
+    for r in range(3):
+        S = int(w.first_height[r])
+        rc = oracle.header_range(2, 4, w.input48(r), w.headers[r], S, int(w.latest[r]), w.validators[r], w.trusted[r])[0]
+        try:
+            CombinedSkipCircuit(V, 2, 4).prove(w.input48(r), InputDataFetcher(w.headers[r], S, int(w.latest[r])), w.validators[r], w.trusted[r])
+            got = T.OK
+        except _lib.BsxError as e:
+            got = e.status
+        assert got == rc, (r, got, rc)
+        assert rc in (T.OK, T.ERR_VOTING_POWER)
+
+
 def test_header_range_failure_codes_match_oracle():
     J, B, v = 2, 4, 10
     circ = CombinedSkipCircuit(v, J, B)
