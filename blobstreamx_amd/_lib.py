@@ -20,7 +20,7 @@ _ctx = {}
 # every symbol include/bsx.h declares (checked by tests/test_abi.py without touching a GPU)
 SYMBOLS = [
     "bsx_version", "bsx_init", "bsx_shutdown", "bsx_last_error", "bsx_status_str", "bsx_device_count",
-    "bsx_map_witness_layout", "bsx_reduce_witness_layout",
+    "bsx_map_witness_layout", "bsx_reduce_witness_layout", "bsx_witness_manifest",
     "bsx_encode_data_root_tuple", "bsx_get_data_commitment", "bsx_header_hashes", "bsx_data_commitment_inputs",
     "bsx_prove_subchain", "bsx_reduce", "bsx_prove_data_commitment", "bsx_prove_next_header_data_commitment",
     "bsx_verify_commits", "bsx_header_range", "bsx_next_header",

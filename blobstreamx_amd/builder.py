@@ -251,3 +251,25 @@ class CombinedSkipCircuit:
             _lib.p(rv), C.c_uint32(self.V), _lib.p(np.frombuffer(self.chain_id, np.uint8).copy()) if self.chain_id else None,
             C.c_uint32(len(self.chain_id)), _lib.p(out), _lib.p(res), _lib.p(wit)))
         return out.tobytes(), res[0], wit
+
+
+def witness_manifest(batch_size):
+    """bsx_witness_manifest -> ndarray[MANIFEST_ENTRY]: the variable groups of one map job's witness (batch_size = 0: of one
+    reduce node) with their element offsets; `witness_view` slices a witness by group name."""
+    L = _lib.lib()
+    n = C.c_uint32(0)
+    _lib.check(L.bsx_witness_manifest(C.c_uint32(batch_size), None, C.c_uint32(0), C.byref(n)))
+    ent = np.zeros(n.value, T.MANIFEST_ENTRY)
+    _lib.check(L.bsx_witness_manifest(C.c_uint32(batch_size), _lib.p(ent), C.c_uint32(n.value), C.byref(n)))
+    return ent
+
+
+def witness_view(manifest, witness, name):
+    """Elements of the group `name` of ONE job's witness -> [repeat, elements_per_record] (u64).  BYTES groups decode with
+    np.packbits(v.astype(np.uint8), axis=1) (MSB first), U32 pairs as lo + (hi << 32)."""
+    e = manifest[[m["name"].decode() == name or m["name"].decode().startswith(name + " ") for m in manifest]]
+    if e.size != 1:
+        raise KeyError(name)
+    e = e[0]
+    idx = int(e["element_offset"]) + np.arange(int(e["repeat"]))[:, None] * int(e["record_stride"]) + np.arange(int(e["elements_per_record"]))[None, :]
+    return np.asarray(witness)[idx]

@@ -70,6 +70,10 @@ assert DH_PROOF.itemsize == 162 and LB_PROOF.itemsize == 200
 assert SHARED_CTX.itemsize == 80 and SUBCHAIN.itemsize == 128
 assert VALIDATOR.itemsize == 256 and COMMIT_RESULT.itemsize == 96
 assert WITNESS_LAYOUT.itemsize == 40
+MANIFEST_ENTRY = np.dtype([("name", "S80"), ("reference", "S24"), ("kind", "<u4"), ("repeat", "<u4"), ("element_offset", "<u8"),
+                           ("elements_per_record", "<u8"), ("record_stride", "<u8")])
+assert MANIFEST_ENTRY.itemsize == 136
+KIND_BYTES, KIND_U32, KIND_BOOL = 0, 1, 2
 
 HEADER_FIELD_NAMES = ["version", "chain_id", "height", "time", "last_block_id"] + ["hash"] * 8 + ["proposer"]
 HEADER_FIELD_CAP = [24, 52, 12, 20, 76] + [36] * 8 + [24]

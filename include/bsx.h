@@ -192,6 +192,26 @@ typedef struct bsx_witness_layout {
 int bsx_map_witness_layout(uint32_t batch_size, bsx_witness_layout* out);
 int bsx_reduce_witness_layout(bsx_witness_layout* out);   /* one reduce node */
 
+/* Witness manifest: which elements of an expanded witness belong to which circuit variable — what a plonky2x shim needs
+ * to hand every value to its `Variable` (DataCommitmentProofVariable / MapReduceSubchainVariable, circuits/vars.rs:13-36;
+ * intermediate variables of circuits/builder.rs:105-271,337-395) without hard-coding offsets.  One entry per variable
+ * group; record r of a group occupies elements [element_offset + r*record_stride, .. + elements_per_record).  The entries
+ * tile [0, n_elements) exactly once.  batch_size = 0: one reduce node.  entries may be NULL to query the count.
+ * Host-side only (works without a GPU). */
+#define BSX_KIND_BYTES 0u   /* BytesVariable: 8 BoolVariable elements per byte, MSB first; elements_per_record = 8 * bytes */
+#define BSX_KIND_U32 1u     /* u32 limbs: a U64Variable is 2 elements, limb 0 (low) first (builder.rs:124-128) */
+#define BSX_KIND_BOOL 2u    /* BoolVariable: one element, 0/1 */
+typedef struct bsx_manifest_entry {
+    char name[80];              /* variable (group) name as in the reference, `[]` = one record per slot / node */
+    char reference[24];         /* file:line under circuits/ that creates it */
+    uint32_t kind;
+    uint32_t repeat;            /* records in the group: BATCH_SIZE, BATCH_SIZE - 1 or 1 */
+    uint64_t element_offset;    /* first element of record 0 */
+    uint64_t elements_per_record;
+    uint64_t record_stride;     /* elements between consecutive records (== elements_per_record when repeat == 1) */
+} bsx_manifest_entry;           /* sizeof == 136 */
+int bsx_witness_manifest(uint32_t batch_size, bsx_manifest_entry* entries, uint32_t capacity, uint32_t* out_n);
+
 /* ------------------------------------------------------------------ host tier */
 
 /* encode_data_root_tuple — circuits/builder.rs:23-27,82-103.  out = 0x00*24 ‖ height BE ‖ data_hash. */

@@ -58,3 +58,31 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src and "orc_" not in src, f
+
+
+def test_witness_manifest_tiles_the_witness_and_matches_the_layout_header():
+    """the manifest covers [0, n_elements) exactly once and agrees with include/bsx_layout.h (through its
+    Python twin) for every batch size the bins use, and for a reduce node."""
+    from blobstreamx_amd.builder import witness_manifest
+    for B in (1, 2, 32, 64, 256, 0):
+        lay = T.map_layout(B) if B else T.reduce_layout()
+        m = witness_manifest(B)
+        n = int(lay["n_elements"])
+        cover = np.zeros(n, np.int32)
+        for e in m:
+            for r in range(int(e["repeat"])):
+                a = int(e["element_offset"]) + r * int(e["record_stride"])
+                cover[a:a + int(e["elements_per_record"])] += 1
+            assert e["reference"].decode().split(":")[0] in ("builder.rs", "vars.rs")
+        assert (cover == 1).all(), (B, np.nonzero(cover != 1)[0][:5])
+        nbits, nw = 8 * int(lay["n_bytes"]), int(lay["n_words"])
+        for e in m:
+            lo = int(e["element_offset"])
+            sec = 0 if lo < nbits else 1 if lo < nbits + nw else 2
+            assert sec == int(e["kind"]), e["name"]
+        names = [e["name"].decode() for e in m]
+        assert len(set(names)) == len(names)
+        if B:
+            assert names[0] == "ctx.start_header_hash" and "record.data_merkle_root" in names and "data_comm_proof.data_hash_proofs[].leaf" in names
+    n = C.c_uint32(0)
+    assert _lib.lib().bsx_witness_manifest(C.c_uint32(3), None, C.c_uint32(0), C.byref(n)) == T.ERR_BAD_ARG

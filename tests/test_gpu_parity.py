@@ -534,6 +534,73 @@ def test_commit_round_nonzero_nil_and_absent_votes_on_gpu(rnd, nil, absent):
         assert rc in (T.OK, T.ERR_VOTING_POWER)
 
 
+def test_mode_s_full_size_2048_x_512_vs_oracle():
+    """BASELINE config #5 in mode S at FULL size on one GPU: one header_range_2048 whose every header carries its own
+    512-validator commit = 1,048,576 signatures (next_header.rs:25-47 per header).  Every per-signature ok bit and all 2048
+    commit results (validators hash, tallies, 2/3 flag, message checks) against the oracle run on all host threads; a
+    sprinkle of tampered signatures / messages / absent validators keeps the verdicts from being all-ones."""
+    import os
+    J, B, V = 32, 64, 512
+    w = synth.Workload(5, 1, J, B, v=V, mode="S", absent_permille=30)
+    vals = w.validators.reshape(J * B, V).copy()
+    rng = np.random.default_rng(5)
+    for c in rng.integers(0, J * B, 40):
+        k = int(rng.integers(0, V))
+        which = int(rng.integers(0, 3))
+        if which == 0:
+            vals[c, k]["signature"][int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+        elif which == 1:
+            vals[c, k]["message"][20] ^= 4                           # inside the block hash: bad message AND bad signature
+        else:
+            vals[c, k]["pubkey"][int(rng.integers(0, 31))] ^= 2       # key no longer matches the table row -> generic fallback
+    res, ok = verify_commits(vals, w.commit_hashes)
+    want, wok = oracle.bench_verify_commits(vals, w.commit_hashes, os.cpu_count() or 1)
+    assert (ok == wok).all(), np.argwhere(ok != wok)[:5]
+    a, b = res.copy(), want.copy()
+    a["_pad"] = 0; b["_pad"] = 0
+    assert a.tobytes() == b.tobytes()
+    assert 0 < (ok == 0).sum() < 0.05 * ok.size and res["n_bad_signature"].sum() >= 20 and res["two_thirds_ok"].all()
+
+
+def test_witness_manifest_decodes_a_real_witness():
+    """bsx_witness_manifest used the way a plonky2x shim would: slice the expanded witness of every map job by variable
+    name and check the decoded VALUES against what the ABI returns separately (records, hint output, public output)."""
+    from blobstreamx_amd.builder import witness_manifest, witness_view
+    J, B, V = 4, 8, 6
+    w = synth.Workload(44, 1, J, B, v=V, n_blocks=27)
+    S = int(w.first_height[0])
+    f = InputDataFetcher(w.headers[0], S, int(w.latest[0]))
+    out, _, wit = CombinedSkipCircuit(V, J, B).prove(w.input48(0), f, w.validators[0], w.trusted[0], want_witness=True)
+    bld = DataCommitmentBuilder()
+    res = bld.prove_data_commitment(f, J, B, S, w.hashes[0, 0].tobytes(), S + 27, w.hashes[0, 27].tobytes())
+    m, mr = witness_manifest(B), witness_manifest(0)
+    nel, rel = int(T.map_layout(B)["n_elements"]), int(T.reduce_layout()["n_elements"])
+    pack = lambda v: np.packbits(v.astype(np.uint8), axis=1)
+    u64 = lambda v: int(v[0, 0]) | (int(v[0, 1]) << 32)
+    for j in range(J):
+        wj = wit[j * nel:(j + 1) * nel]
+        rec = res["records"][j]
+        assert pack(witness_view(m, wj, "record.data_merkle_root"))[0].tobytes() == bytes(rec["data_merkle_root"])
+        assert pack(witness_view(m, wj, "record.end_header"))[0].tobytes() == bytes(rec["end_header"])
+        assert u64(witness_view(m, wj, "record.start_block")) == int(rec["start_block"]) == S + j * B
+        assert u64(witness_view(m, wj, "record.end_block")) == int(rec["end_block"])
+        assert int(witness_view(m, wj, "record.is_enabled")[0, 0]) == int(rec["is_enabled"])
+        assert u64(witness_view(m, wj, "batch_end_block")) == S + (j + 1) * B
+        inp = f.get_data_commitment_inputs(S + j * B, S + (j + 1) * B, B)
+        assert (pack(witness_view(m, wj, "data_comm_proof.data_hash_proofs[].leaf")) == inp["data_hash_proofs"]["leaf"]).all()
+        assert (pack(witness_view(m, wj, "data_comm_proof.last_block_id_proofs[].proof")).reshape(B, 4, 32) == inp["last_block_id_proofs"]["aunts"]).all()
+        heights = witness_view(m, wj, "block_height[]")
+        assert [int(h[0]) | (int(h[1]) << 32) for h in heights] == [S + j * B + i for i in range(B)]
+        roots = pack(witness_view(m, wj, "slot[].data_hash_path"))[:, 128:160]        # last of the 5 path digests
+        for i in range(B):
+            if S + j * B + i < S + 27:
+                assert roots[i].tobytes() == w.hashes[0, j * B + i].tobytes()          # data_hash_proof_root == header hash
+    top = wit[J * nel + (J - 2) * rel:]                                                # the last reduce node = the range result
+    assert pack(witness_view(mr, top, "out.data_merkle_root"))[0].tobytes() == out[32:]
+    with pytest.raises(KeyError):
+        witness_view(m, wit[:nel], "no_such_variable")
+
+
 def test_header_range_failure_codes_match_oracle():
     J, B, v = 2, 4, 10
     circ = CombinedSkipCircuit(v, J, B)
