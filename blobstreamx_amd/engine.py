@@ -274,8 +274,11 @@ class HeaderRangeEngine:
                 main.wait_event(done)
             chk(L.bsx_dev_fill_end_hash(ctx, st, C.c_uint32(R), dp(self.skip_ranges), dp(self.skip_hashes), C.c_uint64(2),
                                         dp(self.target_idx), dp(self.target_hashes), dp(self._skip_hashes_pp[self._parity])))
-            if self.nh_all > RT * self.hpr:
-                self._skip_headers_pp[self._parity][:R * 1024].copy_(self.skip_headers[:R * 1024], non_blocking=True)   # 1 KB per range, d2d
+            if self._h2d is not None:
+                # streamed inputs: headers_all is overwritten early in the next pass, the deferred commit check keeps reading the
+                # (trusted, target) headers -> private copy per parity (1 KB per range, d2d; 0.5 ms when queued behind the
+                # expansion's stores, hence only when needed)
+                self._skip_headers_pp[self._parity][:R * 1024].copy_(self.skip_headers[:R * 1024], non_blocking=True)
             self.fill_done = torch.cuda.Event()
             self.fill_done.record(main)
             if self.commit_with == "hash":
@@ -319,7 +322,8 @@ class HeaderRangeEngine:
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.trusted), C.c_uint32(R), C.c_uint32(V), None, None, dp(self.trusted_res)))
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.validators), C.c_uint32(R), C.c_uint32(V), dp(self.target_hashes), dp(self.ok),
                                    dp(self.commit_res)))
-        chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges_side), dp(self._skip_headers_pp[self._parity]),
+        chk(L.bsx_dev_skip_check(ctx, st, C.c_uint32(R), C.c_uint32(V), dp(self.skip_ranges_side),
+                                 dp(self._skip_headers_pp[self._parity] if self._h2d is not None else self.skip_headers),
                                  C.c_uint64(2), dp(self._skip_hashes_pp[self._parity]), dp(self.validators), dp(self.trusted),
                                  dp(self.ok), dp(self.commit_res), dp(self.trusted_res), dp(self.skip_status), None,
                                  dp(self.target_idx), _lib.p(self.chain_id) if self.chain_id.size else None,

@@ -41,6 +41,7 @@ __global__ void k_issue(uint32_t* out, int iters) {
 }
 
 // BODY 0: gl_mul (4 independent chains)  1: poseidon_permute  2: sha512_compress  3: fe_mul  4: poseidon_mds only  5: gl_pow7 x12
+//      6: fe_sq
 template <int BODY>
 __global__ void k_body(uint32_t* out, int iters) {
     uint32_t x = 0;
@@ -70,7 +71,10 @@ __global__ void k_body(uint32_t* out, int iters) {
     } else {
         fe f, g;
         for (int i = 0; i < 10; i++) { f.v[i] = (int32_t)((threadIdx.x * 2654435761u + i * 40503u) & 0x1ffffff); g.v[i] = (int32_t)((blockIdx.x * 97u + i * 7919u + threadIdx.x) & 0x1ffffff); }
-        for (int r = 0; r < iters; r++) { f = fe_mul(f, g); g = fe_mul(g, f); }
+        for (int r = 0; r < iters; r++) {
+            if (BODY == 3) { f = fe_mul(f, g); g = fe_mul(g, f); }
+            else { f = fe_sq(f); g = fe_sq(g); }
+        }
         for (int i = 0; i < 10; i++) x ^= (uint32_t)f.v[i] ^ (uint32_t)g.v[i];
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x;
@@ -103,10 +107,11 @@ int main() {
         double ops = (double)blocks * threads * iters * 64;
         printf("issue %-15s : %.3f ms  %.2f T lane-ops/s\n", names[mode], ms, ops / ms / 1e9);
     }
-    const char* bn[] = {"gl_mul (Goldilocks 64x64 mod p)", "poseidon_permute", "sha512_compress", "fe_mul (Curve25519, 10 limbs)", "poseidon_mds", "gl_pow7 x 12"};
-    const double per_iter[] = {4, 1, 1, 2, 1, 12};
-    const int it[] = {2000, 40, 200, 400, 1000, 200};
-    for (int body = 0; body < 6; body++)
+    const char* bn[] = {"gl_mul (Goldilocks 64x64 mod p)", "poseidon_permute", "sha512_compress", "fe_mul (Curve25519, 10 limbs)", "poseidon_mds", "gl_pow7 x 12",
+                        "fe_sq (Curve25519)"};
+    const double per_iter[] = {4, 1, 1, 2, 1, 12, 2};
+    const int it[] = {2000, 40, 200, 400, 1000, 200, 400};
+    for (int body = 0; body < 7; body++)
         for (int wps : {1, 2, 4, 8}) {
             const int nb = 256 * wps;
             auto run = [&] {
@@ -116,7 +121,8 @@ int main() {
                     case 2: hipLaunchKernelGGL(k_body<2>, dim3(nb), dim3(256), 0, 0, out, it[body]); break;
                     case 3: hipLaunchKernelGGL(k_body<3>, dim3(nb), dim3(256), 0, 0, out, it[body]); break;
                     case 4: hipLaunchKernelGGL(k_body<4>, dim3(nb), dim3(256), 0, 0, out, it[body]); break;
-                    default: hipLaunchKernelGGL(k_body<5>, dim3(nb), dim3(256), 0, 0, out, it[body]); break;
+                    case 5: hipLaunchKernelGGL(k_body<5>, dim3(nb), dim3(256), 0, 0, out, it[body]); break;
+                    default: hipLaunchKernelGGL(k_body<6>, dim3(nb), dim3(256), 0, 0, out, it[body]); break;
                 }
             };
             float ms = timeit(run, 3);
