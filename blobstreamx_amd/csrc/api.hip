@@ -714,6 +714,9 @@ int bsx_find_block_to_request(bsx_ctx* ctx, uint64_t start_block, uint64_t max_e
         SYNC();
     }
     if (out_evals) memcpy(out_evals, ev.data(), (size_t)n_candidates * sizeof(bsx_skip_eval));
+    for (uint32_t c = 0; c < n_candidates; c++)
+        if (ev[c].power_overflow)
+            return fail(BSX_ERR_BAD_ARG, "candidate %u: a validator set's voting power exceeds MaxTotalVotingPower (MaxInt64 / 8)", c);
     uint64_t curr_end_block = max_end_block;                                  // :61
     for (;;) {                                                                // :62
         if (curr_end_block - start_block == 1) break;                         // :63-65
@@ -762,6 +765,9 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
     D2H(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result));
     if (out_sig_ok) D2H(out_sig_ok, dok.p, n);
     SYNC();
+    for (uint32_t c = 0; c < n_commits; c++)
+        if (out_results[c].power_overflow)
+            return fail(BSX_ERR_BAD_ARG, "commit %u: the voting powers add up to more than MaxTotalVotingPower (MaxInt64 / 8); tallies are meaningless", c);
     return BSX_OK;
 }
 

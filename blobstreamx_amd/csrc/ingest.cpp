@@ -104,7 +104,12 @@ int ifail(int code, const std::string& m) { g_ingest_err = m; return code; }
 bool as_u64(const JVal* v, uint64_t& out) {          // Tendermint encodes 64-bit ints as strings, small ones as numbers
     if (!v || (v->kind != JVal::Str && v->kind != JVal::Num) || v->s.empty()) return false;
     uint64_t x = 0;
-    for (char c : v->s) { if (c < '0' || c > '9') return false; x = x * 10 + (uint64_t)(c - '0'); }
+    for (char c : v->s) {
+        if (c < '0' || c > '9') return false;
+        const uint64_t d = (uint64_t)(c - '0');
+        if (x > (0x7fffffffffffffffull - d) / 10) return false;      // Tendermint integers are int64: anything above is malformed
+        x = x * 10 + d;
+    }
     out = x;
     return true;
 }
@@ -301,8 +306,9 @@ int bsx_ingest_signed_block_json(const char* json, size_t len, const char* valid
     if (!parse_block_id(commit->get("block_id"), bid) || bid.hash.size() != 32) return ifail(BSX_ERR_BAD_ARG, "bad commit.block_id");
     if (out_block_hash) memcpy(out_block_hash, bid.hash.data(), 32);
     uint64_t cheight = 0, round = 0;
-    as_u64(commit->get("height"), cheight);
-    as_u64(commit->get("round"), round);
+    if (!as_u64(commit->get("height"), cheight)) return ifail(BSX_ERR_BAD_ARG, "commit.height missing or malformed");
+    if (cheight != height) return ifail(BSX_ERR_BAD_ARG, "commit.height does not equal header.height");
+    if (commit->get("round") && !as_u64(commit->get("round"), round)) return ifail(BSX_ERR_BAD_ARG, "commit.round malformed");
     if (!out_validators) { if (out_n_validators) *out_n_validators = 0; return BSX_OK; }
 
     JVal vroot;
@@ -336,8 +342,8 @@ int bsx_ingest_signed_block_json(const char* json, size_t len, const char* valid
         for (const JVal& s : sigs->arr) {
             const JVal* sa = s.get("validator_address");
             uint64_t flag = 0;
-            as_u64(s.get("block_id_flag"), flag);
-            if (!sa || sa->s != addr->s || flag != 2) continue;      // 2 = BlockIDFlagCommit: signed this block id
+            if (!as_u64(s.get("block_id_flag"), flag) || flag < 1 || flag > 3) return ifail(BSX_ERR_BAD_ARG, "bad block_id_flag");
+            if (!sa || sa->s != addr->s || flag != 2) continue;      // 2 = BlockIDFlagCommit: signed this block id (1 absent, 3 nil)
             std::vector<uint8_t> sig;
             const JVal* sv = s.get("signature");
             const JVal* ts = s.get("timestamp");

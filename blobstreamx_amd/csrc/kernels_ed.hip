@@ -263,19 +263,20 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
                                                              bsx_commit_result* __restrict__ results) {
     __shared__ uint32_t nodes[2][TL_VMAX * 8];
     __shared__ uint8_t en[2][TL_VMAX];
-    __shared__ unsigned long long s_total, s_signed, s_trusted;
+    __shared__ unsigned long long s_total, s_signed, s_trusted, s_total_hi, s_total_lo;
     __shared__ uint32_t s_nen, s_nsig, s_nbad, s_firstbad, s_nbadmsg;
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     const bsx_validator* cv = vals + (uint64_t)c * v_max;
     uint32_t P = 1;
     while (P < v_max) P *= 2;
-    if (tid == 0) { s_total = 0; s_signed = 0; s_trusted = 0; s_nen = 0; s_nsig = 0; s_nbad = 0; s_firstbad = 0xffffffffu; s_nbadmsg = 0; }
+    if (tid == 0) { s_total = 0; s_signed = 0; s_trusted = 0; s_total_hi = 0; s_total_lo = 0; s_nen = 0; s_nsig = 0; s_nbad = 0; s_firstbad = 0xffffffffu; s_nbadmsg = 0; }
     __syncthreads();
     uint32_t hh[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) hh[k] = header_hashes ? reinterpret_cast<const uint32_t*>(header_hashes + 32 * (uint64_t)c)[k] : 0u;
 
     uint64_t total = 0, signedp = 0, trusted = 0;
+    uint64_t total_hi = 0, total_lo = 0;     // exact sum in two halves: the u64 `total` may wrap
     uint32_t nen = 0, nsig = 0, nbad = 0, nbadmsg = 0;
     for (uint32_t v = tid; v < P; v += TL_THREADS) {
         uint32_t pk[8];
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
             if (enabled) {
                 nen++;
                 total += power;
+                total_hi += power >> 32; total_lo += power & 0xffffffffull;
                 if (is_signed) {
                     nsig++;
                     const bool sig = ok_in ? (ok_in[(uint64_t)c * v_max + v] != 0) : false;
@@ -329,10 +331,12 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     }
     // wave-level reduction, then one LDS atomic per wave
     total = wave_sum_u64(total); signedp = wave_sum_u64(signedp); trusted = wave_sum_u64(trusted);
+    total_hi = wave_sum_u64(total_hi); total_lo = wave_sum_u64(total_lo);
     nen = wave_sum_u32(nen); nsig = wave_sum_u32(nsig); nbad = wave_sum_u32(nbad); nbadmsg = wave_sum_u32(nbadmsg);
     if ((tid & 63) == 0) {
         atomicAdd(&s_total, (unsigned long long)total); atomicAdd(&s_signed, (unsigned long long)signedp);
         atomicAdd(&s_trusted, (unsigned long long)trusted);
+        atomicAdd(&s_total_hi, (unsigned long long)total_hi); atomicAdd(&s_total_lo, (unsigned long long)total_lo);
         atomicAdd(&s_nen, nen); atomicAdd(&s_nsig, nsig); atomicAdd(&s_nbad, nbad); atomicAdd(&s_nbadmsg, nbadmsg);
     }
     __syncthreads();
@@ -359,8 +363,10 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
         o->total_power = s_total; o->signed_power = s_signed; o->trusted_signed_power = s_trusted;
         o->n_enabled = s_nen; o->n_signed = s_nsig; o->n_bad_signature = s_nbad; o->first_bad_signature = s_firstbad;
         o->n_bad_message = s_nbadmsg;
-        o->two_thirds_ok = ((unsigned __int128)s_signed * 3 > (unsigned __int128)s_total * 2) ? 1u : 0u;
-        o->_pad[0] = o->_pad[1] = o->_pad[2] = o->_pad[3] = 0;
+        const bool overflow = (((unsigned __int128)s_total_hi << 32) + s_total_lo) > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER;
+        o->two_thirds_ok = (!overflow && (unsigned __int128)s_signed * 3 > (unsigned __int128)s_total * 2) ? 1u : 0u;
+        o->power_overflow = overflow ? 1u : 0u;
+        o->_pad[0] = o->_pad[1] = o->_pad[2] = 0;
     }
 }
 
@@ -441,6 +447,7 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
         const uint8_t l_chain = th->len[1];
         const uint8_t l_height = th->len[BSX_BLOCK_HEIGHT_INDEX], l_tv = th->len[7], l_rv = tr->len[7];
         const uint32_t n_bad_sig = cr->n_bad_signature, n_bad_msg = cr->n_bad_message, two_thirds = cr->two_thirds_ok;
+        const uint32_t overflow = cr->power_overflow | trc->power_overflow;
         const uint64_t ttotal64 = trc->total_power;
         // the target header's height leaf must encode the target block (varint): byte q of 08 varint(E)
         int hn = 1;
@@ -469,7 +476,8 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
         if (a.target_hashes && tid < 32) a.target_hashes[32 * (uint64_t)r + q] = b_thash;
         if (tid == 0) {
             uint32_t st = BSX_OK;
-            if (!eq_trusted) st = BSX_ERR_ASSERT;
+            if (overflow) st = BSX_ERR_BAD_ARG;          // voting powers beyond MaxTotalVotingPower: the tallies cannot be trusted
+            if (!st && !eq_trusted) st = BSX_ERR_ASSERT;
             if (!st && !heq) st = BSX_ERR_ASSERT;
             if (!st && !ceq) st = BSX_ERR_ASSERT;
             if (!st && (n_bad_sig || n_bad_msg)) st = BSX_ERR_BAD_SIGNATURE;
@@ -492,11 +500,11 @@ __global__ __launch_bounds__(256) void k_skip_eval(const bsx_validator* __restri
                                                    uint32_t v_max, bsx_skip_eval* __restrict__ out) {
     __shared__ uint32_t tpk[TL_VMAX * 8];
     __shared__ uint8_t tsig[TL_VMAX];
-    __shared__ unsigned long long acc[4];          // overlap, start total, signed, target total
+    __shared__ unsigned long long acc[8];          // overlap, start total, signed, target total; exact halves of the two totals
     const uint32_t c = blockIdx.x, tid = threadIdx.x, V = v_max;
     const bsx_validator* tv = cand + (uint64_t)c * V;
-    if (tid < 4) acc[tid] = 0;
-    uint64_t signed_p = 0, target_total = 0;
+    if (tid < 8) acc[tid] = 0;
+    uint64_t signed_p = 0, target_total = 0, tt_hi = 0, tt_lo = 0, st_hi = 0, st_lo = 0;
     for (uint32_t k = tid; k < V; k += 256) {
         uint32_t pk[8];
         load_pk(tv + k, pk);
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(256) void k_skip_eval(const bsx_validator* __restri
         const bool en = (flags.z & 0xffu) != 0, sg = ((flags.z >> 8) & 0xffu) != 0;
         const uint64_t power = (uint64_t)flags.x | ((uint64_t)flags.y << 32);
         tsig[k] = (en && sg) ? 1 : 0;
-        if (en) target_total += power;
+        if (en) { target_total += power; tt_hi += power >> 32; tt_lo += power & 0xffffffffull; }
         if (en && sg) signed_p += power;
     }
     __syncthreads();
@@ -516,6 +524,7 @@ __global__ __launch_bounds__(256) void k_skip_eval(const bsx_validator* __restri
         if ((flags.z & 0xffu) == 0) continue;
         const uint64_t power = (uint64_t)flags.x | ((uint64_t)flags.y << 32);
         start_total += power;
+        st_hi += power >> 32; st_lo += power & 0xffffffffull;
         uint32_t pk[8];
         load_pk(start + i, pk);
         bool found = false;
@@ -530,7 +539,10 @@ __global__ __launch_bounds__(256) void k_skip_eval(const bsx_validator* __restri
     }
     ov = wave_sum_u64(ov); start_total = wave_sum_u64(start_total);
     signed_p = wave_sum_u64(signed_p); target_total = wave_sum_u64(target_total);
+    tt_hi = wave_sum_u64(tt_hi); tt_lo = wave_sum_u64(tt_lo); st_hi = wave_sum_u64(st_hi); st_lo = wave_sum_u64(st_lo);
     if ((tid & 63) == 0) {
+        atomicAdd(&acc[4], (unsigned long long)tt_hi); atomicAdd(&acc[5], (unsigned long long)tt_lo);
+        atomicAdd(&acc[6], (unsigned long long)st_hi); atomicAdd(&acc[7], (unsigned long long)st_lo);
         atomicAdd(&acc[0], (unsigned long long)ov); atomicAdd(&acc[1], (unsigned long long)start_total);
         atomicAdd(&acc[2], (unsigned long long)signed_p); atomicAdd(&acc[3], (unsigned long long)target_total);
     }
@@ -538,8 +550,10 @@ __global__ __launch_bounds__(256) void k_skip_eval(const bsx_validator* __restri
     if (tid == 0) {
         bsx_skip_eval e;
         e.overlap_power = acc[0]; e.start_total_power = acc[1]; e.signed_power = acc[2]; e.target_total_power = acc[3];
-        e.valid = ((unsigned __int128)acc[0] * 3 > (unsigned __int128)acc[1]) ? 1u : 0u;
-        e._pad = 0;
+        const unsigned __int128 cap = BSX_MAX_TOTAL_VOTING_POWER;
+        const bool overflow = (((unsigned __int128)acc[4] << 32) + acc[5]) > cap || (((unsigned __int128)acc[6] << 32) + acc[7]) > cap;
+        e.valid = (!overflow && (unsigned __int128)acc[0] * 3 > (unsigned __int128)acc[1]) ? 1u : 0u;
+        e.power_overflow = overflow ? 1u : 0u;
         out[c] = e;
     }
 }

@@ -56,11 +56,11 @@ VALIDATOR = np.dtype([("pubkey", "u1", 32), ("signature", "u1", 64), ("message",
                       ("message_len", "<u4"), ("voting_power", "<u8"), ("enabled", "u1"), ("is_signed", "u1"),
                       ("present_on_trusted", "u1"), ("_pad", "u1", 21)])
 SKIP_EVAL = np.dtype([("overlap_power", "<u8"), ("start_total_power", "<u8"), ("signed_power", "<u8"),
-                      ("target_total_power", "<u8"), ("valid", "<u4"), ("_pad", "<u4")])      # bsx_skip_eval, 40 B
+                      ("target_total_power", "<u8"), ("valid", "<u4"), ("power_overflow", "<u4")])      # bsx_skip_eval, 40 B
 COMMIT_RESULT = np.dtype([("validators_hash", "u1", 32), ("total_power", "<u8"), ("signed_power", "<u8"),
                           ("trusted_signed_power", "<u8"), ("n_enabled", "<u4"), ("n_signed", "<u4"),
                           ("n_bad_signature", "<u4"), ("first_bad_signature", "<u4"), ("n_bad_message", "<u4"),
-                          ("two_thirds_ok", "<u4"), ("_pad", "<u4", 4)])
+                          ("two_thirds_ok", "<u4"), ("power_overflow", "<u4"), ("_pad", "<u4", 3)])
 WITNESS_LAYOUT = np.dtype([("batch_size", "<u4"), ("n_bytes", "<u4"), ("n_words", "<u4"), ("n_bools", "<u4"),
                            ("compact_stride", "<u4"), ("off_words", "<u4"), ("off_bools", "<u4"), ("_pad", "<u4"),
                            ("n_elements", "<u8")])

@@ -158,8 +158,12 @@ typedef struct bsx_commit_result {
     uint32_t first_bad_signature;           /* index or 0xffffffff */
     uint32_t n_bad_message;                 /* signed validators whose message lacks the header hash */
     uint32_t two_thirds_ok;                 /* 3*signed_power > 2*total_power */
-    uint32_t _pad[4];
+    uint32_t power_overflow;                /* the enabled voting powers add up to more than BSX_MAX_TOTAL_VOTING_POWER
+                                               (Tendermint's MaxTotalVotingPower = MaxInt64 / 8): the u64 sums above are
+                                               meaningless; every entry point that consumes them fails with BSX_ERR_BAD_ARG */
+    uint32_t _pad[3];
 } bsx_commit_result;                        /* sizeof == 96 */
+#define BSX_MAX_TOTAL_VOTING_POWER 1152921504606846975ull   /* (2^63 - 1) / 8 */
 
 typedef struct bsx_ctx bsx_ctx;             /* one per HIP device; calls on distinct contexts are thread-safe */
 
@@ -442,8 +446,8 @@ typedef struct bsx_skip_eval {
     uint64_t start_total_power;
     uint64_t signed_power;        /* candidate-set power that signed */
     uint64_t target_total_power;
-    uint32_t valid;               /* overlap_power * 3 > start_total_power */
-    uint32_t _pad;
+    uint32_t valid;               /* overlap_power * 3 > start_total_power (0 when power_overflow) */
+    uint32_t power_overflow;      /* a set's total exceeds BSX_MAX_TOTAL_VOTING_POWER: bsx_find_block_to_request -> BSX_ERR_BAD_ARG */
 } bsx_skip_eval;                  /* sizeof == 40 */
 /* d_start_validators: v_max records (pubkey, voting_power, enabled); d_candidate_validators: n_candidates * v_max
  * records (pubkey, voting_power, enabled, is_signed). */

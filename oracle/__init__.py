@@ -267,7 +267,7 @@ def next_header(input40, prev_header, next_header_, latest_block, next_validator
 
 
 SKIP_EVAL = np.dtype([("overlap_power", "<u8"), ("start_total_power", "<u8"), ("signed_power", "<u8"),
-                      ("target_total_power", "<u8"), ("valid", "<u4"), ("_pad", "<u4")])
+                      ("target_total_power", "<u8"), ("valid", "<u4"), ("power_overflow", "<u4")])
 
 
 def find_block_to_request(start_block, max_end_block, start_validators, candidate_heights, candidate_validators):

@@ -76,12 +76,14 @@ void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t 
                        uint8_t* sig_ok) {
     memset(out, 0, sizeof *out);
     out->first_bad_signature = 0xffffffffu;
+    unsigned __int128 exact_total = 0;
     for (uint32_t i = 0; i < v_max; i++) {
         const bsx_validator* v = &vals[i];
         uint8_t ok = 0;
         if (v->enabled) {
             out->n_enabled++;
             out->total_power += v->voting_power;
+            exact_total += v->voting_power;
             if (v->is_signed) {
                 out->n_signed++;
                 uint8_t h[32];
@@ -105,8 +107,10 @@ void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t 
         if (sig_ok) sig_ok[i] = ok;
     }
     validators_hash(vals, v_max, out->validators_hash);
+    /* Tendermint caps a set's total at MaxTotalVotingPower = MaxInt64 / 8; beyond it the u64 sums may have wrapped */
+    out->power_overflow = exact_total > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER;
     /* 3*signed > 2*total, in 128-bit to avoid overflow */
-    out->two_thirds_ok = (unsigned __int128)out->signed_power * 3 > (unsigned __int128)out->total_power * 2;
+    out->two_thirds_ok = !out->power_overflow && (unsigned __int128)out->signed_power * 3 > (unsigned __int128)out->total_power * 2;
 }
 
 static int varint_height_field(uint64_t h, uint8_t out[12]) {
@@ -147,7 +151,12 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
     orc_verify_commit(target_validators, v_max, target_hash, &cr, ok);
     if (out_commit) *out_commit = cr;
     int status = BSX_OK;
-    if (cr.n_bad_signature || cr.n_bad_message) status = BSX_ERR_BAD_SIGNATURE;
+    {
+        unsigned __int128 tt = 0;
+        for (uint32_t i = 0; i < v_max; i++) if (trusted_validators[i].enabled) tt += trusted_validators[i].voting_power;
+        if (cr.power_overflow || tt > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER) status = BSX_ERR_BAD_ARG;
+    }
+    if (!status && (cr.n_bad_signature || cr.n_bad_message)) status = BSX_ERR_BAD_SIGNATURE;
     /* validators_hash (field 7 = hash[2]) of both headers */
     if (!status && (th->len[7] != 34 || memcmp(th->hash[2] + 2, cr.validators_hash, 32) != 0)) status = BSX_ERR_ASSERT;
     validators_hash(trusted_validators, v_max, trc.validators_hash);
@@ -342,8 +351,9 @@ void orc_is_valid_skip(const bsx_validator* sv, const bsx_validator* tv, uint32_
     out->start_total_power = (uint64_t)start_total;
     out->signed_power = (uint64_t)signed_p;
     out->target_total_power = (uint64_t)target_total;
-    out->valid = (overlap * 3 > start_total) ? 1u : 0u;
-    out->_pad = 0;
+    const unsigned __int128 cap = BSX_MAX_TOTAL_VOTING_POWER;
+    out->power_overflow = (start_total > cap || target_total > cap) ? 1u : 0u;
+    out->valid = (!out->power_overflow && overlap * 3 > start_total) ? 1u : 0u;
 }
 
 /* fetcher.rs:60-87, line by line; candidates must contain every height the loop visits */
@@ -351,8 +361,12 @@ int orc_find_block_to_request(uint64_t start_block, uint64_t max_end_block, cons
                               uint32_t n_candidates, const uint64_t* heights, const bsx_validator* cand, uint32_t v_max,
                               uint64_t* out_block, orc_skip_eval* out_evals) {
     if (max_end_block <= start_block) return BSX_ERR_BAD_ARG;
-    if (out_evals)
-        for (uint32_t c = 0; c < n_candidates; c++) orc_is_valid_skip(start_validators, cand + (size_t)c * v_max, v_max, out_evals + c);
+    for (uint32_t c = 0; c < n_candidates; c++) {
+        orc_skip_eval e;
+        orc_is_valid_skip(start_validators, cand + (size_t)c * v_max, v_max, &e);
+        if (out_evals) out_evals[c] = e;
+        if (e.power_overflow) return BSX_ERR_BAD_ARG;
+    }
     uint64_t curr_end_block = max_end_block;                                   /* :61 */
     for (;;) {                                                                 /* :62 */
         if (curr_end_block - start_block == 1) { *out_block = curr_end_block; return BSX_OK; }   /* :63-65 */
@@ -386,6 +400,7 @@ int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, co
     free(ok);
     if (out_commit) *out_commit = cr;
     int st = BSX_OK;
+    if (cr.power_overflow) return BSX_ERR_BAD_ARG;
     if (memcmp(hp, prev_hash, 32) != 0) st = BSX_ERR_ASSERT;
     uint8_t hf[12];
     int hl = 0;

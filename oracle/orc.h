@@ -105,7 +105,7 @@ int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, co
  * as the > 1/3 trusted-power overlap rule the circuit enforces -> PARITY UNPINNED for the predicate. */
 typedef struct orc_skip_eval {
     uint64_t overlap_power, start_total_power, signed_power, target_total_power;
-    uint32_t valid, _pad;
+    uint32_t valid, power_overflow;
 } orc_skip_eval;
 void orc_is_valid_skip(const bsx_validator* start_validators, const bsx_validator* target_validators, uint32_t v_max,
                        orc_skip_eval* out);

@@ -601,6 +601,39 @@ def test_witness_manifest_decodes_a_real_witness():
         witness_view(m, wit[:nel], "no_such_variable")
 
 
+def test_voting_power_overflow_guard_on_gpu():
+    """totals beyond MaxTotalVotingPower are flagged by the tally / skip-eval kernels and rejected with
+    BSX_ERR_BAD_ARG by every entry point that consumes them, exactly as the oracle does."""
+    from blobstreamx_amd.builder import find_block_to_request
+    w = synth.Workload(36, 1, 2, 4, v=6)
+    S = int(w.first_height[0])
+    f = InputDataFetcher(w.headers[0], S, int(w.latest[0]))
+    big = w.validators[0].copy()
+    big["voting_power"][:4] = (1 << 62)
+    big["is_signed"][:4] = 0
+    with pytest.raises(_lib.BsxError) as ei:
+        verify_commits(big[None], w.commit_hashes[:1])
+    assert ei.value.status == T.ERR_BAD_ARG
+    edge = w.validators[0].copy()
+    edge["voting_power"] = 0
+    edge["voting_power"][0] = 1152921504606846975
+    res, _ = verify_commits(edge[None], w.commit_hashes[:1])
+    want, _ = oracle.verify_commit(edge, w.commit_hashes[0].tobytes())
+    assert res_bytes(res[0]) == res_bytes(want) and res[0]["power_overflow"] == 0
+    tr = w.trusted[0].copy()
+    tr["voting_power"][:] = (1 << 61)
+    for tv, rv in ((big, w.trusted[0]), (w.validators[0], tr)):
+        assert oracle.header_range(2, 4, w.input48(0), w.headers[0], S, int(w.latest[0]), tv, rv)[0] == T.ERR_BAD_ARG
+        with pytest.raises(_lib.BsxError) as ei:
+            CombinedSkipCircuit(6, 2, 4).prove(w.input48(0), f, tv, rv)
+        assert ei.value.status == T.ERR_BAD_ARG
+    s2 = w.trusted[0].copy()
+    s2["voting_power"][:] = (1 << 61)
+    with pytest.raises(_lib.BsxError) as ei:
+        find_block_to_request(1000, 1002, s2, [1002], w.validators[:1])
+    assert ei.value.status == T.ERR_BAD_ARG
+
+
 def test_header_range_failure_codes_match_oracle():
     J, B, v = 2, 4, 10
     circ = CombinedSkipCircuit(v, J, B)

@@ -55,6 +55,42 @@ def test_ingest_rejects_garbage():
         ingest.signed_block_from_json(blk.replace("2023-09-07T12:45:59.767207173Z", "yesterday"), 4)
 
 
+def test_ingest_commit_height_round_flag_and_int64_rules():
+    """a missing / mismatching commit.height, a malformed round or block_id_flag and integers beyond int64
+    are ingest errors (BSX_ERR_BAD_ARG) — not silently-zero sign-bytes that later look like bad signatures; a commit with
+    round != 0 ingests to sign-bytes with the round field (block hash at offset 25)."""
+    import json
+    blk = json.load(open(os.path.join(FIX, "10000", "signed_block.json")))
+    sb = blk["result"]["signed_header"] if "signed_header" in blk.get("result", {}) else blk.get("result", blk)
+    commit = sb["commit"] if "commit" in sb else blk["result"]["commit"]
+
+    def mutate(fn):
+        b = json.loads(json.dumps(blk))
+        r = b.get("result", b)
+        c = (r["signed_header"] if "signed_header" in r else r)["commit"]
+        fn(c, r)
+        return json.dumps(b)
+    ok = ingest.signed_block_from_json(json.dumps(blk), 4)
+    assert ok["n_validators"] == 2
+    for bad in (mutate(lambda c, r: c.pop("height")), mutate(lambda c, r: c.__setitem__("height", "10001")),
+                mutate(lambda c, r: c.__setitem__("height", "-1")), mutate(lambda c, r: c.__setitem__("round", "x")),
+                mutate(lambda c, r: c["signatures"][0].__setitem__("block_id_flag", 7)),
+                mutate(lambda c, r: c["signatures"][0].pop("block_id_flag")),
+                mutate(lambda c, r: c.__setitem__("height", "18446744073709551617"))):
+        with pytest.raises(_lib.BsxError) as ei:
+            ingest.signed_block_from_json(bad, 4)
+        assert ei.value.status == T.ERR_BAD_ARG
+    big = mutate(lambda c, r: r["validator_set"]["validators"][0].__setitem__("voting_power", "9223372036854775808"))
+    with pytest.raises(_lib.BsxError):
+        ingest.signed_block_from_json(big, 4)
+    rnd = ingest.signed_block_from_json(mutate(lambda c, r: c.__setitem__("round", 5)), 4)
+    v = rnd["validators"][rnd["validators"]["is_signed"] != 0][0]
+    m = bytes(v["message"][:v["message_len"]])
+    assert m[12] == 0x19 and m[13:21] == (5).to_bytes(8, "little") and m[25:57] == bytes(rnd["block_hash"])
+    nil = ingest.signed_block_from_json(mutate(lambda c, r: c["signatures"][0].__setitem__("block_id_flag", 3)), 4)
+    assert nil["validators"]["is_signed"].sum() == ok["validators"]["is_signed"].sum() - 1      # a NIL vote is not a signature
+
+
 def test_time_and_varint_edge_cases():
     import json
     blk = json.load(open(os.path.join(FIX, "10000", "signed_block.json")))

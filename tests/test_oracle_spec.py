@@ -180,6 +180,36 @@ def test_commit_round_nonzero_nil_and_absent_votes():
     assert rc == T.OK and cres["n_signed"] == 10 and out[:32] == w2.hashes[0, 8].tobytes()
 
 
+def test_voting_power_beyond_max_total_is_rejected():
+    """powers that add up beyond Tendermint's MaxTotalVotingPower (MaxInt64 / 8) would wrap the u64 tallies and
+    could pass the 2/3 and 1/3 rules spuriously: flagged (power_overflow) and turned into BSX_ERR_BAD_ARG."""
+    w = synth.Workload(36, 1, 2, 4, v=6)
+    vals = w.validators[0].copy()
+    res, _ = oracle.verify_commit(vals, w.commit_hashes[0].tobytes())
+    assert res["power_overflow"] == 0 and res["two_thirds_ok"] == 1
+    big = vals.copy()
+    big["voting_power"][:4] = (1 << 62)                    # 4 * 2^62 = 2^64: the u64 sum wraps to the two small powers
+    big["is_signed"][:4] = 0                               # nobody big signs: without the guard 2/2 of the WRAPPED total signed
+    res, _ = oracle.verify_commit(big, w.commit_hashes[0].tobytes())
+    assert res["power_overflow"] == 1 and res["two_thirds_ok"] == 0 and res["total_power"] < (1 << 40)
+    edge = vals.copy()
+    edge["voting_power"] = 0
+    edge["voting_power"][0] = 1152921504606846975          # exactly MaxTotalVotingPower is still fine
+    assert oracle.verify_commit(edge, w.commit_hashes[0].tobytes())[0]["power_overflow"] == 0
+    edge["voting_power"][1] = 1
+    assert oracle.verify_commit(edge, w.commit_hashes[0].tobytes())[0]["power_overflow"] == 1
+    args = (2, 4, w.input48(0), w.headers[0], int(w.first_height[0]), int(w.latest[0]))
+    assert oracle.header_range(*args, big, w.trusted[0])[0] == T.ERR_BAD_ARG
+    tr = w.trusted[0].copy()
+    tr["voting_power"][:] = (1 << 61)
+    assert oracle.header_range(*args, w.validators[0], tr)[0] == T.ERR_BAD_ARG
+    start, commit = _skip_search_case()
+    s2 = start.copy()
+    s2["voting_power"][:] = (1 << 61)
+    rc, _, ev = oracle.find_block_to_request(1000, 1002, s2, [1002], commit([0, 1, 2])[None])
+    assert rc == T.ERR_BAD_ARG and ev["power_overflow"][0] == 1 and ev["valid"][0] == 0
+
+
 def _skip_search_case():
     """Start set of 9 validators (total power 100) and commits with chosen signers."""
     V = 9
