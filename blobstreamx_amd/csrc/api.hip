@@ -109,8 +109,11 @@ int bsx_init(int device, bsx_ctx** out) {
         delete c;
         return fail(BSX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
     // constants of the hint's zero-padded proofs (kernels_sha.hip k_zero_paths)
-    e = hipMalloc(reinterpret_cast<void**>(&c->zero_paths), 320);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->zero_paths), 320);
     if (e == hipSuccess) e = bsxk_zero_paths(c->stream, c->zero_paths);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
@@ -126,8 +129,12 @@ void bsx_shutdown(bsx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->zero_paths) (void)hipFree(ctx->zero_paths);
+    if (ctx->keytab) (void)hipFree(ctx->keytab);
     for (auto& b : ctx->vmm) { (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size); }
     delete ctx;
 }
@@ -351,6 +358,23 @@ int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v
 }
 
 // ------------------------------------------------------------------------------------------------ host tier
+// The host tier's fixed-key Ed25519 table lives in the context: a proof request verifies ONE commit of <= 100 signatures, for
+// which the generic kernel is pure latency (256 dependent doublings per lane: 1.3 ms), while consecutive requests are signed
+// by the same validator set — with the table kept, a request pays one key compare per row (0.011 ms) and the 32-doubling
+// keyed kernel.  Rows are rebuilt only when a key changes (bsx_dev_ed25519_keytable).
+static int ctx_keytable(bsx_ctx* ctx, uint32_t v_max, uint8_t** out, hipStream_t stream) {
+    if (ctx->keytab_rows != v_max) {          // the table layout depends on the row count
+        if (ctx->keytab) (void)hipFree(ctx->keytab);
+        ctx->keytab = nullptr;
+        ctx->keytab_rows = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->keytab), bsxk_keytable_bytes(v_max)));
+        HIPCHK(hipMemsetAsync(ctx->keytab, 0, (size_t)v_max * 64, stream));          // key records: nothing to reuse yet
+        ctx->keytab_rows = v_max;
+    }
+    *out = ctx->keytab;
+    return BSX_OK;
+}
+
 #define H2D(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, st))
 #define D2H(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyDeviceToHost, st))
 #define SYNC() HIPCHK(hipStreamSynchronize(st))
@@ -749,17 +773,13 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
     H2D(dv.p, validators, n * sizeof(bsx_validator));
     H2D(dhh.p, header_hashes, (size_t)n_commits * 32);
     HIPCHK(bsxk_sha512_challenge(st, dv.as<bsx_validator>(), n, dh.as<uint8_t>(), nullptr));
-    if (n_commits >= 8) {
-        // many commits, (normally) one validator set: per-key tables from the first commit's slots; slots whose key
-        // differs fall back to the generic path inside bsxk_ed25519_verify_keyed
-        DBuf dtab;
-        RET(dtab.alloc(bsxk_keytable_bytes(v_max)));
-        HIPCHK(hipMemsetAsync(dtab.p, 0, (size_t)v_max * 64, st));        // key records: nothing to reuse in a fresh buffer
-        HIPCHK(bsxk_ed25519_keytable(st, dv.as<bsx_validator>(), v_max, dtab.as<uint8_t>()));
-        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dtab.as<uint8_t>(), v_max, dok.as<uint8_t>()));
-        SYNC();   // dtab is released at scope exit
-    } else {
-        HIPCHK(bsxk_ed25519_verify(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, dok.as<uint8_t>()));
+    {
+        // per-key tables from the first commit's slots (kept in the context between calls); slots whose key differs fall
+        // back to the generic path inside bsxk_ed25519_verify_keyed: same accept set for any input
+        uint8_t* tab = nullptr;
+        RET(ctx_keytable(ctx, v_max, &tab, st));
+        HIPCHK(bsxk_ed25519_keytable(st, dv.as<bsx_validator>(), v_max, tab));
+        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, tab, v_max, dok.as<uint8_t>()));
     }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     D2H(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result));
@@ -789,15 +809,25 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         return fail(BSX_ERR_RANGE_TOO_LONG, "skip: need trusted < target <= trusted + %llu", (unsigned long long)nb_map_jobs * batch_size);
     if (trusted_block < first_height || target_block - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "trusted/target header not supplied");
     hipStream_t st = ctx->stream;
+    // Two streams: the hashing chain (header hashes, hint, prove_subchain, reduce, finalize) on `st`, the commit check
+    // (challenges, key table, signatures, tallies, skip conditions — latency bound at <= 100 signatures) beside it on `sb`.
+    // Both are drained before the arena is rewound, also on the error paths (BothStreams).
+    hipStream_t sb = ctx->stream2;
+    struct BothStreams {
+        hipStream_t a, b;
+        ~BothStreams() { (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(a); }
+    } drain{st, sb};
     bsx_shared_ctx range{};
     range.start_block = trusted_block;
     range.end_block = target_block;
     memcpy(range.start_header_hash, input48 + 8, 32);
     RangeDev rd;
+    DBuf dv, dtv, dh, dok, dres, dtres, dskip, dth, dth2;
+    RET(dth.alloc(32));
     RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd));
-    // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash
-    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, nullptr, nullptr));
-    DBuf dv, dtv, dh, dok, dres, dtres, dskip, dth;
+    // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash (and the first output half)
+    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, dth.as<uint8_t>(), nullptr));
+    HIPCHK(hipEventRecord(ctx->ev_a, st));
     RET(dv.alloc((size_t)v_max * sizeof(bsx_validator)));
     RET(dtv.alloc((size_t)v_max * sizeof(bsx_validator)));
     RET(dh.alloc((size_t)v_max * 32));
@@ -805,23 +835,31 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     RET(dres.alloc(sizeof(bsx_commit_result)));
     RET(dtres.alloc(sizeof(bsx_commit_result)));
     RET(dskip.alloc(4));
-    RET(dth.alloc(32));
-    H2D(dv.p, target_validators, (size_t)v_max * sizeof(bsx_validator));
-    H2D(dtv.p, trusted_validators, (size_t)v_max * sizeof(bsx_validator));
+    RET(dth2.alloc(32));
+    HIPCHK(hipMemcpyAsync(dv.p, target_validators, (size_t)v_max * sizeof(bsx_validator), hipMemcpyHostToDevice, sb));
+    HIPCHK(hipMemcpyAsync(dtv.p, trusted_validators, (size_t)v_max * sizeof(bsx_validator), hipMemcpyHostToDevice, sb));
     const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
-    HIPCHK(bsxk_sha512_challenge(st, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
-    HIPCHK(bsxk_ed25519_verify(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, dok.as<uint8_t>()));
-    HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
-    HIPCHK(bsxk_commit_tally(st, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
-    HIPCHK(bsxk_skip_check(st, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
+    HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
+    {
+        uint8_t* tab = nullptr;
+        RET(ctx_keytable(ctx, v_max, &tab, sb));
+        HIPCHK(bsxk_ed25519_keytable(sb, dv.as<bsx_validator>(), v_max, tab));
+        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, dok.as<uint8_t>()));
+    }
+    HIPCHK(bsxk_commit_tally(sb, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) from `st`
+    HIPCHK(bsxk_commit_tally(sb, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
+    HIPCHK(bsxk_skip_check(sb, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
-                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth.as<uint8_t>(), nullptr, chain_id, chain_id_len));
+                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth2.as<uint8_t>(), nullptr, chain_id, chain_id_len));
+    HIPCHK(hipEventRecord(ctx->ev_b, sb));
     // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58)
     int rc = run_data_commitment(ctx, st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, output64, nullptr, nullptr, witness, nullptr);
     if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
     const std::string dc_err = g_err;
     uint32_t skip = 0;
     bsx_commit_result cr;
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_b, 0));
     D2H(&skip, dskip.p, 4);
     D2H(&cr, dres.p, sizeof cr);
     SYNC();

@@ -28,9 +28,13 @@ struct bsx_vmm_block {
 struct bsx_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t stream2 = nullptr;       // host tier: the commit check of a header_range runs beside its hashing chain
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bsx_arena arena;
     std::vector<bsx_vmm_block> vmm;      // bsx_dev_alloc blocks still alive
     uint8_t* zero_paths = nullptr;       // 320 B: path digests of the hint's zero-padded proofs (k_zero_paths)
+    uint8_t* keytab = nullptr;           // host tier's persistent fixed-key Ed25519 table (rows survive between calls)
+    uint32_t keytab_rows = 0;
 };
 
 namespace bsxapi {
