@@ -279,7 +279,7 @@ def upload_leg(eng, args, steps):
             "note": "inputs streamed H2D from pinned memory on a copy stream each step, overlapped with compute; the witness stays on the device"}
 
 
-def commitment_leg(dev, J, B, V, R=8, leaf_len=135, cap_height=4):
+def commitment_leg(dev, J, B, V, R=32, leaf_len=135, cap_height=4):
     """Poseidon (plonky2 PoseidonGoldilocksConfig) Merkle caps of every map job's witness: fused (elements generated on the
     fly from the compact bytes, the 64x image never exists) vs materialised (expand to HBM, then hash)."""
     import ctypes as C
