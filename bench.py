@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s s
 # Measured integer-ALU ceilings of MI355X for the bodies the ALU-bound kernels are made of (tools/microbench.hip,
 # tools/microbench_alu.hip at 8 waves/SIMD; profiles/r1_microbench.txt, profiles/r2_microbench_alu.txt)
 PEAK = {"sha256_compress_per_s": 27.7e9, "sha512_compress_per_s": 6.40e9, "fe25519_mul_per_s": 197e9, "fe25519_sq_per_s": 268.7e9,
-        "poseidon_permute_per_s": 1.70e9, "goldilocks_mul_per_s": 2.05e12}
+        "poseidon_permute_per_s": 1.835e9, "goldilocks_mul_per_s": 2.05e12}
 # Field operations of ONE fixed-key Ed25519 verification (ed25519.h ed25519_verify_keyed_core, 8 x 32-bit scalar parts):
 # 4 iterations x [8 doublings (4 sq each; 7 x p1p1->p2 = 3 mul, 1 x p1p1->p3 = 4 mul) + 8 cached additions (4 + 4 mul) +
 # 8 affine additions (3 + 4 mul, the last one 3 + 3)] + encoding (inversion: 254 sq + 11 mul, 2 mul)

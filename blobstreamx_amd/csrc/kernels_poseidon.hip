@@ -59,8 +59,11 @@ __device__ __forceinline__ uint64_t compact_elem(const bsx_witness_layout& lay, 
     return c[lay.off_bools + e];
 }
 
+#ifndef BSX_LEAF_WAVES
+#define BSX_LEAF_WAVES 1
+#endif
 template <bool FUSED>
-__global__ __launch_bounds__(PS_THREADS) void k_leaf_hashes(LeafArgs a) {
+__global__ __launch_bounds__(PS_THREADS, BSX_LEAF_WAVES) void k_leaf_hashes(LeafArgs a) {
     const uint64_t g = (uint64_t)blockIdx.x * PS_THREADS + threadIdx.x;
     if (g >= (uint64_t)a.n_trees * a.n_rows) return;
     const uint64_t job = g / a.n_rows, j = g % a.n_rows;

@@ -60,6 +60,17 @@ BSX_HDI void poseidon_mds_limbs(const uint32_t l[12], uint32_t out[12]) {
     out[0] += l[0] * 8u;                                  // diagonal
 }
 
+// a0 + 2^22 a1 + 2^44 a2 (a_k < 2^32) reduced to a u64 representative: the part of a2 above bit 20 has weight 2^64 = EPS
+BSX_HDI uint64_t poseidon_recombine(uint32_t a0, uint32_t a1, uint32_t a2) {
+    const uint64_t x = (uint64_t)a0 + ((uint64_t)a1 << 22);
+    const uint64_t y = (uint64_t)(a2 & 0xfffffu) << 44;
+    uint64_t lo, t;
+    const bool c1 = __builtin_add_overflow(x, y, &lo);
+    const uint64_t hi = (uint64_t)(a2 >> 20) + (c1 ? 1u : 0u);                     // < 2^13
+    const bool c2 = __builtin_add_overflow(lo, (hi << 32) - hi, &t);
+    return t + gl_eps_if(c2);
+}
+
 BSX_HDI void poseidon_mds(uint64_t s[12]) {
     uint32_t l0[12], l1[12], l2[12], a0[12], a1[12], a2[12];
 #pragma unroll
@@ -72,16 +83,54 @@ BSX_HDI void poseidon_mds(uint64_t s[12]) {
     poseidon_mds_limbs(l1, a1);
     poseidon_mds_limbs(l2, a2);
 #pragma unroll
-    for (int r = 0; r < 12; r++) {
-        // a0 + 2^22 a1 + 2^44 a2, a_k < 2^31: the part of a2 above bit 20 has weight 2^64 = EPS
-        const uint64_t x = (uint64_t)a0[r] + ((uint64_t)a1[r] << 22);
-        const uint64_t y = (uint64_t)(a2[r] & 0xfffffu) << 44;
-        uint64_t lo, t;
-        const bool c1 = __builtin_add_overflow(x, y, &lo);
-        const uint64_t hi = (uint64_t)(a2[r] >> 20) + (c1 ? 1u : 0u);                     // < 2^12
-        const bool c2 = __builtin_add_overflow(lo, (hi << 32) - hi, &t);
-        s[r] = t + gl_eps_if(c2);
+    for (int r = 0; r < 12; r++) s[r] = poseidon_recombine(a0[r], a1[r], a2[r]);
+}
+
+// The 22 partial rounds with the state kept in LIMB form.  Only lane 0 goes through the S-box; lanes 1..11 see nothing but
+// "+ constant" and the (linear) MDS from round to round, so instead of recombining them to u64, adding the constant mod p
+// and splitting again (~32 VALU issue slots per lane and round), the MDS output limbs take the next round's constant limb
+// by limb and are carry-normalised in place (~14): t_k = a_k + c_k + carry; the overflow h of the top limb (weight 2^64 =
+// 2^32 - 1) is folded back as l1 += h << 10, l0 -= h (borrowing 2^22 from l1 when l0 < h).  Invariants: l0 < 2^23,
+// l1 < 2^23.4, l2 < 2^21 on entry to an MDS, so every true MDS output is < 284 * 2^23.4 < 2^32 and the wrap-around 32-bit
+// arithmetic of poseidon_mds_limbs stays exact.
+BSX_HDI void poseidon_partial_rounds(uint64_t s[12], const uint64_t* rc) {
+    constexpr uint32_t M22 = 0x3fffffu, M20 = 0xfffffu;
+    uint32_t l0[12], l1[12], l2[12], a0[12], a1[12], a2[12];
+    const int r0 = POSEIDON_FULL_HALF;
+#pragma unroll
+    for (int i = 1; i < 12; i++) {                       // lanes 1..11: split + the first partial round's constants
+        const uint64_t c = rc[12 * r0 + i];
+        l0[i] = ((uint32_t)s[i] & M22) + ((uint32_t)c & M22);
+        l1[i] = ((uint32_t)(s[i] >> 22) & M22) + ((uint32_t)(c >> 22) & M22);
+        l2[i] = (uint32_t)(s[i] >> 44) + (uint32_t)(c >> 44);
     }
+    uint64_t u0 = s[0];
+    for (int k = 0; k < POSEIDON_PARTIAL; k++) {
+        const int r = r0 + k;
+        u0 = gl_pow7(gl_add_canon(u0, rc[12 * r]));
+        l0[0] = (uint32_t)u0 & M22; l1[0] = (uint32_t)(u0 >> 22) & M22; l2[0] = (uint32_t)(u0 >> 44);
+        poseidon_mds_limbs(l0, a0);
+        poseidon_mds_limbs(l1, a1);
+        poseidon_mds_limbs(l2, a2);
+        u0 = poseidon_recombine(a0[0], a1[0], a2[0]);
+        if (k + 1 < POSEIDON_PARTIAL) {
+#pragma unroll
+            for (int i = 1; i < 12; i++) {
+                const uint64_t c = rc[12 * (r + 1) + i];                               // uniform: limb split on the scalar unit
+                const uint32_t t0 = a0[i] + ((uint32_t)c & M22);
+                const uint32_t t1 = a1[i] + ((uint32_t)(c >> 22) & M22) + (t0 >> 22);
+                const uint32_t t2 = a2[i] + (uint32_t)(c >> 44) + (t1 >> 22);
+                const uint32_t h = t2 >> 20, q0 = t0 & M22;
+                const uint32_t b = q0 < h ? 1u : 0u;
+                l0[i] = q0 - h + (b << 22);
+                l1[i] = (t1 & M22) + (h << 10) - b;
+                l2[i] = t2 & M20;
+            }
+        }
+    }
+    s[0] = u0;
+#pragma unroll
+    for (int i = 1; i < 12; i++) s[i] = poseidon_recombine(a0[i], a1[i], a2[i]);
 }
 
 // rc: the 360 round constants, round-major
@@ -92,12 +141,8 @@ BSX_HDI void poseidon_permute(uint64_t s[12], const uint64_t* rc) {
         for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_canon(s[i], rc[12 * r + i]));
         poseidon_mds(s);
     }
-    for (int k = 0; k < POSEIDON_PARTIAL; k++, r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add_canon(s[i], rc[12 * r + i]);
-        s[0] = gl_pow7(s[0]);
-        poseidon_mds(s);
-    }
+    poseidon_partial_rounds(s, rc);
+    r += POSEIDON_PARTIAL;
     for (int k = 0; k < POSEIDON_FULL_HALF; k++, r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_canon(s[i], rc[12 * r + i]));

@@ -103,7 +103,7 @@ def test_mds_layer_vs_definition(hc):
 
 def test_permutation_device_source_vs_oracle_random(hc):
     rng = np.random.default_rng(9)
-    for t in range(200):
+    for t in range(4000):                 # enough to hit the rare borrow path of the limb-form partial rounds (~3 % of states)
         st = rng.integers(0, 1 << 64, 12, dtype=np.uint64) if t % 3 else np.array([EDGE[int(k)] for k in rng.integers(0, len(EDGE), 12)], np.uint64)
         a = st.copy()
         hc.hc_poseidon_permute(a.ctypes.data_as(C.c_void_p))
