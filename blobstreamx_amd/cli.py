@@ -55,6 +55,8 @@ def main(argv=None):
     ap.add_argument("--validators", type=int)
     ap.add_argument("--output", default="output.json")
     ap.add_argument("--witness")
+    ap.add_argument("--caps", help="also write the Poseidon Merkle caps of the witness columns (one per map job / reduce node; "
+                                   "PoseidonGoldilocksConfig, rows of 135 elements, cap height 4) to this JSON file")
     ap.add_argument("--chain-id", help="C::CHAIN_ID_BYTES (default: mocha-4 for the *_mocha circuits, celestia otherwise; config.rs:6-28)")
     a = ap.parse_args(argv)
     chain_id = (a.chain_id or ("mocha-4" if a.circuit.endswith("_mocha") else "celestia")).encode()
@@ -93,7 +95,7 @@ def main(argv=None):
         tr = blocks[trusted]["validators"].copy()
         tr["is_signed"] = 0
         out, commit, wit = CombinedSkipCircuit(V, J, B, chain_id=chain_id).prove(inp, fetcher, blocks[target]["validators"], tr,
-                                                              want_witness=bool(a.witness))
+                                                              want_witness=bool(a.witness or a.caps))
     else:
         if len(inp) != 40:
             raise SystemExit("next_header input must be 40 bytes (uint64 ‖ bytes32)")
@@ -107,6 +109,17 @@ def main(argv=None):
     json.dump({"type": "res_bytes", "data": {"output": "0x" + out.hex()}}, open(a.output, "w"))
     if a.witness and wit is not None:
         wit.astype("<u8").tofile(a.witness)
+    if a.caps and wit is not None:
+        # what the prover commits to first: Merkle caps of the witness columns
+        from .poseidon import witness_leaf_count, witness_merkle_caps
+        ml, rl = T.map_layout(B), T.reduce_layout()
+        nm = J * int(ml["n_elements"])
+        hexd = lambda caps_: [["0x" + "".join(f"{int(x):016x}" for x in d) for d in c] for c in caps_]
+        ch = lambda lay: min(4, witness_leaf_count(int(lay["n_elements"]), 135).bit_length() - 1)
+        caps = {"leaf_len": 135, "cap_height": {"map_jobs": ch(ml), "reduce_nodes": ch(rl)},
+                "map_jobs": hexd(witness_merkle_caps(ml, wit[:nm], J, 135, ch(ml))),
+                "reduce_nodes": hexd(witness_merkle_caps(rl, wit[nm:], J - 1, 135, ch(rl))) if J > 1 else []}
+        json.dump(caps, open(a.caps, "w"))
     print("0x" + out.hex())
     return 0
 

@@ -127,3 +127,43 @@ def test_poseidon_argument_errors():
         MerkleTree(np.arange(100, dtype=np.uint64), 7, 2, n_leaves=8)           # does not cover the elements
     with pytest.raises(_lib.BsxError):
         MerkleTree(np.arange(100, dtype=np.uint64), 7, 9, n_leaves=16)          # cap above the root
+
+
+def test_merkle_caps_of_different_heights_are_consistent_at_full_size():
+    """Size-independent property at the production shape (one 32x64 map job: 449,755 elements, 4096 leaves of 135): the cap
+    of height h is the pairwise two_to_one fold of the cap of height h + 1, down to the root, for the fused path — and a
+    one-bit change of the compact witness moves exactly one leaf digest and the single cap node above it."""
+    import torch
+    from blobstreamx_amd.engine import HeaderRangeEngine
+    from blobstreamx_amd.poseidon import PoseidonHash, WitnessCommitter
+    J, B, V = 32, 64, 4
+    w = synth.Workload(13, 1, J, B, v=V)
+    eng = HeaderRangeEngine(J, B, V, 1, with_witness=False)
+    eng.upload_workload(w)
+    eng.step()
+    torch.cuda.synchronize()
+    caps = {}
+    for h in (5, 4, 1, 0):
+        wc = WitnessCommitter(eng.ml, J, 135, h)
+        wc.commit_compact(eng.compact)
+        caps[h] = wc.caps_numpy().copy()
+        assert wc.n_leaves == 4096 and caps[h].shape == (J, 1 << h, 4)
+    H = PoseidonHash()
+    fold = caps[5]
+    for h in (4, 3, 2, 1, 0):
+        fold = H.two_to_one(fold[:, 0::2].reshape(-1, 4), fold[:, 1::2].reshape(-1, 4)).reshape(J, 1 << h, 4)
+        if h in caps:
+            assert (fold == caps[h]).all(), h
+    wc = WitnessCommitter(eng.ml, J, 135, 4)
+    wc.commit_compact(eng.compact)
+    before = wc.trees_numpy().copy()
+    stride = int(eng.ml["compact_stride"])
+    byte = 3 * stride + 20000                                # job 3, bit 160000..160007 -> leaf 160000 // 135 = 1185
+    eng.compact[byte] ^= 0x10
+    wc.commit_compact(eng.compact)
+    after = wc.trees_numpy()
+    diff = np.argwhere((before != after).any(axis=2))
+    assert set(diff[:, 0]) == {3}
+    leaf = (20000 * 8 + 3) // 135
+    assert leaf in set(diff[:, 1]) and (diff[:, 1] < 4096).sum() == 1          # exactly one leaf digest changed
+    assert (before[3, -16:] != after[3, -16:]).any(axis=1).sum() == 1            # and one of the 16 cap nodes

@@ -152,8 +152,18 @@ def test_cli_prove_input_json(tmp_path, golden):
     out = tmp_path / "output.json"
     wit = tmp_path / "w.bin"
     inp.write_text(json.dumps({"type": "req_bytes", "releaseId": "x", "data": {"input": "0x" + golden["kats"]["header_range_input_10000_10004"]}}))
+    caps = tmp_path / "caps.json"
     assert cli.main(["header_range_mocha", "prove", str(inp), "--fixtures", FIX, "--jobs", "2", "--batch", "2", "--validators", "4",
-                     "--output", str(out), "--witness", str(wit)]) == 0
+                     "--output", str(out), "--witness", str(wit), "--caps", str(caps)]) == 0
+    import oracle
+    cj = json.load(open(caps))
+    wv = np.fromfile(wit, dtype="<u8")
+    nel = int(T.map_layout(2)["n_elements"])
+    n_leaves = 1
+    while n_leaves * 135 < nel:
+        n_leaves *= 2
+    _, cap = oracle.poseidon_merkle_tree(wv[nel:2 * nel], 135, n_leaves, min(4, n_leaves.bit_length() - 1))
+    assert cj["map_jobs"][1] == ["0x" + "".join(f"{int(x):016x}" for x in d) for d in cap]
     got = json.load(open(out))["data"]["output"]
     assert got == "0x" + golden["blocks"]["10004"]["header_hash"] + golden["data_commitments"]["10000-10004"]
     ml, rl = T.map_layout(2), T.reduce_layout()
