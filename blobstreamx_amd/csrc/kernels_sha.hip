@@ -121,7 +121,10 @@ __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* 
                                                               uint8_t* __restrict__ lb_aunts, uint8_t* __restrict__ paths,
                                                               uint32_t* __restrict__ status) {
     BSX_CHAIN_PRIO();
-    const uint64_t me = (uint64_t)blockIdx.x * HM_THREADS + threadIdx.x;
+    // grid-strided: the launcher may cap the grid (resident workgroups per CU) so that this 162-VGPR kernel leaves register
+    // file for the HBM-bound expansion running beside it — three of its waves fill a SIMD's 512 registers completely
+    for (uint64_t me = (uint64_t)blockIdx.x * HM_THREADS + threadIdx.x; me < ((n + HM_THREADS - 1) / HM_THREADS) * HM_THREADS;
+         me += (uint64_t)gridDim.x * HM_THREADS) {
     const bool live = me < n;
     const uint8_t* my = reinterpret_cast<const uint8_t*>(hdr + (live ? me : 0));
     // byte offsets: version 16, chain_id 40, height 92, time 104, last_block_id 124, hash[j] 200+36j, proposer 488
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* 
     // wave-ballot reduction of the "bad header" predicate: one atomic per wave
     const unsigned long long m = __ballot(live && bad);
     if (m && (threadIdx.x & 63) == 0 && status) atomicOr(status, 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_assemble_inputs
@@ -867,7 +871,10 @@ using namespace bsx;
 hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint8_t* paths,
                               uint32_t* status) {
     if (!n) return hipSuccess;
-    const uint32_t grid = (uint32_t)((n + HM_THREADS - 1) / HM_THREADS);
+    uint32_t grid = (uint32_t)((n + HM_THREADS - 1) / HM_THREADS);
+    // BSX_MERKLE_WGS: cap on the grid (workgroups stride over the headers); 0 = one workgroup per 256 headers
+    static const long cap = getenv("BSX_MERKLE_WGS") ? atol(getenv("BSX_MERKLE_WGS")) : 0;
+    if (cap > 0 && grid > (uint32_t)cap) grid = (uint32_t)cap;
     hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status);
     return hipGetLastError();
 }
