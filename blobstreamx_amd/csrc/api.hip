@@ -32,7 +32,8 @@ hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, ui
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
 uint64_t bsxk_keytable_bytes(uint32_t);
 hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
-hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, uint8_t*);
+hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, uint8_t*, void*);
+uint64_t bsxk_ed25519_scratch_bytes(uint64_t);
 hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
                            const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
@@ -305,6 +306,7 @@ int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
 }
 
 uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys) { return bsxk_keytable_bytes(n_keys); }
+uint64_t bsx_ed25519_verify_scratch_bytes(uint64_t n) { return bsxk_ed25519_scratch_bytes(n); }
 
 int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys, void* d_table) {
     DEV_ENTER();
@@ -315,12 +317,13 @@ int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_
 }
 
 int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n,
-                                 uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok) {
+                                 uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok, void* d_scratch) {
     DEV_ENTER();
     if (n && (!d_validators || !d_h || !d_ok)) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
-    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, d_ok));
+    if ((uintptr_t)d_scratch & 15) return fail(BSX_ERR_BAD_ARG, "scratch must be 16-byte aligned");
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, d_ok, d_scratch));
     return BSX_OK;
 }
 
@@ -779,7 +782,9 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
         uint8_t* tab = nullptr;
         RET(ctx_keytable(ctx, v_max, &tab, st));
         HIPCHK(bsxk_ed25519_keytable(st, dv.as<bsx_validator>(), v_max, tab));
-        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, tab, v_max, dok.as<uint8_t>()));
+        DBuf dscr;                                  // batch inversion pays from a few thousand signatures on (one more launch)
+        if (n >= 4096) RET(dscr.alloc(bsxk_ed25519_scratch_bytes(n)));
+        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, tab, v_max, dok.as<uint8_t>(), dscr.p));
     }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     D2H(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result));
@@ -844,7 +849,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         uint8_t* tab = nullptr;
         RET(ctx_keytable(ctx, v_max, &tab, sb));
         HIPCHK(bsxk_ed25519_keytable(sb, dv.as<bsx_validator>(), v_max, tab));
-        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, dok.as<uint8_t>()));
+        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, dok.as<uint8_t>(), nullptr));
     }
     HIPCHK(bsxk_commit_tally(sb, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) from `st`

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_sha512_challenge(const bsx_valid
 // ------------------------------------------------------------------------------------------------ k_ed25519_verify
 constexpr int ED_THREADS = 64;   // one wave per workgroup: a 100-signature commit spreads over 2 CUs, R commits over 2R
 constexpr uint8_t ED_DEFERRED = 2;   // ok_out marker: the fixed-key kernel left this slot to the generic one
+constexpr uint8_t ED_PENDING = 3;    // ok_out marker: projective result parked in the scratch slot, k_ed25519_finish decides
 // ONLY_DEFERRED: second pass behind k_ed25519_verify_keyed — touch only the slots it marked (normally none: the
 // waves read one byte per lane and retire)
 template <bool ONLY_DEFERRED>
@@ -177,10 +178,15 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_entries(uint32_t n_keys
 
 // one lane per validator slot; slot (me % v_max) uses key table row (me % v_max) when the record's public key is the
 // table's key, and falls back to the generic per-signature path otherwise (a validator-set change inside the batch)
+// scratch slot of the deferred-encode form: X, Y, Z (10 limbs each), prefix product (10), = 160 bytes per signature
+constexpr uint32_t ED_SLOT_I32 = 40;
+constexpr uint32_t ED_FIN_K = 16;       // signatures per lane of k_ed25519_finish: one inversion amortised over 8
+template <bool DEFER>
 __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
                                                                      const uint8_t* __restrict__ hs, uint64_t n,
                                                                      uint32_t v_max, const uint8_t* __restrict__ table,
-                                                                     uint32_t n_keys, uint8_t* __restrict__ ok_out) {
+                                                                     uint32_t n_keys, uint8_t* __restrict__ ok_out,
+                                                                     int32_t* __restrict__ scratch) {
     const uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
     if (me >= n) return;
     const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
@@ -212,9 +218,66 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
             return;
         }
         const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
+        if (DEFER) {
+            ge_p2 q;
+            const bool pre = decodes && ed25519_verify_keyed_core_t<true>(kt, sr, ss, h, &q);
+            int32_t* d = scratch + me * ED_SLOT_I32;
+#pragma unroll
+            for (int i = 0; i < 10; i++) { d[i] = q.X.v[i]; d[10 + i] = q.Y.v[i]; d[20 + i] = q.Z.v[i]; }
+            ok_out[me] = pre ? ED_PENDING : 0;          // k_ed25519_finish turns ED_PENDING into the verdict
+            return;
+        }
         ok = decodes && ed25519_verify_keyed_core(kt, sr, ss, h);
     }
     ok_out[me] = ok ? 1 : 0;
+}
+
+// Encoding + comparison of the deferred results: lane j owns signatures [j*K, (j+1)*K).  Montgomery's trick: prefix
+// products of the Z coordinates (stored in the slots), one inversion of the total, then backwards 1/Z_i = inv * prefix_{i-1},
+// inv *= Z_i.  Z of a point produced by the complete twisted-Edwards formulas from points on the curve is never zero.
+__global__ __launch_bounds__(ED_THREADS) void k_ed25519_finish(const bsx_validator* __restrict__ vals, uint64_t n,
+                                                               uint8_t* __restrict__ ok_out, int32_t* __restrict__ scratch) {
+    const uint64_t lane = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
+    const uint64_t first = lane * ED_FIN_K;
+    if (first >= n) return;
+    const uint32_t cnt = (uint32_t)((n - first < ED_FIN_K) ? (n - first) : ED_FIN_K);
+    fe acc = fe_one();
+    for (uint32_t i = 0; i < cnt; i++) {
+        int32_t* d = scratch + (first + i) * ED_SLOT_I32;
+        if (ok_out[first + i] == ED_PENDING) {
+            fe z;
+#pragma unroll
+            for (int k = 0; k < 10; k++) z.v[k] = d[20 + k];
+            acc = fe_mul(acc, z);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; k++) d[30 + k] = acc.v[k];          // prefix product INCLUDING element i
+    }
+    fe inv = fe_invert(acc);
+    for (uint32_t ii = cnt; ii-- > 0;) {
+        const uint64_t me = first + ii;
+        if (ok_out[me] != ED_PENDING) continue;
+        const int32_t* d = scratch + me * ED_SLOT_I32;
+        fe x, y, z, prev = fe_one();
+#pragma unroll
+        for (int k = 0; k < 10; k++) { x.v[k] = d[k]; y.v[k] = d[10 + k]; z.v[k] = d[20 + k]; }
+        if (ii > 0) {
+            const int32_t* dp = scratch + (me - 1) * ED_SLOT_I32;
+#pragma unroll
+            for (int k = 0; k < 10; k++) prev.v[k] = dp[30 + k];
+        }
+        const fe zi = fe_mul(inv, prev);            // 1 / Z_i
+        inv = fe_mul(inv, z);                       // 1 / (Z_0 .. Z_{i-1})
+        const fe ax = fe_mul(x, zi), ay = fe_mul(y, zi);
+        uint32_t enc[8];
+        fe_tobytes(enc, ay);
+        enc[7] ^= (uint32_t)fe_isnegative(ax) << 31;
+        const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
+        const uint4 r0 = rec[2], r1 = rec[3];
+        const uint32_t diff = (enc[0] ^ r0.x) | (enc[1] ^ r0.y) | (enc[2] ^ r0.z) | (enc[3] ^ r0.w) | (enc[4] ^ r1.x) | (enc[5] ^ r1.y) |
+                              (enc[6] ^ r1.z) | (enc[7] ^ r1.w);
+        ok_out[me] = diff == 0 ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_commit_tally
@@ -583,11 +646,19 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
     hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, n_keys, table);
     return hipGetLastError();
 }
+uint64_t bsxk_ed25519_scratch_bytes(uint64_t n) { return n * ED_SLOT_I32 * 4; }
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
-                                     const uint8_t* table, uint32_t n_keys, uint8_t* ok) {
+                                     const uint8_t* table, uint32_t n_keys, uint8_t* ok, void* scratch) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_ed25519_verify_keyed, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n,
-                       v_max, table, n_keys, ok);
+    const dim3 grid((uint32_t)((n + ED_THREADS - 1) / ED_THREADS));
+    if (scratch) {
+        hipLaunchKernelGGL(k_ed25519_verify_keyed<true>, grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, ok, static_cast<int32_t*>(scratch));
+        const uint64_t lanes = (n + ED_FIN_K - 1) / ED_FIN_K;
+        hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok,
+                           static_cast<int32_t*>(scratch));
+    } else {
+        hipLaunchKernelGGL(k_ed25519_verify_keyed<false>, grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, ok, nullptr);
+    }
     hipLaunchKernelGGL(k_ed25519_verify<true>, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
     return hipGetLastError();
 }

@@ -316,7 +316,7 @@ class HeaderRangeEngine:
             return
         if self.ed_path == "keyed":
             chk(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(self.validators), dp(self.h), C.c_uint64(n), C.c_uint32(V),
-                                               dp(self.keytable), C.c_uint32(V), dp(self.ok)))
+                                               dp(self.keytable), C.c_uint32(V), dp(self.ok), None))
         else:
             chk(L.bsx_dev_ed25519_verify(ctx, st, dp(self.validators), dp(self.h), C.c_uint64(n), dp(self.ok)))
         chk(L.bsx_dev_commit_tally(ctx, st, dp(self.trusted), C.c_uint32(R), C.c_uint32(V), None, None, dp(self.trusted_res)))

@@ -420,7 +420,12 @@ uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys);
 int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys,
                              void* d_table);
 int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
-                                 uint64_t n, uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok);
+                                 uint64_t n, uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok,
+                                 void* d_scratch);
+/* d_scratch (optional, bsx_ed25519_verify_scratch_bytes(n) bytes, 16-byte aligned): with it the signature lanes stop
+ * before the point encoding (a field inversion, 27 % of a verification) and a second kernel encodes 8 results per lane
+ * with ONE inversion (Montgomery's trick); the verdicts are identical.  NULL: every lane inverts for itself. */
+uint64_t bsx_ed25519_verify_scratch_bytes(uint64_t n);
 /* CombinedStepCircuit::define — circuits/next_header.rs:25-46 (bin/next_header{,_mocha}.rs).  input40 =
  * prev_block_number (u64 big endian) ‖ prev_header_hash; output64 = next_header_hash ‖ data_commitment.
  * builder.step (:32-36) is [UPSTREAM] tendermintx v1.0.0; checked here: prev_header hashes to

@@ -360,8 +360,14 @@ def test_ed25519_fixed_key_path_matches_generic_and_oracle(n_keys):
     _lib.check(L.bsx_dev_ed25519_verify(ctx, st, dp(dv), dp(dh), C.c_uint64(n), dp(ok_g)))
     _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab)))
     _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v_max), dp(tab),
-                                              C.c_uint32(n_keys), dp(ok_k)))
+                                              C.c_uint32(n_keys), dp(ok_k), None))
+    # the same with the batch-inversion scratch (projective results parked, 8 encodings per inversion): identical verdicts
+    ok_b = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+    scr = torch.zeros(int(L.bsx_ed25519_verify_scratch_bytes(C.c_uint64(n))), dtype=torch.uint8, device="cuda")
+    _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v_max), dp(tab),
+                                              C.c_uint32(n_keys), dp(ok_b), dp(scr)))
     torch.cuda.synchronize()
+    assert torch.equal(ok_b, ok_k)
     ok_g, ok_k = ok_g.cpu().numpy().reshape(n_commits, v_max), ok_k.cpu().numpy().reshape(n_commits, v_max)
     for c in range(n_commits):
         _, rok = oracle.verify_commit(vals[c], hh[c].tobytes())
@@ -394,7 +400,9 @@ def test_ed25519_key_table_reuse_across_calls_and_validator_set_changes():
         ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
         _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(dv), C.c_uint64(n), dp(dh), None))
         _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab)))
-        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v), dp(tab), C.c_uint32(n_keys), dp(ok)))
+        scr = torch.zeros(int(L.bsx_ed25519_verify_scratch_bytes(C.c_uint64(n))), dtype=torch.uint8, device="cuda")
+        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v), dp(tab), C.c_uint32(n_keys), dp(ok),
+                                                  dp(scr) if vals.shape[0] % 2 else None))
         torch.cuda.synchronize()
         ok = ok.cpu().numpy().reshape(vals.shape[0], v)
         for c in range(vals.shape[0]):

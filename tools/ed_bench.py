@@ -22,6 +22,7 @@ def main():
         dh = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
         dok = torch.zeros(n, dtype=torch.uint8, device=dev)
         dok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+        scr = torch.zeros(n * 160, dtype=torch.uint8, device=dev) if os.environ.get('ED_BATCH_INV', '1') == '1' else None
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         for it in range(3):
             ev[0].record()
@@ -31,7 +32,7 @@ def main():
             ev[2].record()
             _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(V), dp(tab)))
             ev[3].record()
-            _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(V), dp(tab), C.c_uint32(V), dp(dok2)))
+            _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(V), dp(tab), C.c_uint32(V), dp(dok2), dp(scr) if scr is not None else None))
             ev[4].record()
             torch.cuda.synchronize()
         assert int(dok.sum().item()) == n and int(dok2.sum().item()) == n
