@@ -5,10 +5,12 @@
 //
 //   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, records staged via LDS
 //   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
-//   k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed
-//                       P7, fixed-key form: per-validator tables of j*(-2^(32k) A) (k = 0..7, j = 1..128) built once per
-//                           pass, signatures checked with 8-bit windows over scalars split in four; slots whose key is not the
-//                           table row's key are deferred to k_ed25519_verify<true> (same accept set)
+//   k_keytable_check / k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed / k_ed25519_finish
+//                       P7, fixed-key form: per-validator tables of j*(-2^(32k) A) (k = 0..7, j = 1..128), rows kept across
+//                           calls and rebuilt only when their key changes; signatures checked with 8-bit windows over scalars
+//                           split in eight 32-bit parts; optionally the point encodings go through a per-lane batch inversion
+//                           (k_ed25519_finish); slots whose key is not the table row's key are deferred to
+//                           k_ed25519_verify<true> (same accept set)
 //   k_skip_eval         operator skip-target search (fetcher.rs:60-87): is_valid_skip of every candidate in one launch
 //   k_commit_tally     P8+P9 validator-set hash (masked Merkle tree), voting-power sums, message checks;
 //                           one workgroup per commit, wave-shuffle + LDS reductions
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_check(const bsx_validat
     reinterpret_cast<uint32_t*>(rec + 3)[2] = (force || !same) ? 1u : 0u;
 }
 
-// one lane per key: decode, negate, and run the 3 x 64 doublings that give the base points of the upper scalar parts
+// one lane per key: decode, negate, and run the 7 x 32 doublings that give the base points of the upper scalar parts
 __global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validator* __restrict__ vals, uint32_t n_keys,
                                                                uint8_t* __restrict__ table) {
     const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
