@@ -85,6 +85,24 @@ def parse():
     return ap.parse_args()
 
 
+def host_threads():
+    """Threads for the CPU legs and what the box really grants: the GPU boxes show 256 logical CPUs but run the container
+    under a cgroup CPU quota (cpu.max 1600000/100000 = 16 CPUs): 256 threads then thrash the quota (152 k Ed25519 verifies/s
+    vs 278 k at 32 threads, tools/cpu_probe.py).  -> (threads to use, description)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(per)
+    except Exception:
+        pass
+    if quota and quota < n:
+        t = max(1, min(n, int(round(2 * quota))))
+        return t, f"{t} threads (cgroup CPU quota {quota:g} CPUs of {n} logical)"
+    return n, f"{n} threads (no CPU quota)"
+
+
 # ---------------------------------------------------------------------------------------------------------------- checkers
 def cpu_baseline_witness_check(eng, w, J, B, per_chunk=2):
     """Download the Goldilocks witness of `per_chunk` sampled ranges of every pipelined chunk — as the TIMED loop left it in
@@ -125,7 +143,7 @@ def cpu_baseline(w, J, B, V, seconds, gpu_out64, n_ranges):
     """Oracle (oracle/, C) timed on the host cores on a bounded sample of the SAME workload; its outputs double as a
     check of the GPU's public outputs for the sampled ranges."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores, cores_desc = host_threads()
     n = n_ranges
 
     def run(reps):
@@ -142,7 +160,7 @@ def cpu_baseline(w, J, B, V, seconds, gpu_out64, n_ranges):
     assert (out == gpu_out64[:n]).all(), "GPU public outputs differ from the oracle on the sampled ranges"
     return {"value": n * reps * J * B / dt, "unit": "headers/s", "cores": cores, "kind": "port",
             "sample": f"the {n} header_range_{J * B} instances of the GPU step x {reps} repetitions = {n * reps} ranges "
-                      f"(same inputs, witness expansion included), {dt:.1f} s wall on {cores} threads; outputs checked equal to the GPU's",
+                      f"(same inputs, witness expansion included), {dt:.1f} s wall on {cores_desc}; outputs checked equal to the GPU's",
             "sha_ni": bool(oracle.has_shani())}
 
 
@@ -229,7 +247,7 @@ def stress(args, dev, V, cpu_seconds):
     gpu_ok = dok.cpu().numpy().reshape(nh, V)
     gpu_res = dres.cpu().numpy().view(T.COMMIT_RESULT)
     # CPU leg = checker: the oracle's verify_commit of EVERY commit on all host threads, repeated to fill ~cpu_seconds
-    cores = os.cpu_count() or 1
+    cores, cores_desc = host_threads()
     t0 = time.perf_counter()
     res, ok = oracle.bench_verify_commits(w.validators.reshape(nh, V), w.commit_hashes, cores, reps=1)
     dt = time.perf_counter() - t0
@@ -270,7 +288,7 @@ def stress(args, dev, V, cpu_seconds):
                                               "frac_of_measured_peak": 2 * n / t_sha * 1e3 / PEAK["sha512_compress_per_s"],
                                               "algorithmic_GBps": n * 237 / t_sha / 1e6}},
             "cpu_baseline": {"value": nh * creps / dt, "unit": "headers/s", "verifies_per_s": n * creps / dt, "cores": cores, "kind": "port",
-                             "sample": f"oracle verify_commit of all {nh} commits x {creps} repetitions, {dt:.1f} s wall on {cores} threads; "
+                             "sample": f"oracle verify_commit of all {nh} commits x {creps} repetitions, {dt:.1f} s wall on {cores_desc}; "
                                        "every verdict and commit result compared with the GPU's"}}
 
 

@@ -562,7 +562,7 @@ def test_mode_s_full_size_2048_x_512_vs_oracle():
         else:
             vals[c, k]["pubkey"][int(rng.integers(0, 31))] ^= 2       # key no longer matches the table row -> generic fallback
     res, ok = verify_commits(vals, w.commit_hashes)
-    want, wok = oracle.bench_verify_commits(vals, w.commit_hashes, os.cpu_count() or 1)
+    want, wok = oracle.bench_verify_commits(vals, w.commit_hashes, min(32, os.cpu_count() or 1))     # the GPU boxes grant ~16 CPUs
     assert (ok == wok).all(), np.argwhere(ok != wok)[:5]
     a, b = res.copy(), want.copy()
     a["_pad"] = 0; b["_pad"] = 0
