@@ -33,6 +33,11 @@ __global__ void k_issue(uint32_t* out, int iters) {
                 if (MODE == 3) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
                 if (MODE == 4) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i]) : "v"(m), "v"(k));
                 if (MODE == 5) asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(q[i]) : "v"(q[(i + 1) & 7]));
+                if (MODE == 6) asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(a[i]));
+                if (MODE == 7) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(k));
+                if (MODE == 8) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(m), "v"(k));
+                if (MODE == 9) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+                if (MODE == 10) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(m) : "vcc");
             }
     }
     uint32_t x = 0;
@@ -90,7 +95,8 @@ static float timeit(F f, int reps) {
 
 int main() {
     uint32_t* out; hipMalloc(&out, 64u << 20);
-    const char* names[] = {"v_add_u32", "v_mad_u32_u24", "v_mad_u64_u32", "v_mul_lo_u32", "v_bitop3_b32", "v_lshl_add_u64"};
+    const char* names[] = {"v_add_u32", "v_mad_u32_u24", "v_mad_u64_u32", "v_mul_lo_u32", "v_bitop3_b32", "v_lshl_add_u64",
+                           "v_alignbit_b32", "v_add3_u32", "v_bfi_b32", "v_cndmask_b32", "v_add_co_u32"};
     const int blocks = 256 * 8, threads = 256, iters = 200;          // 8 waves per SIMD
     auto issue = [&](int mode) {
         switch (mode) {
@@ -99,10 +105,15 @@ int main() {
             case 2: hipLaunchKernelGGL(k_issue<2>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
             case 3: hipLaunchKernelGGL(k_issue<3>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
             case 4: hipLaunchKernelGGL(k_issue<4>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
-            default: hipLaunchKernelGGL(k_issue<5>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
+            case 5: hipLaunchKernelGGL(k_issue<5>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
+            case 6: hipLaunchKernelGGL(k_issue<6>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
+            case 7: hipLaunchKernelGGL(k_issue<7>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
+            case 8: hipLaunchKernelGGL(k_issue<8>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
+            case 9: hipLaunchKernelGGL(k_issue<9>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
+            default: hipLaunchKernelGGL(k_issue<10>, dim3(blocks), dim3(threads), 0, 0, out, iters); break;
         }
     };
-    for (int mode = 0; mode < 6; mode++) {
+    for (int mode = 0; mode < 11; mode++) {
         float ms = timeit([&] { issue(mode); }, 3);
         double ops = (double)blocks * threads * iters * 64;
         printf("issue %-15s : %.3f ms  %.2f T lane-ops/s\n", names[mode], ms, ops / ms / 1e9);
