@@ -6,7 +6,8 @@
 //                             FUSED = true   rows of the witness generated ON THE FLY from the COMPACT bytes: the 64x
 //                                            expanded image (8 B per bit) is never written or read — the expansion
 //                                            (P10, k_expand_witness' job) is fused into its consumer
-//   k_zero_leaf / k_copy_zero_leaves  the all-zero padding rows of every tree share one digest: computed once, copied
+//   k_copy_zero_leaves        the all-zero padding rows of every tree share one digest: computed once (an extra lane of
+//                             k_leaf_hashes), copied
 //   k_merkle_level            PoseidonHash::two_to_one over one tree level of all trees, one lane per parent
 //
 // What it replaces: plonky2 `Poseidon::poseidon`, `hash_n_to_hash_no_pad`, `PoseidonHash::{hash_or_noop,two_to_one}`,
@@ -65,9 +66,14 @@ __device__ __forceinline__ uint64_t compact_elem(const bsx_witness_layout& lay, 
 template <bool FUSED>
 __global__ __launch_bounds__(PS_THREADS, BSX_LEAF_WAVES) void k_leaf_hashes(LeafArgs a) {
     const uint64_t g = (uint64_t)blockIdx.x * PS_THREADS + threadIdx.x;
-    if (g >= (uint64_t)a.n_trees * a.n_rows) return;
-    const uint64_t job = g / a.n_rows, j = g % a.n_rows;
-    const uint64_t nel = a.lay.n_elements, e0 = j * a.leaf_len;
+    const uint64_t n_real = (uint64_t)a.n_trees * a.n_rows;
+    // one extra lane hashes the all-zero row (the padding rows [n_rows, n_leaves) of every tree share that digest) into slot
+    // (tree 0, row n_rows): as one more lane of this launch it costs nothing, as a launch of its own it was 1.3 ms of pure
+    // single-lane latency (17 dependent permutations)
+    const bool zero_lane = a.n_rows < a.n_leaves && g == n_real;
+    if (g >= n_real && !zero_lane) return;
+    const uint64_t job = zero_lane ? 0 : g / a.n_rows, j = zero_lane ? a.n_rows : g % a.n_rows;
+    const uint64_t nel = zero_lane ? 0 : a.lay.n_elements, e0 = j * a.leaf_len;
     uint64_t d[4];
     if (FUSED) {
         const uint8_t* c = a.compact + job * a.lay.compact_stride;
@@ -86,17 +92,8 @@ __global__ __launch_bounds__(PS_THREADS, BSX_LEAF_WAVES) void k_leaf_hashes(Leaf
     reinterpret_cast<ulonglong2*>(o)[1] = make_ulonglong2(d[2], d[3]);
 }
 
-// rows [n_rows, n_leaves) of every tree are all zero and share one digest: one lane hashes the zero row into slot
-// (tree 0, row n_rows), k_copy_zero_leaves spreads it (19 % of the leaf slots at B = 64, leaf_len 135).
-__global__ void k_zero_leaf(LeafArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t d[4];
-    auto get = [](uint64_t) -> uint64_t { return 0ull; };
-    if (a.noop_small) poseidon_hash_or_noop(get, a.leaf_len, POSEIDON_RC, d);
-    else poseidon_hash_no_pad(get, a.leaf_len, POSEIDON_RC, d);
-    uint64_t* o = a.tree + 4 * a.n_rows;
-    for (int i = 0; i < 4; i++) o[i] = d[i];
-}
+// rows [n_rows, n_leaves) of every tree are all zero and share one digest: the extra lane of k_leaf_hashes wrote it to slot
+// (tree 0, row n_rows); spread it (19 % of the leaf slots at B = 64, leaf_len 135)
 __global__ __launch_bounds__(PS_THREADS) void k_copy_zero_leaves(LeafArgs a) {
     const uint64_t n_pad = a.n_leaves - a.n_rows;
     const uint64_t g = (uint64_t)blockIdx.x * PS_THREADS + threadIdx.x;
@@ -144,14 +141,13 @@ hipError_t bsxk_leaf_hashes(hipStream_t s, const bsx_witness_layout* lay, uint32
     uint64_t n_rows = (lay->n_elements + leaf_len - 1) / leaf_len;
     if (n_rows > n_leaves) n_rows = n_leaves;
     LeafArgs a{*lay, n_trees, leaf_len, n_leaves, (uint32_t)noop_small, n_rows, tree_stride, compact, elements, tree};
-    const uint64_t lanes = (uint64_t)n_trees * n_rows;
+    const uint64_t lanes = (uint64_t)n_trees * n_rows + (n_rows < n_leaves ? 1 : 0);
     if (lanes) {
         const dim3 grid((uint32_t)((lanes + PS_THREADS - 1) / PS_THREADS));
         if (compact) hipLaunchKernelGGL(k_leaf_hashes<true>, grid, dim3(PS_THREADS), 0, s, a);
         else hipLaunchKernelGGL(k_leaf_hashes<false>, grid, dim3(PS_THREADS), 0, s, a);
     }
     if (n_rows < n_leaves) {
-        hipLaunchKernelGGL(k_zero_leaf, dim3(1), dim3(64), 0, s, a);
         const uint64_t pads = (uint64_t)n_trees * (n_leaves - n_rows);
         hipLaunchKernelGGL(k_copy_zero_leaves, dim3((uint32_t)((pads + PS_THREADS - 1) / PS_THREADS)), dim3(PS_THREADS), 0, s, a);
     }
