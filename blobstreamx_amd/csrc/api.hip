@@ -18,7 +18,7 @@
 #include "api_internal.h"
 
 extern "C" {
-hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*);
+hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t);
 hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
 hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
@@ -212,11 +212,23 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
     return fail(BSX_ERR_BAD_ARG, "bsx_dev_free: pointer was not returned by bsx_dev_alloc on this context");
 }
 
+int bsx_set_tuning(bsx_ctx* ctx, uint32_t key, uint64_t value) {
+    if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");
+    switch (key) {
+    case BSX_TUNE_MERKLE_WORKGROUPS:
+        if (value > 0xffffffffull) return fail(BSX_ERR_BAD_ARG, "BSX_TUNE_MERKLE_WORKGROUPS: %llu out of range", (unsigned long long)value);
+        ctx->merkle_wgs = (uint32_t)value;
+        return BSX_OK;
+    default:
+        return fail(BSX_ERR_BAD_ARG, "bsx_set_tuning: unknown key %u", key);
+    }
+}
+
 int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_headers, uint64_t n, uint8_t* d_hashes,
                           uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint8_t* d_paths, uint32_t* d_status) {
     DEV_ENTER();
     if (n && !d_headers) return fail(BSX_ERR_BAD_ARG, "null headers");
-    HIPCHK(bsxk_header_merkle(S(ctx, stream), d_headers, n, d_hashes, d_dh_aunts, d_lb_aunts, d_paths, d_status));
+    HIPCHK(bsxk_header_merkle(S(ctx, stream), d_headers, n, d_hashes, d_dh_aunts, d_lb_aunts, d_paths, d_status, ctx->merkle_wgs));
     return BSX_OK;
 }
 
@@ -438,7 +450,7 @@ int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8
     uint8_t* d_lb = d_dh + n * 128;
     H2D(dh.p, headers, n * sizeof(bsx_header));
     HIPCHK(hipMemsetAsync(dst.p, 0, 4, st));
-    HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, nullptr, dst.as<uint32_t>()));
+    HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, nullptr, dst.as<uint32_t>(), 0));
     std::vector<uint8_t> tmp(n * 288);
     uint32_t hs = 0;
     D2H(tmp.data(), d_hash, n * 288);
@@ -488,7 +500,7 @@ static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers,
     HIPCHK(hipMemsetAsync(rd.hstatus.p, 0, 4, st));
     HIPCHK(hipMemsetAsync(rd.astatus.p, 0, 4, st));
     HIPCHK(bsxk_header_merkle(st, rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
-                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>()));
+                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>(), 0));
     (void)ctx;
     return BSX_OK;
 }

@@ -94,13 +94,25 @@ __device__ __forceinline__ Digest leaf_from_global(const uint32_t* f, int len) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_header_merkle
-// One lane per header; the 14-leaf tree stays in registers: 15 leaf blocks + 13 x 2 inner blocks = 41 compressions.
-// Each lane streams its own 512-byte record (every fetched line is consumed completely by the same lane, so HBM traffic
-// equals the algorithmic 512 B/header) in TWO bursts of 16-byte loads — dwords [0,80) for leaves 0..7, dwords [76,128)
-// for leaves 8..13 — and writes its digests in two bursts of stores: every call of the (not inlined) compression
-// function drains the wave's outstanding memory operations, so a load or store between two compressions is a full
-// round trip (3 per lane now, one per leaf before), several times longer beside the other chunk's HBM-bound expansion.
-constexpr int HM_THREADS = 256;
+// The 14-leaf tree of a header (15 leaf blocks + 13 x 2 inner blocks = 41 compressions) is cut at its natural joints —
+// tendermint splits 14 = 8 | 6, 8 = 4 | 4, 6 = 4 | 2 — into four SUB-TREES hashed by four different waves of a
+// workgroup, one lane per header each:
+//     role 0  leaves 0..3   -> n0123   10 compressions        role 2  leaves 8..11  -> n8_11  10 compressions
+//     role 1  leaves 4..7   -> n4567   11 (last_block_id = 2)  role 3  leaves 12,13  -> n12_13  4, then after the barrier the
+//                                                                      three joining nodes left, right, root: + 6 = 10
+// Why not one lane per whole header (round 1): 41 compressions per lane is a coarse unit.  It needed 199 VGPRs (80 record
+// dwords resident) = 2 waves per SIMD, and 2049 x 128 headers = 4104 waves on 2048 slots ran as two full rounds plus a
+// round of 8 straggler waves: 0.57 ms where the compressions take 0.39 ms at the ALU ceiling.  Quarter units need a quarter
+// of the record in registers (4 waves per SIMD) and balance 4x finer; the roles rotate with the group index so that every
+// SIMD of a CU sees the same mix.  Digests cross waves through 9 KB of LDS (stride 9 dwords: conflict free).
+// A lane reads each field of its own 512-byte record right before hashing it and stores a digest as soon as it exists:
+// values that live across a call of the (not inlined) compression function sit in callee-saved registers, which the
+// AMDGPU calling convention interleaves with caller-saved ones — a record quarter kept resident costs twice its size in
+// register index.  The price is a memory round trip per leaf (every call drains the wave's outstanding operations);
+// with four waves per SIMD the other three issue meanwhile.
+constexpr int HM_THREADS = 256;           // 4 waves = the 4 sub-trees of 64 headers
+constexpr int HM_GROUP = 64;              // headers per workgroup pass
+constexpr int HM_LDS_STRIDE = 9;
 
 // leaf of a field held in registers: W = dwords [BASE, BASE + N) of the record, field at dword OFF, ND dwords
 template <int ND, int OFF, int BASE, int N>
@@ -110,116 +122,126 @@ __device__ __forceinline__ Digest leaf_from_regs(const uint32_t (&W)[N], int len
     for (int j = 0; j < 14; j++) d[j] = (j < ND) ? W[OFF - BASE + j] : 0u;
     return leaf_hash_1block(d, len);
 }
+// dwords [BASE, BASE + N) of a record, N a multiple of 4
+template <int BASE, int N>
+__device__ __forceinline__ void hm_load(const uint8_t* rec, uint32_t (&W)[N]) {
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) {
+        const uint4 v = ldu4(rec + 4 * BASE + 16 * k);
+        W[4 * k] = v.x; W[4 * k + 1] = v.y; W[4 * k + 2] = v.z; W[4 * k + 3] = v.w;
+    }
+}
+// field length i (byte i of the record), clamped to the field's capacity (bsx.h); a violation sets `bad`
+__device__ __forceinline__ int hm_len(uint32_t lens, int i, int cap, bool& bad) {
+    int l = (int)((lens >> (8 * (i & 3))) & 0xff);
+    if (l > cap) { bad = true; l = cap; }
+    return l;
+}
 
 // paths (optional): per header the 7 distinct digests of the two inclusion-proof PATHS prove_subchain materialises for it
 // (builder.rs:189-199) — [L6, n67, L4, n45, n4567, left, root]: data_hash path = L6, n67, n4567, left, root; last_block_id path
 // = L4, n45, n4567, left, root.  They are nodes of the tree hashed here anyway; handing them to the hint (k_assemble_inputs)
 // lets prove_subchain skip re-deriving them from the proofs (19 of its 21 compressions per slot).
 constexpr uint32_t HM_PATH_BYTES = 7 * 32;
-__global__ __launch_bounds__(HM_THREADS) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
+__global__ __launch_bounds__(HM_THREADS, 4) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
                                                               uint8_t* __restrict__ lb_aunts, uint8_t* __restrict__ paths,
                                                               uint32_t* __restrict__ status) {
     BSX_CHAIN_PRIO();
-    // grid-strided: the launcher may cap the grid (resident workgroups per CU) so that this 162-VGPR kernel leaves register
-    // file for the HBM-bound expansion running beside it — three of its waves fill a SIMD's 512 registers completely
-    for (uint64_t me = (uint64_t)blockIdx.x * HM_THREADS + threadIdx.x; me < ((n + HM_THREADS - 1) / HM_THREADS) * HM_THREADS;
-         me += (uint64_t)gridDim.x * HM_THREADS) {
-    const bool live = me < n;
-    const uint8_t* my = reinterpret_cast<const uint8_t*>(hdr + (live ? me : 0));
-    // byte offsets: version 16, chain_id 40, height 92, time 104, last_block_id 124, hash[j] 200+36j, proposer 488
-    uint32_t W1[80];
-#pragma unroll
-    for (int k = 0; k < 20; k++) {
-        const uint4 v = ldu4(my + 16 * k);
-        W1[4 * k] = v.x; W1[4 * k + 1] = v.y; W1[4 * k + 2] = v.z; W1[4 * k + 3] = v.w;
-    }
-    int len[14];
-#pragma unroll
-    for (int i = 0; i < 14; i++) len[i] = (int)((W1[i >> 2] >> (8 * (i & 3))) & 0xff);
-    // capacity rules (bsx.h): violations flagged, lengths clamped so nothing reads out of bounds
-    bool bad = false;
-    {
-        constexpr int cap[14] = {24, 52, 12, 20, 76, 36, 36, 36, 36, 36, 36, 36, 36, 24};
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-            if (len[i] > cap[i]) { bad = true; len[i] = cap[i]; }
-        }
-    }
-    Digest left, right;
-    {
-        Digest n0123, n45, n67, L5, L7;
-        {
-            const Digest L0 = leaf_from_regs<6, 4, 0>(W1, len[0]);
-            const Digest L1 = leaf_from_regs<13, 10, 0>(W1, len[1]);
+    // double-buffered by pass parity: the joining wave of pass p reads buffer p & 1 while the other three waves already
+    // write pass p + 1's sub-tree roots into the other one; pass p + 2 reuses buffer p & 1 only behind the barrier of pass
+    // p + 1, which the joining wave of pass p reaches after its reads
+    __shared__ uint32_t sub2[2][3][HM_GROUP * HM_LDS_STRIDE];
+    uint32_t pass = 0;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t n_groups = (n + HM_GROUP - 1) / HM_GROUP;
+    // grid-strided: the launcher may cap the grid (BSX_MERKLE_WGS)
+    for (uint64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x, pass ^= 1) {
+        uint32_t (*sub)[HM_GROUP * HM_LDS_STRIDE] = sub2[pass];
+        const uint32_t role = (wave + (uint32_t)grp) & 3;            // wave-uniform
+        const uint64_t me = grp * HM_GROUP + lane;
+        const bool live = me < n;
+        const uint8_t* my = reinterpret_cast<const uint8_t*>(hdr + (live ? me : 0));
+        // byte offsets: lengths 0..13, version 16, chain_id 40, height 92, time 104, last_block_id 124, hash[j] 200+36j, proposer 488
+        bool bad = false;
+        Digest top;                                                  // this role's sub-tree root
+        const uint32_t* rec = reinterpret_cast<const uint32_t*>(my);
+        const uint32_t lens = rec[role];                             // lengths 4 role .. 4 role + 3
+        if (role == 0) {
+            const Digest L0 = leaf_from_global<6>(rec + 4, hm_len(lens, 0, 24, bad));
+            const Digest L1 = leaf_from_global<13>(rec + 10, hm_len(lens, 1, 52, bad));
             const Digest n01 = inner_hash(L0, L1);
-            const Digest L2 = leaf_from_regs<3, 23, 0>(W1, len[2]);
-            const Digest L3 = leaf_from_regs<5, 26, 0>(W1, len[3]);
-            n0123 = inner_hash(n01, inner_hash(L2, L3));
-        }
-        {
-            uint32_t d[19];
-#pragma unroll
-            for (int j = 0; j < 19; j++) d[j] = W1[31 + j];
-            const Digest L4 = (len[4] <= 54) ? leaf_hash_1block(d, len[4]) : leaf_hash_2block(d, len[4]);
-            L5 = leaf_from_regs<9, 50, 0>(W1, len[5]);
-            n45 = inner_hash(L4, L5);
-            if (live && paths) store_digest_u(paths + me * HM_PATH_BYTES + 64, L4);
-        }
-        {
-            const Digest L6 = leaf_from_regs<9, 59, 0>(W1, len[6]);   // data_hash
-            L7 = leaf_from_regs<9, 68, 0>(W1, len[7]);
-            n67 = inner_hash(L6, L7);
-            if (live && paths) store_digest_u(paths + me * HM_PATH_BYTES, L6);
-        }
-        const Digest n4567 = inner_hash(n45, n67);
-        left = inner_hash(n0123, n4567);
-        if (live && paths) {
-            store_digest_u(paths + me * HM_PATH_BYTES + 32, n67);
-            store_digest_u(paths + me * HM_PATH_BYTES + 96, n45);
-            store_digest_u(paths + me * HM_PATH_BYTES + 128, n4567);
-            store_digest_u(paths + me * HM_PATH_BYTES + 160, left);
-        }
-        if (live) {
-            if (lb_aunts) {  // index 4: [L5, n67, n0123, right]
-                store_digest_u(lb_aunts + me * 128, L5);
-                store_digest_u(lb_aunts + me * 128 + 32, n67);
-                store_digest_u(lb_aunts + me * 128 + 64, n0123);
+            const Digest L2 = leaf_from_global<3>(rec + 23, hm_len(lens, 2, 12, bad));
+            const Digest L3 = leaf_from_global<5>(rec + 26, hm_len(lens, 3, 20, bad));
+            top = inner_hash(n01, inner_hash(L2, L3));               // n0123
+            if (live) {
+                if (lb_aunts) store_digest_u(lb_aunts + me * 128 + 64, top);
+                if (dh_aunts) store_digest_u(dh_aunts + me * 128 + 64, top);
             }
-            if (dh_aunts) {  // index 6: [L7, n45, n0123, right]
-                store_digest_u(dh_aunts + me * 128, L7);
-                store_digest_u(dh_aunts + me * 128 + 32, n45);
-                store_digest_u(dh_aunts + me * 128 + 64, n0123);
+        } else if (role == 1) {
+            uint8_t* p = paths ? paths + me * HM_PATH_BYTES : nullptr;
+            Digest L4;
+            {
+                uint32_t d[19];
+#pragma unroll
+                for (int j = 0; j < 19; j++) d[j] = rec[31 + j];
+                const int l4 = hm_len(lens, 4, 76, bad);
+                L4 = (l4 <= 54) ? leaf_hash_1block(d, l4) : leaf_hash_2block(d, l4);
+            }
+            if (live && p) store_digest_u(p + 64, L4);
+            const Digest L5 = leaf_from_global<9>(rec + 50, hm_len(lens, 5, 36, bad));
+            if (live && lb_aunts) store_digest_u(lb_aunts + me * 128, L5);                 // index 4: [L5, n67, n0123, right]
+            const Digest n45 = inner_hash(L4, L5);
+            if (live && p) store_digest_u(p + 96, n45);
+            if (live && dh_aunts) store_digest_u(dh_aunts + me * 128 + 32, n45);           // index 6: [L7, n45, n0123, right]
+            const Digest L6 = leaf_from_global<9>(rec + 59, hm_len(lens, 6, 36, bad));    // data_hash
+            if (live && p) store_digest_u(p, L6);
+            const Digest L7 = leaf_from_global<9>(rec + 68, hm_len(lens, 7, 36, bad));
+            if (live && dh_aunts) store_digest_u(dh_aunts + me * 128, L7);
+            const Digest n67 = inner_hash(L6, L7);
+            if (live && p) store_digest_u(p + 32, n67);
+            if (live && lb_aunts) store_digest_u(lb_aunts + me * 128 + 32, n67);
+            top = inner_hash(n45, n67);                              // n4567
+            if (live && p) store_digest_u(p + 128, top);
+        } else if (role == 2) {
+            const Digest L8 = leaf_from_global<9>(rec + 77, hm_len(lens, 8, 36, bad));
+            const Digest L9 = leaf_from_global<9>(rec + 86, hm_len(lens, 9, 36, bad));
+            const Digest n89 = inner_hash(L8, L9);
+            const Digest L10 = leaf_from_global<9>(rec + 95, hm_len(lens, 10, 36, bad));
+            const Digest L11 = leaf_from_global<9>(rec + 104, hm_len(lens, 11, 36, bad));
+            top = inner_hash(n89, inner_hash(L10, L11));             // n8_11
+        } else {
+            const Digest L12 = leaf_from_global<9>(rec + 113, hm_len(lens, 12, 36, bad));
+            const Digest L13 = leaf_from_global<6>(rec + 122, hm_len(lens, 13, 24, bad));
+            top = inner_hash(L12, L13);                              // n12_13
+        }
+        if (role != 3) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sub[role][lane * HM_LDS_STRIDE + k] = top.w[k];
+        }
+        __syncthreads();
+        if (role == 3) {
+            Digest a, b;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { a.w[k] = sub[0][lane * HM_LDS_STRIDE + k]; b.w[k] = sub[1][lane * HM_LDS_STRIDE + k]; }
+            const Digest left = inner_hash(a, b);
+#pragma unroll
+            for (int k = 0; k < 8; k++) a.w[k] = sub[2][lane * HM_LDS_STRIDE + k];
+            const Digest right = inner_hash(a, top);
+            const Digest root = inner_hash(left, right);
+            if (live) {
+                if (hashes) store_digest_u(hashes + me * 32, root);
+                if (paths) {
+                    store_digest_u(paths + me * HM_PATH_BYTES + 160, left);
+                    store_digest_u(paths + me * HM_PATH_BYTES + 192, root);
+                }
+                if (lb_aunts) store_digest_u(lb_aunts + me * 128 + 96, right);
+                if (dh_aunts) store_digest_u(dh_aunts + me * 128 + 96, right);
             }
         }
-    }
-    {
-        uint32_t W2[52];      // dwords [76, 128)
-#pragma unroll
-        for (int k = 0; k < 13; k++) {
-            const uint4 v = ldu4(my + 304 + 16 * k);
-            W2[4 * k] = v.x; W2[4 * k + 1] = v.y; W2[4 * k + 2] = v.z; W2[4 * k + 3] = v.w;
-        }
-        const Digest L8 = leaf_from_regs<9, 77, 76>(W2, len[8]);
-        const Digest L9 = leaf_from_regs<9, 86, 76>(W2, len[9]);
-        const Digest n89 = inner_hash(L8, L9);
-        const Digest L10 = leaf_from_regs<9, 95, 76>(W2, len[10]);
-        const Digest L11 = leaf_from_regs<9, 104, 76>(W2, len[11]);
-        const Digest n8_11 = inner_hash(n89, inner_hash(L10, L11));
-        const Digest L12 = leaf_from_regs<9, 113, 76>(W2, len[12]);
-        const Digest L13 = leaf_from_regs<6, 122, 76>(W2, len[13]);
-        right = inner_hash(n8_11, inner_hash(L12, L13));
-    }
-    const Digest root = inner_hash(left, right);
-    if (live) {
-        if (hashes) store_digest_u(hashes + me * 32, root);
-        if (paths) store_digest_u(paths + me * HM_PATH_BYTES + 192, root);
-        if (lb_aunts) store_digest_u(lb_aunts + me * 128 + 96, right);
-        if (dh_aunts) store_digest_u(dh_aunts + me * 128 + 96, right);
-    }
-    // wave-ballot reduction of the "bad header" predicate: one atomic per wave
-    const unsigned long long m = __ballot(live && bad);
-    if (m && (threadIdx.x & 63) == 0 && status) atomicOr(status, 1u);
+        // wave-ballot reduction of the "bad header" predicate: one atomic per wave
+        const unsigned long long m = __ballot(live && bad);
+        if (m && lane == 0 && status) atomicOr(status, 1u);
     }
 }
 
@@ -869,11 +891,13 @@ extern "C" {
 using namespace bsx;
 
 hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint8_t* paths,
-                              uint32_t* status) {
+                              uint32_t* status, uint32_t max_wgs) {
     if (!n) return hipSuccess;
-    uint32_t grid = (uint32_t)((n + HM_THREADS - 1) / HM_THREADS);
-    // BSX_MERKLE_WGS: cap on the grid (workgroups stride over the headers); 0 = one workgroup per 256 headers
-    static const long cap = getenv("BSX_MERKLE_WGS") ? atol(getenv("BSX_MERKLE_WGS")) : 0;
+    uint32_t grid = (uint32_t)((n + HM_GROUP - 1) / HM_GROUP);
+    // cap on the grid (the workgroups then stride over the header groups): the context's BSX_TUNE_MERKLE_WORKGROUPS, or the
+    // BSX_MERKLE_WGS environment variable (experiments); 0 = one workgroup per 64 headers
+    static const long env_cap = getenv("BSX_MERKLE_WGS") ? atol(getenv("BSX_MERKLE_WGS")) : -1;
+    const long cap = env_cap >= 0 ? env_cap : (long)max_wgs;
     if (cap > 0 && grid > (uint32_t)cap) grid = (uint32_t)cap;
     hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status);
     return hipGetLastError();

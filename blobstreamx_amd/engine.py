@@ -482,6 +482,12 @@ class PipelinedEngines:
         self._expand_token = None
         self._pending_verify = None
         self.verify_after_merkle = os.environ.get("BSX_VERIFY_AFTER_MERKLE", "1") == "1"
+        # k_header_merkle alone fills the register file (4 waves x 128 VGPRs per SIMD); beside an expansion it is held to
+        # 2 workgroups per CU so that the expansion's waves keep half of it (bsx.h BSX_TUNE_MERKLE_WORKGROUPS): +2 % per step
+        e0 = self.engines[0]
+        _lib.check(e0.L.bsx_set_tuning(e0.ctx, C.c_uint32(T.TUNE_MERKLE_WORKGROUPS),
+                                       C.c_uint64(2 * torch.cuda.get_device_properties(self.dev).multi_processor_count
+                                                  if e0.with_witness and n_engines > 1 else 0)))
 
     def sel(self, e):
         return np.concatenate([np.arange(g * self.R + e * self.Rc, g * self.R + (e + 1) * self.Rc) for g in range(self.world)])

@@ -329,7 +329,16 @@ int bsx_ingest_data_commitment_json(const char* json, size_t len, uint8_t out[32
 int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr);
 int bsx_dev_free(bsx_ctx* ctx, void* ptr);
 
-/* P5: one lane per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be
+/* Launch tuning of a context (optional; results never depend on it).
+ * BSX_TUNE_MERKLE_WORKGROUPS: resident workgroups of the header-hashing kernel; its workgroups then stride over the
+ *   header groups.  0 (default) = one workgroup per 64 headers, the fastest form when the kernel has the GPU to itself
+ *   (4 waves per SIMD: the register file is full).  A pipeline that runs the HBM-bound witness expansion of one chunk
+ *   beside the hashing of the next (blobstreamx_amd/engine.py) sets 512 = 2 workgroups per CU, which leaves half of the
+ *   register file to the expansion's waves: +2 % whole-step throughput on MI355X. */
+#define BSX_TUNE_MERKLE_WORKGROUPS 1u
+int bsx_set_tuning(bsx_ctx* ctx, uint32_t key, uint64_t value);
+
+/* P5: four lanes (of four waves) per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be
  * NULL.  d_status (1 u32, optional): bit0 = a header violates the field-size rules.
  * d_paths (optional, n * BSX_HEADER_PATH_BYTES): the 7 distinct digests of the two inclusion-proof paths of each header
  * [L6, n67, L4, n45, n4567, left, root] — what prove_subchain's get_root_from_merkle_proof calls (builder.rs:189-199)
