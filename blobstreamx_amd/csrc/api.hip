@@ -32,7 +32,8 @@ hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, ui
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
 uint64_t bsxk_keytable_bytes(uint32_t);
 hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
-hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, uint8_t*, void*);
+hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*);
+hipError_t bsxk_ed25519_btable(hipStream_t, uint8_t*);
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t);
 hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
@@ -116,10 +117,12 @@ int bsx_init(int device, bsx_ctx** out) {
     // constants of the hint's zero-padded proofs (kernels_sha.hip k_zero_paths)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->zero_paths), 320);
     if (e == hipSuccess) e = bsxk_zero_paths(c->stream, c->zero_paths);
+    // the fixed-key Ed25519 table of the base point B (512 KB; kernels_ed.hip), shared by every keyed verification
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->btab), bsxk_keytable_bytes(1));
+    if (e == hipSuccess) e = bsxk_ed25519_btable(c->stream, c->btab);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
-        (void)hipStreamDestroy(c->stream);
-        delete c;
+        bsx_shutdown(c);                  // releases whatever was created
         return fail(BSX_ERR_HIP, "bsx_init: %s", hipGetErrorString(e));
     }
     *out = c;
@@ -136,6 +139,7 @@ void bsx_shutdown(bsx_ctx* ctx) {
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->zero_paths) (void)hipFree(ctx->zero_paths);
     if (ctx->keytab) (void)hipFree(ctx->keytab);
+    if (ctx->btab) (void)hipFree(ctx->btab);
     for (auto& b : ctx->vmm) { (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size); }
     delete ctx;
 }
@@ -335,7 +339,7 @@ int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator
     if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
     if ((uintptr_t)d_scratch & 15) return fail(BSX_ERR_BAD_ARG, "scratch must be 16-byte aligned");
-    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, d_ok, d_scratch));
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch));
     return BSX_OK;
 }
 
@@ -796,7 +800,7 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
         HIPCHK(bsxk_ed25519_keytable(st, dv.as<bsx_validator>(), v_max, tab));
         DBuf dscr;                                  // batch inversion pays from a few thousand signatures on (one more launch)
         if (n >= 4096) RET(dscr.alloc(bsxk_ed25519_scratch_bytes(n)));
-        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, tab, v_max, dok.as<uint8_t>(), dscr.p));
+        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), dscr.p));
     }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     D2H(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result));
@@ -861,7 +865,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         uint8_t* tab = nullptr;
         RET(ctx_keytable(ctx, v_max, &tab, sb));
         HIPCHK(bsxk_ed25519_keytable(sb, dv.as<bsx_validator>(), v_max, tab));
-        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, dok.as<uint8_t>(), nullptr));
+        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), nullptr));
     }
     HIPCHK(bsxk_commit_tally(sb, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) from `st`

@@ -35,6 +35,7 @@ struct bsx_ctx {
     uint8_t* zero_paths = nullptr;       // 320 B: path digests of the hint's zero-padded proofs (k_zero_paths)
     uint8_t* keytab = nullptr;           // host tier's persistent fixed-key Ed25519 table (rows survive between calls)
     uint32_t keytab_rows = 0;
+    uint8_t* btab = nullptr;             // fixed-key Ed25519 table of the base point B (built by bsx_init)
     uint32_t merkle_wgs = 0;             // BSX_TUNE_MERKLE_WORKGROUPS
 };
 

@@ -161,19 +161,21 @@ BSX_HDI bool ed25519_verify_core(const uint32_t pk[8], const uint32_t sig_r[8], 
 }
 
 // ------------------------------------------------------------------------------------------------ fixed-key path
-// A validator set signs every commit of a range batch with the same keys, so the per-key work (decompression and
-// the multiples table) is hoisted out of the per-signature lane: per key we keep j*(-2^(32k) A), k = 0..7, j = 1..128
-// (cached form, 40 int32 each), and the 253-bit scalars h and s are split into KT_PARTS parts and recoded into signed
-// radix-256 digits.  With eight 32-bit parts one signature costs 32 doublings + 64 additions instead of 256 + 128 and no
-// decompression (two parts of 128 bits, the first version: 128 + 64; four parts of 64 bits: 64 + 64).
-#include "ed25519_btab8.h"   // ge_b8_limb: j * 2^(32k) * B, k = 0..7, j = 1..128 (generated)
-
-constexpr int KT_ENTRY_I32 = 40;          // one cached point
+// A validator set signs every commit of a range batch with the same keys, and B is everybody's key, so ALL the per-key
+// work is hoisted out of the per-signature lane: per point P (a validator's -A, or B) a table holds j * 2^(8k) P for
+// k = 0..31, j = 1..128 in AFFINE form (y + x, y - x, 2 d x y; 32 int32 = one 128-byte cache line per entry, 30 used).
+// The 253-bit scalars h and s are recoded into 32 signed radix-256 digits, and
+//     [s]B + [h](-A) = sum_k  T_B[k][s_k] + T_A[k][h_k]
+// is 64 mixed additions (7 multiplications each) and NO doubling, NO decompression.  History: 2 parts of 128 bits with
+// cached (projective) entries = 128 doublings + 64 additions; 8 parts of 32 bits = 32 + 64 (round 2, 576 mul + 128 sq);
+// this form = 0 + 64 (447 mul).  A table is 32 x 128 x 128 B = 512 KB per key, built once per key and kept while the key
+// stays (kernels_ed.hip); the B table is built by the same code from the encoding of -B when a context is created.
+constexpr int KT_ENTRY_I32 = 32;          // one affine entry, padded to a cache line
 constexpr int KT_HALF_ENTRIES = 128;      // j = 1..128 per part
-constexpr int KT_PARTS = GE_B8_PARTS;     // scalar parts of 256 / KT_PARTS bits (8 parts of 32 bits = 4 radix-256 digits each)
-static_assert(GE_B8_PARTS * GE_B8_PART_BITS == 256, "the generated B table must cover 256 scalar bits");
-constexpr int KT_PART_DIGITS = 32 / KT_PARTS;
+constexpr int KT_PARTS = 32;              // one signed radix-256 digit per part
 constexpr int KT_KEY_I32 = KT_PARTS * KT_HALF_ENTRIES * KT_ENTRY_I32;
+// encoding of -B (B = (x, 4/5) with x even: the encoding of B is 0x58, 0x66 x 31; -B sets the sign bit of x)
+constexpr uint32_t GE_NEG_B_ENC[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0xe6666666u};
 
 // r = x + 0x8080...80 (x < 2^253, so no carry out); digit_i = byte_i(r) - 128 in [-128, 127]
 BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
@@ -187,24 +189,20 @@ BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
 }
 BSX_HDI int sc_digit8(const uint32_t r[8], int i) { return (int)((pick8(r, i >> 2) >> (8 * (i & 3))) & 255) - 128; }
 
-// per key: base[0] = -A (false when the key does not decode, RFC 8032 strict), base[k] = 2^(part bits) * base[k-1]
+// base[k + 1] = 2^8 * base[k]
 BSX_HDI ge_p3 ge_keytable_next_base(const ge_p3& prev) {
     ge_p2 q{prev.X, prev.Y, prev.Z};
     ge_p1p1 t = ge_dbl_inl(q.X, q.Y, q.Z);
 #pragma unroll 1
-    for (int i = 1; i < 8 * KT_PART_DIGITS; i++) {
+    for (int i = 1; i < 8; i++) {
         q = p1p1_to_p2_inl(t);
         t = ge_dbl_inl(q.X, q.Y, q.Z);
     }
     return p1p1_to_p3_inl(t);
 }
-BSX_HDI bool ge_keytable_bases(const uint32_t pk[8], ge_p3 (&base)[KT_PARTS]) {      // host check / small uses
-    const bool ok = ge_frombytes_negate(base[0], pk);
-    for (int k = 1; k < KT_PARTS; k++) base[k] = ge_keytable_next_base(base[k - 1]);
-    return ok;
-}
-// j * base, j in 1..128, by an 8-step double-and-add that is uniform across lanes (the addition is selected, not branched)
-BSX_HDI ge_cached ge_keytable_entry(const ge_p3& base, int j) {
+// j * base, j in 1..128, by an 8-step double-and-add that is uniform across lanes (the addition is selected, not
+// branched), then to affine form (one inversion per entry: the build runs once per key)
+BSX_HDI ge_precomp ge_keytable_entry(const ge_p3& base, int j) {
     const ge_cached cb = p3_to_cached(base);
     ge_p3 acc{fe_zero(), fe_one(), fe_one(), fe_zero()};
     for (int bit = 7; bit >= 0; bit--) {
@@ -216,83 +214,61 @@ BSX_HDI ge_cached ge_keytable_entry(const ge_p3& base, int j) {
         acc.Z = fe_select(take, sum.Z, acc.Z);
         acc.T = fe_select(take, sum.T, acc.T);
     }
-    return p3_to_cached(acc);
+    const fe zi = fe_invert(acc.Z);
+    const fe x = fe_mul(acc.X, zi), y = fe_mul(acc.Y, zi);
+    return ge_precomp{fe_add(y, x), fe_sub(y, x), fe_mul(fe_mul(x, y), fe_d2())};
 }
-BSX_HDI void cached_store(int32_t* dst, const ge_cached& c) {
+BSX_HDI void precomp_store(int32_t* dst, const ge_precomp& e) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        dst[i] = c.YplusX.v[i];
-        dst[10 + i] = c.YminusX.v[i];
-        dst[20 + i] = c.Z.v[i];
-        dst[30 + i] = c.T2d.v[i];
+        dst[i] = e.yplusx.v[i];
+        dst[10 + i] = e.yminusx.v[i];
+        dst[20 + i] = e.xy2d.v[i];
     }
+    dst[30] = 0;
+    dst[31] = 0;
 }
-BSX_HDI ge_cached cached_load(const int32_t* src_) {
+BSX_HDI ge_precomp precomp_load(const int32_t* src_) {
     const int32_t* src = static_cast<const int32_t*>(__builtin_assume_aligned(src_, 16));
-    ge_cached c;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        c.YplusX.v[i] = src[i];
-        c.YminusX.v[i] = src[10 + i];
-        c.Z.v[i] = src[20 + i];
-        c.T2d.v[i] = src[30 + i];
-    }
-    return c;
-}
-BSX_HDI ge_precomp ge_b8_entry(int half, int k) {  // (k+1) * 2^(32*part) * B
     ge_precomp e;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        e.yplusx.v[i] = ge_b8_limb(half, k, i);
-        e.yminusx.v[i] = ge_b8_limb(half, k, 10 + i);
-        e.xy2d.v[i] = ge_b8_limb(half, k, 20 + i);
+        e.yplusx.v[i] = src[i];
+        e.yminusx.v[i] = src[10 + i];
+        e.xy2d.v[i] = src[20 + i];
     }
     return e;
 }
-BSX_HDI ge_cached keytable_pick(const int32_t* half_tab, int d) {
+// entry |d| of one part's 128 entries, negated for d < 0, the identity for d == 0
+BSX_HDI ge_precomp keytable_pick(const int32_t* part_tab, int d) {
     const int a = d < 0 ? -d : d;
-    ge_cached c = cached_load(half_tab + (a ? a - 1 : 0) * KT_ENTRY_I32);
-    c = cached_cneg(c, d < 0);
-    if (a == 0) c = cached_identity();
-    return c;
-}
-BSX_HDI ge_precomp b8_pick(int half, int d) {
-    const int a = d < 0 ? -d : d;
-    ge_precomp e = ge_b8_entry(half, a ? a - 1 : 0);
+    ge_precomp e = precomp_load(part_tab + (a ? a - 1 : 0) * KT_ENTRY_I32);
     e = precomp_cneg(e, d < 0);
     if (a == 0) e = precomp_identity();
     return e;
 }
 
-// Same accept set as ed25519_verify_core for a key whose table was built by ge_keytable_bases/entry
-// (key_tab: KT_KEY_I32 int32: [part][j-1][40]); the caller has already established that the key decodes.
-// DEFER: stop before the encoding (which costs a field inversion: 254 squarings + 11 multiplications, 27 % of a
+// Same accept set as ed25519_verify_core for a key whose table (key_tab: KT_KEY_I32 int32, [part][j-1][32]) was built from
+// -A; b_tab: the same for B.  The caller has already established that the key decodes.
+// DEFER: stop before the encoding (which costs a field inversion: 254 squarings + 11 multiplications, a third of a
 // verification) and hand back the projective result; k_ed25519_finish then inverts the Z of several signatures per lane
 // with ONE inversion (Montgomery's trick: 3 multiplications per extra element).
 template <bool DEFER>
-BSX_HDI bool ed25519_verify_keyed_core_t(const int32_t* key_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
+BSX_HDI bool ed25519_verify_keyed_core_t(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
                                          const uint32_t h[8], ge_p2* out_q) {
     const bool ok = sc_is_canonical(sig_s);
     uint32_t hr[8], sr[8];
     sc_recode8(h, hr);
     sc_recode8(sig_s, sr);
-    ge_p2 q{fe_zero(), fe_one(), fe_one()};
-    for (int i = KT_PART_DIGITS - 1; i >= 0; i--) {
-        ge_p1p1 t = ge_dbl(q.X, q.Y, q.Z);
-        for (int d = 0; d < 7; d++) {
-            q = p1p1_to_p2(t);
-            t = ge_dbl(q.X, q.Y, q.Z);
-        }
-        ge_p3 p = p1p1_to_p3(t);
-        // not unrolled on the device: four table entries (160 registers) prefetched at once would spill
+    ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
+    // not unrolled on the device: entries prefetched several at a time would spill
 #pragma unroll 1
-        for (int k = 0; k < KT_PARTS; k++)
-            p = p1p1_to_p3(ge_add(p, keytable_pick(key_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(hr, KT_PART_DIGITS * k + i))));
+    for (int k = 0; k < KT_PARTS; k++)
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(hr, k))));
 #pragma unroll 1
-        for (int k = 0; k < KT_PARTS - 1; k++)
-            p = p1p1_to_p3(ge_madd(p, b8_pick(k, sc_digit8(sr, KT_PART_DIGITS * k + i))));
-        q = p1p1_to_p2(ge_madd(p, b8_pick(KT_PARTS - 1, sc_digit8(sr, KT_PART_DIGITS * (KT_PARTS - 1) + i))));
-    }
+    for (int k = 0; k < KT_PARTS - 1; k++)
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(sr, k))));
+    const ge_p2 q = p1p1_to_p2(ge_madd(p, keytable_pick(b_tab + (KT_PARTS - 1) * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(sr, KT_PARTS - 1))));
     if (DEFER) {
         *out_q = q;
         return ok;
@@ -304,9 +280,9 @@ BSX_HDI bool ed25519_verify_keyed_core_t(const int32_t* key_tab, const uint32_t 
     for (int k = 0; k < 8; k++) diff |= enc[k] ^ sig_r[k];
     return ok && diff == 0;
 }
-BSX_HDI bool ed25519_verify_keyed_core(const int32_t* key_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
+BSX_HDI bool ed25519_verify_keyed_core(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
                                        const uint32_t h[8]) {
-    return ed25519_verify_keyed_core_t<false>(key_tab, sig_r, sig_s, h, nullptr);
+    return ed25519_verify_keyed_core_t<false>(key_tab, b_tab, sig_r, sig_s, h, nullptr);
 }
 
 }  // namespace bsx

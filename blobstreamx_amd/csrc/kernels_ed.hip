@@ -6,10 +6,11 @@
 //   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, records staged via LDS
 //   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
 //   k_keytable_check / k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed / k_ed25519_finish
-//                       P7, fixed-key form: per-validator tables of j*(-2^(32k) A) (k = 0..7, j = 1..128), rows kept across
-//                           calls and rebuilt only when their key changes; signatures checked with 8-bit windows over scalars
-//                           split in eight 32-bit parts; optionally the point encodings go through a per-lane batch inversion
-//                           (k_ed25519_finish); slots whose key is not the table row's key are deferred to
+//                       P7, fixed-key form: per-validator tables of j*(-2^(8k) A) (k = 0..31, j = 1..128, affine), rows kept
+//                           across calls and rebuilt only when their key changes, and the same table of B (k_btable_bases,
+//                           per context); a signature is 64 mixed additions of table entries picked by the signed
+//                           radix-256 digits of h and s; optionally the point encodings go through a per-lane batch
+//                           inversion (k_ed25519_finish); slots whose key is not the table row's key are deferred to
 //                           k_ed25519_verify<true> (same accept set)
 //   k_skip_eval         operator skip-target search (fetcher.rs:60-87): is_valid_skip of every candidate in one launch
 //   k_commit_tally     P8+P9 validator-set hash (masked Merkle tree), voting-power sums, message checks;
@@ -98,11 +99,12 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validat
 
 // ------------------------------------------------------------------------------------------------ fixed-key tables
 // Key table in HBM (bsx_ed25519_keytable_bytes): [n_keys x 64 B key records: pubkey, decodes flag]
-//                                                [n_keys x KT_PARTS x 40 i32 base points -2^(32k) A (X, Y, Z, T)]
-//                                                [n_keys x KT_PARTS x 128 x 40 i32 cached multiples]
+//                                                [n_keys x KT_PARTS x 40 i32 base points -2^(8k) A (X, Y, Z, T)]
+//                                                [n_keys x KT_PARTS x 128 x 32 i32 affine multiples, one cache line each]
 constexpr uint64_t KT_REC_BYTES = 64, KT_BASE_I32 = 40 * KT_PARTS;
 __host__ __device__ inline uint64_t kt_bases_off(uint64_t n_keys) { return n_keys * KT_REC_BYTES; }
-__host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys) { return n_keys * (KT_REC_BYTES + KT_BASE_I32 * 4); }
+// entries start on a cache line (the table itself must: hipMalloc / torch / arena allocations are 256-byte aligned)
+__host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys) { return (n_keys * (KT_REC_BYTES + KT_BASE_I32 * 4) + 127) & ~127ull; }
 __host__ __device__ inline uint64_t kt_bytes(uint64_t n_keys) { return kt_entries_off(n_keys) + n_keys * (uint64_t)KT_KEY_I32 * 4; }
 
 __device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) {
@@ -130,14 +132,8 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_check(const bsx_validat
     reinterpret_cast<uint32_t*>(rec + 3)[2] = (force || !same) ? 1u : 0u;
 }
 
-// one lane per key: decode, negate, and run the 7 x 32 doublings that give the base points of the upper scalar parts
-__global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validator* __restrict__ vals, uint32_t n_keys,
-                                                               uint8_t* __restrict__ table) {
-    const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
-    if (k >= n_keys) return;
-    if (reinterpret_cast<const uint32_t*>(table + k * KT_REC_BYTES)[14] == 0) return;      // clean row (k_keytable_check)
-    uint32_t pk[8];
-    load_pk(vals + k, pk);
+// decode, negate, and run the 31 x 8 doublings that give the base points of the upper scalar parts; row k of `table`
+__device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint32_t k, uint32_t n_keys, uint8_t* __restrict__ table) {
     ge_p3 b;
     const bool ok = ge_frombytes_negate(b, pk);
     uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
@@ -158,8 +154,26 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validat
         }
     }
 }
+// one lane per key
+__global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validator* __restrict__ vals, uint32_t n_keys,
+                                                               uint8_t* __restrict__ table) {
+    const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
+    if (k >= n_keys) return;
+    if (reinterpret_cast<const uint32_t*>(table + k * KT_REC_BYTES)[14] == 0) return;      // clean row (k_keytable_check)
+    uint32_t pk[8];
+    load_pk(vals + k, pk);
+    keytable_build_bases(pk, k, n_keys, table);
+}
+// the context's table of B: a one-row key table built from the encoding of -B ("-A" = B)
+__global__ void k_btable_bases(uint8_t* __restrict__ table) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t pk[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) pk[i] = GE_NEG_B_ENC[i];
+    keytable_build_bases(pk, 0, 1, table);
+}
 
-// one lane per (key, half, j): j * base in cached form
+// one lane per (key, part, j): j * base in affine form
 __global__ __launch_bounds__(ED_THREADS) void k_keytable_entries(uint32_t n_keys, uint8_t* __restrict__ table) {
     const uint32_t idx = blockIdx.x * ED_THREADS + threadIdx.x;
     if (idx >= n_keys * (uint32_t)KT_PARTS * KT_HALF_ENTRIES) return;
@@ -174,8 +188,8 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_entries(uint32_t n_keys
         base.Z.v[i] = src[20 + i];
         base.T.v[i] = src[30 + i];
     }
-    const ge_cached e = ge_keytable_entry(base, (int)j);
-    cached_store(reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)idx * KT_ENTRY_I32, e);
+    const ge_precomp e = ge_keytable_entry(base, (int)j);
+    precomp_store(reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)idx * KT_ENTRY_I32, e);
 }
 
 // one lane per validator slot; slot (me % v_max) uses key table row (me % v_max) when the record's public key is the
@@ -185,13 +199,31 @@ constexpr uint32_t ED_SLOT_I32 = 40;
 // signatures per lane of k_ed25519_finish (one inversion amortised over K): 8 keeps enough lanes busy at a few 100 k
 // signatures (160 vs 158 M verifies/s at 204,800), 16 amortises better at a million (233 vs 221 M/s)
 __host__ __device__ inline uint32_t ed_fin_k(uint64_t n) { return n >= 400000 ? 16u : 8u; }
-template <bool DEFER>
+// Lane order.  Signature me = commit * v_max + slot.  With many commits the lanes of a wave take 64 COMMITS of ONE slot
+// (BY_KEY): all of them walk the same key's table, part by part, so a wave's 64 lookups of a step fall into one 16 KB part
+// (lines shared between lanes, L2-resident) instead of 64 different 512 KB tables; the workgroups of a key are
+// consecutive, and the block index is remapped so that each XCD (workgroups are dealt to the 8 XCDs round-robin) owns
+// a contiguous run of keys.  With few commits (a single proof: 1 x 100 signatures) lanes take consecutive signatures.
+template <bool DEFER, bool BY_KEY>
 __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
                                                                      const uint8_t* __restrict__ hs, uint64_t n,
                                                                      uint32_t v_max, const uint8_t* __restrict__ table,
-                                                                     uint32_t n_keys, uint8_t* __restrict__ ok_out,
+                                                                     uint32_t n_keys, const int32_t* __restrict__ b_tab,
+                                                                     uint8_t* __restrict__ ok_out,
                                                                      int32_t* __restrict__ scratch) {
-    const uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
+    uint64_t me;
+    if (BY_KEY) {
+        const uint32_t per_xcd = gridDim.x >> 3;                               // the launcher pads the grid to a multiple of 8
+        const uint32_t blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // logical block: XCD x owns [x, x + 1) * per_xcd
+        const uint64_t n_commits = (n + v_max - 1) / v_max;
+        const uint32_t wpk = (uint32_t)((n_commits + ED_THREADS - 1) / ED_THREADS);   // workgroups per key
+        const uint32_t slot_ = blk / wpk;
+        const uint64_t commit = (uint64_t)(blk % wpk) * ED_THREADS + threadIdx.x;
+        if (slot_ >= v_max || commit >= n_commits) return;
+        me = commit * v_max + slot_;
+    } else {
+        me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
+    }
     if (me >= n) return;
     const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
     const uint4 flags = rec[14];
@@ -224,14 +256,14 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
         const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
         if (DEFER) {
             ge_p2 q;
-            const bool pre = decodes && ed25519_verify_keyed_core_t<true>(kt, sr, ss, h, &q);
+            const bool pre = decodes && ed25519_verify_keyed_core_t<true>(kt, b_tab, sr, ss, h, &q);
             int32_t* d = scratch + me * ED_SLOT_I32;
 #pragma unroll
             for (int i = 0; i < 10; i++) { d[i] = q.X.v[i]; d[10 + i] = q.Y.v[i]; d[20 + i] = q.Z.v[i]; }
             ok_out[me] = pre ? ED_PENDING : 0;          // k_ed25519_finish turns ED_PENDING into the verdict
             return;
         }
-        ok = decodes && ed25519_verify_keyed_core(kt, sr, ss, h);
+        ok = decodes && ed25519_verify_keyed_core(kt, b_tab, sr, ss, h);
     }
     ok_out[me] = ok ? 1 : 0;
 }
@@ -650,19 +682,37 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
     hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, n_keys, table);
     return hipGetLastError();
 }
+// the B table of a context (kt_bytes(1) bytes, 128-byte aligned): built once, on `s`
+hipError_t bsxk_ed25519_btable(hipStream_t s, uint8_t* table) {
+    hipLaunchKernelGGL(k_btable_bases, dim3(1), dim3(64), 0, s, table);
+    const uint32_t n_entries = (uint32_t)KT_PARTS * KT_HALF_ENTRIES;
+    hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, 1u, table);
+    return hipGetLastError();
+}
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t n) { return n * ED_SLOT_I32 * 4; }
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
-                                     const uint8_t* table, uint32_t n_keys, uint8_t* ok, void* scratch) {
+                                     const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch) {
     if (n == 0) return hipSuccess;
-    const dim3 grid((uint32_t)((n + ED_THREADS - 1) / ED_THREADS));
-    if (scratch) {
-        hipLaunchKernelGGL(k_ed25519_verify_keyed<true>, grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, ok, static_cast<int32_t*>(scratch));
+    const int32_t* b_tab = reinterpret_cast<const int32_t*>(btable + kt_entries_off(1));
+    int32_t* scr = static_cast<int32_t*>(scratch);
+    const uint64_t n_commits = (n + v_max - 1) / v_max;
+    // BSX_ED_BY_KEY (experiments): 0 / 1 forces the lane order; default: by key from 32 commits on (waves at least half full)
+    static const long env_by_key = getenv("BSX_ED_BY_KEY") ? atol(getenv("BSX_ED_BY_KEY")) : -1;
+    const bool by_key = env_by_key >= 0 ? env_by_key != 0 : n_commits >= 32;
+    if (by_key) {
+        const uint64_t wpk = (n_commits + ED_THREADS - 1) / ED_THREADS;
+        const dim3 grid((uint32_t)((wpk * v_max + 7) / 8 * 8));                 // k_ed25519_verify_keyed: XCD remap needs a multiple of 8
+        if (scr) hipLaunchKernelGGL((k_ed25519_verify_keyed<true, true>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
+        else hipLaunchKernelGGL((k_ed25519_verify_keyed<false, true>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
+    } else {
+        const dim3 grid((uint32_t)((n + ED_THREADS - 1) / ED_THREADS));
+        if (scr) hipLaunchKernelGGL((k_ed25519_verify_keyed<true, false>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
+        else hipLaunchKernelGGL((k_ed25519_verify_keyed<false, false>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
+    }
+    if (scr) {
         const uint32_t K = ed_fin_k(n);
         const uint64_t lanes = (n + K - 1) / K;
-        hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok,
-                           static_cast<int32_t*>(scratch), K);
-    } else {
-        hipLaunchKernelGGL(k_ed25519_verify_keyed<false>, grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, ok, nullptr);
+        hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
     }
     hipLaunchKernelGGL(k_ed25519_verify<true>, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
     return hipGetLastError();
