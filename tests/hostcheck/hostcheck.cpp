@@ -89,17 +89,33 @@ void hc_fe_invert(const uint8_t* a, uint8_t out[32]) {
     fe_tobytes(o, fe_invert(fe_frombytes(x)));
     memcpy(out, o, 32);
 }
-// fixed-key path: build the per-key table on the host exactly as the precompute kernels do, then verify
+// fixed-key path: build the per-key table (and, once, the table of B from the encoding of -B) on the host exactly as
+// the precompute kernels do, then verify
+static bool hc_build_table(const uint32_t pk[8], int32_t* tab) {
+    ge_p3 base;
+    const bool ok = ge_frombytes_negate(base, pk);
+    for (int part = 0; part < KT_PARTS; part++) {
+        if (part) base = ge_keytable_next_base(base);
+        for (int j = 1; j <= KT_HALF_ENTRIES; j++)
+            precomp_store(tab + (part * KT_HALF_ENTRIES + (j - 1)) * KT_ENTRY_I32, ge_keytable_entry(base, j));
+    }
+    return ok;
+}
 int hc_ed25519_verify_keyed(const uint8_t* pk, const uint8_t* sig, const uint8_t* h) {
     uint32_t p[8], r[8], s[8], hh[8];
     load_le(p, pk, 32, 8); load_le(r, sig, 32, 8); load_le(s, sig + 32, 32, 8); load_le(hh, h, 32, 8);
-    ge_p3 base[KT_PARTS];
-    if (!ge_keytable_bases(p, base)) return 0;
-    static thread_local int32_t tab[KT_KEY_I32];
-    for (int half = 0; half < KT_PARTS; half++)
-        for (int j = 1; j <= KT_HALF_ENTRIES; j++)
-            cached_store(tab + (half * KT_HALF_ENTRIES + (j - 1)) * KT_ENTRY_I32, ge_keytable_entry(base[half], j));
-    return ed25519_verify_keyed_core(tab, r, s, hh) ? 1 : 0;
+    alignas(16) static int32_t btab[KT_KEY_I32];
+    static const bool b_ok = hc_build_table(GE_NEG_B_ENC, btab);
+    // the table of the most recent key is kept (tables persist across calls on the device too; the tests mostly repeat a key)
+    alignas(16) static thread_local int32_t tab[KT_KEY_I32];
+    static thread_local uint32_t tab_pk[8];
+    static thread_local int tab_state = -1;                   // -1 none, 0 key does not decode, 1 built
+    if (tab_state < 0 || memcmp(tab_pk, p, 32) != 0) {
+        tab_state = hc_build_table(p, tab) ? 1 : 0;
+        memcpy(tab_pk, p, 32);
+    }
+    if (!b_ok || tab_state != 1) return 0;
+    return ed25519_verify_keyed_core(tab, btab, r, s, hh) ? 1 : 0;
 }
 
 // ---- Goldilocks / Poseidon (goldilocks.h, poseidon.h): the device source on the host
