@@ -34,6 +34,7 @@ uint64_t bsxk_keytable_bytes(uint32_t);
 hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*);
 hipError_t bsxk_ed25519_btable(hipStream_t, uint8_t*);
+uint64_t bsxk_ed25519_btable_bytes();
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t);
 hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
@@ -118,7 +119,7 @@ int bsx_init(int device, bsx_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->zero_paths), 320);
     if (e == hipSuccess) e = bsxk_zero_paths(c->stream, c->zero_paths);
     // the fixed-key Ed25519 table of the base point B (512 KB; kernels_ed.hip), shared by every keyed verification
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->btab), bsxk_keytable_bytes(1));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->btab), bsxk_ed25519_btable_bytes());
     if (e == hipSuccess) e = bsxk_ed25519_btable(c->stream, c->btab);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {

@@ -164,12 +164,13 @@ BSX_HDI bool ed25519_verify_core(const uint32_t pk[8], const uint32_t sig_r[8], 
 // A validator set signs every commit of a range batch with the same keys, and B is everybody's key, so ALL the per-key
 // work is hoisted out of the per-signature lane: per point P (a validator's -A, or B) a table holds j * 2^(8k) P for
 // k = 0..31, j = 1..128 in AFFINE form (y + x, y - x, 2 d x y; 32 int32 = one 128-byte cache line per entry, 30 used).
-// The 253-bit scalars h and s are recoded into 32 signed radix-256 digits, and
-//     [s]B + [h](-A) = sum_k  T_B[k][s_k] + T_A[k][h_k]
-// is 64 mixed additions (7 multiplications each) and NO doubling, NO decompression.  History: 2 parts of 128 bits with
-// cached (projective) entries = 128 doublings + 64 additions; 8 parts of 32 bits = 32 + 64 (round 2, 576 mul + 128 sq);
-// this form = 0 + 64 (447 mul).  A table is 32 x 128 x 128 B = 512 KB per key, built once per key and kept while the key
-// stays (kernels_ed.hip); the B table is built by the same code from the encoding of -B when a context is created.
+// The 253-bit scalar h is recoded into 32 signed radix-256 digits (s: into 16 signed radix-65536 digits, below), and
+//     [s]B + [h](-A) = sum_k T_A[k][h_k] + sum_k T_B[k][s_k]
+// is 32 + 16 mixed additions (7 multiplications each) and NO doubling, NO decompression.  History: 2 parts of 128 bits
+// with cached (projective) entries = 128 doublings + 64 additions; 8 parts of 32 bits = 32 + 64 (round 2, 576 mul + 128
+// sq); one-digit parts = 0 + 64 (447 mul); wide digits for B = 0 + 48 (335 mul).  A key's table is 32 x 128 x 128 B =
+// 512 KB, built once per key and kept while the key stays (kernels_ed.hip); the B table (16 x 32768 x 128 B = 64 MB) is
+// built by the same code from the encoding of -B when a context is created.
 constexpr int KT_ENTRY_I32 = 32;          // one affine entry, padded to a cache line
 constexpr int KT_HALF_ENTRIES = 128;      // j = 1..128 per part
 constexpr int KT_PARTS = 32;              // one signed radix-256 digit per part
@@ -189,23 +190,63 @@ BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
 }
 BSX_HDI int sc_digit8(const uint32_t r[8], int i) { return (int)((pick8(r, i >> 2) >> (8 * (i & 3))) & 255) - 128; }
 
-// base[k + 1] = 2^8 * base[k]
-BSX_HDI ge_p3 ge_keytable_next_base(const ge_p3& prev) {
+// The table of B is shared by every signature of every key, so it can afford wider digits than the per-key tables:
+// BT_W-bit signed digits = BT_PARTS additions for [s]B instead of 32, from BT_PARTS x 2^(BT_W-1) entries.  Measured
+// (1,048,576 signatures, M verifies/s): W = 8: 335, 10: 354, 11: 365, 12: 376, 13: 383, 16: 412 — the 64 MB table of
+// W = 16 lives in the 256 MB Infinity Cache and its loads do not depend on the point arithmetic.
+#ifndef BSX_BT_W
+#define BSX_BT_W 16
+#endif
+constexpr int BT_W = BSX_BT_W;
+constexpr int BT_PARTS = (253 + BT_W) / BT_W;             // digits cover >= 254 bits: s + the recoding constant < 2^254
+constexpr int BT_HALF_ENTRIES = 1 << (BT_W - 1);          // j = 1..2^(W-1) per part
+constexpr int BT_I32 = BT_PARTS * BT_HALF_ENTRIES * KT_ENTRY_I32;
+static_assert(BT_W >= 8 && BT_W <= 16 && BT_W * BT_PARTS >= 254 && BT_W * BT_PARTS <= 288, "B-table digit width");
+// r = s + sum_i 2^(W-1) 2^(W i) (9 dwords); digit_i = ((r >> W i) mod 2^W) - 2^(W-1) in [-2^(W-1), 2^(W-1))
+BSX_HDI void sc_recode_w(const uint32_t s[8], uint32_t r[9]) {
+    uint32_t cst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < BT_PARTS; i++) {
+        const int bit = BT_W * i + BT_W - 1;
+        cst[bit >> 5] |= 1u << (bit & 31);
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        c += (uint64_t)(i < 8 ? s[i] : 0u) + cst[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+BSX_HDI uint32_t pick9(const uint32_t r[9], int w) {
+    uint32_t v = r[0];
+#pragma unroll
+    for (int k = 1; k < 9; k++) v = (w == k) ? r[k] : v;
+    return v;
+}
+BSX_HDI int sc_digit_w(const uint32_t r[9], int i) {
+    const int bit = BT_W * i, wd = bit >> 5, sh = bit & 31;
+    const uint64_t two = ((uint64_t)pick9(r, wd + 1 < 9 ? wd + 1 : 8) << 32) | pick9(r, wd);
+    return (int)((uint32_t)(two >> sh) & ((1u << BT_W) - 1)) - (1 << (BT_W - 1));
+}
+
+// base[k + 1] = 2^bits * base[k]
+BSX_HDI ge_p3 ge_keytable_next_base(const ge_p3& prev, int bits = 8) {
     ge_p2 q{prev.X, prev.Y, prev.Z};
     ge_p1p1 t = ge_dbl_inl(q.X, q.Y, q.Z);
 #pragma unroll 1
-    for (int i = 1; i < 8; i++) {
+    for (int i = 1; i < bits; i++) {
         q = p1p1_to_p2_inl(t);
         t = ge_dbl_inl(q.X, q.Y, q.Z);
     }
     return p1p1_to_p3_inl(t);
 }
-// j * base, j in 1..128, by an 8-step double-and-add that is uniform across lanes (the addition is selected, not
-// branched), then to affine form (one inversion per entry: the build runs once per key)
-BSX_HDI ge_precomp ge_keytable_entry(const ge_p3& base, int j) {
+// j * base, j in 1..2^(bits-1), by a bits-step double-and-add that is uniform across lanes (the addition is selected,
+// not branched), then to affine form (one inversion per entry: the build runs once per key)
+BSX_HDI ge_precomp ge_keytable_entry(const ge_p3& base, int j, int bits = 8) {
     const ge_cached cb = p3_to_cached(base);
     ge_p3 acc{fe_zero(), fe_one(), fe_one(), fe_zero()};
-    for (int bit = 7; bit >= 0; bit--) {
+    for (int bit = bits - 1; bit >= 0; bit--) {
         acc = p1p1_to_p3(ge_dbl(acc.X, acc.Y, acc.Z));
         const ge_p3 sum = p1p1_to_p3(ge_add(acc, cb));
         const bool take = ((j >> bit) & 1) != 0;
@@ -249,7 +290,7 @@ BSX_HDI ge_precomp keytable_pick(const int32_t* part_tab, int d) {
 }
 
 // Same accept set as ed25519_verify_core for a key whose table (key_tab: KT_KEY_I32 int32, [part][j-1][32]) was built from
-// -A; b_tab: the same for B.  The caller has already established that the key decodes.
+// -A; b_tab: the table of B (BT_I32 int32, [part][j-1][32], BT_W-bit digits).  The caller has already established that the key decodes.
 // DEFER: stop before the encoding (which costs a field inversion: 254 squarings + 11 multiplications, a third of a
 // verification) and hand back the projective result; k_ed25519_finish then inverts the Z of several signatures per lane
 // with ONE inversion (Montgomery's trick: 3 multiplications per extra element).
@@ -257,18 +298,18 @@ template <bool DEFER>
 BSX_HDI bool ed25519_verify_keyed_core_t(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
                                          const uint32_t h[8], ge_p2* out_q) {
     const bool ok = sc_is_canonical(sig_s);
-    uint32_t hr[8], sr[8];
+    uint32_t hr[8], sr[9];
     sc_recode8(h, hr);
-    sc_recode8(sig_s, sr);
+    sc_recode_w(sig_s, sr);
     ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
     // not unrolled on the device: entries prefetched several at a time would spill
 #pragma unroll 1
     for (int k = 0; k < KT_PARTS; k++)
         p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(hr, k))));
 #pragma unroll 1
-    for (int k = 0; k < KT_PARTS - 1; k++)
-        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(sr, k))));
-    const ge_p2 q = p1p1_to_p2(ge_madd(p, keytable_pick(b_tab + (KT_PARTS - 1) * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(sr, KT_PARTS - 1))));
+    for (int k = 0; k < BT_PARTS - 1; k++)
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_w(sr, k))));
+    const ge_p2 q = p1p1_to_p2(ge_madd(p, keytable_pick(b_tab + (int64_t)(BT_PARTS - 1) * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_w(sr, BT_PARTS - 1))));
     if (DEFER) {
         *out_q = q;
         return ok;

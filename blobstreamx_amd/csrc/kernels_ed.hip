@@ -164,13 +164,46 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validat
     load_pk(vals + k, pk);
     keytable_build_bases(pk, k, n_keys, table);
 }
-// the context's table of B: a one-row key table built from the encoding of -B ("-A" = B)
+// The context's table of B (bt_bytes()): [BT_PARTS x 40 i32 base points 2^(W k) B][pad][BT_PARTS x 2^(W-1) x 32 i32 entries],
+// built by the key-table arithmetic from the encoding of -B ("-A" = B).
+__host__ __device__ inline uint64_t bt_entries_off() { return ((uint64_t)BT_PARTS * 160 + 127) & ~127ull; }
+__host__ __device__ inline uint64_t bt_bytes() { return bt_entries_off() + (uint64_t)BT_I32 * 4; }
 __global__ void k_btable_bases(uint8_t* __restrict__ table) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t pk[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) pk[i] = GE_NEG_B_ENC[i];
-    keytable_build_bases(pk, 0, 1, table);
+    ge_p3 b;
+    (void)ge_frombytes_negate(b, pk);
+    int32_t* dst = reinterpret_cast<int32_t*>(table);
+#pragma unroll 1
+    for (int part = 0; part < BT_PARTS; part++) {
+        if (part) b = ge_keytable_next_base(b, BT_W);
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            dst[part * 40 + i] = b.X.v[i];
+            dst[part * 40 + 10 + i] = b.Y.v[i];
+            dst[part * 40 + 20 + i] = b.Z.v[i];
+            dst[part * 40 + 30 + i] = b.T.v[i];
+        }
+    }
+}
+// one lane per (part, j)
+__global__ __launch_bounds__(ED_THREADS) void k_btable_entries(uint8_t* __restrict__ table) {
+    const uint32_t idx = blockIdx.x * ED_THREADS + threadIdx.x;
+    if (idx >= (uint32_t)BT_PARTS * BT_HALF_ENTRIES) return;
+    const uint32_t part = idx / BT_HALF_ENTRIES, j = idx % BT_HALF_ENTRIES + 1;
+    const int32_t* src = reinterpret_cast<const int32_t*>(table) + part * 40;
+    ge_p3 base;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        base.X.v[i] = src[i];
+        base.Y.v[i] = src[10 + i];
+        base.Z.v[i] = src[20 + i];
+        base.T.v[i] = src[30 + i];
+    }
+    const ge_precomp e = ge_keytable_entry(base, (int)j, BT_W);
+    precomp_store(reinterpret_cast<int32_t*>(table + bt_entries_off()) + (uint64_t)idx * KT_ENTRY_I32, e);
 }
 
 // one lane per (key, part, j): j * base in affine form
@@ -682,18 +715,19 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
     hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, n_keys, table);
     return hipGetLastError();
 }
-// the B table of a context (kt_bytes(1) bytes, 128-byte aligned): built once, on `s`
+// the B table of a context (bsxk_ed25519_btable_bytes() bytes, 128-byte aligned): built once, on `s`
+uint64_t bsxk_ed25519_btable_bytes() { return bt_bytes(); }
 hipError_t bsxk_ed25519_btable(hipStream_t s, uint8_t* table) {
     hipLaunchKernelGGL(k_btable_bases, dim3(1), dim3(64), 0, s, table);
-    const uint32_t n_entries = (uint32_t)KT_PARTS * KT_HALF_ENTRIES;
-    hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, 1u, table);
+    const uint32_t n_entries = (uint32_t)BT_PARTS * BT_HALF_ENTRIES;
+    hipLaunchKernelGGL(k_btable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, table);
     return hipGetLastError();
 }
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t n) { return n * ED_SLOT_I32 * 4; }
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
                                      const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch) {
     if (n == 0) return hipSuccess;
-    const int32_t* b_tab = reinterpret_cast<const int32_t*>(btable + kt_entries_off(1));
+    const int32_t* b_tab = reinterpret_cast<const int32_t*>(btable + bt_entries_off());
     int32_t* scr = static_cast<int32_t*>(scratch);
     const uint64_t n_commits = (n + v_max - 1) / v_max;
     // BSX_ED_BY_KEY (experiments): 0 / 1 forces the lane order; default: by key from 32 commits on (waves at least half full)

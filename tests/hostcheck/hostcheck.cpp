@@ -1,7 +1,9 @@
 // tests/hostcheck/hostcheck.cpp — TEST HARNESS: compiles the device arithmetic headers
 // (blobstreamx_amd/csrc/*.h, written __host__ __device__) with g++ so the exact kernel source can be
 // checked against the oracle and hashlib on a machine without a GPU.  Never loaded by the product.
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <cstdint>
 
 #include "../../blobstreamx_amd/csrc/sha256.h"
@@ -104,8 +106,38 @@ static bool hc_build_table(const uint32_t pk[8], int32_t* tab) {
 int hc_ed25519_verify_keyed(const uint8_t* pk, const uint8_t* sig, const uint8_t* h) {
     uint32_t p[8], r[8], s[8], hh[8];
     load_le(p, pk, 32, 8); load_le(r, sig, 32, 8); load_le(s, sig + 32, 32, 8); load_le(hh, h, 32, 8);
-    alignas(16) static int32_t btab[KT_KEY_I32];
-    static const bool b_ok = hc_build_table(GE_NEG_B_ENC, btab);
+    // The table of B (64 MB at 16-bit digits) is built here by repeated addition + one batch inversion per part — NOT the
+    // device's builder (double-and-add + an inversion per entry, 60 s on one host core): an independently built table under
+    // the device's verification code; the device-built table is checked by the GPU parity tests.
+    static int32_t* btab = nullptr;
+    static const bool b_ok = [] {
+        btab = static_cast<int32_t*>(aligned_alloc(128, (size_t)BT_I32 * 4));
+        ge_p3 base;
+        const bool ok = ge_frombytes_negate(base, GE_NEG_B_ENC);
+        std::vector<ge_p3> pts(BT_HALF_ENTRIES);
+        std::vector<fe> pre(BT_HALF_ENTRIES);
+        for (int part = 0; part < BT_PARTS; part++) {
+            if (part) base = ge_keytable_next_base(base, BT_W);
+            const ge_cached cb = p3_to_cached(base);
+            ge_p3 acc = base;
+            fe prod = fe_one();
+            for (int j = 0; j < BT_HALF_ENTRIES; j++) {          // pts[j] = (j + 1) * base
+                pts[j] = acc;
+                prod = fe_mul(prod, acc.Z);
+                pre[j] = prod;
+                acc = p1p1_to_p3(ge_add(acc, cb));
+            }
+            fe inv = fe_invert(prod);
+            for (int j = BT_HALF_ENTRIES - 1; j >= 0; j--) {
+                const fe zi = j ? fe_mul(inv, pre[j - 1]) : inv;
+                inv = fe_mul(inv, pts[j].Z);
+                const fe x = fe_mul(pts[j].X, zi), y = fe_mul(pts[j].Y, zi);
+                precomp_store(btab + ((size_t)part * BT_HALF_ENTRIES + j) * KT_ENTRY_I32,
+                              ge_precomp{fe_add(y, x), fe_sub(y, x), fe_mul(fe_mul(x, y), fe_d2())});
+            }
+        }
+        return ok;
+    }();
     // the table of the most recent key is kept (tables persist across calls on the device too; the tests mostly repeat a key)
     alignas(16) static thread_local int32_t tab[KT_KEY_I32];
     static thread_local uint32_t tab_pk[8];

@@ -174,7 +174,9 @@ def test_fixed_key_path_digit_edges(hc):
     a = int.from_bytes(d, "little")
     assert _enc(_mul(a, B)) == pk
     edges = [0, 1, 2**128 - 1, 2**128, 2**128 + 1, int("80" * 31, 16), int("7f" * 31, 16), int("ff" * 31, 16), L - 1,
-             2**252, 2**252 + 2**127, int("0080" * 15, 16), int("7f80" * 15, 16)]
+             2**252, 2**252 + 2**127, int("0080" * 15, 16), int("7f80" * 15, 16),
+             # radix-65536 digits of s (the B table): -32768, 32767, 0 and alternations
+             int("8000" * 15, 16), int("7fff" * 15, 16), int("ffff" * 15, 16), int("00008000" * 7, 16), int("7fff8000" * 7, 16)]
     pairs = [(h, s) for h in edges for s in (edges[3], edges[5], edges[8])] + [(edges[1], s) for s in edges]
     for h, s in pairs:
         h, s = h % L, s % L
