@@ -325,5 +325,23 @@ BSX_HDI bool ed25519_verify_keyed_core(const int32_t* key_tab, const int32_t* b_
                                        const uint32_t h[8]) {
     return ed25519_verify_keyed_core_t<false>(key_tab, b_tab, sig_r, sig_s, h, nullptr);
 }
+// One of SPLIT partial sums of [s]B + [h](-A): the table parts k = part0 (mod SPLIT).  Without doublings the sum splits
+// freely — SPLIT lanes per signature shorten the dependent chain from 48 to 48 / SPLIT additions (+ log2 SPLIT full
+// additions to join, kernels_ed.hip) at 20 % more total work: the form for small batches, where latency is all there is.
+template <int SPLIT>
+BSX_HDI ge_p3 ed25519_keyed_partial(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_s[8], const uint32_t h[8], int part0) {
+    static_assert(KT_PARTS % SPLIT == 0 && BT_PARTS % SPLIT == 0, "parts must split evenly");
+    uint32_t hr[8], sr[9];
+    sc_recode8(h, hr);
+    sc_recode_w(sig_s, sr);
+    ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
+#pragma unroll 1
+    for (int k = part0; k < KT_PARTS; k += SPLIT)
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(hr, k))));
+#pragma unroll 1
+    for (int k = part0; k < BT_PARTS; k += SPLIT)
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_w(sr, k))));
+    return p;
+}
 
 }  // namespace bsx

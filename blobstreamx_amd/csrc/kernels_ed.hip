@@ -232,32 +232,38 @@ constexpr uint32_t ED_SLOT_I32 = 40;
 // signatures per lane of k_ed25519_finish (one inversion amortised over K): 8 keeps enough lanes busy at a few 100 k
 // signatures (160 vs 158 M verifies/s at 204,800), 16 amortises better at a million (233 vs 221 M/s)
 __host__ __device__ inline uint32_t ed_fin_k(uint64_t n) { return n >= 400000 ? 16u : 8u; }
+// below this many signatures a verification is spread over 4 lanes (k_ed25519_verify_keyed SPLIT)
+constexpr uint64_t ED_SPLIT_BELOW = 300000;
 // Lane order.  Signature me = commit * v_max + slot.  With many commits the lanes of a wave take 64 COMMITS of ONE slot
 // (BY_KEY): all of them walk the same key's table, part by part, so a wave's 64 lookups of a step fall into one 16 KB part
 // (lines shared between lanes, L2-resident) instead of 64 different 512 KB tables; the workgroups of a key are
 // consecutive, and the block index is remapped so that each XCD (workgroups are dealt to the 8 XCDs round-robin) owns
 // a contiguous run of keys.  With few commits (a single proof: 1 x 100 signatures) lanes take consecutive signatures.
-template <bool DEFER, bool BY_KEY>
+// SPLIT lanes per signature (1 or 4): each sums its share of the 48 table entries, the shares are joined by a butterfly of
+// full additions through wave shuffles (ed25519.h ed25519_keyed_partial).  SPLIT = 4 is the small-batch form.
+template <bool DEFER, bool BY_KEY, int SPLIT>
 __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
                                                                      const uint8_t* __restrict__ hs, uint64_t n,
                                                                      uint32_t v_max, const uint8_t* __restrict__ table,
                                                                      uint32_t n_keys, const int32_t* __restrict__ b_tab,
                                                                      uint8_t* __restrict__ ok_out,
                                                                      int32_t* __restrict__ scratch) {
+    constexpr uint32_t SIGS = ED_THREADS / SPLIT;                              // signatures per workgroup
+    const uint32_t sub = threadIdx.x / SPLIT, part0 = threadIdx.x % SPLIT;
     uint64_t me;
     if (BY_KEY) {
         const uint32_t per_xcd = gridDim.x >> 3;                               // the launcher pads the grid to a multiple of 8
         const uint32_t blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // logical block: XCD x owns [x, x + 1) * per_xcd
         const uint64_t n_commits = (n + v_max - 1) / v_max;
-        const uint32_t wpk = (uint32_t)((n_commits + ED_THREADS - 1) / ED_THREADS);   // workgroups per key
+        const uint32_t wpk = (uint32_t)((n_commits + SIGS - 1) / SIGS);        // workgroups per key
         const uint32_t slot_ = blk / wpk;
-        const uint64_t commit = (uint64_t)(blk % wpk) * ED_THREADS + threadIdx.x;
+        const uint64_t commit = (uint64_t)(blk % wpk) * SIGS + sub;
         if (slot_ >= v_max || commit >= n_commits) return;
         me = commit * v_max + slot_;
     } else {
-        me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
+        me = (uint64_t)blockIdx.x * SIGS + sub;
     }
-    if (me >= n) return;
+    if (me >= n) return;                        // whole groups of SPLIT lanes leave together (every test below is per signature)
     const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
     const uint4 flags = rec[14];
     const bool active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
@@ -283,22 +289,54 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
             decodes = kr[2].x != 0;
         }
         if (!keyed) {
-            ok_out[me] = ED_DEFERRED;   // left to k_ed25519_verify<true>, launched right behind on the same stream
+            if (part0 == 0) ok_out[me] = ED_DEFERRED;   // left to k_ed25519_verify<true>, launched right behind on the same stream
             return;
         }
         const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
-        if (DEFER) {
-            ge_p2 q;
-            const bool pre = decodes && ed25519_verify_keyed_core_t<true>(kt, b_tab, sr, ss, h, &q);
-            int32_t* d = scratch + me * ED_SLOT_I32;
+        if (SPLIT == 1) {
+            if (DEFER) {
+                ge_p2 q;
+                const bool pre = decodes && ed25519_verify_keyed_core_t<true>(kt, b_tab, sr, ss, h, &q);
+                int32_t* d = scratch + me * ED_SLOT_I32;
 #pragma unroll
-            for (int i = 0; i < 10; i++) { d[i] = q.X.v[i]; d[10 + i] = q.Y.v[i]; d[20 + i] = q.Z.v[i]; }
-            ok_out[me] = pre ? ED_PENDING : 0;          // k_ed25519_finish turns ED_PENDING into the verdict
-            return;
+                for (int i = 0; i < 10; i++) { d[i] = q.X.v[i]; d[10 + i] = q.Y.v[i]; d[20 + i] = q.Z.v[i]; }
+                ok_out[me] = pre ? ED_PENDING : 0;          // k_ed25519_finish turns ED_PENDING into the verdict
+                return;
+            }
+            ok = decodes && ed25519_verify_keyed_core(kt, b_tab, sr, ss, h);
+        } else {
+            ge_p3 p = ed25519_keyed_partial<SPLIT>(kt, b_tab, ss, h, (int)part0);
+            // butterfly over the SPLIT lanes of the signature (adjacent lanes of one wave): afterwards every lane holds the sum
+#pragma unroll
+            for (int m = 1; m < SPLIT; m <<= 1) {
+                ge_p3 o;
+#pragma unroll
+                for (int i = 0; i < 10; i++) {
+                    o.X.v[i] = __shfl_xor(p.X.v[i], m, 64);
+                    o.Y.v[i] = __shfl_xor(p.Y.v[i], m, 64);
+                    o.Z.v[i] = __shfl_xor(p.Z.v[i], m, 64);
+                    o.T.v[i] = __shfl_xor(p.T.v[i], m, 64);
+                }
+                p = p1p1_to_p3(ge_add(p, p3_to_cached(o)));
+            }
+            if (part0 != 0) return;
+            const bool pre = decodes && sc_is_canonical(ss);
+            if (DEFER) {
+                int32_t* d = scratch + me * ED_SLOT_I32;
+#pragma unroll
+                for (int i = 0; i < 10; i++) { d[i] = p.X.v[i]; d[10 + i] = p.Y.v[i]; d[20 + i] = p.Z.v[i]; }
+                ok_out[me] = pre ? ED_PENDING : 0;
+                return;
+            }
+            uint32_t enc[8];
+            ge_tobytes(enc, p.X, p.Y, p.Z);
+            uint32_t diff = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) diff |= enc[k] ^ sr[k];
+            ok = pre && diff == 0;
         }
-        ok = decodes && ed25519_verify_keyed_core(kt, b_tab, sr, ss, h);
     }
-    ok_out[me] = ok ? 1 : 0;
+    if (part0 == 0) ok_out[me] = ok ? 1 : 0;
 }
 
 // Encoding + comparison of the deferred results: lane j owns signatures [j*K, (j+1)*K).  Montgomery's trick: prefix
@@ -732,17 +770,29 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     const uint64_t n_commits = (n + v_max - 1) / v_max;
     // BSX_ED_BY_KEY (experiments): 0 / 1 forces the lane order; default: by key from 32 commits on (waves at least half full)
     static const long env_by_key = getenv("BSX_ED_BY_KEY") ? atol(getenv("BSX_ED_BY_KEY")) : -1;
-    const bool by_key = env_by_key >= 0 ? env_by_key != 0 : n_commits >= 32;
+    // BSX_ED_SPLIT (experiments): 1 / 4 lanes per signature; default: 4 while the batch cannot fill the GPU's wave slots
+    // anyway (latency is what counts) or fills them so barely that finer units balance better, 1 above (20 % less work)
+    static const long env_split = getenv("BSX_ED_SPLIT") ? atol(getenv("BSX_ED_SPLIT")) : -1;
+    const bool split4 = env_split >= 0 ? env_split == 4 : n < ED_SPLIT_BELOW;
+    const uint32_t sigs = split4 ? ED_THREADS / 4 : ED_THREADS;               // signatures per workgroup
+    const bool by_key = env_by_key >= 0 ? env_by_key != 0 : n_commits >= sigs / 2;
+    dim3 grid;
     if (by_key) {
-        const uint64_t wpk = (n_commits + ED_THREADS - 1) / ED_THREADS;
-        const dim3 grid((uint32_t)((wpk * v_max + 7) / 8 * 8));                 // k_ed25519_verify_keyed: XCD remap needs a multiple of 8
-        if (scr) hipLaunchKernelGGL((k_ed25519_verify_keyed<true, true>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
-        else hipLaunchKernelGGL((k_ed25519_verify_keyed<false, true>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
+        const uint64_t wpk = (n_commits + sigs - 1) / sigs;
+        grid = dim3((uint32_t)((wpk * v_max + 7) / 8 * 8));                   // k_ed25519_verify_keyed: the XCD remap needs a multiple of 8
     } else {
-        const dim3 grid((uint32_t)((n + ED_THREADS - 1) / ED_THREADS));
-        if (scr) hipLaunchKernelGGL((k_ed25519_verify_keyed<true, false>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
-        else hipLaunchKernelGGL((k_ed25519_verify_keyed<false, false>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr);
+        grid = dim3((uint32_t)((n + sigs - 1) / sigs));
     }
+#define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_) \
+    hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr)
+    if (split4) {
+        if (scr) { if (by_key) BSX_LAUNCH_KEYED(true, true, 4); else BSX_LAUNCH_KEYED(true, false, 4); }
+        else     { if (by_key) BSX_LAUNCH_KEYED(false, true, 4); else BSX_LAUNCH_KEYED(false, false, 4); }
+    } else {
+        if (scr) { if (by_key) BSX_LAUNCH_KEYED(true, true, 1); else BSX_LAUNCH_KEYED(true, false, 1); }
+        else     { if (by_key) BSX_LAUNCH_KEYED(false, true, 1); else BSX_LAUNCH_KEYED(false, false, 1); }
+    }
+#undef BSX_LAUNCH_KEYED
     if (scr) {
         const uint32_t K = ed_fin_k(n);
         const uint64_t lanes = (n + K - 1) / K;
