@@ -1,0 +1,100 @@
+"""Every launch form of the fixed-key Ed25519 kernel (1 or 4 lanes per signature x signature-major or key-major lane order
+x with / without the batch-inversion scratch) against the oracle, on signatures FORGED for chosen (h, s): scalars whose
+radix-256 (h, per-key tables) and radix-65536 (s, table of B) recodings hit the extreme digits, plus random ones, valid and
+invalid.  The forms are chosen by the library from the batch size; BSX_ED_SPLIT / BSX_ED_BY_KEY force them, and are read
+once per process — hence one subprocess per form."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L_ORDER = 2 ** 252 + 27742317777372353535851937790883648493
+
+
+def _forge():
+    """(pk, [(sig64, h32, want)])"""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import oracle
+    import synth
+    from test_hostcheck import _BY, _enc, _mul, _recover_x
+    B = (_recover_x(_BY, 0), _BY)
+    seed = bytes(range(32))
+    pk = synth.ed25519_keypair(seed)
+    d = bytearray(hashlib.sha512(seed).digest()[:32])
+    d[0] &= 248; d[31] &= 127; d[31] |= 64
+    a = int.from_bytes(d, "little")
+    edges = [0, 1, 2 ** 128 - 1, 2 ** 128, int("80" * 31, 16), int("7f" * 31, 16), int("ff" * 31, 16), L_ORDER - 1, 2 ** 252,
+             int("0080" * 15, 16), int("7f80" * 15, 16), int("8000" * 15, 16), int("7fff" * 15, 16), int("ffff" * 15, 16),
+             int("00008000" * 7, 16), int("7fff8000" * 7, 16)]
+    rng = np.random.default_rng(5)
+    rnd = [int.from_bytes(rng.bytes(32), "little") % L_ORDER for _ in range(12)]
+    pairs = [(h, s) for h in edges for s in (edges[4], edges[7], edges[11])] + [(edges[1], s) for s in edges] + list(zip(rnd, rnd[::-1]))
+    out = []
+    for h, s in pairs:
+        h, s = h % L_ORDER, s % L_ORDER
+        R = _enc(_mul((s - h * a) % L_ORDER, B))
+        sig, hb = R + s.to_bytes(32, "little"), h.to_bytes(32, "little")
+        out.append((sig, hb, 1))
+        out.append((sig, ((h + 1) % L_ORDER).to_bytes(32, "little"), 0))
+        out.append((R + ((s + 1) % L_ORDER).to_bytes(32, "little"), hb, 0))
+    out.append((out[0][0][:32] + (int.from_bytes(out[0][0][32:], "little") + L_ORDER).to_bytes(32, "little"), out[0][1], 0))   # s + L
+    for sig, hb, want in out:
+        assert int(bool(oracle.ed25519_verify_h(pk, sig, hb))) == want
+    return pk, out
+
+
+def _child():
+    import ctypes as C
+    import torch
+    sys.path.insert(0, ROOT)
+    from blobstreamx_amd import _lib
+    from blobstreamx_amd import types as T
+    pk, cases = _forge()
+    v_max = 3                                    # three slots, all holding the same key; slot 2 of the table is left unbuilt
+    n_commits = (len(cases) + v_max - 1) // v_max
+    vals = np.zeros(n_commits * v_max, T.VALIDATOR)
+    hs = np.zeros((n_commits * v_max, 32), np.uint8)
+    want = np.zeros(n_commits * v_max, np.uint8)
+    for i, (sig, hb, w) in enumerate(cases):
+        vals[i]["pubkey"] = np.frombuffer(pk, np.uint8)
+        vals[i]["signature"] = np.frombuffer(sig, np.uint8)
+        vals[i]["enabled"], vals[i]["is_signed"] = 1, 1
+        hs[i] = np.frombuffer(hb, np.uint8)
+        want[i] = w
+    n = vals.size
+    L, ctx, dp = _lib.lib(), _lib.context(0), _lib.dp
+    dv = torch.from_numpy(vals.view(np.uint8).copy()).cuda()
+    dh = torch.from_numpy(hs.reshape(-1).copy()).cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n_keys = 2                                   # slot 2 has no table row: generic fallback inside the same call
+    tab = torch.zeros(int(L.bsx_ed25519_keytable_bytes(C.c_uint32(n_keys))), dtype=torch.uint8, device="cuda")
+    _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab)))
+    scr = torch.zeros(int(L.bsx_ed25519_verify_scratch_bytes(C.c_uint64(n))), dtype=torch.uint8, device="cuda")
+    for scratch in (None, scr):
+        ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v_max), dp(tab), C.c_uint32(n_keys),
+                                                  dp(ok), dp(scratch) if scratch is not None else None))
+        torch.cuda.synchronize()
+        got = ok.cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (os.environ.get("BSX_ED_SPLIT"), os.environ.get("BSX_ED_BY_KEY"), scratch is not None, bad[:8], got[bad[:8]])
+    print("ok", n, int(want.sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split,by_key", [(1, 0), (1, 1), (4, 0), (4, 1), (None, None)])
+def test_every_launch_form_on_forged_digit_edges(split, by_key):
+    env = dict(os.environ)
+    env.pop("BSX_ED_SPLIT", None); env.pop("BSX_ED_BY_KEY", None)
+    if split is not None:
+        env["BSX_ED_SPLIT"], env["BSX_ED_BY_KEY"] = str(split), str(by_key)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-1500:]
+
+
+if __name__ == "__main__" and sys.argv[1:] == ["child"]:
+    _child()
