@@ -607,7 +607,9 @@ def main():
         fused = bool(e0.fused_hint)
         exec_per_slot = (2 + 2 * (B - 1) / B) if fused else (21 + 2 * (B - 1) / B)     # tuple leaf + tree (+ both proof paths)
         comp_s = slots * exec_per_slot / t_sub * 1e3
-        out["kernels"] = [{"kernel": "k_prove_subchain (k_slot_hashes + k_tree_level x n + k_batch_finish)", "avg_launch_ms": t_sub, "slots_per_launch": slots,
+        one_launch = fused and not (e0.subchain_flags & 2)
+        out["kernels"] = [{"kernel": "prove_subchain (k_batch_finish<fused>: tuple leaf hashes + every tree level + predicates in one launch)" if one_launch
+                           else "prove_subchain (k_slot_hashes + k_tree_level x n + k_batch_finish)", "avg_launch_ms": t_sub, "slots_per_launch": slots,
                            "compact_bytes_per_slot": 874, "achieved_GBps": sub_bytes / t_sub / 1e6,
                            "frac_of_hbm_peak": sub_bytes / t_sub / 1e6 / HBM_PEAK_GBS,
                            "fused_hint": fused, "sha256_compressions_executed_per_slot": exec_per_slot,

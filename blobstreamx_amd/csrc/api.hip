@@ -258,7 +258,7 @@ int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32
     DEV_ENTER();
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "batch_size must be a power of two <= %d", BSX_MAX_BATCH);
     if (!d_ranges || !d_compact || !d_records) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    if (flags & ~BSX_SUBCHAIN_PATHS_FROM_HINT) return fail(BSX_ERR_BAD_ARG, "unknown flags 0x%x", flags);
+    if (flags & ~(BSX_SUBCHAIN_PATHS_FROM_HINT | BSX_SUBCHAIN_SEPARATE_LAUNCHES)) return fail(BSX_ERR_BAD_ARG, "unknown flags 0x%x", flags);
     HIPCHK(bsxk_prove_subchain(S(ctx, stream), n_ranges, batch_size, job_count, d_ranges, d_compact, d_records, flags));
     return BSX_OK;
 }

@@ -565,13 +565,19 @@ __global__ __launch_bounds__(TR_THREADS) void k_tree_level(SubchainArgs a) {
 // per-slot assertion bits are reduced with a wave ballot and at most one LDS atomic per failing lane.
 constexpr int BF_THREADS = 256;
 constexpr uint32_t BF_TOP_WIDTH = 8;
-__global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
+// FUSED (the hint supplied the path digests, BSX_SUBCHAIN_PATHS_FROM_HINT): the whole of prove_subchain in this one launch —
+// the slot's data-root tuple and its leaf hash (what k_slot_hashes<false> does), then EVERY level of the commitment tree
+// through LDS, then the predicates.  The separate launches (k_slot_hashes, one k_tree_level per wide level) each held a few
+// compressions per lane and cost 25-45 us of launch gap and memory round trips: 0.23 -> 0.1 ms per 262,144 slots.
+template <bool FUSED>
+__global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) {
     BSX_CHAIN_PRIO();
     __shared__ uint32_t job_fail[BF_THREADS];
     __shared__ uint32_t job_first_bad[BF_THREADS];
-    // the top of every job's commitment tree (levels of width <= BF_TOP_WIDTH) is folded here instead of by one
-    // k_tree_level launch per level: those launches held 4 .. 32 nodes per job and cost ~28 us each, mostly launch gap
+    // the top of every job's commitment tree (levels of width <= BF_TOP_WIDTH; FUSED: all levels) is folded here instead of
+    // by one k_tree_level launch per level: those launches held 4 .. 32 nodes per job and cost ~28 us each, mostly launch gap
     __shared__ uint32_t top_nodes[2][BF_THREADS / 2 * 8];
+    __shared__ uint32_t leaf_lds[FUSED ? BF_THREADS * 8 : 8];
     const uint32_t B = a.batch, tid = threadIdx.x;
     const uint64_t total = (uint64_t)a.n_jobs * B;
     const uint64_t gs0 = (uint64_t)blockIdx.x * BF_THREADS;
@@ -590,6 +596,29 @@ __global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
     uint64_t batch_start, batch_end, temp_end, end_block_num;
     batch_bounds(W, E, batch_start, batch_end, temp_end, end_block_num);
     const uint64_t curr_idx = batch_start + i;                       // builder.rs:182 / :134
+    Digest tleaf = Digest{};
+    if (FUSED && live) {
+        // data-root tuple (builder.rs:82-103,134-137) and its leaf hash (:144-147): data_hash = data_hash_proofs[i].leaf[2..34]
+        const uint8_t* pr = cw + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * i;
+        const uint4 l0 = ldu4(pr + 128), l1 = ldu4(pr + 144);
+        const uint32_t l2 = (uint32_t)reinterpret_cast<const uint16_t*>(pr + 160)[0];
+        const uint32_t lf[9] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2};
+        uint32_t t[16];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = 0;
+        t[6] = (uint32_t)(curr_idx >> 32);
+        t[7] = (uint32_t)curr_idx;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[8 + k] = bswap32(funnel_r(lf[k + 1], lf[k], 16));
+        tleaf = leaf_hash_tuple(t);
+        uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            stu4(tp + 16 * k, make_uint4(bswap32(t[4 * k]), bswap32(t[4 * k + 1]), bswap32(t[4 * k + 2]), bswap32(t[4 * k + 3])));
+        store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
+#pragma unroll
+        for (int k = 0; k < 8; k++) leaf_lds[tid * 8 + k] = tleaf.w[k];
+    }
 
     // Enabled slots form a prefix [0, m) of the batch (closed form of the :174-175,:225 recurrence).
     const bool batch_enabled = batch_start < E;                      // :174
@@ -640,37 +669,53 @@ __global__ __launch_bounds__(BF_THREADS) void k_batch_finish(SubchainArgs a) {
         }
     }
     __syncthreads();
-    // top tree levels: level a.level (width a.width, at a.level_off) reads what the last k_tree_level launch (or, for
-    // B <= 2 * BF_TOP_WIDTH, k_slot_hashes) left in global memory; the levels above hand over through LDS
+    // tree levels: level a.level (width a.width, at a.level_off) reads what the last k_tree_level launch (or, for
+    // B <= 2 * BF_TOP_WIDTH, k_slot_hashes) left in global memory — FUSED: this workgroup's leaf hashes in LDS; the levels
+    // above hand over through LDS.  The nodes of a level are dealt to the workgroup's lanes DENSELY (node n of the block =
+    // lane n, whatever job it belongs to), so that a level of 128 / 64 / 32 nodes occupies 2 / 1 / 1 waves and the other waves
+    // skip it, instead of every wave issuing every level for a shrinking prefix of its lanes.
+    __shared__ uint32_t job_nb[BF_THREADS];
+    if (live && i == 0) job_nb[jl] = nb_enabled;
+    __syncthreads();
     Digest root = start_header;
     if (B > 1) {
+        const uint32_t q0 = (uint32_t)(gs0 / B), jobs_here = BF_THREADS / B;
         uint32_t level = a.level, level_off = a.level_off, cur = 0;
         for (uint32_t width = a.width; width >= 1; width /= 2, level++) {
-            if (live && i < width) {
+            const uint32_t jn = tid / width, t = tid % width;          // job (inside the block) and node of this lane
+            if (jn < jobs_here && q0 + jn < a.n_jobs) {
+                uint8_t* cwn = a.compact + (uint64_t)(q0 + jn) * a.compact_stride;
                 Digest l, r;
-                if (width == a.width) {
-                    const uint8_t* ch = (level == 1) ? cw + bsx_off_leaf_hashes(B) + 64 * i
-                                                     : cw + bsx_off_nodes(B) + 32 * (level_off - 2 * width + 2 * i);
+                if (FUSED && width == a.width) {                         // level 1: slot jn * B + 2 t of this workgroup
+                    const uint32_t* s = &leaf_lds[(jn * B + 2 * t) * 8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { l.w[k] = s[k]; r.w[k] = s[8 + k]; }
+                } else if (width == a.width) {
+                    const uint8_t* ch = (level == 1) ? cwn + bsx_off_leaf_hashes(B) + 64 * t
+                                                     : cwn + bsx_off_nodes(B) + 32 * (level_off - 2 * width + 2 * t);
                     l = load_digest_global(ch); r = load_digest_global(ch + 32);
                 } else {
-                    const uint32_t* s = &top_nodes[cur][(jl * a.width + 2 * i) * 8];
+                    const uint32_t* s = &top_nodes[cur][(jn * a.width + 2 * t) * 8];
 #pragma unroll
                     for (int k = 0; k < 8; k++) { l.w[k] = s[k]; r.w[k] = s[8 + k]; }
                 }
-                const Digest node = tree_node(cw, a.off_bools, B, level, level_off, i, nb_enabled, l, r);
-                uint32_t* d = &top_nodes[cur ^ 1][(jl * a.width + i) * 8];
+                const Digest node = tree_node(cwn, a.off_bools, B, level, level_off, t, job_nb[jn], l, r);
+                uint32_t* d = &top_nodes[cur ^ 1][(jn * a.width + t) * 8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) d[k] = node.w[k];
-                if (width == 1) root = node;
             }
             __syncthreads();
             cur ^= 1;
             level_off += width;
         }
+        if (live && i == 0) {                                            // the root: node 0 of the last level written
+#pragma unroll
+            for (int k = 0; k < 8; k++) root.w[k] = top_nodes[cur][(jl * a.width) * 8 + k];
+        }
     }
     // batch tail + record (builder.rs:229-270): one lane per job
     if (live && i == 0) {
-        if (B == 1) root = load_digest_global(cw + bsx_off_leaf_hashes(B));
+        if (B == 1) root = FUSED ? tleaf : load_digest_global(cw + bsx_off_leaf_hashes(B));
         const bool curr_enabled_end = batch_enabled && !(jstar < (uint64_t)B);   // enabled after the last slot
         const Digest curr_final = (m > 0) ? load_digest_global(slots + BSX_SLOT_BYTES * (m - 1) + 160 + 128) : start_header;
         const Digest end_header = load_digest_global(cw + bsx_off_end_header());
@@ -932,6 +977,14 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     const uint32_t n_jobs = n_ranges * job_count;
     SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
     const uint64_t slots = (uint64_t)n_jobs * B;
+    // BSX_SUBCHAIN_FUSED=0 / 1 (experiments) overrides BSX_SUBCHAIN_SEPARATE_LAUNCHES
+    static const long env_fuse = getenv("BSX_SUBCHAIN_FUSED") ? atol(getenv("BSX_SUBCHAIN_FUSED")) : -1;
+    const bool fuse = env_fuse >= 0 ? env_fuse != 0 : !(flags & BSX_SUBCHAIN_SEPARATE_LAUNCHES);
+    if ((flags & BSX_SUBCHAIN_PATHS_FROM_HINT) && fuse) {
+        a.level = 1; a.width = B / 2; a.level_off = 0;        // every level inside the one launch
+        hipLaunchKernelGGL(k_batch_finish<true>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
+        return hipGetLastError();
+    }
     if (flags & BSX_SUBCHAIN_PATHS_FROM_HINT)
         hipLaunchKernelGGL(k_slot_hashes<false>, dim3((uint32_t)((slots + SH_THREADS - 1) / SH_THREADS)), dim3(SH_THREADS), 0, s, a);
     else
@@ -945,7 +998,7 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     }
     // the remaining levels (width <= BF_TOP_WIDTH) run inside k_batch_finish
     a.level = level; a.width = B / 2 < BF_TOP_WIDTH ? B / 2 : BF_TOP_WIDTH; a.level_off = level_off;
-    hipLaunchKernelGGL(k_batch_finish, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_batch_finish<false>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, uint64_t stride_range,

@@ -113,6 +113,8 @@ class HeaderRangeEngine:
         # the proofs-only hand-over
         self.fused_hint = os.environ.get("BSX_FUSED_HINT", "1") != "0"
         self.paths = _u8(self.nh_all * 224, d) if self.fused_hint else None
+        # bsx.h: BSX_SUBCHAIN_PATHS_FROM_HINT (1); PipelinedEngines adds BSX_SUBCHAIN_SEPARATE_LAUNCHES (2) beside an expansion
+        self.subchain_flags = 1 if self.fused_hint else 0
         self.ranges = _u8(RT * 80, d)
         self.latest = _u8(RT * 8, d)
         self.status = torch.zeros(8, dtype=torch.int32, device=d)       # [0] header, [1] assemble
@@ -294,7 +296,7 @@ class HeaderRangeEngine:
         if ev:
             ev[0].record(main)
         chk(L.bsx_dev_prove_subchain(ctx, st, C.c_uint32(RT), C.c_uint32(B), C.c_uint32(jc), dp(self.ranges), dp(self.compact),
-                                     dp(self.records), C.c_uint32(1 if self.fused_hint else 0)))
+                                     dp(self.records), C.c_uint32(self.subchain_flags)))
         if ev:
             ev[1].record(main)
         chk(L.bsx_dev_reduce(ctx, st, C.c_uint32(RT), C.c_uint32(jc), dp(self.records), dp(self.partial),
@@ -485,6 +487,9 @@ class PipelinedEngines:
         # k_header_merkle alone fills the register file (4 waves x 128 VGPRs per SIMD); beside an expansion it is held to
         # 2 workgroups per CU so that the expansion's waves keep half of it (bsx.h BSX_TUNE_MERKLE_WORKGROUPS): +2 % per step
         e0 = self.engines[0]
+        if e0.with_witness and n_engines > 1:
+            for e in self.engines:           # the one-launch prove_subchain holds 4 x 128 registers per SIMD: same trade
+                e.subchain_flags |= 2 if e.fused_hint else 0
         _lib.check(e0.L.bsx_set_tuning(e0.ctx, C.c_uint32(T.TUNE_MERKLE_WORKGROUPS),
                                        C.c_uint64(2 * torch.cuda.get_device_properties(self.dev).multi_processor_count
                                                   if e0.with_witness and n_engines > 1 else 0)))

@@ -375,6 +375,11 @@ int bsx_dev_prove_subchain(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32
  * compressions per slot are not repeated (the witness is bit-identical; every link assertion A3-A6 is still evaluated on
  * those digests).  Never set it for proofs that came from a caller. */
 #define BSX_SUBCHAIN_PATHS_FROM_HINT 1u
+/* with BSX_SUBCHAIN_PATHS_FROM_HINT: keep the stages in separate launches (tuple leaf hashes, one launch per wide tree
+ * level, predicates) instead of the single launch that is the default.  The single launch is 40 % faster on its own
+ * (0.235 -> 0.137 ms per 262,144 slots) but holds 4 waves x 128 registers per SIMD; a pipeline that runs an HBM-bound
+ * witness expansion beside this call (engine.py) loses 0.5 % per step to it and sets this flag.  Same results. */
+#define BSX_SUBCHAIN_SEPARATE_LAUNCHES 2u
 
 /* Binary reduce (builder.rs:337-395) of `n` consecutive records per range -> 1, n a power of two <= 256.
  * d_reduce_compact (optional) receives n-1 reduce-node compact witnesses per range. */

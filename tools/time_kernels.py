@@ -21,7 +21,7 @@ RT, jc, hpr = eng.RT, eng.jc, eng.hpr
 calls = [
     ("header_merkle", lambda: L.bsx_dev_header_merkle(ctx, st, dp(eng.headers), C.c_uint64(RT * hpr), dp(eng.hashes), dp(eng.dh_aunts), dp(eng.lb_aunts), dp(eng.paths), dp(eng.status))),
     ("assemble", lambda: L.bsx_dev_assemble_inputs(ctx, st, C.c_uint32(RT), C.c_uint32(J), C.c_uint32(B), C.c_uint32(0), C.c_uint32(jc), C.c_uint32(B), dp(eng.ranges), dp(eng.latest), dp(eng.headers), C.c_uint64(hpr), C.c_uint64(0), dp(eng.hashes), dp(eng.dh_aunts), dp(eng.lb_aunts), dp(eng.compact), dp(eng.status[1:]), dp(eng.paths))),
-    ("prove_subchain", lambda: L.bsx_dev_prove_subchain(ctx, st, C.c_uint32(RT), C.c_uint32(B), C.c_uint32(jc), dp(eng.ranges), dp(eng.compact), dp(eng.records), C.c_uint32(1 if eng.fused_hint else 0))),
+    ("prove_subchain", lambda: L.bsx_dev_prove_subchain(ctx, st, C.c_uint32(RT), C.c_uint32(B), C.c_uint32(jc), dp(eng.ranges), dp(eng.compact), dp(eng.records), C.c_uint32(eng.subchain_flags))),
     ("reduce", lambda: L.bsx_dev_reduce(ctx, st, C.c_uint32(RT), C.c_uint32(jc), dp(eng.records), dp(eng.partial), dp(eng.red_compact_local))),
     ("expand", lambda: L.bsx_dev_expand_witness(ctx, st, _lib.p(eng._ml), C.c_uint32(RT * jc), dp(eng.compact), dp(eng.witness_map))),
 ]
