@@ -431,14 +431,20 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
                                                              const uint8_t* __restrict__ header_hashes,
                                                              const uint8_t* __restrict__ ok_in,
                                                              bsx_commit_result* __restrict__ results) {
-    __shared__ uint32_t nodes[2][TL_VMAX * 8];
-    __shared__ uint8_t en[2][TL_VMAX];
+    // dynamic LDS sized by the padded validator count P (launcher): nodes[2][P * 8] u32, then en[2][P] u8 — 8.4 KB at
+    // V = 100 instead of the 33 KB of the 512-slot maximum, so that 2048 commits are resident at once (mode S)
+    extern __shared__ uint32_t tl_lds[];
     __shared__ unsigned long long s_total, s_signed, s_trusted, s_total_hi, s_total_lo;
     __shared__ uint32_t s_nen, s_nsig, s_nbad, s_firstbad, s_nbadmsg;
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     const bsx_validator* cv = vals + (uint64_t)c * v_max;
     uint32_t P = 1;
     while (P < v_max) P *= 2;
+    uint32_t* const nodes0 = tl_lds;
+    uint8_t* const en0 = reinterpret_cast<uint8_t*>(tl_lds + 2 * P * 8);
+#define nodes(b, idx) nodes0[(b) * P * 8 + (idx)]
+#define en(b, idx) en0[(b) * P + (idx)]
+    const uint32_t nthreads = blockDim.x;
     if (tid == 0) { s_total = 0; s_signed = 0; s_trusted = 0; s_total_hi = 0; s_total_lo = 0; s_nen = 0; s_nsig = 0; s_nbad = 0; s_firstbad = 0xffffffffu; s_nbadmsg = 0; }
     __syncthreads();
     uint32_t hh[8];
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     uint64_t total = 0, signedp = 0, trusted = 0;
     uint64_t total_hi = 0, total_lo = 0;     // exact sum in two halves: the u64 `total` may wrap
     uint32_t nen = 0, nsig = 0, nbad = 0, nbadmsg = 0;
-    for (uint32_t v = tid; v < P; v += TL_THREADS) {
+    for (uint32_t v = tid; v < P; v += nthreads) {
         uint32_t pk[8];
         uint64_t power = 0;
         bool enabled = false;
@@ -495,8 +501,8 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
         {
             const Digest lh = leaf_hash_1block(d, len);
 #pragma unroll
-            for (int k = 0; k < 8; k++) nodes[0][v * 8 + k] = lh.w[k];
-            en[0][v] = enabled ? 1 : 0;
+            for (int k = 0; k < 8; k++) nodes(0, v * 8 + k) = lh.w[k];
+            en(0, v) = enabled ? 1 : 0;
         }
     }
     // wave-level reduction, then one LDS atomic per wave
@@ -512,16 +518,16 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     __syncthreads();
     int cur = 0;
     for (uint32_t width = P / 2; width >= 1; width /= 2) {
-        for (uint32_t t = tid; t < width; t += TL_THREADS) {
+        for (uint32_t t = tid; t < width; t += nthreads) {
             Digest l, r;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { l.w[k] = nodes[cur][(2 * t) * 8 + k]; r.w[k] = nodes[cur][(2 * t + 1) * 8 + k]; }
-            const bool el = en[cur][2 * t] != 0, er = en[cur][2 * t + 1] != 0;
+            for (int k = 0; k < 8; k++) { l.w[k] = nodes(cur, (2 * t) * 8 + k); r.w[k] = nodes(cur, (2 * t + 1) * 8 + k); }
+            const bool el = en(cur, 2 * t) != 0, er = en(cur, 2 * t + 1) != 0;
             const Digest in = inner_hash(l, r);
             const Digest node = (el && er) ? in : l;
 #pragma unroll
-            for (int k = 0; k < 8; k++) nodes[cur ^ 1][t * 8 + k] = node.w[k];
-            en[cur ^ 1][t] = (el || er) ? 1 : 0;
+            for (int k = 0; k < 8; k++) nodes(cur ^ 1, t * 8 + k) = node.w[k];
+            en(cur ^ 1, t) = (el || er) ? 1 : 0;
         }
         __syncthreads();
         cur ^= 1;
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     if (tid == 0) {
         bsx_commit_result* o = results + c;
 #pragma unroll
-        for (int k = 0; k < 8; k++) reinterpret_cast<uint32_t*>(o->validators_hash)[k] = bswap32(nodes[cur][k]);
+        for (int k = 0; k < 8; k++) reinterpret_cast<uint32_t*>(o->validators_hash)[k] = bswap32(nodes(cur, k));
         o->total_power = s_total; o->signed_power = s_signed; o->trusted_signed_power = s_trusted;
         o->n_enabled = s_nen; o->n_signed = s_nsig; o->n_bad_signature = s_nbad; o->first_bad_signature = s_firstbad;
         o->n_bad_message = s_nbadmsg;
@@ -538,6 +544,8 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
         o->power_overflow = overflow ? 1u : 0u;
         o->_pad[0] = o->_pad[1] = o->_pad[2] = 0;
     }
+#undef nodes
+#undef en
 }
 
 // ------------------------------------------------------------------------------------------------ k_skip_check
@@ -804,7 +812,12 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
 hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,
                              const uint8_t* ok, bsx_commit_result* results) {
     if (!n_commits) return hipSuccess;
-    hipLaunchKernelGGL(k_commit_tally, dim3(n_commits), dim3(TL_THREADS), 0, s, vals, v_max, header_hashes, ok, results);
+    uint32_t P = 1;
+    while (P < v_max) P *= 2;
+    // a commit of <= 128 validator slots is two waves' worth of leaves: a 128-thread workgroup (and 8.4 KB of LDS) lets twice
+    // as many commits be resident; the tree is a latency chain either way
+    const uint32_t threads = P <= 128 ? 128 : TL_THREADS;
+    hipLaunchKernelGGL(k_commit_tally, dim3(n_commits), dim3(threads), 2 * P * 8 * 4 + 2 * P, s, vals, v_max, header_hashes, ok, results);
     return hipGetLastError();
 }
 hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* ranges, const bsx_header* headers,
