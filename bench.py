@@ -53,12 +53,12 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s s
 # tools/microbench_alu.hip at 8 waves/SIMD; profiles/r1_microbench.txt, profiles/r2_microbench_alu.txt)
 PEAK = {"sha256_compress_per_s": 27.7e9, "sha512_compress_per_s": 6.40e9, "fe25519_mul_per_s": 197e9, "fe25519_sq_per_s": 268.7e9,
         "poseidon_permute_per_s": 1.835e9, "goldilocks_mul_per_s": 2.05e12}
-# Field operations of ONE fixed-key Ed25519 verification (ed25519.h ed25519_verify_keyed_core: affine tables, 32 radix-256
-# digits of h for the key, 16 radix-65536 digits of s for B): 48 mixed additions (3 + 4 mul each, the last one 3 + 3), no
+# Field operations of ONE fixed-key Ed25519 verification (ed25519.h ed25519_verify_keyed_core: affine tables, 22 radix-4096
+# digits of h for the key, 16 radix-65536 digits of s for B): 38 mixed additions (3 + 4 mul each, the last one 3 + 3), no
 # doubling + encoding.
 # With the batch-inversion scratch (k_ed25519_finish) the encoding costs 5 multiplications per signature plus one
 # inversion (254 sq + 11 mul) per 8 / 16 signatures — counted at 16.
-FE_MUL_PER_VERIFY = 48 * 7 - 1 + 5 + 11 / 16
+FE_MUL_PER_VERIFY = 38 * 7 - 1 + 5 + 11 / 16
 FE_SQ_PER_VERIFY = 254 / 16
 # the ALU ceiling those counts imply: every multiplication at the measured fe_mul rate, every squaring at the fe_sq rate
 PEAK_KEYED_VERIFIES_PER_S = 1.0 / (FE_MUL_PER_VERIFY / PEAK["fe25519_mul_per_s"] + FE_SQ_PER_VERIFY / PEAK["fe25519_sq_per_s"])
@@ -273,8 +273,8 @@ def stress(args, dev, V, cpu_seconds):
             "signatures": n, "checked_against_oracle": {"sig_ok_bits": n, "commit_results": nh},
             "stage_ms": {"sha512_challenge": t_sha, "keytable": t_tab, "ed25519_verify_keyed": t_ed, "tally_validator_hash": t_tally,
                          "keytable_cold_build": cold[1]},
-            "ed25519_path": "fixed-key affine tables: 32 radix-256 digits of h for every validator key, 16 radix-65536 digits of s for B = 48 mixed "
-                            "additions, no doubling; table rows reused while the validator set is unchanged; "
+            "ed25519_path": "fixed-key affine tables: 22 radix-4096 digits of h for every validator key (5.8 MB per key), 16 radix-65536 digits of "
+                            "s for B (64 MB) = 38 mixed additions, no doubling; table rows reused while the validator set is unchanged; "
                             "encodings through per-lane Montgomery batch inversion (8 / 16 signatures per inversion)",
             "roofline": {"kernel": "k_ed25519_verify_keyed", "bound": "valu", "unit": "M Ed25519 verifications/s",
                          "achieved": ver_per_s / 1e6, "peak": PEAK_KEYED_VERIFIES_PER_S / 1e6, "frac": ver_per_s / PEAK_KEYED_VERIFIES_PER_S,

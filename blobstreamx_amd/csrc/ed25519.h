@@ -162,72 +162,69 @@ BSX_HDI bool ed25519_verify_core(const uint32_t pk[8], const uint32_t sig_r[8], 
 
 // ------------------------------------------------------------------------------------------------ fixed-key path
 // A validator set signs every commit of a range batch with the same keys, and B is everybody's key, so ALL the per-key
-// work is hoisted out of the per-signature lane: per point P (a validator's -A, or B) a table holds j * 2^(8k) P for
-// k = 0..31, j = 1..128 in AFFINE form (y + x, y - x, 2 d x y; 32 int32 = one 128-byte cache line per entry, 30 used).
-// The 253-bit scalar h is recoded into 32 signed radix-256 digits (s: into 16 signed radix-65536 digits, below), and
+// work is hoisted out of the per-signature lane: per point P (a validator's -A, or B) a table holds j * 2^(W k) P for
+// every digit position k and j = 1..2^(W-1) in AFFINE form (y + x, y - x, 2 d x y; 32 int32 = one 128-byte cache line per
+// entry, 30 used).  The 253-bit scalars are recoded into signed radix-2^W digits (h: 22 of 12 bits, s: 16 of 16 bits), and
 //     [s]B + [h](-A) = sum_k T_A[k][h_k] + sum_k T_B[k][s_k]
-// is 32 + 16 mixed additions (7 multiplications each) and NO doubling, NO decompression.  History: 2 parts of 128 bits
+// is 22 + 16 mixed additions (7 multiplications each) and NO doubling, NO decompression.  History: 2 parts of 128 bits
 // with cached (projective) entries = 128 doublings + 64 additions; 8 parts of 32 bits = 32 + 64 (round 2, 576 mul + 128
-// sq); one-digit parts = 0 + 64 (447 mul); wide digits for B = 0 + 48 (335 mul).  A key's table is 32 x 128 x 128 B =
-// 512 KB, built once per key and kept while the key stays (kernels_ed.hip); the B table (16 x 32768 x 128 B = 64 MB) is
-// built by the same code from the encoding of -B when a context is created.
+// sq); one radix-256 digit per part = 0 + 64 (447 mul); 16-bit digits for B = 0 + 48 (335 mul); 12-bit digits for the keys
+// = 0 + 38 (265 mul).  A key's table is 22 x 2048 x 128 B = 5.8 MB, built once per key and kept while the key stays
+// (kernels_ed.hip k_table_entries: batch inversion, 2 ms per 100 keys); the B table (16 x 32768 x 128 B = 64 MB) is built
+// by the same code from the encoding of -B when a context is created.
 constexpr int KT_ENTRY_I32 = 32;          // one affine entry, padded to a cache line
-constexpr int KT_HALF_ENTRIES = 128;      // j = 1..128 per part
-constexpr int KT_PARTS = 32;              // one signed radix-256 digit per part
-constexpr int KT_KEY_I32 = KT_PARTS * KT_HALF_ENTRIES * KT_ENTRY_I32;
-// encoding of -B (B = (x, 4/5) with x even: the encoding of B is 0x58, 0x66 x 31; -B sets the sign bit of x)
-constexpr uint32_t GE_NEG_B_ENC[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0xe6666666u};
-
-// r = x + 0x8080...80 (x < 2^253, so no carry out); digit_i = byte_i(r) - 128 in [-128, 127]
-BSX_HDI void sc_recode8(const uint32_t s[8], uint32_t r[8]) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)s[i] + 0x80808080u;
-        r[i] = (uint32_t)c;
-        c >>= 32;
-    }
-}
-BSX_HDI int sc_digit8(const uint32_t r[8], int i) { return (int)((pick8(r, i >> 2) >> (8 * (i & 3))) & 255) - 128; }
-
-// The table of B is shared by every signature of every key, so it can afford wider digits than the per-key tables:
-// BT_W-bit signed digits = BT_PARTS additions for [s]B instead of 32, from BT_PARTS x 2^(BT_W-1) entries.  Measured
-// (1,048,576 signatures, M verifies/s): W = 8: 335, 10: 354, 11: 365, 12: 376, 13: 383, 16: 412 — the 64 MB table of
-// W = 16 lives in the 256 MB Infinity Cache and its loads do not depend on the point arithmetic.
+// Digit widths (bits): per-key tables (h) and the table of B (s).  A table has PARTS = ceil(254 / W) parts of 2^(W-1)
+// entries (signed digits); a signature costs KT_PARTS + BT_PARTS additions.
+// Per-key tables, measured (M verifies/s at 204,800 / 1,048,576 signatures, BSX_BT_W = 16): W = 8 (0.5 MB per key): 291 /
+// 408, 10 (1.7 MB): 298 / 466, 12 (5.8 MB): 326 / 532, 13 (10.5 MB): 341 / 531.
+#ifndef BSX_KT_W
+#define BSX_KT_W 12
+#endif
+// The table of B is shared by every signature of every key, so it can afford wider digits than the per-key tables.  Measured
+// (1,048,576 signatures, M verifies/s, BSX_KT_W = 8): BSX_BT_W = 8: 335, 10: 354, 11: 365, 12: 376, 13: 383, 16: 412 — the
+// 64 MB table of W = 16 lives in the 256 MB Infinity Cache and its loads do not depend on the point arithmetic.
 #ifndef BSX_BT_W
 #define BSX_BT_W 16
 #endif
-constexpr int BT_W = BSX_BT_W;
-constexpr int BT_PARTS = (253 + BT_W) / BT_W;             // digits cover >= 254 bits: s + the recoding constant < 2^254
-constexpr int BT_HALF_ENTRIES = 1 << (BT_W - 1);          // j = 1..2^(W-1) per part
+constexpr int KT_W = BSX_KT_W, BT_W = BSX_BT_W;
+constexpr int KT_PARTS = (253 + KT_W) / KT_W, BT_PARTS = (253 + BT_W) / BT_W;   // digits cover >= 254 bits: x + the recoding constant < 2^254
+constexpr int KT_HALF_ENTRIES = 1 << (KT_W - 1), BT_HALF_ENTRIES = 1 << (BT_W - 1);   // j = 1..2^(W-1) per part
+constexpr int KT_KEY_I32 = KT_PARTS * KT_HALF_ENTRIES * KT_ENTRY_I32;
 constexpr int BT_I32 = BT_PARTS * BT_HALF_ENTRIES * KT_ENTRY_I32;
+static_assert(KT_W >= 8 && KT_W <= 16 && KT_W * KT_PARTS >= 254 && KT_W * KT_PARTS <= 288, "key-table digit width");
 static_assert(BT_W >= 8 && BT_W <= 16 && BT_W * BT_PARTS >= 254 && BT_W * BT_PARTS <= 288, "B-table digit width");
-// r = s + sum_i 2^(W-1) 2^(W i) (9 dwords); digit_i = ((r >> W i) mod 2^W) - 2^(W-1) in [-2^(W-1), 2^(W-1))
-BSX_HDI void sc_recode_w(const uint32_t s[8], uint32_t r[9]) {
+// encoding of -B (B = (x, 4/5) with x even: the encoding of B is 0x58, 0x66 x 31; -B sets the sign bit of x)
+constexpr uint32_t GE_NEG_B_ENC[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0xe6666666u};
+
+// Signed radix-2^W recoding without a carry chain: r = x + sum_i 2^(W-1) 2^(W i) (9 dwords; x < 2^253);
+// digit_i = ((r >> W i) mod 2^W) - 2^(W-1) in [-2^(W-1), 2^(W-1))
+template <int W, int PARTS>
+BSX_HDI void sc_recode_t(const uint32_t x[8], uint32_t r[9]) {
     uint32_t cst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < BT_PARTS; i++) {
-        const int bit = BT_W * i + BT_W - 1;
+    for (int i = 0; i < PARTS; i++) {
+        const int bit = W * i + W - 1;
         cst[bit >> 5] |= 1u << (bit & 31);
     }
     uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        c += (uint64_t)(i < 8 ? s[i] : 0u) + cst[i];
+        c += (uint64_t)(i < 8 ? x[i] : 0u) + cst[i];
         r[i] = (uint32_t)c;
         c >>= 32;
     }
 }
-BSX_HDI uint32_t pick9(const uint32_t r[9], int w) {
+BSX_HDI uint32_t pick9(const uint32_t r[9], int w) {  // r[w] for a runtime w without private-memory indexing
     uint32_t v = r[0];
 #pragma unroll
     for (int k = 1; k < 9; k++) v = (w == k) ? r[k] : v;
     return v;
 }
-BSX_HDI int sc_digit_w(const uint32_t r[9], int i) {
-    const int bit = BT_W * i, wd = bit >> 5, sh = bit & 31;
+template <int W>
+BSX_HDI int sc_digit_t(const uint32_t r[9], int i) {
+    const int bit = W * i, wd = bit >> 5, sh = bit & 31;
     const uint64_t two = ((uint64_t)pick9(r, wd + 1 < 9 ? wd + 1 : 8) << 32) | pick9(r, wd);
-    return (int)((uint32_t)(two >> sh) & ((1u << BT_W) - 1)) - (1 << (BT_W - 1));
+    return (int)((uint32_t)(two >> sh) & ((1u << W) - 1)) - (1 << (W - 1));
 }
 
 // base[k + 1] = 2^bits * base[k]
@@ -241,22 +238,26 @@ BSX_HDI ge_p3 ge_keytable_next_base(const ge_p3& prev, int bits = 8) {
     }
     return p1p1_to_p3_inl(t);
 }
-// j * base, j in 1..2^(bits-1), by a bits-step double-and-add that is uniform across lanes (the addition is selected,
-// not branched), then to affine form (one inversion per entry: the build runs once per key)
-BSX_HDI ge_precomp ge_keytable_entry(const ge_p3& base, int j, int bits = 8) {
+// m * base, 1 <= m < 2^bits, by a bits-step double-and-add that is uniform across lanes (the addition is selected, not
+// branched)
+BSX_HDI ge_p3 ge_mul_small(const ge_p3& base, int m, int bits) {
     const ge_cached cb = p3_to_cached(base);
     ge_p3 acc{fe_zero(), fe_one(), fe_one(), fe_zero()};
+#pragma unroll 1
     for (int bit = bits - 1; bit >= 0; bit--) {
         acc = p1p1_to_p3(ge_dbl(acc.X, acc.Y, acc.Z));
         const ge_p3 sum = p1p1_to_p3(ge_add(acc, cb));
-        const bool take = ((j >> bit) & 1) != 0;
+        const bool take = ((m >> bit) & 1) != 0;
         acc.X = fe_select(take, sum.X, acc.X);
         acc.Y = fe_select(take, sum.Y, acc.Y);
         acc.Z = fe_select(take, sum.Z, acc.Z);
         acc.T = fe_select(take, sum.T, acc.T);
     }
-    const fe zi = fe_invert(acc.Z);
-    const fe x = fe_mul(acc.X, zi), y = fe_mul(acc.Y, zi);
+    return acc;
+}
+// affine table entry of the point (X : Y : Z) given 1 / Z
+BSX_HDI ge_precomp ge_to_precomp(const fe& X, const fe& Y, const fe& zinv) {
+    const fe x = fe_mul(X, zinv), y = fe_mul(Y, zinv);
     return ge_precomp{fe_add(y, x), fe_sub(y, x), fe_mul(fe_mul(x, y), fe_d2())};
 }
 BSX_HDI void precomp_store(int32_t* dst, const ge_precomp& e) {
@@ -298,18 +299,18 @@ template <bool DEFER>
 BSX_HDI bool ed25519_verify_keyed_core_t(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
                                          const uint32_t h[8], ge_p2* out_q) {
     const bool ok = sc_is_canonical(sig_s);
-    uint32_t hr[8], sr[9];
-    sc_recode8(h, hr);
-    sc_recode_w(sig_s, sr);
+    uint32_t hr[9], sr[9];
+    sc_recode_t<KT_W, KT_PARTS>(h, hr);
+    sc_recode_t<BT_W, BT_PARTS>(sig_s, sr);
     ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
     // not unrolled on the device: entries prefetched several at a time would spill
 #pragma unroll 1
     for (int k = 0; k < KT_PARTS; k++)
-        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(hr, k))));
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + (int64_t)k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<KT_W>(hr, k))));
 #pragma unroll 1
     for (int k = 0; k < BT_PARTS - 1; k++)
-        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_w(sr, k))));
-    const ge_p2 q = p1p1_to_p2(ge_madd(p, keytable_pick(b_tab + (int64_t)(BT_PARTS - 1) * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_w(sr, BT_PARTS - 1))));
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<BT_W>(sr, k))));
+    const ge_p2 q = p1p1_to_p2(ge_madd(p, keytable_pick(b_tab + (int64_t)(BT_PARTS - 1) * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<BT_W>(sr, BT_PARTS - 1))));
     if (DEFER) {
         *out_q = q;
         return ok;
@@ -330,17 +331,16 @@ BSX_HDI bool ed25519_verify_keyed_core(const int32_t* key_tab, const int32_t* b_
 // additions to join, kernels_ed.hip) at 20 % more total work: the form for small batches, where latency is all there is.
 template <int SPLIT>
 BSX_HDI ge_p3 ed25519_keyed_partial(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_s[8], const uint32_t h[8], int part0) {
-    static_assert(KT_PARTS % SPLIT == 0 && BT_PARTS % SPLIT == 0, "parts must split evenly");
-    uint32_t hr[8], sr[9];
-    sc_recode8(h, hr);
-    sc_recode_w(sig_s, sr);
+    uint32_t hr[9], sr[9];
+    sc_recode_t<KT_W, KT_PARTS>(h, hr);
+    sc_recode_t<BT_W, BT_PARTS>(sig_s, sr);
     ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
 #pragma unroll 1
     for (int k = part0; k < KT_PARTS; k += SPLIT)
-        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit8(hr, k))));
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + (int64_t)k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<KT_W>(hr, k))));
 #pragma unroll 1
     for (int k = part0; k < BT_PARTS; k += SPLIT)
-        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_w(sr, k))));
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<BT_W>(sr, k))));
     return p;
 }
 

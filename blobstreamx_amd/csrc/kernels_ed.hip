@@ -6,10 +6,10 @@
 //   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, records staged via LDS
 //   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
 //   k_keytable_check / k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed / k_ed25519_finish
-//                       P7, fixed-key form: per-validator tables of j*(-2^(8k) A) (k = 0..31, j = 1..128, affine), rows kept
-//                           across calls and rebuilt only when their key changes, and the same table of B (k_btable_bases,
-//                           per context); a signature is 64 mixed additions of table entries picked by the signed
-//                           radix-256 digits of h and s; optionally the point encodings go through a per-lane batch
+//                       P7, fixed-key form: per-validator tables of j*(-2^(12k) A) (k = 0..21, j = 1..2048, affine), rows kept
+//                           across calls and rebuilt only when their key changes, and a 16-bit-digit table of B
+//                           (k_btable_bases, per context; both filled by k_table_entries); a signature is 22 + 16 mixed
+//                           additions of table entries picked by the signed digits of h and s; optionally the point encodings go through a per-lane batch
 //                           inversion (k_ed25519_finish); slots whose key is not the table row's key are deferred to
 //                           k_ed25519_verify<true> (same accept set)
 //   k_skip_eval         operator skip-target search (fetcher.rs:60-87): is_valid_skip of every candidate in one launch
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validat
 
 // ------------------------------------------------------------------------------------------------ fixed-key tables
 // Key table in HBM (bsx_ed25519_keytable_bytes): [n_keys x 64 B key records: pubkey, decodes flag]
-//                                                [n_keys x KT_PARTS x 40 i32 base points -2^(8k) A (X, Y, Z, T)]
-//                                                [n_keys x KT_PARTS x 128 x 32 i32 affine multiples, one cache line each]
+//                                                [n_keys x KT_PARTS x 40 i32 base points -2^(W k) A (X, Y, Z, T)]
+//                                                [n_keys x KT_PARTS x 2^(W-1) x 32 i32 affine multiples, one cache line each]
 constexpr uint64_t KT_REC_BYTES = 64, KT_BASE_I32 = 40 * KT_PARTS;
 __host__ __device__ inline uint64_t kt_bases_off(uint64_t n_keys) { return n_keys * KT_REC_BYTES; }
 // entries start on a cache line (the table itself must: hipMalloc / torch / arena allocations are 256-byte aligned)
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_check(const bsx_validat
     reinterpret_cast<uint32_t*>(rec + 3)[2] = (force || !same) ? 1u : 0u;
 }
 
-// decode, negate, and run the 31 x 8 doublings that give the base points of the upper scalar parts; row k of `table`
+// decode, negate, and run the (KT_PARTS - 1) x KT_W doublings that give the base points of the upper digit positions; row k of `table`
 __device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint32_t k, uint32_t n_keys, uint8_t* __restrict__ table) {
     ge_p3 b;
     const bool ok = ge_frombytes_negate(b, pk);
@@ -144,7 +144,7 @@ __device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint3
     int32_t* dst = reinterpret_cast<int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)k * KT_BASE_I32;
 #pragma unroll 1
     for (int half = 0; half < KT_PARTS; half++) {          // one base point live at a time (40 VGPRs), stored as it is produced
-        if (half) b = ge_keytable_next_base(b);
+        if (half) b = ge_keytable_next_base(b, KT_W);
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             dst[half * 40 + i] = b.X.v[i];
@@ -188,12 +188,29 @@ __global__ void k_btable_bases(uint8_t* __restrict__ table) {
         }
     }
 }
-// one lane per (part, j)
-__global__ __launch_bounds__(ED_THREADS) void k_btable_entries(uint8_t* __restrict__ table) {
-    const uint32_t idx = blockIdx.x * ED_THREADS + threadIdx.x;
-    if (idx >= (uint32_t)BT_PARTS * BT_HALF_ENTRIES) return;
-    const uint32_t part = idx / BT_HALF_ENTRIES, j = idx % BT_HALF_ENTRIES + 1;
-    const int32_t* src = reinterpret_cast<const int32_t*>(table) + part * 40;
+// Table entries, for key tables and the table of B alike.  Row = one (point, part) pair with its base point 2^(W part) P
+// in `bases`; its 2^(W-1) entries j * base are produced KB_G at a time per lane: the group's first multiple by a uniform
+// double-and-add, the rest by repeated addition, and ONE field inversion per group turns them affine (Montgomery's trick:
+// prefix products of the Z's — kept in LDS, one column per lane — then 1/Z_j = inv * prefix_(j-1), inv *= Z_j walking back).
+// ~43 multiplications per entry instead of the ~420 of a double-and-add plus an inversion of its own per entry: that
+// is what makes 12- and 16-bit digit tables (45,056 / 524,288 entries per point) cheap to build.
+constexpr int KB_G = 16;
+struct TableBuildArgs {
+    const int32_t* bases;       // [n_rows][40]
+    int32_t* entries;           // [n_rows][half][32]
+    const uint8_t* recs;        // key records (dirty flag at dword 14), or null: build every row
+    uint32_t n_rows, parts, half, bits;
+};
+__global__ __launch_bounds__(ED_THREADS) void k_table_entries(TableBuildArgs a) {
+    __shared__ int32_t pre[KB_G * 10 * ED_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t gl = (uint64_t)blockIdx.x * ED_THREADS + tid;
+    const uint32_t groups = a.half / KB_G;
+    const uint64_t row = gl / groups;
+    const uint32_t g = (uint32_t)(gl % groups);
+    if (row >= a.n_rows) return;
+    if (a.recs && reinterpret_cast<const uint32_t*>(a.recs + (row / a.parts) * KT_REC_BYTES)[14] == 0) return;   // clean row
+    const int32_t* src = a.bases + row * 40;
     ge_p3 base;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
@@ -202,27 +219,36 @@ __global__ __launch_bounds__(ED_THREADS) void k_btable_entries(uint8_t* __restri
         base.Z.v[i] = src[20 + i];
         base.T.v[i] = src[30 + i];
     }
-    const ge_precomp e = ge_keytable_entry(base, (int)j, BT_W);
-    precomp_store(reinterpret_cast<int32_t*>(table + bt_entries_off()) + (uint64_t)idx * KT_ENTRY_I32, e);
-}
-
-// one lane per (key, part, j): j * base in affine form
-__global__ __launch_bounds__(ED_THREADS) void k_keytable_entries(uint32_t n_keys, uint8_t* __restrict__ table) {
-    const uint32_t idx = blockIdx.x * ED_THREADS + threadIdx.x;
-    if (idx >= n_keys * (uint32_t)KT_PARTS * KT_HALF_ENTRIES) return;
-    const uint32_t kh = idx / KT_HALF_ENTRIES, j = idx % KT_HALF_ENTRIES + 1;
-    if (reinterpret_cast<const uint32_t*>(table + (uint64_t)(kh / KT_PARTS) * KT_REC_BYTES)[14] == 0) return;   // clean row
-    const int32_t* src = reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)kh * 40;
-    ge_p3 base;
+    int32_t* out = a.entries + (row * a.half + (uint64_t)g * KB_G) * KT_ENTRY_I32;
+    ge_p3 acc = ge_mul_small(base, (int)(g * KB_G + 1), (int)a.bits);
+    const ge_cached cb = p3_to_cached(base);
+    fe prod = fe_one();
+#pragma unroll 1
+    for (int j = 0; j < KB_G; j++) {
+        int32_t* d = out + j * KT_ENTRY_I32;
 #pragma unroll
-    for (int i = 0; i < 10; i++) {
-        base.X.v[i] = src[i];
-        base.Y.v[i] = src[10 + i];
-        base.Z.v[i] = src[20 + i];
-        base.T.v[i] = src[30 + i];
+        for (int i = 0; i < 10; i++) { d[i] = acc.X.v[i]; d[10 + i] = acc.Y.v[i]; d[20 + i] = acc.Z.v[i]; }
+        prod = fe_mul(prod, acc.Z);
+#pragma unroll
+        for (int i = 0; i < 10; i++) pre[(j * 10 + i) * ED_THREADS + tid] = prod.v[i];
+        if (j + 1 < KB_G) acc = p1p1_to_p3(ge_add(acc, cb));
     }
-    const ge_precomp e = ge_keytable_entry(base, (int)j);
-    precomp_store(reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)idx * KT_ENTRY_I32, e);
+    fe inv = fe_invert(prod);
+#pragma unroll 1
+    for (int j = KB_G - 1; j >= 0; j--) {
+        int32_t* d = out + j * KT_ENTRY_I32;
+        fe X, Y, Z, zi = inv;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { X.v[i] = d[i]; Y.v[i] = d[10 + i]; Z.v[i] = d[20 + i]; }
+        if (j > 0) {
+            fe p;
+#pragma unroll
+            for (int i = 0; i < 10; i++) p.v[i] = pre[((j - 1) * 10 + i) * ED_THREADS + tid];
+            zi = fe_mul(inv, p);
+        }
+        inv = fe_mul(inv, Z);
+        precomp_store(d, ge_to_precomp(X, Y, zi));
+    }
 }
 
 // one lane per validator slot; slot (me % v_max) uses key table row (me % v_max) when the record's public key is the
@@ -757,16 +783,20 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
     static const uint32_t force = getenv("BSX_KEYTABLE_REUSE") && atol(getenv("BSX_KEYTABLE_REUSE")) == 0 ? 1u : 0u;
     hipLaunchKernelGGL(k_keytable_check, dim3((n_keys + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, vals, n_keys, table, force);
     hipLaunchKernelGGL(k_keytable_bases, dim3((n_keys + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, vals, n_keys, table);
-    const uint32_t n_entries = n_keys * (uint32_t)KT_PARTS * KT_HALF_ENTRIES;
-    hipLaunchKernelGGL(k_keytable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, n_keys, table);
+    TableBuildArgs a{reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)), reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)), table,
+                     n_keys * (uint32_t)KT_PARTS, (uint32_t)KT_PARTS, (uint32_t)KT_HALF_ENTRIES, (uint32_t)KT_W};
+    const uint64_t lanes = (uint64_t)a.n_rows * (KT_HALF_ENTRIES / KB_G);
+    hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, a);
     return hipGetLastError();
 }
 // the B table of a context (bsxk_ed25519_btable_bytes() bytes, 128-byte aligned): built once, on `s`
 uint64_t bsxk_ed25519_btable_bytes() { return bt_bytes(); }
 hipError_t bsxk_ed25519_btable(hipStream_t s, uint8_t* table) {
     hipLaunchKernelGGL(k_btable_bases, dim3(1), dim3(64), 0, s, table);
-    const uint32_t n_entries = (uint32_t)BT_PARTS * BT_HALF_ENTRIES;
-    hipLaunchKernelGGL(k_btable_entries, dim3((n_entries + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, table);
+    TableBuildArgs a{reinterpret_cast<const int32_t*>(table), reinterpret_cast<int32_t*>(table + bt_entries_off()), nullptr,
+                     (uint32_t)BT_PARTS, (uint32_t)BT_PARTS, (uint32_t)BT_HALF_ENTRIES, (uint32_t)BT_W};
+    const uint64_t lanes = (uint64_t)a.n_rows * (BT_HALF_ENTRIES / KB_G);
+    hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, a);
     return hipGetLastError();
 }
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t n) { return n * ED_SLOT_I32 * 4; }

@@ -421,10 +421,11 @@ int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
                            uint64_t n, uint8_t* d_ok);
 /* P7, fixed-key form.  A range batch is signed by one validator set, so the per-key work of P7 (decoding A and its
  * multiples table) is done once per key instead of once per signature.  bsx_dev_ed25519_keytable builds the table
- * for the public keys of d_validators[0..n_keys) into d_table (bsx_ed25519_keytable_bytes(n_keys) bytes — 517 KB per key:
- * j * 2^(8k) * (-A), k < 32, j <= 128, affine, one cache line per entry — 128-byte aligned); the same table of the base
- * point B belongs to the context (built by bsx_init).  bsx_dev_ed25519_verify_keyed then checks n = n_commits*v_max slots,
- * slot i of every commit against table row i: 64 mixed point additions per signature, no doubling, no decompression.  A slot whose public key differs from its table row (validator-set change inside the batch, or
+ * for the public keys of d_validators[0..n_keys) into d_table (bsx_ed25519_keytable_bytes(n_keys) bytes — 5.8 MB per key:
+ * j * 2^(12k) * (-A), k < 22, j <= 2048, affine, one cache line per entry — 128-byte aligned; 2.2 ms for 100 keys); the
+ * table of the base point B (16-bit digits, 64 MB) belongs to the context (built by bsx_init).
+ * bsx_dev_ed25519_verify_keyed then checks n = n_commits*v_max slots, slot i of every commit against table row i:
+ * 22 + 16 mixed point additions per signature, no doubling, no decompression.  A slot whose public key differs from its table row (validator-set change inside the batch, or
  * i >= n_keys) is verified by the generic per-signature path inside the same kernel, so the accept set is
  * exactly bsx_dev_ed25519_verify's for any input.
  * d_table persists between calls: its first n_keys * 64 bytes (the key records) must be ZERO before the first call;

@@ -91,59 +91,47 @@ void hc_fe_invert(const uint8_t* a, uint8_t out[32]) {
     fe_tobytes(o, fe_invert(fe_frombytes(x)));
     memcpy(out, o, 32);
 }
-// fixed-key path: build the per-key table (and, once, the table of B from the encoding of -B) on the host exactly as
-// the precompute kernels do, then verify
-static bool hc_build_table(const uint32_t pk[8], int32_t* tab) {
+// fixed-key path: the table of a point (W-bit digits: parts x 2^(W-1) affine entries) built on the host by repeated
+// addition + one batch inversion per part — NOT the device's builder (double-and-add + an inversion per entry, a minute
+// per wide table on one host core): an independently built table under the device's verification code; the device-built
+// tables are checked by the GPU parity tests.  pk = encoding of the NEGATED point.
+static bool hc_build_table(const uint32_t pk[8], int32_t* tab, int W, int parts, int half) {
     ge_p3 base;
     const bool ok = ge_frombytes_negate(base, pk);
-    for (int part = 0; part < KT_PARTS; part++) {
-        if (part) base = ge_keytable_next_base(base);
-        for (int j = 1; j <= KT_HALF_ENTRIES; j++)
-            precomp_store(tab + (part * KT_HALF_ENTRIES + (j - 1)) * KT_ENTRY_I32, ge_keytable_entry(base, j));
+    std::vector<ge_p3> pts(half);
+    std::vector<fe> pre(half);
+    for (int part = 0; part < parts; part++) {
+        if (part) base = ge_keytable_next_base(base, W);
+        const ge_cached cb = p3_to_cached(base);
+        ge_p3 acc = base;
+        fe prod = fe_one();
+        for (int j = 0; j < half; j++) {          // pts[j] = (j + 1) * base
+            pts[j] = acc;
+            prod = fe_mul(prod, acc.Z);
+            pre[j] = prod;
+            acc = p1p1_to_p3(ge_add(acc, cb));
+        }
+        fe inv = fe_invert(prod);
+        for (int j = half - 1; j >= 0; j--) {
+            const fe zi = j ? fe_mul(inv, pre[j - 1]) : inv;
+            inv = fe_mul(inv, pts[j].Z);
+            const fe x = fe_mul(pts[j].X, zi), y = fe_mul(pts[j].Y, zi);
+            precomp_store(tab + ((size_t)part * half + j) * KT_ENTRY_I32, ge_precomp{fe_add(y, x), fe_sub(y, x), fe_mul(fe_mul(x, y), fe_d2())});
+        }
     }
     return ok;
 }
 int hc_ed25519_verify_keyed(const uint8_t* pk, const uint8_t* sig, const uint8_t* h) {
     uint32_t p[8], r[8], s[8], hh[8];
     load_le(p, pk, 32, 8); load_le(r, sig, 32, 8); load_le(s, sig + 32, 32, 8); load_le(hh, h, 32, 8);
-    // The table of B (64 MB at 16-bit digits) is built here by repeated addition + one batch inversion per part — NOT the
-    // device's builder (double-and-add + an inversion per entry, 60 s on one host core): an independently built table under
-    // the device's verification code; the device-built table is checked by the GPU parity tests.
-    static int32_t* btab = nullptr;
-    static const bool b_ok = [] {
-        btab = static_cast<int32_t*>(aligned_alloc(128, (size_t)BT_I32 * 4));
-        ge_p3 base;
-        const bool ok = ge_frombytes_negate(base, GE_NEG_B_ENC);
-        std::vector<ge_p3> pts(BT_HALF_ENTRIES);
-        std::vector<fe> pre(BT_HALF_ENTRIES);
-        for (int part = 0; part < BT_PARTS; part++) {
-            if (part) base = ge_keytable_next_base(base, BT_W);
-            const ge_cached cb = p3_to_cached(base);
-            ge_p3 acc = base;
-            fe prod = fe_one();
-            for (int j = 0; j < BT_HALF_ENTRIES; j++) {          // pts[j] = (j + 1) * base
-                pts[j] = acc;
-                prod = fe_mul(prod, acc.Z);
-                pre[j] = prod;
-                acc = p1p1_to_p3(ge_add(acc, cb));
-            }
-            fe inv = fe_invert(prod);
-            for (int j = BT_HALF_ENTRIES - 1; j >= 0; j--) {
-                const fe zi = j ? fe_mul(inv, pre[j - 1]) : inv;
-                inv = fe_mul(inv, pts[j].Z);
-                const fe x = fe_mul(pts[j].X, zi), y = fe_mul(pts[j].Y, zi);
-                precomp_store(btab + ((size_t)part * BT_HALF_ENTRIES + j) * KT_ENTRY_I32,
-                              ge_precomp{fe_add(y, x), fe_sub(y, x), fe_mul(fe_mul(x, y), fe_d2())});
-            }
-        }
-        return ok;
-    }();
+    static int32_t* btab = static_cast<int32_t*>(aligned_alloc(128, (size_t)BT_I32 * 4));
+    static const bool b_ok = hc_build_table(GE_NEG_B_ENC, btab, BT_W, BT_PARTS, BT_HALF_ENTRIES);
     // the table of the most recent key is kept (tables persist across calls on the device too; the tests mostly repeat a key)
-    alignas(16) static thread_local int32_t tab[KT_KEY_I32];
+    static thread_local int32_t* tab = static_cast<int32_t*>(aligned_alloc(128, (size_t)KT_KEY_I32 * 4));
     static thread_local uint32_t tab_pk[8];
     static thread_local int tab_state = -1;                   // -1 none, 0 key does not decode, 1 built
     if (tab_state < 0 || memcmp(tab_pk, p, 32) != 0) {
-        tab_state = hc_build_table(p, tab) ? 1 : 0;
+        tab_state = hc_build_table(p, tab, KT_W, KT_PARTS, KT_HALF_ENTRIES) ? 1 : 0;
         memcpy(tab_pk, p, 32);
     }
     if (!b_ok || tab_state != 1) return 0;
