@@ -99,12 +99,14 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validat
 
 // ------------------------------------------------------------------------------------------------ fixed-key tables
 // Key table in HBM (bsx_ed25519_keytable_bytes): [n_keys x 64 B key records: pubkey, decodes flag]
+//                                                [64 B table word: dword 0 = some row is dirty (k_keytable_check)]
 //                                                [n_keys x KT_PARTS x 40 i32 base points -2^(W k) A (X, Y, Z, T)]
 //                                                [n_keys x KT_PARTS x 2^(W-1) x 32 i32 affine multiples, one cache line each]
 constexpr uint64_t KT_REC_BYTES = 64, KT_BASE_I32 = 40 * KT_PARTS;
-__host__ __device__ inline uint64_t kt_bases_off(uint64_t n_keys) { return n_keys * KT_REC_BYTES; }
+__host__ __device__ inline uint64_t kt_flag_off(uint64_t n_keys) { return n_keys * KT_REC_BYTES; }
+__host__ __device__ inline uint64_t kt_bases_off(uint64_t n_keys) { return (n_keys + 1) * KT_REC_BYTES; }
 // entries start on a cache line (the table itself must: hipMalloc / torch / arena allocations are 256-byte aligned)
-__host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys) { return (n_keys * (KT_REC_BYTES + KT_BASE_I32 * 4) + 127) & ~127ull; }
+__host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys) { return (kt_bases_off(n_keys) + n_keys * KT_BASE_I32 * 4 + 127) & ~127ull; }
 __host__ __device__ inline uint64_t kt_bytes(uint64_t n_keys) { return kt_entries_off(n_keys) + n_keys * (uint64_t)KT_KEY_I32 * 4; }
 
 __device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) {
@@ -118,18 +120,27 @@ __device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) 
 // build kernels skip clean rows.  The reference's validator set is fixed per proof and changes on the chain's
 // unbonding time scale (header_range.rs:42-48 takes it from the trusted/target headers), so in steady state a step pays
 // one 100-lane compare instead of 192 serial point doublings per key — and a changed key costs exactly its own rebuild.
+// ONE workgroup: it also leaves "some row is dirty" in the table word, which lets every wave of the two build launches
+// leave after one (shared, cached) load in the steady state — their grids are sized for a full rebuild (4,400 waves at
+// V = 100), and a per-row flag load per wave cost 0.17 ms beside an expansion.
 constexpr uint32_t KT_MAGIC = 0x4b54324bu;
-__global__ __launch_bounds__(ED_THREADS) void k_keytable_check(const bsx_validator* __restrict__ vals, uint32_t n_keys,
+constexpr int KC_THREADS = 256;
+__global__ __launch_bounds__(KC_THREADS) void k_keytable_check(const bsx_validator* __restrict__ vals, uint32_t n_keys,
                                                                uint8_t* __restrict__ table, uint32_t force) {
-    const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
-    if (k >= n_keys) return;
-    uint32_t pk[8];
-    load_pk(vals + k, pk);
-    uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
-    const uint4 k0 = rec[0], k1 = rec[1], tag = rec[3];
-    const bool same = tag.x == KT_MAGIC && tag.y == n_keys && k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] &&
-                      k1.x == pk[4] && k1.y == pk[5] && k1.z == pk[6] && k1.w == pk[7];
-    reinterpret_cast<uint32_t*>(rec + 3)[2] = (force || !same) ? 1u : 0u;
+    int any = 0;
+    for (uint32_t k = threadIdx.x; k < n_keys; k += KC_THREADS) {
+        uint32_t pk[8];
+        load_pk(vals + k, pk);
+        uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
+        const uint4 k0 = rec[0], k1 = rec[1], tag = rec[3];
+        const bool same = tag.x == KT_MAGIC && tag.y == n_keys && k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] &&
+                          k1.x == pk[4] && k1.y == pk[5] && k1.z == pk[6] && k1.w == pk[7];
+        const uint32_t dirty = (force || !same) ? 1u : 0u;
+        reinterpret_cast<uint32_t*>(rec + 3)[2] = dirty;
+        any |= (int)dirty;
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(table + kt_flag_off(n_keys)) = any ? 1u : 0u;
 }
 
 // decode, negate, and run the (KT_PARTS - 1) x KT_W doublings that give the base points of the upper digit positions; row k of `table`
@@ -159,6 +170,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validat
                                                                uint8_t* __restrict__ table) {
     const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
     if (k >= n_keys) return;
+    if (*reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)) == 0) return;      // nothing to rebuild
     if (reinterpret_cast<const uint32_t*>(table + k * KT_REC_BYTES)[14] == 0) return;      // clean row (k_keytable_check)
     uint32_t pk[8];
     load_pk(vals + k, pk);
@@ -199,6 +211,7 @@ struct TableBuildArgs {
     const int32_t* bases;       // [n_rows][40]
     int32_t* entries;           // [n_rows][half][32]
     const uint8_t* recs;        // key records (dirty flag at dword 14), or null: build every row
+    const uint32_t* any_dirty;  // with recs: the table word, 0 = no row is dirty
     uint32_t n_rows, parts, half, bits;
 };
 __global__ __launch_bounds__(ED_THREADS) void k_table_entries(TableBuildArgs a) {
@@ -209,6 +222,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_table_entries(TableBuildArgs a) 
     const uint64_t row = gl / groups;
     const uint32_t g = (uint32_t)(gl % groups);
     if (row >= a.n_rows) return;
+    if (a.any_dirty && *a.any_dirty == 0) return;
     if (a.recs && reinterpret_cast<const uint32_t*>(a.recs + (row / a.parts) * KT_REC_BYTES)[14] == 0) return;   // clean row
     const int32_t* src = a.bases + row * 40;
     ge_p3 base;
@@ -781,10 +795,10 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
     if (n_keys == 0) return hipSuccess;
     // BSX_KEYTABLE_REUSE=0 forces a full rebuild on every call (cold-build measurements)
     static const uint32_t force = getenv("BSX_KEYTABLE_REUSE") && atol(getenv("BSX_KEYTABLE_REUSE")) == 0 ? 1u : 0u;
-    hipLaunchKernelGGL(k_keytable_check, dim3((n_keys + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, vals, n_keys, table, force);
+    hipLaunchKernelGGL(k_keytable_check, dim3(1), dim3(KC_THREADS), 0, s, vals, n_keys, table, force);
     hipLaunchKernelGGL(k_keytable_bases, dim3((n_keys + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, vals, n_keys, table);
     TableBuildArgs a{reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)), reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)), table,
-                     n_keys * (uint32_t)KT_PARTS, (uint32_t)KT_PARTS, (uint32_t)KT_HALF_ENTRIES, (uint32_t)KT_W};
+                     reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)), n_keys * (uint32_t)KT_PARTS, (uint32_t)KT_PARTS, (uint32_t)KT_HALF_ENTRIES, (uint32_t)KT_W};
     const uint64_t lanes = (uint64_t)a.n_rows * (KT_HALF_ENTRIES / KB_G);
     hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, a);
     return hipGetLastError();
@@ -793,7 +807,7 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
 uint64_t bsxk_ed25519_btable_bytes() { return bt_bytes(); }
 hipError_t bsxk_ed25519_btable(hipStream_t s, uint8_t* table) {
     hipLaunchKernelGGL(k_btable_bases, dim3(1), dim3(64), 0, s, table);
-    TableBuildArgs a{reinterpret_cast<const int32_t*>(table), reinterpret_cast<int32_t*>(table + bt_entries_off()), nullptr,
+    TableBuildArgs a{reinterpret_cast<const int32_t*>(table), reinterpret_cast<int32_t*>(table + bt_entries_off()), nullptr, nullptr,
                      (uint32_t)BT_PARTS, (uint32_t)BT_PARTS, (uint32_t)BT_HALF_ENTRIES, (uint32_t)BT_W};
     const uint64_t lanes = (uint64_t)a.n_rows * (BT_HALF_ENTRIES / KB_G);
     hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, a);
