@@ -3,7 +3,7 @@
 // circuits/next_header.rs:32-36; circuit body [UPSTREAM] tendermintx v1.0.0; host twin is_valid_skip,
 // circuits/fetcher.rs:76-80).
 //
-//   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, records staged via LDS
+//   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, one message block resident at a time
 //   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
 //   k_keytable_check / k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed / k_ed25519_finish
 //                       P7, fixed-key form: per-validator tables of j*(-2^(12k) A) (k = 0..21, j = 1..2048, affine), rows kept
@@ -29,32 +29,54 @@
 namespace bsx {
 
 // ------------------------------------------------------------------------------------------------ k_sha512_challenge
+// One lane per validator slot, each reading its own 256-byte record (every fetched line is consumed by the lane that
+// fetched it).  The two blocks of R ‖ A ‖ M are built one after the other — the second half of the message is loaded after the
+// first compression — so that the lane holds one block of message at a time: 96 VGPRs instead of 144 + spills for the
+// whole padded stream, and no LDS (the round-1 version staged the records through 31 KB of LDS per 128 lanes, which held the
+// kernel to 2.5 waves per SIMD).
 constexpr int CH_THREADS = 128;
-constexpr int CH_BYTES = 240, CH_STRIDE = 61;   // staged bytes per record, LDS dwords per record (odd)
 
 __global__ __launch_bounds__(CH_THREADS) void k_sha512_challenge(const bsx_validator* __restrict__ vals, uint64_t n,
                                                                  uint8_t* __restrict__ out_h, uint8_t* __restrict__ out_digest) {
-    __shared__ uint32_t lds[CH_THREADS * CH_STRIDE];
-    const int tid = threadIdx.x;
-    const uint64_t base = (uint64_t)blockIdx.x * CH_THREADS, me = base + tid;
-    for (int c = tid; c < CH_THREADS * (CH_BYTES / 16); c += CH_THREADS) {
-        const int vl = c / (CH_BYTES / 16), piece = c % (CH_BYTES / 16);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (base + vl < n) v = reinterpret_cast<const uint4*>(vals + base + vl)[piece];
-        uint32_t* d = lds + vl * CH_STRIDE + piece * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
+    const uint64_t me = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
     if (me >= n) return;
-    const uint32_t* my = lds + tid * CH_STRIDE;
-    uint32_t a[8], r[8], m[31], dig[16], h[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { a[k] = my[k]; r[k] = my[8 + k]; }
-#pragma unroll
-    for (int k = 0; k < 31; k++) m[k] = my[24 + k];
-    int len = (int)my[55];
+    const uint4* rec = reinterpret_cast<const uint4*>(vals + me);       // pubkey 0, R 32, s 64, message 96..219, message_len 220
+    int len = (int)rec[13].w;
     if (len > BSX_VALIDATOR_MSG_MAX) len = BSX_VALIDATOR_MSG_MAX;
-    sha512_ram(r, a, m, len, dig);
+    const uint64_t bits = (uint64_t)(64 + len) * 8;
+    const bool two = (64 + len) >= 112;                                 // 0x80 + 16-byte length no longer fit the first block
+    uint64_t st[8], w[16];
+    sha512_init(st);
+    {
+        const uint4 a0 = rec[0], a1 = rec[1], r0 = rec[2], r1 = rec[3];
+        const uint32_t ra[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = ((uint64_t)bswap32(ra[2 * k]) << 32) | bswap32(ra[2 * k + 1]);
+        const uint4 m0 = rec[6], m1 = rec[7], m2 = rec[8], m3 = rec[9];
+        const uint32_t m[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            w[8 + k] = ((uint64_t)bswap32(sha512_ram_m_dword(m[2 * k], 2 * k, len)) << 32) | bswap32(sha512_ram_m_dword(m[2 * k + 1], 2 * k + 1, len));
+        if (!two) w[15] = bits;
+        sha512_compress(st, w);
+    }
+    if (two) {
+        const uint4 m4 = rec[10], m5 = rec[11], m6 = rec[12], m7 = rec[13];
+        const uint32_t m[16] = {m4.x, m4.y, m4.z, m4.w, m5.x, m5.y, m5.z, m5.w, m6.x, m6.y, m6.z, m6.w, m7.x, m7.y, m7.z, 0u};   // dword 31 is message_len
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            w[k] = ((uint64_t)bswap32(sha512_ram_m_dword(m[2 * k], 16 + 2 * k, len)) << 32) | bswap32(sha512_ram_m_dword(m[2 * k + 1], 17 + 2 * k, len));
+#pragma unroll
+        for (int k = 8; k < 15; k++) w[k] = 0;
+        w[15] = bits;
+        sha512_compress(st, w);
+    }
+    uint32_t dig[16], h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        dig[2 * k] = bswap32((uint32_t)(st[k] >> 32));
+        dig[2 * k + 1] = bswap32((uint32_t)st[k]);
+    }
     sc_reduce64(dig, h);
     uint4* oh = reinterpret_cast<uint4*>(out_h + me * 32);
     oh[0] = make_uint4(h[0], h[1], h[2], h[3]);

@@ -65,20 +65,21 @@ BSX_HDI void sha512_compress(uint64_t st[8], uint64_t w[16]) {
 // Inputs as little-endian dwords: r[8], a[8], m[31] (message bytes beyond len are ignored).
 // 64 + len <= 188 bytes -> always exactly 2 blocks (64+len+17 <= 256, and 64+len+17 > 128 iff len >= 48;
 // shorter messages take 1 block: handled).
+// dword j of the M part of the padded byte stream: message bytes below len, the 0x80 terminator, zeros above
+BSX_HDI uint32_t sha512_ram_m_dword(uint32_t d, int j, int len) {
+    const int rr = len - 4 * j;
+    const uint32_t keep = (rr >= 4) ? 0xffffffffu : (rr <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rr)));
+    uint32_t v = d & keep;
+    if (rr >= 0 && rr < 4) v |= 0x80u << (8 * rr);
+    return v;
+}
 BSX_HDI void sha512_ram(const uint32_t r[8], const uint32_t a[8], const uint32_t* m, int len, uint32_t out_le[16]) {
     // byte stream as LE dwords: 16 dwords of R‖A, then up to 31 of M, then padding
     uint32_t s[64];
 #pragma unroll
     for (int i = 0; i < 8; i++) { s[i] = r[i]; s[8 + i] = a[i]; }
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        uint32_t d = (j < 31) ? m[j] : 0u;
-        int rr = len - 4 * j;
-        uint32_t keep = (rr >= 4) ? 0xffffffffu : (rr <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rr)));
-        uint32_t v = d & keep;
-        if (rr >= 0 && rr < 4) v |= 0x80u << (8 * rr);
-        s[16 + j] = v;
-    }
+    for (int j = 0; j < 32; j++) s[16 + j] = sha512_ram_m_dword((j < 31) ? m[j] : 0u, j, len);
 #pragma unroll
     for (int j = 48; j < 64; j++) s[j] = 0;
     const uint64_t bits = (uint64_t)(64 + len) * 8;
