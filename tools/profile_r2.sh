@@ -37,4 +37,6 @@ python tools/pmc_summary.py $(find $O/pmcSQ -name "*counter_collection.csv") > $
 ./tools/microbench_alu > $O/r2_microbench_alu.txt 2>&1
 ./tools/microbench > $O/r2_microbench.txt 2>&1
 rm -rf $O/kt $O/kt1024 $O/ktS $O/pmc_* $O/pmc1024_* $O/pmcS $O/pmcSQ     # raw traces stay on the box (size)
+# 8. the other profile scripts: Poseidon kernels, compact-only pipeline, one host-tier call, headline timeline
+for s in profile_r2_poseidon profile_r2_compact profile_latency profile_headline_timeline; do bash tools/$s.sh > $O/$s.log 2>&1; done
 ls -la $O
