@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--mode", choices=["F", "S"], default="F", help="F: one commit per range (a reference proof); S: a commit on every header")
     ap.add_argument("--event-every", type=int, default=1, help="record the per-kernel HIP events on every n-th timed step")
     ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
+    ap.add_argument("--alternate", type=int, default=1, help="K engine sets over the same ranges stepped in turn (pipelining across steps; the compact-only leg uses 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only: none of the secondary objects")
@@ -485,7 +486,11 @@ def main():
     w = synth.Workload(4, R * world, J, B, v=V)          # config #4 seed; identical on every rank
     t_gen = time.perf_counter() - t0
     E = args.engines
-    eng = PipelinedEngines(J, B, V, R, n_engines=E, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
+    if args.alternate > 1:
+        from blobstreamx_amd.engine import AlternatingPipelines
+        eng = AlternatingPipelines(args.alternate, J, B, V, R, n_engines=E, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
+    else:
+        eng = PipelinedEngines(J, B, V, R, n_engines=E, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
     eng.upload_workload(w)
 
     # correctness gate before timing: statuses clean, public output = (target header hash, commitment) for every owned range
@@ -569,7 +574,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"header_range_{J * B} ({J} map jobs x {B} headers), {V} validators, mode F (one target commit per range), "
                                    f"{R} ranges per GPU per step, Goldilocks witness {'off' if args.no_witness else 'materialised'}",
-                       "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": E,
+                       "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": E, "alternating_engine_sets": args.alternate,
                        "parallelism": (f"{world} x ({J // world} of {J} map jobs = {J * B // world} headers of every range), 1 all-gather of 128-B "
                                        f"records per chunk; {'strong: ' + str(R * world) + ' ranges in total' if strong else 'weak: ' + str(R) + ' ranges per GPU'}")
                        if world > 1 else "1 GPU",
@@ -633,7 +638,8 @@ def main():
                 out["stress"] = {"v100": stress(args, dev, 100, 6.0), "v512": stress(args, dev, 512, 6.0)}
             # one chunk per step: without an expansion to run beside there is nothing to pipeline against, and a chunk of 256
             # ranges quantises better (8196 header groups on 4096 wave slots) than two of 128
-            d, err = subprocess_leg(args, ["--no-witness", "--engines", "1"])
+            # ... and two engine sets stepped in turn: step i + 1 starts while step i's chain of small kernels drains
+            d, err = subprocess_leg(args, ["--no-witness", "--engines", "1", "--alternate", "2"])
             out["compact_only"] = {"error": err} if d is None else {
                 "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                 "prove_subchain_ms": d["kernels"][0]["avg_launch_ms"], "sha256_compressions_per_s_prove_subchain": d["kernels"][0]["sha256_compressions_per_s"],
@@ -642,7 +648,7 @@ def main():
                 "sha256_compressions_per_s_whole_step": d["value"] * (41 + d["kernels"][0]["sha256_compressions_executed_per_slot"]),
                 "frac_of_measured_alu_peak_whole_step": d["value"] * (41 + d["kernels"][0]["sha256_compressions_executed_per_slot"]) / PEAK["sha256_compress_per_s"],
                 "reference_equivalent_compressions_per_s_whole_step": d["value"] * (41 + 23),
-                "note": "no Goldilocks expansion, one chunk per step: header hashing (41 compressions/header) + prove_subchain + commit check "
+                "note": "no Goldilocks expansion, one chunk per step, two engine sets stepped in turn: header hashing (41 compressions/header) + prove_subchain + commit check "
                         "(Ed25519, SHA-512) on the side stream; fractions are of the measured 27.7 G/s SHA-256 ceiling; the step is bounded by "
                         "the commit check's latency chain, not by the ALUs (DESIGN.md)"}
             if (J, B) == (32, 64):
