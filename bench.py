@@ -57,7 +57,7 @@ PEAK = {"sha256_compress_per_s": 27.7e9, "sha512_compress_per_s": 6.40e9, "fe255
 # digits of h for the key, 16 radix-65536 digits of s for B): 38 mixed additions (3 + 4 mul each, the last one 3 + 3), no
 # doubling + encoding.
 # With the batch-inversion scratch (k_ed25519_finish) the encoding costs 5 multiplications per signature plus one
-# inversion (254 sq + 11 mul) per 8 / 16 signatures — counted at 16.
+# inversion (254 sq + 11 mul) per 8 / 16 / 32 signatures — counted at 16.
 FE_MUL_PER_VERIFY = 38 * 7 - 1 + 5 + 11 / 16
 FE_SQ_PER_VERIFY = 254 / 16
 # the ALU ceiling those counts imply: every multiplication at the measured fe_mul rate, every squaring at the fe_sq rate
@@ -276,7 +276,7 @@ def stress(args, dev, V, cpu_seconds):
                          "keytable_cold_build": cold[1]},
             "ed25519_path": "fixed-key affine tables: 22 radix-4096 digits of h for every validator key (5.8 MB per key), 16 radix-65536 digits of "
                             "s for B (64 MB) = 38 mixed additions, no doubling; table rows reused while the validator set is unchanged; "
-                            "encodings through per-lane Montgomery batch inversion (8 / 16 signatures per inversion)",
+                            "encodings through per-lane Montgomery batch inversion (8 / 16 / 32 signatures per inversion)",
             "roofline": {"kernel": "k_ed25519_verify_keyed", "bound": "valu", "unit": "M Ed25519 verifications/s",
                          "achieved": ver_per_s / 1e6, "peak": PEAK_KEYED_VERIFIES_PER_S / 1e6, "frac": ver_per_s / PEAK_KEYED_VERIFIES_PER_S,
                          "avg_launch_ms": t_ed, "traffic": None,

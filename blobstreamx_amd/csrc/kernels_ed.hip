@@ -291,9 +291,9 @@ __global__ __launch_bounds__(ED_THREADS) void k_table_entries(TableBuildArgs a) 
 // table's key, and falls back to the generic per-signature path otherwise (a validator-set change inside the batch)
 // scratch slot of the deferred-encode form: X, Y, Z (10 limbs each), prefix product (10), = 160 bytes per signature
 constexpr uint32_t ED_SLOT_I32 = 40;
-// signatures per lane of k_ed25519_finish (one inversion amortised over K): 8 keeps enough lanes busy at a few 100 k
-// signatures (160 vs 158 M verifies/s at 204,800), 16 amortises better at a million (233 vs 221 M/s)
-__host__ __device__ inline uint32_t ed_fin_k(uint64_t n) { return n >= 400000 ? 16u : 8u; }
+// signatures per lane of k_ed25519_finish (one inversion amortised over K), measured with the 38-addition signature kernel
+// (M verifies/s, K = 2 / 4 / 8 / 16 / 32): 204,800 signatures 269 / 296 / 325 / 310 / 280, 1,048,576: 406 / 462 / 470 / 476 / 492
+__host__ __device__ inline uint32_t ed_fin_k(uint64_t n) { return n >= 800000 ? 32u : n >= 400000 ? 16u : 8u; }
 // below this many signatures a verification is spread over 4 lanes (k_ed25519_verify_keyed SPLIT)
 constexpr uint64_t ED_SPLIT_BELOW = 300000;
 // Lane order.  Signature me = commit * v_max + slot.  With many commits the lanes of a wave take 64 COMMITS of ONE slot
@@ -868,7 +868,8 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     }
 #undef BSX_LAUNCH_KEYED
     if (scr) {
-        const uint32_t K = ed_fin_k(n);
+        static const long env_k = getenv("BSX_ED_FIN_K") ? atol(getenv("BSX_ED_FIN_K")) : 0;     // experiments
+        const uint32_t K = env_k > 0 ? (uint32_t)env_k : ed_fin_k(n);
         const uint64_t lanes = (n + K - 1) / K;
         hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
     }
