@@ -99,3 +99,38 @@ def test_engine_fuzz_sharded_shapes(seed):
         for r in range(R * world):
             full = oracle.expand_witness(ml, J, refs[r][1]["compact"])
             assert (wm[r * nm:(r + 1) * nm] == full[g * nm:(g + 1) * nm]).all(), (seed, g, r, world, J, B, n_blocks)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BSX_COMMIT_FUZZ_SEEDS", "10"))))
+def test_verify_commits_fuzz(seed):
+    """Random validator-set sizes and commit counts around the points where the fixed-key signature kernel changes form
+    (signature-major / key-major lane order at 8 and 32 commits; table path from 8 commits on in the host tier), random
+    absent / nil / tampered votes and keys that differ from their table row: per-signature verdicts and every commit
+    result against the oracle."""
+    from blobstreamx_amd.builder import verify_commits
+    rng = np.random.default_rng(9000 + seed)
+    v_max = int(rng.choice([1, 3, 8, 21, 64, 100, 130]))
+    v = int(rng.integers(1, v_max + 1))
+    nc = int(rng.choice([1, 2, 7, 8, 9, 31, 32, 33, 70]))
+    w = synth.Workload(300 + seed, nc, 1, 2, v=v, v_max=v_max, absent_permille=int(rng.choice([0, 100, 500])),
+                       nil_permille=int(rng.choice([0, 200])))
+    vals = w.validators.copy()
+    hh = w.commit_hashes.copy()
+    for _ in range(int(rng.integers(0, 2 * nc + 1))):
+        c, k = int(rng.integers(0, nc)), int(rng.integers(0, v_max))
+        what = int(rng.integers(0, 4))
+        if what == 0:
+            vals[c, k]["signature"][int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+        elif what == 1:
+            vals[c, k]["pubkey"][int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))      # differs from the table row
+        elif what == 2:
+            vals[c, k]["message"][int(rng.integers(0, 60))] ^= 1 << int(rng.integers(0, 8))
+        else:
+            vals[c, k] = vals[int(rng.integers(0, nc)), int(rng.integers(0, v_max))]               # another slot's record
+    res, ok = verify_commits(vals, hh)
+    for c in range(nc):
+        ref, rok = oracle.verify_commit(vals[c], hh[c].tobytes())
+        assert (ok[c] == rok).all(), (seed, c, np.nonzero(ok[c] != rok))
+        a, b = np.array(res[c]).copy(), np.array(ref).copy()
+        a["_pad"] = 0; b["_pad"] = 0
+        assert a.tobytes() == b.tobytes(), (seed, c)
