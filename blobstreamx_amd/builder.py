@@ -36,6 +36,16 @@ class InputDataFetcher:
 
     def __init__(self, headers, first_height, latest_block, device=0):
         self.headers = np.ascontiguousarray(headers, dtype=T.HEADER).reshape(-1)
+        if self.headers.nbytes >= 1 << 16:
+            # page-locked copy: the host tier uploads the headers by direct DMA instead of through the driver's staging buffer
+            try:
+                import torch
+                self._pinned = torch.empty(self.headers.nbytes, dtype=torch.uint8, pin_memory=True)
+                pin = self._pinned.numpy().view(T.HEADER)
+                pin[:] = self.headers
+                self.headers = pin
+            except Exception:
+                pass
         self.first_height = int(first_height)
         self.latest_block = int(latest_block)
         self.device = device
