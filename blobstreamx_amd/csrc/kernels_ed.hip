@@ -239,13 +239,15 @@ struct TableBuildArgs {
 __global__ __launch_bounds__(ED_THREADS) void k_table_entries(TableBuildArgs a) {
     __shared__ int32_t pre[KB_G * 10 * ED_THREADS];
     const uint32_t tid = threadIdx.x;
-    const uint64_t gl = (uint64_t)blockIdx.x * ED_THREADS + tid;
+    if (a.any_dirty && *a.any_dirty == 0) return;
     const uint32_t groups = a.half / KB_G;
+    const uint64_t total = (uint64_t)a.n_rows * groups;
+    // grid-strided: the launcher caps the grid at what can be resident (LDS: 4 workgroups per CU), so that the steady-state
+    // launch — every workgroup leaves after the one load above — is 1,024 workgroups, not one per 64 x 16 entries
+    for (uint64_t gl = (uint64_t)blockIdx.x * ED_THREADS + tid; gl < total; gl += (uint64_t)gridDim.x * ED_THREADS) {
     const uint64_t row = gl / groups;
     const uint32_t g = (uint32_t)(gl % groups);
-    if (row >= a.n_rows) return;
-    if (a.any_dirty && *a.any_dirty == 0) return;
-    if (a.recs && reinterpret_cast<const uint32_t*>(a.recs + (row / a.parts) * KT_REC_BYTES)[14] == 0) return;   // clean row
+    if (a.recs && reinterpret_cast<const uint32_t*>(a.recs + (row / a.parts) * KT_REC_BYTES)[14] == 0) continue;   // clean row
     const int32_t* src = a.bases + row * 40;
     ge_p3 base;
 #pragma unroll
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_table_entries(TableBuildArgs a) 
         }
         inv = fe_mul(inv, Z);
         precomp_store(d, ge_to_precomp(X, Y, zi));
+    }
     }
 }
 
@@ -822,7 +825,8 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
     TableBuildArgs a{reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)), reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)), table,
                      reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)), n_keys * (uint32_t)KT_PARTS, (uint32_t)KT_PARTS, (uint32_t)KT_HALF_ENTRIES, (uint32_t)KT_W};
     const uint64_t lanes = (uint64_t)a.n_rows * (KT_HALF_ENTRIES / KB_G);
-    hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, a);
+    const uint64_t wgs = (lanes + ED_THREADS - 1) / ED_THREADS;
+    hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)(wgs < 1024 ? wgs : 1024)), dim3(ED_THREADS), 0, s, a);
     return hipGetLastError();
 }
 // the B table of a context (bsxk_ed25519_btable_bytes() bytes, 128-byte aligned): built once, on `s`
@@ -832,7 +836,8 @@ hipError_t bsxk_ed25519_btable(hipStream_t s, uint8_t* table) {
     TableBuildArgs a{reinterpret_cast<const int32_t*>(table), reinterpret_cast<int32_t*>(table + bt_entries_off()), nullptr, nullptr,
                      (uint32_t)BT_PARTS, (uint32_t)BT_PARTS, (uint32_t)BT_HALF_ENTRIES, (uint32_t)BT_W};
     const uint64_t lanes = (uint64_t)a.n_rows * (BT_HALF_ENTRIES / KB_G);
-    hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, a);
+    const uint64_t wgs = (lanes + ED_THREADS - 1) / ED_THREADS;
+    hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)(wgs < 1024 ? wgs : 1024)), dim3(ED_THREADS), 0, s, a);
     return hipGetLastError();
 }
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t n) { return n * ED_SLOT_I32 * 4; }
