@@ -115,6 +115,7 @@ class HeaderRangeEngine:
         self.paths = _u8(self.nh_all * 224, d) if self.fused_hint else None
         # bsx.h: BSX_SUBCHAIN_PATHS_FROM_HINT (1); PipelinedEngines adds BSX_SUBCHAIN_SEPARATE_LAUNCHES (2) beside an expansion
         self.subchain_flags = 1 if self.fused_hint else 0
+        self.expand_done = None                    # set by step_final(expand_stream=...)
         self.ranges = _u8(RT * 80, d)
         self.latest = _u8(RT * 8, d)
         self.status = torch.zeros(8, dtype=torch.int32, device=d)       # [0] header, [1] assemble
@@ -287,6 +288,9 @@ class HeaderRangeEngine:
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
                     self._commit(self._st(), "all")
+        if self.expand_done is not None:           # the previous pass's expansion (on the shared expansion stream) reads `compact`
+            main.wait_event(self.expand_done)
+            self.expand_done = None
         chk(L.bsx_dev_assemble_inputs(ctx, st, C.c_uint32(RT), C.c_uint32(self.J), C.c_uint32(B), C.c_uint32(self.jf),
                                       C.c_uint32(jc), C.c_uint32(B), dp(self.ranges), dp(self.latest), dp(self.headers),
                                       C.c_uint64(self.hpr), C.c_uint64(self.hfr), dp(self.hashes), dp(self.dh_aunts),
@@ -387,13 +391,18 @@ class HeaderRangeEngine:
         with torch.cuda.stream(self.side):
             self._commit(self._st(), "verify")
 
-    def step_final(self, result_records, time_kernels=False, before_expand=None, launch_verify=True, after_expand=None):
+    def step_final(self, result_records, time_kernels=False, before_expand=None, launch_verify=True, after_expand=None,
+                   expand_stream=None):
         """finalize + (commit verification on the side stream) + witness expansion.  before_expand: hook called right
         before the expansion is enqueued (PipelinedEngines waits for the other chunk's expansion there, so that the tiny
         finalize kernel and the side-stream launch do not sit between two expansions); after_expand: hook called right
         behind the map-job expansion (PipelinedEngines releases the other chunk's expansion there).
         result_records None = the exchange was only begun (step_exchange_begin): top fold, finalize and the top
-        reduce nodes' expansion then run behind the map-job expansion."""
+        reduce nodes' expansion then run behind the map-job expansion.
+        expand_stream: launch the map-job / local reduce-node expansions there instead of on the current stream
+        (PipelinedEngines: ONE stream for the expansions of all chunks, so that consecutive expansions are consecutive
+        packets of one hardware queue instead of an event hand-over between two: the hand-over left HBM idle for 50-80 us
+        per expansion); this chunk's next hint then waits for `expand_done`."""
         L, ctx, st, dp, chk = self.L, self.ctx, self._st(), _lib.dp, _lib.check
         ev = self.events if time_kernels else None
         own_ranges = self.skip_ranges if self.with_commit else self.ranges[self.rank * self.R * 80:]
@@ -413,15 +422,24 @@ class HeaderRangeEngine:
         if before_expand is not None:
             before_expand()
         if self.with_witness:
+            xs, stx = torch.cuda.current_stream(self.dev), st
+            if expand_stream is not None:
+                ready = torch.cuda.Event()
+                ready.record(xs)                       # the compact witnesses (hint, prove_subchain, reduce) are complete
+                expand_stream.wait_event(ready)
+                xs, stx = expand_stream, C.c_void_p(expand_stream.cuda_stream)
             if ev:
-                ev[2].record(torch.cuda.current_stream(self.dev))
-            chk(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._ml), C.c_uint32(self.RT * self.jc), dp(self.compact),
+                ev[2].record(xs)
+            chk(L.bsx_dev_expand_witness(ctx, stx, _lib.p(self._ml), C.c_uint32(self.RT * self.jc), dp(self.compact),
                                          dp(self.witness_map)))
             if ev:
-                ev[3].record(torch.cuda.current_stream(self.dev))
+                ev[3].record(xs)
             if self.jc > 1:
-                chk(L.bsx_dev_expand_witness(ctx, st, _lib.p(self._rl), C.c_uint32(self.RT * (self.jc - 1)),
+                chk(L.bsx_dev_expand_witness(ctx, stx, _lib.p(self._rl), C.c_uint32(self.RT * (self.jc - 1)),
                                              dp(self.red_compact_local), dp(self.witness_red_local)))
+            if expand_stream is not None:
+                self.expand_done = torch.cuda.Event()
+                self.expand_done.record(xs)
         if after_expand is not None:
             after_expand()
         if late:
@@ -484,6 +502,10 @@ class PipelinedEngines:
         self._expand_token = None
         self._pending_verify = None
         self.verify_after_merkle = os.environ.get("BSX_VERIFY_AFTER_MERKLE", "1") == "1"
+        # one stream for the expansions of all chunks (step_final): BSX_EXPAND_STREAM=0 puts them back on the chunks' own
+        # streams with an event token between them
+        self.xstream = (torch.cuda.Stream(device=self.dev) if n_engines > 1 and self.engines[0].with_witness
+                        and os.environ.get("BSX_EXPAND_STREAM", "1") == "1" else None)
         # k_header_merkle alone fills the register file (4 waves x 128 VGPRs per SIMD); beside an expansion it is held to
         # 2 workgroups per CU so that the expansion's waves keep half of it (bsx.h BSX_TUNE_MERKLE_WORKGROUPS): +2 % per step
         e0 = self.engines[0]
@@ -527,14 +549,14 @@ class PipelinedEngines:
                 if self.E > 1:
                     self._hash_token = torch.cuda.Event()
                     self._hash_token.record(s)
-                tok = self._expand_token if self.E > 1 else None
+                tok = self._expand_token if self.E > 1 and self.xstream is None else None
                 defer = self.verify_after_merkle and self.E > 1
                 def release(s=s):
-                    if self.E > 1:
+                    if self.E > 1 and self.xstream is None:
                         self._expand_token = torch.cuda.Event()
                         self._expand_token.record(s)
                 eng.step_final(res, time_kernels, before_expand=(lambda s=s, tok=tok: s.wait_event(tok)) if tok is not None else None,
-                               launch_verify=not defer, after_expand=release)
+                               launch_verify=not defer, after_expand=release, expand_stream=self.xstream)
                 if defer:
                     self._pending_verify = eng
                 # the commit check is NOT joined here: its inputs are double-buffered by pass parity (HeaderRangeEngine), so
@@ -545,6 +567,8 @@ class PipelinedEngines:
             self._pending_verify.launch_verify()
             self._pending_verify = None
         cur = torch.cuda.current_stream(self.dev)
+        if self.xstream is not None:
+            cur.wait_stream(self.xstream)
         for s, eng in zip(self.streams, self.engines):
             cur.wait_stream(s)
             if eng.with_commit and eng.R:
