@@ -328,7 +328,7 @@ uint64_t bsx_ed25519_verify_scratch_bytes(uint64_t n) { return bsxk_ed25519_scra
 int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys, void* d_table) {
     DEV_ENTER();
     if (n_keys && (!d_validators || !d_table)) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    if (((uintptr_t)d_table & 15) != 0) return fail(BSX_ERR_BAD_ARG, "key table must be 16-byte aligned");
+    if (((uintptr_t)d_table & 127) != 0) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
     HIPCHK(bsxk_ed25519_keytable(S(ctx, stream), d_validators, n_keys, static_cast<uint8_t*>(d_table)));
     return BSX_OK;
 }
@@ -339,6 +339,7 @@ int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator
     if (n && (!d_validators || !d_h || !d_ok)) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
+    if ((uintptr_t)d_table & 127) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
     if ((uintptr_t)d_scratch & 15) return fail(BSX_ERR_BAD_ARG, "scratch must be 16-byte aligned");
     HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch));
     return BSX_OK;
