@@ -502,10 +502,10 @@ class PipelinedEngines:
         self._expand_token = None
         self._pending_verify = None
         self.verify_after_merkle = os.environ.get("BSX_VERIFY_AFTER_MERKLE", "1") == "1"
-        # one stream for the expansions of all chunks (step_final): BSX_EXPAND_STREAM=0 puts them back on the chunks' own
-        # streams with an event token between them
+        # BSX_EXPAND_STREAM=1 (experiment, off): one stream for the expansions of all chunks (step_final) instead of the chunks'
+        # own streams with an event token between them: +1 % per step at header_range_2048, -6 % at header_range_1024
         self.xstream = (torch.cuda.Stream(device=self.dev) if n_engines > 1 and self.engines[0].with_witness
-                        and os.environ.get("BSX_EXPAND_STREAM", "1") == "1" else None)
+                        and os.environ.get("BSX_EXPAND_STREAM", "0") == "1" else None)
         # k_header_merkle alone fills the register file (4 waves x 128 VGPRs per SIMD); beside an expansion it is held to
         # 2 workgroups per CU so that the expansion's waves keep half of it (bsx.h BSX_TUNE_MERKLE_WORKGROUPS): +2 % per step
         e0 = self.engines[0]
