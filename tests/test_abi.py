@@ -86,3 +86,8 @@ def test_witness_manifest_tiles_the_witness_and_matches_the_layout_header():
             assert names[0] == "ctx.start_header_hash" and "record.data_merkle_root" in names and "data_comm_proof.data_hash_proofs[].leaf" in names
     n = C.c_uint32(0)
     assert _lib.lib().bsx_witness_manifest(C.c_uint32(3), None, C.c_uint32(0), C.byref(n)) == T.ERR_BAD_ARG
+
+
+def test_set_tuning_rejects_a_null_context():
+    assert _lib.lib().bsx_set_tuning(None, C.c_uint32(T.TUNE_MERKLE_WORKGROUPS), C.c_uint64(512)) == T.ERR_BAD_ARG
+
