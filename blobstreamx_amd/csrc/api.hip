@@ -115,6 +115,7 @@ int bsx_init(int device, bsx_ctx** out) {
     e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming);
     // constants of the hint's zero-padded proofs (kernels_sha.hip k_zero_paths)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->zero_paths), 320);
     if (e == hipSuccess) e = bsxk_zero_paths(c->stream, c->zero_paths);
@@ -141,6 +142,8 @@ void bsx_shutdown(bsx_ctx* ctx) {
     if (ctx->zero_paths) (void)hipFree(ctx->zero_paths);
     if (ctx->keytab) (void)hipFree(ctx->keytab);
     if (ctx->btab) (void)hipFree(ctx->btab);
+    if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+    if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
     for (auto& b : ctx->vmm) { (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size); }
     delete ctx;
 }
@@ -479,13 +482,41 @@ int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8
     return BSX_OK;
 }
 
+// The small inputs and results of bsx_header_range as ONE device block mirrored in page-locked host memory: one H2D and one
+// D2H per call instead of four + eight copies between pageable stack variables and separate device buffers (each of those
+// is a staged, host-blocking copy of 10-20 us: a third of the 0.4 ms a proof request took).
+//   in : range (80 B) @0, latest @128, target validators @256, trusted validators @256 + v_max * 256
+//   out: output64 @+0, result record @+64, header status @+192, hint status @+196, final status @+200, skip status @+204,
+//        commit result @+256 (96 B)
+struct SmallIO {
+    uint8_t* d = nullptr;
+    uint8_t* h = nullptr;
+    size_t in_bytes = 0, out_off = 0;
+    static constexpr size_t OUT_BYTES = 384;
+    uint8_t* dout(size_t off) const { return d + out_off + off; }
+    const uint8_t* hout(size_t off) const { return h + out_off + off; }
+};
+static int ctx_hstage(bsx_ctx* ctx, size_t bytes, uint8_t** out) {
+    if (ctx->hstage_cap < bytes) {
+        if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+        ctx->hstage = nullptr;
+        ctx->hstage_cap = 0;
+        const size_t cap = (bytes + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->hstage), cap, hipHostMallocDefault));
+        ctx->hstage_cap = cap;
+    }
+    *out = ctx->hstage;
+    return BSX_OK;
+}
+static void dbuf_alias(DBuf& b, void* p) { b.p = p; b.owned = false; }
+
 // Shared by the hint-level entry points: uploads headers [S .. ) of one range and runs P5.
 struct RangeDev {
     DBuf headers, hashes, dh, lb, paths, ranges, latest, hstatus, astatus;
     uint64_t hpr = 0;
 };
 static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
-                        uint64_t S_, const bsx_shared_ctx& range, uint64_t latest_block, RangeDev& rd) {
+                        uint64_t S_, const bsx_shared_ctx& range, uint64_t latest_block, RangeDev& rd, const SmallIO* io = nullptr) {
     if (!headers || !n_headers) return fail(BSX_ERR_BAD_ARG, "no headers supplied");
     if (S_ < first_height || S_ - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "header for start block %llu not supplied (first_height %llu, n %llu)", (unsigned long long)S_, (unsigned long long)first_height, (unsigned long long)n_headers);
     if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
@@ -496,15 +527,23 @@ static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers,
     RET(rd.dh.alloc(rd.hpr * 128));
     RET(rd.lb.alloc(rd.hpr * 128));
     RET(rd.paths.alloc(rd.hpr * BSX_HEADER_PATH_BYTES));
-    RET(rd.ranges.alloc(sizeof(bsx_shared_ctx)));
-    RET(rd.latest.alloc(8));
-    RET(rd.hstatus.alloc(4));
-    RET(rd.astatus.alloc(4));
-    H2D(rd.headers.p, h0, rd.hpr * sizeof(bsx_header));
-    H2D(rd.ranges.p, &range, sizeof range);
-    H2D(rd.latest.p, &latest_block, 8);
-    HIPCHK(hipMemsetAsync(rd.hstatus.p, 0, 4, st));
-    HIPCHK(hipMemsetAsync(rd.astatus.p, 0, 4, st));
+    if (io) {                              // range / latest already uploaded, status words already zeroed (SmallIO)
+        dbuf_alias(rd.ranges, io->d);
+        dbuf_alias(rd.latest, io->d + 128);
+        dbuf_alias(rd.hstatus, io->dout(192));
+        dbuf_alias(rd.astatus, io->dout(196));
+        H2D(rd.headers.p, h0, rd.hpr * sizeof(bsx_header));
+    } else {
+        RET(rd.ranges.alloc(sizeof(bsx_shared_ctx)));
+        RET(rd.latest.alloc(8));
+        RET(rd.hstatus.alloc(4));
+        RET(rd.astatus.alloc(4));
+        H2D(rd.headers.p, h0, rd.hpr * sizeof(bsx_header));
+        H2D(rd.ranges.p, &range, sizeof range);
+        H2D(rd.latest.p, &latest_block, 8);
+        HIPCHK(hipMemsetAsync(rd.hstatus.p, 0, 4, st));
+        HIPCHK(hipMemsetAsync(rd.astatus.p, 0, 4, st));
+    }
     HIPCHK(bsxk_header_merkle(st, rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
                               rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>(), 0));
     (void)ctx;
@@ -627,17 +666,36 @@ int bsx_reduce(bsx_ctx* ctx, const bsx_subchain* records, uint32_t n, bsx_subcha
 }
 
 // prove_data_commitment on one range whose device state (headers hashed) is in rd.  d_target_hashes optional.
+// the host-side end of run_data_commitment: statuses -> return code, outputs
+static int finish_data_commitment(const uint8_t o[64], const bsx_subchain& result, uint32_t hs, uint32_t as, uint32_t stv,
+                                  uint8_t out_commitment[32], uint8_t output64[64], bsx_subchain* out_result, uint32_t* out_status) {
+    RET(header_status_to_rc(hs, as));
+    if (out_commitment) memcpy(out_commitment, o + 32, 32);
+    if (output64) memcpy(output64, o, 64);
+    if (out_result) { *out_result = result; out_result->assert_fail = stv; }
+    if (out_status) *out_status = stv;
+    if (stv) return fail(BSX_ERR_ASSERT, "prove_data_commitment: assertion mask 0x%x (A7 builder.rs:292-297, A8 :350-355, A9 :401-406; A1-A6 from the map jobs)", stv);
+    return BSX_OK;
+}
+// io (bsx_header_range): results go to the SmallIO block and are NOT fetched here — the caller fetches the block once and
+// calls finish_data_commitment itself
 static int run_data_commitment(bsx_ctx* ctx, hipStream_t st, uint32_t J, uint32_t B, RangeDev& rd, const uint8_t* d_target_hashes,
                                uint8_t out_commitment[32], uint8_t output64[64], bsx_subchain* out_result, bsx_subchain* records,
-                               uint64_t* witness, uint32_t* out_status) {
+                               uint64_t* witness, uint32_t* out_status, const SmallIO* io = nullptr) {
     const bsx_witness_layout L = bsx_map_layout(B), R = bsx_reduce_layout();
     DBuf cw, rcw, recs, res, o64, stw, wit;
     RET(cw.alloc((size_t)J * L.compact_stride));
     RET(rcw.alloc((size_t)(J > 1 ? J - 1 : 1) * R.compact_stride));
     RET(recs.alloc((size_t)J * sizeof(bsx_subchain)));
-    RET(res.alloc(sizeof(bsx_subchain)));
-    RET(o64.alloc(64));
-    RET(stw.alloc(4));
+    if (io) {
+        dbuf_alias(o64, io->dout(0));
+        dbuf_alias(res, io->dout(64));
+        dbuf_alias(stw, io->dout(200));
+    } else {
+        RET(res.alloc(sizeof(bsx_subchain)));
+        RET(o64.alloc(64));
+        RET(stw.alloc(4));
+    }
     HIPCHK(hipMemsetAsync(cw.p, 0, (size_t)J * L.compact_stride, st));
     HIPCHK(bsxk_assemble_inputs(st, 1, J, B, 0, J, B, rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(), rd.headers.as<bsx_header>(), rd.hpr, 0,
                                 rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(), cw.as<uint8_t>(), rd.astatus.as<uint32_t>(),
@@ -662,6 +720,10 @@ static int run_data_commitment(bsx_ctx* ctx, hipStream_t st, uint32_t J, uint32_
         }
         D2H(witness, wit.p, (nmap + nred) * 8);
     }
+    if (io) {
+        if (records) D2H(records, recs.p, (size_t)J * sizeof(bsx_subchain));
+        return BSX_OK;
+    }
     uint8_t o[64];
     bsx_subchain result;
     uint32_t hs = 0, as = 0, stv = 0;
@@ -672,13 +734,7 @@ static int run_data_commitment(bsx_ctx* ctx, hipStream_t st, uint32_t J, uint32_
     D2H(&as, rd.astatus.p, 4);
     D2H(&stv, stw.p, 4);
     SYNC();
-    RET(header_status_to_rc(hs, as));
-    if (out_commitment) memcpy(out_commitment, o + 32, 32);
-    if (output64) memcpy(output64, o, 64);
-    if (out_result) { *out_result = result; out_result->assert_fail = stv; }
-    if (out_status) *out_status = stv;
-    if (stv) return fail(BSX_ERR_ASSERT, "prove_data_commitment: assertion mask 0x%x (A7 builder.rs:292-297, A8 :350-355, A9 :401-406; A1-A6 from the map jobs)", stv);
-    return BSX_OK;
+    return finish_data_commitment(o, result, hs, as, stv, out_commitment, output64, out_result, out_status);
 }
 
 int bsx_prove_data_commitment(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const bsx_shared_ctx* range, const bsx_header* headers,
@@ -845,25 +901,40 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     range.end_block = target_block;
     memcpy(range.start_header_hash, input48 + 8, 32);
     RangeDev rd;
-    DBuf dv, dtv, dh, dok, dres, dtres, dskip, dth, dth2;
+    DBuf dio, dv, dtv, dh, dok, dres, dtres, dskip, dth, dth2;
+    // small inputs and results: one block, one copy each way (SmallIO)
+    SmallIO io;
+    const size_t vbytes = (size_t)v_max * sizeof(bsx_validator);
+    io.in_bytes = 256 + 2 * vbytes;
+    io.out_off = io.in_bytes;
+    RET(dio.alloc(io.out_off + SmallIO::OUT_BYTES));
+    io.d = dio.as<uint8_t>();
+    RET(ctx_hstage(ctx, io.out_off + SmallIO::OUT_BYTES, &io.h));
+    memset(io.h, 0, 256);
+    memcpy(io.h, &range, sizeof range);
+    memcpy(io.h + 128, &latest_block, 8);
+    memcpy(io.h + 256, target_validators, vbytes);
+    memcpy(io.h + 256 + vbytes, trusted_validators, vbytes);
+    HIPCHK(hipMemcpyAsync(io.d, io.h, io.in_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(io.dout(0), 0, SmallIO::OUT_BYTES, st));
+    HIPCHK(hipEventRecord(ctx->ev_c, st));
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_c, 0));                       // the commit check's inputs
+    dbuf_alias(dv, io.d + 256);
+    dbuf_alias(dtv, io.d + 256 + vbytes);
+    dbuf_alias(dskip, io.dout(204));
+    dbuf_alias(dres, io.dout(256));
     RET(dth.alloc(32));
-    RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd));
+    RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd, &io));
     // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash (and the first output half)
     HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, dth.as<uint8_t>(), nullptr));
-    RET(dv.alloc((size_t)v_max * sizeof(bsx_validator)));
-    RET(dtv.alloc((size_t)v_max * sizeof(bsx_validator)));
     RET(dh.alloc((size_t)v_max * 32));
     RET(dok.alloc(v_max));
-    RET(dres.alloc(sizeof(bsx_commit_result)));
     RET(dtres.alloc(sizeof(bsx_commit_result)));
-    RET(dskip.alloc(4));
     RET(dth2.alloc(32));
     // the trusted set's hash and power sum need nothing from the signature check: on the hashing stream (which has the
     // slack), not in the commit check's chain on `sb` — 46 us off the critical path of a proof
-    HIPCHK(hipMemcpyAsync(dtv.p, trusted_validators, (size_t)v_max * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
     HIPCHK(bsxk_commit_tally(st, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
     HIPCHK(hipEventRecord(ctx->ev_a, st));
-    HIPCHK(hipMemcpyAsync(dv.p, target_validators, (size_t)v_max * sizeof(bsx_validator), hipMemcpyHostToDevice, sb));
     const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
     HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
     {
@@ -878,16 +949,23 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
                            dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth2.as<uint8_t>(), nullptr, chain_id, chain_id_len));
     HIPCHK(hipEventRecord(ctx->ev_b, sb));
-    // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58)
-    int rc = run_data_commitment(ctx, st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, output64, nullptr, nullptr, witness, nullptr);
+    // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58); results stay in the block
+    RET(run_data_commitment(ctx, st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, nullptr, nullptr, nullptr, witness, nullptr, &io));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_b, 0));
+    HIPCHK(hipMemcpyAsync(io.h + io.out_off, io.dout(0), SmallIO::OUT_BYTES, hipMemcpyDeviceToHost, st));
+    SYNC();
+    bsx_subchain result;
+    bsx_commit_result cr;
+    uint32_t hs, as, stv, skip;
+    memcpy(&result, io.hout(64), sizeof result);
+    memcpy(&hs, io.hout(192), 4);
+    memcpy(&as, io.hout(196), 4);
+    memcpy(&stv, io.hout(200), 4);
+    memcpy(&skip, io.hout(204), 4);
+    memcpy(&cr, io.hout(256), sizeof cr);
+    const int rc = finish_data_commitment(io.hout(0), result, hs, as, stv, nullptr, output64, nullptr, nullptr);
     if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
     const std::string dc_err = g_err;
-    uint32_t skip = 0;
-    bsx_commit_result cr;
-    HIPCHK(hipStreamWaitEvent(st, ctx->ev_b, 0));
-    D2H(&skip, dskip.p, 4);
-    D2H(&cr, dres.p, sizeof cr);
-    SYNC();
     if (out_commit) *out_commit = cr;
     if (skip) return fail((int)skip, "skip verification failed: %s (bad signatures %u, first %u; bad messages %u; signed %llu of %llu; trusted overlap %llu)",
                           bsx_status_str((int)skip), cr.n_bad_signature, cr.first_bad_signature, cr.n_bad_message,

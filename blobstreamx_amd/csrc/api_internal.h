@@ -36,6 +36,9 @@ struct bsx_ctx {
     uint8_t* keytab = nullptr;           // host tier's persistent fixed-key Ed25519 table (rows survive between calls)
     uint32_t keytab_rows = 0;
     uint8_t* btab = nullptr;             // fixed-key Ed25519 table of the base point B (built by bsx_init)
+    uint8_t* hstage = nullptr;           // page-locked host staging of the host tier's small inputs / results (SmallIO)
+    size_t hstage_cap = 0;
+    hipEvent_t ev_c = nullptr;
     uint32_t merkle_wgs = 0;             // BSX_TUNE_MERKLE_WORKGROUPS
 };
 

@@ -404,6 +404,88 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
     if (part0 == 0) ok_out[me] = ok ? 1 : 0;
 }
 
+// The small-batch form (a single proof: 100 signatures): latency is everything, and a third of a signature's dependent
+// chain is the field inversion that encodes the result for the byte comparison with R.  Here a SECOND wave of the workgroup
+// decodes R instead (RFC 8032 strict: canonical y, on the curve, x = 0 only with sign 0 — a square root chain of the same
+// length as the inversion, but independent of the point arithmetic, so the two waves run side by side), and the first
+// wave compares projectively: (X : Y : Z) == (x_R, y_R)  <=>  X = x_R Z and Y = y_R Z.  Same accept set: the encoding of a
+// point is canonical, so "encode(P) == R bytes" holds exactly when R decodes strictly and decodes to P.
+// 16 signatures per workgroup: wave 0 = 16 x 4 lanes of partial sums, wave 1 = 16 lanes of decoding.
+constexpr int EL_SIGS = 16;
+__global__ __launch_bounds__(128) void k_ed25519_verify_keyed_small(const bsx_validator* __restrict__ vals, const uint8_t* __restrict__ hs,
+                                                                  uint64_t n, uint32_t v_max, const uint8_t* __restrict__ table,
+                                                                  uint32_t n_keys, const int32_t* __restrict__ b_tab,
+                                                                  uint8_t* __restrict__ ok_out) {
+    __shared__ int32_t rdec[EL_SIGS][21];                 // -x_R (10 limbs), y_R (10), decodes
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t sub = wave == 0 ? lane / 4 : lane, part0 = lane % 4;
+    const uint64_t me = (uint64_t)blockIdx.x * EL_SIGS + sub;
+    const bool in_range = sub < EL_SIGS && me < n;
+    uint32_t sr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool active = false;
+    if (in_range) {
+        const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
+        const uint4 flags = rec[14];
+        active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
+        const uint4 r0 = rec[2], r1 = rec[3], s0 = rec[4], s1 = rec[5];
+        sr[0] = r0.x; sr[1] = r0.y; sr[2] = r0.z; sr[3] = r0.w; sr[4] = r1.x; sr[5] = r1.y; sr[6] = r1.z; sr[7] = r1.w;
+        ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
+    }
+    bool keyed = false, decodes = false;
+    ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
+    if (wave == 1) {
+        if (in_range && active) {
+            ge_p3 nr;
+            const bool rok = ge_frombytes_negate(nr, sr);
+#pragma unroll
+            for (int i = 0; i < 10; i++) { rdec[sub][i] = nr.X.v[i]; rdec[sub][10 + i] = nr.Y.v[i]; }
+            rdec[sub][20] = rok ? 1 : 0;
+        }
+    } else if (in_range && active) {
+        uint32_t pk[8], h[8];
+        load_pk(vals + me, pk);
+        const uint4* hp = reinterpret_cast<const uint4*>(hs + me * 32);
+        const uint4 h0 = hp[0], h1 = hp[1];
+        h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
+        const uint32_t slot = (uint32_t)(me % v_max);
+        keyed = slot < n_keys;
+        if (keyed) {
+            const uint4* kr = reinterpret_cast<const uint4*>(table + (uint64_t)slot * KT_REC_BYTES);
+            const uint4 k0 = kr[0], k1 = kr[1];
+            keyed = k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] && k1.x == pk[4] && k1.y == pk[5] &&
+                    k1.z == pk[6] && k1.w == pk[7];
+            decodes = kr[2].x != 0;
+        }
+        if (keyed) {                                        // the 4 lanes of a signature agree on every test above
+            const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
+            p = ed25519_keyed_partial<4>(kt, b_tab, ss, h, (int)part0);
+#pragma unroll
+            for (int m = 1; m < 4; m <<= 1) {
+                ge_p3 o;
+#pragma unroll
+                for (int i = 0; i < 10; i++) {
+                    o.X.v[i] = __shfl_xor(p.X.v[i], m, 64);
+                    o.Y.v[i] = __shfl_xor(p.Y.v[i], m, 64);
+                    o.Z.v[i] = __shfl_xor(p.Z.v[i], m, 64);
+                    o.T.v[i] = __shfl_xor(p.T.v[i], m, 64);
+                }
+                p = p1p1_to_p3(ge_add(p, p3_to_cached(o)));
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0 || part0 != 0 || !in_range) return;
+    if (!active) { ok_out[me] = 0; return; }
+    if (!keyed) { ok_out[me] = ED_DEFERRED; return; }        // left to k_ed25519_verify<true>, launched right behind
+    fe nx, ry;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { nx.v[i] = rdec[sub][i]; ry.v[i] = rdec[sub][10 + i]; }
+    const bool rok = rdec[sub][20] != 0;
+    const bool same_x = !fe_isnonzero(fe_add(p.X, fe_mul(nx, p.Z)));      // X - x_R Z, with nx = -x_R
+    const bool same_y = !fe_isnonzero(fe_sub(p.Y, fe_mul(ry, p.Z)));
+    ok_out[me] = (decodes && sc_is_canonical(ss) && rok && same_x && same_y) ? 1 : 0;
+}
+
 // Encoding + comparison of the deferred results: lane j owns signatures [j*K, (j+1)*K).  Montgomery's trick: prefix
 // products of the Z coordinates (stored in the slots), one inversion of the total, then backwards 1/Z_i = inv * prefix_{i-1},
 // inv *= Z_i.  Z of a point produced by the complete twisted-Edwards formulas from points on the curve is never zero.
@@ -864,7 +946,12 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     }
 #define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_) \
     hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr)
-    if (split4) {
+    // BSX_ED_SMALL=0 (experiments): no decode-R form for small batches
+    static const bool small_form = !(getenv("BSX_ED_SMALL") && atol(getenv("BSX_ED_SMALL")) == 0);
+    if (split4 && !scr && !by_key && small_form) {
+        hipLaunchKernelGGL(k_ed25519_verify_keyed_small, dim3((uint32_t)((n + EL_SIGS - 1) / EL_SIGS)), dim3(128), 0, s, vals, h, n, v_max, table,
+                           n_keys, b_tab, ok);
+    } else if (split4) {
         if (scr) { if (by_key) BSX_LAUNCH_KEYED(true, true, 4); else BSX_LAUNCH_KEYED(true, false, 4); }
         else     { if (by_key) BSX_LAUNCH_KEYED(false, true, 4); else BSX_LAUNCH_KEYED(false, false, 4); }
     } else {

@@ -44,6 +44,29 @@ def _forge():
     out.append((out[0][0][:32] + (int.from_bytes(out[0][0][32:], "little") + L_ORDER).to_bytes(32, "little"), out[0][1], 0))   # s + L
     for sig, hb, want in out:
         assert int(bool(oracle.ed25519_verify_h(pk, sig, hb))) == want
+    # adversarial ENCODINGS of R (the small-batch kernel decodes R and compares points, the others encode and compare bytes:
+    # the accept sets must coincide).  [s]B - [h]A = identity for s = h a: the true R is (0, 1).
+    P = 2 ** 255 - 19
+    adv = []
+    for h in (1, rnd[0], edges[7]):
+        s_ = h * a % L_ORDER
+        sb, hb = s_.to_bytes(32, "little"), (h % L_ORDER).to_bytes(32, "little")
+        adv.append(((1).to_bytes(32, "little") + sb, hb))                              # identity, canonical: valid
+        adv.append(((1 | 1 << 255).to_bytes(32, "little") + sb, hb))                   # x = 0 with the sign bit set
+        adv.append(((P + 1).to_bytes(32, "little") + sb, hb))                          # y = p + 1: non-canonical identity
+        adv.append(((P - 1).to_bytes(32, "little") + sb, hb))                          # (0, -1): on the curve, another point
+    sig0, hb0, _ = out[0]
+    r0 = int.from_bytes(sig0[:32], "little")
+    adv.append(((r0 ^ (1 << 255)).to_bytes(32, "little") + sig0[32:], hb0))            # -R: same y, other sign
+    adv.append(((2).to_bytes(32, "little") + sig0[32:], hb0))                          # y = 2 is not on the curve
+    adv.append((((r0 & (2 ** 255 - 1)) + P if (r0 & (2 ** 255 - 1)) < 19 else P + 3).to_bytes(32, "little") + sig0[32:], hb0))   # non-canonical y
+    adv.append(((2 ** 255 - 1).to_bytes(32, "little") + sig0[32:], hb0))               # y = 2^255 - 1 >= p
+    n_valid = 0
+    for sig, hb in adv:
+        want = int(bool(oracle.ed25519_verify_h(pk, sig, hb)))
+        n_valid += want
+        out.append((sig, hb, want))
+    assert n_valid == 3                                                                # exactly the canonical identity encodings
     return pk, out
 
 
@@ -86,10 +109,12 @@ def _child():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split,by_key", [(1, 0), (1, 1), (4, 0), (4, 1), (None, None)])
-def test_every_launch_form_on_forged_digit_edges(split, by_key):
+@pytest.mark.parametrize("split,by_key,small", [(1, 0, 1), (1, 1, 1), (4, 0, 1), (4, 0, 0), (4, 1, 1), (None, None, 1)])
+def test_every_launch_form_on_forged_digit_edges(split, by_key, small):
+    """(4, 0, 1) is the small-batch form that decodes R in a second wave and compares projectively instead of encoding."""
     env = dict(os.environ)
     env.pop("BSX_ED_SPLIT", None); env.pop("BSX_ED_BY_KEY", None)
+    env["BSX_ED_SMALL"] = str(small)
     if split is not None:
         env["BSX_ED_SPLIT"], env["BSX_ED_BY_KEY"] = str(split), str(by_key)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
