@@ -399,6 +399,37 @@ static int ctx_keytable(bsx_ctx* ctx, uint32_t v_max, uint8_t** out, hipStream_t
     return BSX_OK;
 }
 
+static int ctx_hstage(bsx_ctx* ctx, size_t bytes, uint8_t** out);
+// Small results of a host-tier call: a D2H copy into the caller's (pageable) memory blocks the host until the data has
+// arrived — one stream round trip per copy.  Staged: each copy lands in the context's page-locked staging buffer (truly
+// asynchronous), ONE synchronisation, then plain memcpys to the caller's pointers.  Large results go direct.
+struct StagedD2H {
+    bsx_ctx* ctx;
+    hipStream_t st;
+    uint8_t* base = nullptr;
+    size_t off = 0;
+    struct Item { void* dst; size_t off, n; };
+    std::vector<Item> items;
+    static constexpr size_t CAP = 1u << 20, DIRECT_FROM = 256u << 10;
+    StagedD2H(bsx_ctx* c, hipStream_t s) : ctx(c), st(s) {}
+    int copy(void* dst, const void* dsrc, size_t n) {
+        if (!n) return BSX_OK;
+        const size_t a = (n + 63) & ~(size_t)63;
+        if (n >= DIRECT_FROM || off + a > CAP) { HIPCHK(hipMemcpyAsync(dst, dsrc, n, hipMemcpyDeviceToHost, st)); return BSX_OK; }
+        if (!base) RET(ctx_hstage(ctx, CAP, &base));
+        HIPCHK(hipMemcpyAsync(base + off, dsrc, n, hipMemcpyDeviceToHost, st));
+        items.push_back(Item{dst, off, n});
+        off += a;
+        return BSX_OK;
+    }
+    int sync() {
+        HIPCHK(hipStreamSynchronize(st));
+        for (const Item& it : items) memcpy(it.dst, base + it.off, it.n);
+        items.clear();
+        off = 0;
+        return BSX_OK;
+    }
+};
 #define H2D(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, st))
 #define D2H(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyDeviceToHost, st))
 #define SYNC() HIPCHK(hipStreamSynchronize(st))
@@ -462,9 +493,10 @@ int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8
     HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, nullptr, dst.as<uint32_t>(), 0));
     std::vector<uint8_t> tmp(n * 288);
     uint32_t hs = 0;
-    D2H(tmp.data(), d_hash, n * 288);
-    D2H(&hs, dst.p, 4);
-    SYNC();
+    StagedD2H back(ctx, st);
+    RET(back.copy(tmp.data(), d_hash, n * 288));
+    RET(back.copy(&hs, dst.p, 4));
+    RET(back.sync());
     RET(header_status_to_rc(hs, 0));
     if (out_hashes) memcpy(out_hashes, tmp.data(), n * 32);
     for (uint64_t i = 0; i < n; i++) {
@@ -497,6 +529,7 @@ struct SmallIO {
     const uint8_t* hout(size_t off) const { return h + out_off + off; }
 };
 static int ctx_hstage(bsx_ctx* ctx, size_t bytes, uint8_t** out) {
+    if (bytes < StagedD2H::CAP) bytes = StagedD2H::CAP;        // never shrinks below what StagedD2H takes
     if (ctx->hstage_cap < bytes) {
         if (ctx->hstage) (void)hipHostFree(ctx->hstage);
         ctx->hstage = nullptr;
@@ -727,13 +760,14 @@ static int run_data_commitment(bsx_ctx* ctx, hipStream_t st, uint32_t J, uint32_
     uint8_t o[64];
     bsx_subchain result;
     uint32_t hs = 0, as = 0, stv = 0;
-    D2H(o, o64.p, 64);
-    D2H(&result, res.p, sizeof result);
-    if (records) D2H(records, recs.p, (size_t)J * sizeof(bsx_subchain));
-    D2H(&hs, rd.hstatus.p, 4);
-    D2H(&as, rd.astatus.p, 4);
-    D2H(&stv, stw.p, 4);
-    SYNC();
+    StagedD2H back(ctx, st);
+    RET(back.copy(o, o64.p, 64));
+    RET(back.copy(&result, res.p, sizeof result));
+    if (records) RET(back.copy(records, recs.p, (size_t)J * sizeof(bsx_subchain)));
+    RET(back.copy(&hs, rd.hstatus.p, 4));
+    RET(back.copy(&as, rd.astatus.p, 4));
+    RET(back.copy(&stv, stw.p, 4));
+    RET(back.sync());
     return finish_data_commitment(o, result, hs, as, stv, out_commitment, output64, out_result, out_status);
 }
 
@@ -861,9 +895,10 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
         HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), dscr.p));
     }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
-    D2H(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result));
-    if (out_sig_ok) D2H(out_sig_ok, dok.p, n);
-    SYNC();
+    StagedD2H back(ctx, st);
+    RET(back.copy(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result)));
+    if (out_sig_ok) RET(back.copy(out_sig_ok, dok.p, n));
+    RET(back.sync());
     for (uint32_t c = 0; c < n_commits; c++)
         if (out_results[c].power_overflow)
             return fail(BSX_ERR_BAD_ARG, "commit %u: the voting powers add up to more than MaxTotalVotingPower (MaxInt64 / 8); tallies are meaningless", c);
