@@ -950,8 +950,8 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     memcpy(io.h + 128, &latest_block, 8);
     memcpy(io.h + 256, target_validators, vbytes);
     memcpy(io.h + 256 + vbytes, trusted_validators, vbytes);
-    HIPCHK(hipMemcpyAsync(io.d, io.h, io.in_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(io.dout(0), 0, SmallIO::OUT_BYTES, st));
+    memset(io.h + io.out_off, 0, SmallIO::OUT_BYTES);                   // the result block starts zeroed: same copy
+    HIPCHK(hipMemcpyAsync(io.d, io.h, io.out_off + SmallIO::OUT_BYTES, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(ctx->ev_c, st));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_c, 0));                       // the commit check's inputs
     dbuf_alias(dv, io.d + 256);

@@ -5,7 +5,7 @@
 //
 //   k_sha512_challenge  P6  h = SHA512(R ‖ A ‖ M) mod L          one lane per validator slot, one message block resident at a time
 //   k_ed25519_verify    P7  [s]B + [h](-A) == R                   one lane per validator slot, ALU bound (no byte roofline)
-//   k_keytable_check / k_keytable_bases / k_keytable_entries / k_ed25519_verify_keyed / k_ed25519_finish
+//   k_keytable_check / k_table_entries / k_ed25519_verify_keyed(_small) / k_ed25519_finish
 //                       P7, fixed-key form: per-validator tables of j*(-2^(12k) A) (k = 0..21, j = 1..2048, affine), rows kept
 //                           across calls and rebuilt only when their key changes, and a 16-bit-digit table of B
 //                           (k_btable_bases, per context; both filled by k_table_entries); a signature is 22 + 16 mixed
@@ -137,34 +137,7 @@ __device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) 
     pk[0] = p0.x; pk[1] = p0.y; pk[2] = p0.z; pk[3] = p0.w; pk[4] = p1.x; pk[5] = p1.y; pk[6] = p1.z; pk[7] = p1.w;
 }
 
-// Reuse across calls: a key record ends with {KT_MAGIC, n_keys, dirty, 0}.  k_keytable_check marks row k dirty when the
-// table does not hold THIS key for THIS n_keys (fresh zeroed table, validator-set change, different layout); the two
-// build kernels skip clean rows.  The reference's validator set is fixed per proof and changes on the chain's
-// unbonding time scale (header_range.rs:42-48 takes it from the trusted/target headers), so in steady state a step pays
-// one 100-lane compare instead of 192 serial point doublings per key — and a changed key costs exactly its own rebuild.
-// ONE workgroup: it also leaves "some row is dirty" in the table word, which lets every wave of the two build launches
-// leave after one (shared, cached) load in the steady state — their grids are sized for a full rebuild (4,400 waves at
-// V = 100), and a per-row flag load per wave cost 0.17 ms beside an expansion.
 constexpr uint32_t KT_MAGIC = 0x4b54324bu;
-constexpr int KC_THREADS = 256;
-__global__ __launch_bounds__(KC_THREADS) void k_keytable_check(const bsx_validator* __restrict__ vals, uint32_t n_keys,
-                                                               uint8_t* __restrict__ table, uint32_t force) {
-    int any = 0;
-    for (uint32_t k = threadIdx.x; k < n_keys; k += KC_THREADS) {
-        uint32_t pk[8];
-        load_pk(vals + k, pk);
-        uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
-        const uint4 k0 = rec[0], k1 = rec[1], tag = rec[3];
-        const bool same = tag.x == KT_MAGIC && tag.y == n_keys && k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] &&
-                          k1.x == pk[4] && k1.y == pk[5] && k1.z == pk[6] && k1.w == pk[7];
-        const uint32_t dirty = (force || !same) ? 1u : 0u;
-        reinterpret_cast<uint32_t*>(rec + 3)[2] = dirty;
-        any |= (int)dirty;
-    }
-    any = __syncthreads_or(any);
-    if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(table + kt_flag_off(n_keys)) = any ? 1u : 0u;
-}
-
 // decode, negate, and run the (KT_PARTS - 1) x KT_W doublings that give the base points of the upper digit positions; row k of `table`
 __device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint32_t k, uint32_t n_keys, uint8_t* __restrict__ table) {
     ge_p3 b;
@@ -187,17 +160,42 @@ __device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint3
         }
     }
 }
-// one lane per key
-__global__ __launch_bounds__(ED_THREADS) void k_keytable_bases(const bsx_validator* __restrict__ vals, uint32_t n_keys,
-                                                               uint8_t* __restrict__ table) {
-    const uint32_t k = blockIdx.x * ED_THREADS + threadIdx.x;
-    if (k >= n_keys) return;
-    if (*reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)) == 0) return;      // nothing to rebuild
-    if (reinterpret_cast<const uint32_t*>(table + k * KT_REC_BYTES)[14] == 0) return;      // clean row (k_keytable_check)
-    uint32_t pk[8];
-    load_pk(vals + k, pk);
-    keytable_build_bases(pk, k, n_keys, table);
+// Reuse across calls: a key record ends with {KT_MAGIC, n_keys, dirty, 0}.  k_keytable_check marks row k dirty when the
+// table does not hold THIS key for THIS n_keys (fresh zeroed table, validator-set change, different layout); the two
+// build kernels skip clean rows.  The reference's validator set is fixed per proof and changes on the chain's
+// unbonding time scale (header_range.rs:42-48 takes it from the trusted/target headers), so in steady state a step pays
+// one 100-lane compare instead of 192 serial point doublings per key — and a changed key costs exactly its own rebuild.
+// ONE workgroup: it also leaves "some row is dirty" in the table word, which lets every wave of the two build launches
+// leave after one (shared, cached) load in the steady state — their grids are sized for a full rebuild (4,400 waves at
+// V = 100), and a per-row flag load per wave cost 0.17 ms beside an expansion.
+constexpr int KC_THREADS = 256;
+__global__ __launch_bounds__(KC_THREADS) void k_keytable_check(const bsx_validator* __restrict__ vals, uint32_t n_keys,
+                                                               uint8_t* __restrict__ table, uint32_t force) {
+    int any = 0;
+    for (uint32_t k = threadIdx.x; k < n_keys; k += KC_THREADS) {
+        uint32_t pk[8];
+        load_pk(vals + k, pk);
+        uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
+        const uint4 k0 = rec[0], k1 = rec[1], tag = rec[3];
+        const bool same = tag.x == KT_MAGIC && tag.y == n_keys && k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] &&
+                          k1.x == pk[4] && k1.y == pk[5] && k1.z == pk[6] && k1.w == pk[7];
+        const uint32_t dirty = (force || !same) ? 1u : 0u;
+        reinterpret_cast<uint32_t*>(rec + 3)[2] = dirty;
+        any |= (int)dirty;
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(table + kt_flag_off(n_keys)) = any ? 1u : 0u;
+    if (!any) return;
+    // rebuild: the base points of the dirty rows, here (one lane per key; the rows of a validator set fit one or two passes
+    // of this workgroup) — a launch of its own cost a proof request 10 us of host time for nothing in the steady state
+    for (uint32_t k = threadIdx.x; k < n_keys; k += KC_THREADS) {
+        if (reinterpret_cast<const uint32_t*>(table + k * KT_REC_BYTES)[14] == 0) continue;
+        uint32_t pk[8];
+        load_pk(vals + k, pk);
+        keytable_build_bases(pk, k, n_keys, table);
+    }
 }
+
 // The context's table of B (bt_bytes()): [BT_PARTS x 40 i32 base points 2^(W k) B][pad][BT_PARTS x 2^(W-1) x 32 i32 entries],
 // built by the key-table arithmetic from the encoding of -B ("-A" = B).
 __host__ __device__ inline uint64_t bt_entries_off() { return ((uint64_t)BT_PARTS * 160 + 127) & ~127ull; }
@@ -903,7 +901,6 @@ hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint3
     // BSX_KEYTABLE_REUSE=0 forces a full rebuild on every call (cold-build measurements)
     static const uint32_t force = getenv("BSX_KEYTABLE_REUSE") && atol(getenv("BSX_KEYTABLE_REUSE")) == 0 ? 1u : 0u;
     hipLaunchKernelGGL(k_keytable_check, dim3(1), dim3(KC_THREADS), 0, s, vals, n_keys, table, force);
-    hipLaunchKernelGGL(k_keytable_bases, dim3((n_keys + ED_THREADS - 1) / ED_THREADS), dim3(ED_THREADS), 0, s, vals, n_keys, table);
     TableBuildArgs a{reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)), reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)), table,
                      reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)), n_keys * (uint32_t)KT_PARTS, (uint32_t)KT_PARTS, (uint32_t)KT_HALF_ENTRIES, (uint32_t)KT_W};
     const uint64_t lanes = (uint64_t)a.n_rows * (KT_HALF_ENTRIES / KB_G);
