@@ -10,7 +10,11 @@
  *
  * Two tiers:
  *   bsx_*      host-pointer tier: synchronous, copies in/out — what a Rust `AsyncHint` /
- *              builder shim binds.
+ *              builder shim binds.  Small inputs and results travel through the
+ *              context's own page-locked staging; LARGE buffers (the headers of a range, the
+ *              witness) are copied straight from / to the caller's memory — page-lock them
+ *              (hipHostMalloc / hipHostRegister) and a header_range_2048 witness arrives in
+ *              2.5 ms instead of 12.
  *   bsx_dev_*  device-pointer tier: every pointer marked `d_` is HIP device memory, the call
  *              only enqueues kernels on `stream` (a hipStream_t passed as void*) and returns.
  *              The host tier is implemented on top of it.
