@@ -99,10 +99,18 @@ def host_threads():
             quota = int(q) / int(per)
     except Exception:
         pass
+    model = "unknown CPU"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     if quota and quota < n:
         t = max(1, min(n, int(round(2 * quota))))
-        return t, f"{t} threads (cgroup CPU quota {quota:g} CPUs of {n} logical)"
-    return n, f"{n} threads (no CPU quota)"
+        return t, f"{t} threads of {model} (cgroup CPU quota {quota:g} CPUs of {n} logical)"
+    return n, f"{n} threads of {model} (no CPU quota)"
 
 
 # ---------------------------------------------------------------------------------------------------------------- checkers
