@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--validators", type=int, default=100)
     ap.add_argument("--engines", type=int, default=2, help="chunks of the step pipelined on separate HIP streams (the ALU-bound hashing "
-                    "of one chunk beside the HBM-bound expansion of the other).  Measured: 72.8 / 80.5-81.3 / ~52 M headers/s at 1 / 2 / 4 chunks")
+                    "of one chunk beside the HBM-bound expansion of the other).  Measured on one box: 83.7 / 90.4 M headers/s at 1 / 2 chunks")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--mode", choices=["F", "S"], default="F", help="F: one commit per range (a reference proof); S: a commit on every header")
     ap.add_argument("--event-every", type=int, default=1, help="record the per-kernel HIP events on every n-th timed step")
