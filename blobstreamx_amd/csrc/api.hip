@@ -119,7 +119,8 @@ int bsx_init(int device, bsx_ctx** out) {
     // constants of the hint's zero-padded proofs (kernels_sha.hip k_zero_paths)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->zero_paths), 320);
     if (e == hipSuccess) e = bsxk_zero_paths(c->stream, c->zero_paths);
-    // the fixed-key Ed25519 table of the base point B (512 KB; kernels_ed.hip), shared by every keyed verification
+    // the fixed-key Ed25519 table of the base point B (16 x 32768 affine entries of 128 B = 64 MB; kernels_ed.hip), shared by
+    // every keyed verification
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->btab), bsxk_ed25519_btable_bytes());
     if (e == hipSuccess) e = bsxk_ed25519_btable(c->stream, c->btab);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -188,7 +189,8 @@ int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr) {
     bsx_vmm_block b{nullptr, size, {}};
     HIPCHK(hipMemCreate(&b.handle, size, &prop, 0));
     hipError_t e = hipMemAddressReserve(&b.va, size, 1ull << 30, nullptr, 0);
-    if (e == hipSuccess) e = hipMemMap(b.va, size, 0, b.handle, 0);
+    bool mapped = false;
+    if (e == hipSuccess) { e = hipMemMap(b.va, size, 0, b.handle, 0); mapped = e == hipSuccess; }
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
@@ -196,6 +198,7 @@ int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr) {
     if (e == hipSuccess) e = hipMemsetAsync(b.va, 0, size, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
+        if (mapped) (void)hipMemUnmap(b.va, size);
         (void)hipMemRelease(b.handle);
         if (b.va) (void)hipMemAddressFree(b.va, size);
         return fail(BSX_ERR_HIP, "bsx_dev_alloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
@@ -209,10 +212,11 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
     DEV_ENTER();
     for (size_t i = 0; i < ctx->vmm.size(); i++)
         if (ctx->vmm[i].va == ptr) {
+            // the block stays registered until its teardown has succeeded: a failure here leaves it to bsx_shutdown
             const bsx_vmm_block b = ctx->vmm[i];
-            ctx->vmm.erase(ctx->vmm.begin() + (long)i);
             HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipMemUnmap(b.va, b.size));
+            ctx->vmm.erase(ctx->vmm.begin() + (long)i);
             HIPCHK(hipMemRelease(b.handle));
             HIPCHK(hipMemAddressFree(b.va, b.size));
             return BSX_OK;
@@ -391,11 +395,32 @@ static int ctx_keytable(bsx_ctx* ctx, uint32_t v_max, uint8_t** out, hipStream_t
         if (ctx->keytab) (void)hipFree(ctx->keytab);
         ctx->keytab = nullptr;
         ctx->keytab_rows = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->keytab), bsxk_keytable_bytes(v_max)));
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->keytab), bsxk_keytable_bytes(v_max)) != hipSuccess) {
+            // 5.8 MB per validator slot (2.9 GB at v_max = 512) did not fit: the caller verifies with the generic
+            // per-signature kernel instead (same accept set, no table)
+            (void)hipGetLastError();
+            ctx->keytab = nullptr;
+            *out = nullptr;
+            return BSX_OK;
+        }
         HIPCHK(hipMemsetAsync(ctx->keytab, 0, (size_t)v_max * 64, stream));          // key records: nothing to reuse yet
         ctx->keytab_rows = v_max;
     }
     *out = ctx->keytab;
+    return BSX_OK;
+}
+// signature check of n = n_commits * v_max slots: keyed (table of the first commit's keys, kept in the context) or, when the
+// table could not be allocated, generic
+static int ctx_verify(bsx_ctx* ctx, hipStream_t st, const bsx_validator* dv, const uint8_t* dh, uint64_t n, uint32_t v_max, uint8_t* dok,
+                      void* dscratch) {
+    uint8_t* tab = nullptr;
+    RET(ctx_keytable(ctx, v_max, &tab, st));
+    if (!tab) {
+        HIPCHK(bsxk_ed25519_verify(st, dv, dh, n, dok));
+        return BSX_OK;
+    }
+    HIPCHK(bsxk_ed25519_keytable(st, dv, v_max, tab));
+    HIPCHK(bsxk_ed25519_verify_keyed(st, dv, dh, n, v_max, tab, v_max, ctx->btab, dok, dscratch));
     return BSX_OK;
 }
 
@@ -887,12 +912,9 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
     {
         // per-key tables from the first commit's slots (kept in the context between calls); slots whose key differs fall
         // back to the generic path inside bsxk_ed25519_verify_keyed: same accept set for any input
-        uint8_t* tab = nullptr;
-        RET(ctx_keytable(ctx, v_max, &tab, st));
-        HIPCHK(bsxk_ed25519_keytable(st, dv.as<bsx_validator>(), v_max, tab));
         DBuf dscr;                                  // batch inversion pays from a few thousand signatures on (one more launch)
         if (n >= 4096) RET(dscr.alloc(bsxk_ed25519_scratch_bytes(n)));
-        HIPCHK(bsxk_ed25519_verify_keyed(st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), dscr.p));
+        RET(ctx_verify(ctx, st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dok.as<uint8_t>(), dscr.p));
     }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     StagedD2H back(ctx, st);
@@ -972,12 +994,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     HIPCHK(hipEventRecord(ctx->ev_a, st));
     const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
     HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
-    {
-        uint8_t* tab = nullptr;
-        RET(ctx_keytable(ctx, v_max, &tab, sb));
-        HIPCHK(bsxk_ed25519_keytable(sb, dv.as<bsx_validator>(), v_max, tab));
-        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), nullptr));
-    }
+    RET(ctx_verify(ctx, sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, dok.as<uint8_t>(), nullptr));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) + trusted tally from `st`
     HIPCHK(bsxk_commit_tally(sb, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     HIPCHK(bsxk_skip_check(sb, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),

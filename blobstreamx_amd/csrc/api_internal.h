@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "../../include/bsx.h"
@@ -40,6 +41,11 @@ struct bsx_ctx {
     size_t hstage_cap = 0;
     hipEvent_t ev_c = nullptr;
     uint32_t merkle_wgs = 0;             // BSX_TUNE_MERKLE_WORKGROUPS
+    // The host tier keeps per-context mutable state (arena, page-locked staging, key table, stream2 + events): host-tier
+    // entry points serialise on this lock, so ONE context may be shared by any number of threads (they take turns);
+    // recursive because host-tier entry points nest (bsx_next_header -> bsx_header_hashes).  The device tier holds no
+    // per-call context state and does not take it.
+    std::recursive_mutex host_mu;
 };
 
 namespace bsxapi {
@@ -64,9 +70,10 @@ extern thread_local bsx_arena* tl_arena;      // arena of the host-tier call run
 
 // RAII of one host-tier entry point (nested entry points share the outermost scope)
 struct ArenaScope {
+    std::lock_guard<std::recursive_mutex> lock;   // first member: taken before, released after the arena bookkeeping
     bsx_arena* a;
     bsx_arena* prev;
-    explicit ArenaScope(bsx_ctx* ctx) : a(&ctx->arena), prev(tl_arena) {
+    explicit ArenaScope(bsx_ctx* ctx) : lock(ctx->host_mu), a(&ctx->arena), prev(tl_arena) {
         tl_arena = a;
         a->depth++;
     }

@@ -169,7 +169,12 @@ typedef struct bsx_commit_result {
 } bsx_commit_result;                        /* sizeof == 96 */
 #define BSX_MAX_TOTAL_VOTING_POWER 1152921504606846975ull   /* (2^63 - 1) / 8 */
 
-typedef struct bsx_ctx bsx_ctx;             /* one per HIP device; calls on distinct contexts are thread-safe */
+/* One context per HIP device (several per device are fine).  Threading: calls on DISTINCT contexts run concurrently.  The
+ * host tier keeps per-context state (scratch arena, page-locked staging, the persistent Ed25519 key table, a second stream),
+ * so host-tier calls on ONE context serialise on a lock inside the context: sharing a context between threads (e.g. the
+ * async hints of a tokio runtime, header_range.rs:180-181) is safe, they simply take turns — use one context per worker for
+ * concurrency.  Device-tier calls (bsx_dev_*) only enqueue on the caller's stream and keep no per-call state. */
+typedef struct bsx_ctx bsx_ctx;
 
 /* ------------------------------------------------------------------ lifecycle */
 uint32_t bsx_version(void);

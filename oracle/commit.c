@@ -139,13 +139,18 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
     int rc;
     if ((rc = orc_header_hash(th, target_hash, NULL, NULL))) return rc;
     if ((rc = orc_header_hash(tr, trusted_hash, NULL, NULL))) return rc;
-    if (memcmp(trusted_hash, trusted_header_hash, 32) != 0) return BSX_ERR_ASSERT;
+    /* The three header assertions below, the commit's verdicts and the power rules are all evaluated; the status reported
+     * is the FIRST failing one in this fixed order (the product's k_skip_check uses the same order): voting-power overflow
+     * (the tallies cannot be trusted) -> trusted hash -> height leaf -> chain-id leaf -> signatures -> validator-set hashes
+     * -> 2/3 -> 1/3. */
+    int header_assert = 0;
+    if (memcmp(trusted_hash, trusted_header_hash, 32) != 0) header_assert = 1;
     uint8_t hf[12];
     int hn = varint_height_field(target_block, hf);
-    if (th->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(th->height, hf, (size_t)hn) != 0) return BSX_ERR_ASSERT;
+    if (th->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(th->height, hf, (size_t)hn) != 0) header_assert = 1;
     /* builder.skip is called with C::CHAIN_ID_BYTES (:42-43): the target header's chain-id leaf is 0a len bytes */
     if (chain_id_len > 50 || th->len[1] != chain_id_len + 2 || th->chain_id[0] != 0x0a || th->chain_id[1] != chain_id_len ||
-        memcmp(th->chain_id + 2, chain_id, chain_id_len) != 0) return BSX_ERR_ASSERT;
+        memcmp(th->chain_id + 2, chain_id, chain_id_len) != 0) header_assert = 1;
     bsx_commit_result cr, trc;
     uint8_t* ok = malloc(v_max);
     orc_verify_commit(target_validators, v_max, target_hash, &cr, ok);
@@ -156,6 +161,7 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
         for (uint32_t i = 0; i < v_max; i++) if (trusted_validators[i].enabled) tt += trusted_validators[i].voting_power;
         if (cr.power_overflow || tt > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER) status = BSX_ERR_BAD_ARG;
     }
+    if (!status && header_assert) status = BSX_ERR_ASSERT;
     if (!status && (cr.n_bad_signature || cr.n_bad_message)) status = BSX_ERR_BAD_SIGNATURE;
     /* validators_hash (field 7 = hash[2]) of both headers */
     if (!status && (th->len[7] != 34 || memcmp(th->hash[2] + 2, cr.validators_hash, 32) != 0)) status = BSX_ERR_ASSERT;

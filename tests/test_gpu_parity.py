@@ -834,3 +834,39 @@ def test_tuning_and_launch_forms_do_not_change_results():
     assert outs[0][:4] == outs[3][:4] and outs[0][5] == outs[3][5]          # flags 0 = paths recomputed from the proofs: same witness
     assert L.bsx_set_tuning(_lib.context(0), C.c_uint32(99), C.c_uint64(1)) == T.ERR_BAD_ARG
 
+
+
+def test_status_priority_with_several_faults_matches_the_oracle():
+    """an input with several faults at once must get the SAME status from the product and its checker.  Order
+    (k_skip_check = orc_header_range): voting-power overflow -> trusted hash -> height leaf -> chain-id leaf -> signatures ->
+    validator-set hashes -> 2/3 -> 1/3.  Combined cases: overflow + wrong chain id, overflow + wrong trusted hash,
+    wrong chain id + bad signature, bad signature + broken validator-set hash."""
+    from blobstreamx_amd.engine import HeaderRangeEngine
+    J, B, V = 2, 4, 6
+
+    def run(w, cid=b"celestia", inp=None):
+        S = int(w.first_height[0])
+        inp = inp if inp is not None else w.input48(0)
+        want = oracle.header_range(J, B, inp, w.headers[0], S, int(w.latest[0]), w.validators[0], w.trusted[0], chain_id=cid)[0]
+        try:
+            CombinedSkipCircuit(V, J, B, chain_id=cid).prove(inp, InputDataFetcher(w.headers[0], S, int(w.latest[0])), w.validators[0], w.trusted[0])
+            rc = T.OK
+        except _lib.BsxError as e:
+            rc = e.status
+        assert rc == want, (rc, want)
+        eng = HeaderRangeEngine(J, B, V, 1, chain_id=cid)
+        eng.upload_workload(w)
+        eng.step()
+        assert eng.download()["skip_status"][0] == want
+        return want
+
+    w = synth.Workload(36, 1, J, B, v=V)
+    w.validators[0]["voting_power"][:4] = 1 << 62                       # overflow ...
+    assert run(w, cid=b"mocha-4") == T.ERR_BAD_ARG                      # ... + wrong chain id
+    bad_in = bytearray(w.input48(0)); bad_in[9] ^= 1
+    assert run(w, inp=bytes(bad_in)) == T.ERR_BAD_ARG                   # ... + wrong trusted hash
+    w = synth.Workload(36, 1, J, B, v=V)
+    w.validators[0, 1]["signature"][2] ^= 1
+    assert run(w, cid=b"mocha-4") == T.ERR_ASSERT                       # wrong chain id outranks the bad signature
+    w.trusted[0, 0]["voting_power"] += 1
+    assert run(w) == T.ERR_BAD_SIGNATURE                                # bad signature outranks the trusted-set hash

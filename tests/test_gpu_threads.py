@@ -70,3 +70,46 @@ def test_two_contexts_two_threads():
         L.bsx_shutdown(h)
     assert not errors, errors
     assert want[1][1][0] == T.ERR_BAD_SIGNATURE and want[0][0][0] == T.OK
+
+
+def test_one_context_shared_by_two_threads():
+    """the host tier keeps per-context state (arena, staging block, key table, stream2/events), and
+    `_lib.context()` hands every Python thread the SAME context per device.  Host-tier calls therefore serialise on a lock
+    inside the context (bsx.h): two threads hammering one context with different circuits must each get the oracle's answer —
+    without the lock their arena allocations and staging bytes overlap."""
+    L = _lib.lib()
+    shapes = [(8, 32, 20), (4, 16, 9)]
+    R, rounds = 3, 16
+    ws = [synth.Workload(70 + t, R, J, B, v=V) for t, (J, B, V) in enumerate(shapes)]
+    ws[0].validators[2, 1]["signature"][7] ^= 4
+    want = []
+    for (J, B, V), w in zip(shapes, ws):
+        want.append([oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r],
+                                         w.trusted[r])[:2] for r in range(R)])
+    h = C.c_void_p()
+    assert L.bsx_init(C.c_int(0), C.byref(h)) == T.OK
+    errors = []
+    go = threading.Barrier(len(shapes))
+
+    def worker(t):
+        (J, B, V), w = shapes[t], ws[t]
+        try:
+            go.wait()
+            for i in range(rounds):
+                r = i % R
+                rc, out, msg = _call(L, h, J, B, V, w, r)
+                wrc, wout = want[t][r]
+                assert rc == wrc, (t, r, rc, wrc, msg)
+                if rc == T.OK:
+                    assert out == wout, (t, r)
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(len(shapes))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    L.bsx_shutdown(h)
+    assert not errors, errors
+    assert want[0][2][0] == T.ERR_BAD_SIGNATURE

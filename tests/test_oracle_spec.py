@@ -260,3 +260,20 @@ def test_find_block_to_request_follows_the_reference_loop():
     third["is_signed"][:3] = 1
     rc, blk, ev = oracle.find_block_to_request(S, S + 2, start3, [S + 2], third[None])
     assert blk == S + 1 and ev["valid"][0] == 0 and ev["overlap_power"][0] * 3 == ev["start_total_power"][0]
+
+
+def test_ed25519_public_vectors_parity_unpinned_by_reference():
+    """tests/golden/ed25519_vectors.json (RFC 8032 §7.1 TEST 1-3 + SHA(abc); constructed edge cases with verdicts from the
+    stdlib big-integer verifier of tests/golden/gen_ed25519_vectors.py): the oracle must give every listed verdict, and its
+    SHA-512 must give the listed challenge digests."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ed25519_vectors.json")))
+    assert len(d["rfc8032"]) == 4 and len(d["edge"]) >= 20
+    for e in d["rfc8032"] + d["edge"]:
+        pk, m, sig = (bytes.fromhex(e[k]) for k in ("public_key", "message", "signature"))
+        assert oracle.ed25519_verify(pk, m, sig) == e["valid"], e["name"]
+        if "sha512_challenge" in e:
+            assert oracle.sha512(sig[:32] + pk + m).hex() == e["sha512_challenge"]
+    assert oracle.sha512(b"abc").hex() == d["rfc8032"][3]["message"]
+    assert any(e.get("discriminates") == "cofactorless" and not e["valid"] for e in d["edge"])
