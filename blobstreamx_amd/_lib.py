@@ -33,6 +33,9 @@ SYMBOLS = [
     "bsx_witness_leaf_count", "bsx_poseidon_merkle_tree", "bsx_witness_merkle_caps",
     "bsx_dev_poseidon_permute", "bsx_dev_poseidon_leaf_hashes", "bsx_dev_witness_leaf_hashes", "bsx_dev_poseidon_merkle_caps",
     "bsx_ingest_last_error", "bsx_ingest_header_json", "bsx_ingest_signed_block_json", "bsx_ingest_data_commitment_json",
+    "bsx_pipeline_create", "bsx_pipeline_destroy", "bsx_pipeline_upload", "bsx_pipeline_enable_input_streaming", "bsx_pipeline_step",
+    "bsx_pipeline_join", "bsx_pipeline_set_allgather", "bsx_pipeline_get_results", "bsx_pipeline_buffer", "bsx_pipeline_set_timing",
+    "bsx_pipeline_timing", "bsx_calibrate", "bsx_dev_verify_commits", "bsx_dev_verify_commits_scratch_bytes",
 ]
 
 
@@ -74,6 +77,8 @@ def lib():
             L.bsx_last_error.restype = C.c_char_p
             L.bsx_status_str.restype = C.c_char_p
             L.bsx_ingest_last_error.restype = C.c_char_p
+            L.bsx_pipeline_destroy.restype = None
+            L.bsx_dev_verify_commits_scratch_bytes.restype = C.c_uint64
             for s in SYMBOLS:
                 getattr(L, s)   # AttributeError here = header/library drift
             _lib = L

@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,35 +18,7 @@
 #include "../../include/bsx_layout.h"
 #include "api_internal.h"
 
-extern "C" {
-hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t);
-hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
-hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
-                                const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
-                                uint8_t*, uint32_t*, const uint8_t*, const uint8_t*);
-hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*, uint32_t);
-hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
-hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_subchain*, const uint8_t*,
-                         uint8_t*, uint32_t*);
-hipError_t bsxk_expand_witness(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, uint64_t*);
-hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, uint8_t*, uint8_t*);
-hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
-uint64_t bsxk_keytable_bytes(uint32_t);
-hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
-hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*);
-hipError_t bsxk_ed25519_btable(hipStream_t, uint8_t*);
-uint64_t bsxk_ed25519_btable_bytes();
-uint64_t bsxk_ed25519_scratch_bytes(uint64_t);
-hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
-hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
-                           const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
-                           uint32_t*, uint8_t*, const uint32_t*, const uint8_t*, uint32_t);
-hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
-hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
-hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*, uint8_t*, uint8_t*);
-int bsxk_tally_vmax(void);
-hipError_t bsxk_skip_eval(hipStream_t, const bsx_validator*, const bsx_validator*, uint32_t, uint32_t, bsx_skip_eval*);
-}
+#include "kernels.h"
 
 static_assert(sizeof(bsx_header) == 512, "bsx_header");
 static_assert(sizeof(bsx_data_hash_proof) == 162 && sizeof(bsx_last_block_id_proof) == 200, "proofs");
@@ -53,6 +26,7 @@ static_assert(sizeof(bsx_shared_ctx) == 80 && sizeof(bsx_subchain) == 128, "reco
 static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "commit");
 static_assert(sizeof(bsx_witness_layout) == 40, "layout");
 static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
+static_assert(sizeof(bsx_commit_fold) == 128 && sizeof(bsx_pipeline_config) == 104 && sizeof(bsx_calibration) == 80, "pipeline / fold / calibration");
 
 namespace bsxapi {
 thread_local std::string g_err;
@@ -85,6 +59,13 @@ using bsxapi::use;
 hipStream_t S(bsx_ctx*, void* s) { return static_cast<hipStream_t>(s); }
 
 }  // namespace
+
+// HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.  A pipeline
+// drives 2 main + 2 commit-check streams beside the context's own two, copy and exchange streams: with 4 queues the second
+// chunk's stream lands on the first chunk's side-stream queue (measured: 3.2 -> 4.8 ms per step).  The variable is read when
+// the HIP runtime initialises, i.e. at the first HIP call of the process — normally after this library has been loaded, so
+// the default is raised here; a value the caller has set is left alone.
+__attribute__((constructor)) static void bsx_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 extern "C" {
 
@@ -382,6 +363,32 @@ int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v
     if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     HIPCHK(bsxk_skip_check(S(ctx, stream), n_ranges, v_max, d_ranges, d_headers, headers_per_range, d_hashes, d_target, d_trusted,
                            d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes, d_target_index, chain_id, chain_id_len));
+    return BSX_OK;
+}
+
+uint64_t bsx_dev_verify_commits_scratch_bytes(uint32_t n_commits, uint32_t v_max) {
+    const uint64_t n = (uint64_t)n_commits * v_max;
+    return ((n * 32 + 255) & ~255ull) + ((bsxk_ed25519_scratch_bytes(n) + 255) & ~255ull) + bsxk_commit_fold_scratch_bytes(n_commits);
+}
+
+int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits, uint32_t v_max,
+                           const uint8_t* d_header_hashes, uint32_t first_index, void* d_keytable, void* d_scratch, uint8_t* d_ok,
+                           bsx_commit_result* d_results, bsx_commit_fold* d_fold) {
+    DEV_ENTER();
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+    if (!n_commits || n_commits > BSX_COMMIT_FOLD_MAX) return fail(BSX_ERR_UNSUPPORTED, "n_commits %u not in 1..%u", n_commits, BSX_COMMIT_FOLD_MAX);
+    if (!d_validators || !d_header_hashes || !d_keytable || !d_scratch || !d_ok || !d_results || !d_fold) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (((uintptr_t)d_keytable & 127) || ((uintptr_t)d_scratch & 255)) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte, scratch 256-byte aligned");
+    hipStream_t st = S(ctx, stream);
+    const uint64_t n = (uint64_t)n_commits * v_max;
+    uint8_t* d_h = static_cast<uint8_t*>(d_scratch);
+    uint8_t* d_ed = d_h + ((n * 32 + 255) & ~255ull);
+    uint8_t* d_fs = d_ed + ((bsxk_ed25519_scratch_bytes(n) + 255) & ~255ull);
+    HIPCHK(bsxk_sha512_challenge(st, d_validators, n, d_h, nullptr));
+    HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable)));
+    HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed));
+    HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results));
+    HIPCHK(bsxk_commit_fold(st, d_results, n_commits, first_index, d_fs, d_fold));
     return BSX_OK;
 }
 

@@ -4,13 +4,7 @@
 
 #include "api_internal.h"
 
-extern "C" {
-hipError_t bsxk_poseidon_permute(hipStream_t, const uint64_t*, uint64_t, uint64_t*);
-hipError_t bsxk_leaf_hashes(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, const uint64_t*, uint32_t, uint32_t, int,
-                            uint64_t, uint64_t*);
-hipError_t bsxk_merkle_caps(hipStream_t, uint64_t*, uint32_t, uint64_t, uint32_t, uint32_t);
-hipError_t bsxk_merkle_one_level(hipStream_t, uint64_t*, uint64_t);
-}
+#include "kernels.h"
 
 using bsxapi::DBuf;
 using bsxapi::fail;

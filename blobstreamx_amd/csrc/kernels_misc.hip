@@ -78,10 +78,102 @@ __global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const
         for (uint64_t k = 0; k < hpr; k++) hashes_copy[((uint64_t)r * hpr + k) * 32 + t] = hashes[((uint64_t)r * hpr + k) * 32 + t];
 }
 
+// ------------------------------------------------------------------------------------------------ k_commit_fold
+// Mode S across GPUs ("in S mode commits shard with their headers"; next_header.rs:25-47 per header): a rank's
+// slice of per-header commit results folded into ONE 128-byte record — the unit of the mode-S all-gather.
+//   digest(c) = inner( leaf(result[c] bytes 0..64), leaf(result[c] bytes 64..84 ‖ u32 LE commit index ‖ 40 zero bytes) )
+//   root      = binary SHA-256 tree (RFC 6962 inner nodes) over digest(0..n) padded with all-zero digests to a power of two
+// leaf / inner are the Tendermint Merkle primitives (0x00 / 0x01 prefixes).  One workgroup; digests live in `scratch` (P x 32 B).
+__global__ __launch_bounds__(256) void k_commit_fold(const bsx_commit_result* __restrict__ res, uint32_t n, uint32_t first_index, uint32_t P,
+                                                     uint32_t* __restrict__ scratch, bsx_commit_fold* __restrict__ out) {
+    __shared__ unsigned long long s_ok, s_sigs;
+    __shared__ uint32_t s_first;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_ok = 0; s_sigs = 0; s_first = 0xffffffffu; }
+    __syncthreads();
+    uint64_t ok = 0, sigs = 0;
+    uint32_t first = 0xffffffffu;
+    for (uint32_t c = tid; c < P; c += 256) {
+        Digest d;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d.w[k] = 0;
+        if (c < n) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(res + c);
+            uint32_t t[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) t[k] = bswap32(p[k]);          // bytes 0..64 as big-endian message words
+            const Digest a = leaf_hash_tuple(t);
+#pragma unroll
+            for (int k = 0; k < 5; k++) t[k] = bswap32(p[16 + k]);      // n_bad_signature .. power_overflow
+            t[5] = bswap32(first_index + c);
+#pragma unroll
+            for (int k = 6; k < 16; k++) t[k] = 0;
+            const Digest b = leaf_hash_tuple(t);
+            d = inner_hash(a, b);
+            const bsx_commit_result& r = res[c];
+            const bool good = r.two_thirds_ok && !r.n_bad_signature && !r.n_bad_message && !r.power_overflow;
+            ok += good ? 1 : 0;
+            sigs += r.n_signed - r.n_bad_signature;
+            if (!good && first == 0xffffffffu) first = first_index + c;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) scratch[(uint64_t)c * 8 + k] = d.w[k];
+    }
+    atomicAdd(&s_ok, (unsigned long long)ok);
+    atomicAdd(&s_sigs, (unsigned long long)sigs);
+    atomicMin(&s_first, first);
+    __syncthreads();
+    for (uint32_t width = P / 2; width >= 1; width /= 2) {
+        // parents are written over the left half of the level (node i <- children 2i, 2i+1): a lane reads both children before
+        // the barrier and writes after it, so no lane overwrites a digest another lane still has to read
+        Digest nd[8];
+        uint32_t cnt = 0;
+        for (uint32_t i = tid; i < width; i += 256, cnt++) {
+            Digest l, r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { l.w[k] = scratch[(uint64_t)(2 * i) * 8 + k]; r.w[k] = scratch[(uint64_t)(2 * i + 1) * 8 + k]; }
+            if (cnt < 8) nd[cnt] = inner_hash(l, r);
+        }
+        __syncthreads();
+        cnt = 0;
+        for (uint32_t i = tid; i < width; i += 256, cnt++)
+            if (cnt < 8) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) scratch[(uint64_t)i * 8 + k] = nd[cnt].w[k];
+            }
+        __syncthreads();
+    }
+    if (tid < 8) {
+        const uint32_t w = scratch[tid];
+        out->root[4 * tid] = (uint8_t)(w >> 24); out->root[4 * tid + 1] = (uint8_t)(w >> 16);
+        out->root[4 * tid + 2] = (uint8_t)(w >> 8); out->root[4 * tid + 3] = (uint8_t)w;
+    }
+    if (tid == 0) {
+        out->n_commits = n;
+        out->n_ok = s_ok;
+        out->n_signatures_ok = s_sigs;
+        out->first_index = first_index;
+        out->first_failing = s_first;
+        for (int k = 0; k < 16; k++) out->_pad[k] = 0;
+    }
+}
+
 }  // namespace bsx
 
 extern "C" {
 using namespace bsx;
+// n <= BSX_COMMIT_FOLD_MAX commits; scratch: bsxk_commit_fold_scratch_bytes(n)
+uint64_t bsxk_commit_fold_scratch_bytes(uint32_t n) {
+    uint32_t P = 1;
+    while (P < n) P *= 2;
+    return (uint64_t)P * 32;
+}
+hipError_t bsxk_commit_fold(hipStream_t s, const bsx_commit_result* res, uint32_t n, uint32_t first_index, void* scratch, bsx_commit_fold* out) {
+    uint32_t P = 1;
+    while (P < n) P *= 2;
+    hipLaunchKernelGGL(k_commit_fold, dim3(1), dim3(256), 0, s, res, n, first_index, P, static_cast<uint32_t*>(scratch), out);
+    return hipGetLastError();
+}
 hipError_t bsxk_encode_tuple(hipStream_t s, const uint8_t* data_hash, uint64_t height, uint8_t* out) {
     hipLaunchKernelGGL(k_encode_tuple, dim3(1), dim3(64), 0, s, data_hash, height, out);
     return hipGetLastError();

@@ -1,0 +1,698 @@
+// pipeline.hip — the batched header_range pipeline behind the C ABI (include/bsx.h, bsx_pipeline_*).
+//
+// The object that produces the headline throughput: R independent header_range instances per step, inputs resident in
+// HBM, cut into chunks that run on their own HIP streams in complementary phases (the integer-ALU-bound hashing of one chunk
+// beside the HBM-bound witness expansion of the other), the commit check of every chunk on a side stream, double-buffered by
+// step parity so that consecutive steps need no join.  Reference dataflow per range: CombinedSkipCircuit::define
+// (circuits/header_range.rs:32-59) = builder.skip (:42-48) + prove_data_commitment (circuits/builder.rs:273-409, map closure
+// :305-336 with the hint of circuits/data_commitment.rs:18-45 -> circuits/input.rs:149-271, reduce :337-395).
+//
+// Host code only: buffer ownership, stream/event choreography, argument validation.  All arithmetic is in kernels_*.hip.
+// No environment variables, no Python, no torch: a Rust caller binds exactly this.
+#include <cstring>
+#include <vector>
+
+#include "../../include/bsx_layout.h"
+#include "api_internal.h"
+#include "kernels.h"
+
+using bsxapi::fail;
+using bsxapi::pow2;
+using bsxapi::use;
+
+namespace {
+
+struct TimingSlot {
+    hipEvent_t ev[6];       // prove_subchain [0,1], map expansion [2,3], Poseidon commitment [4,5]
+    bool sub, exp, caps;
+};
+
+struct Chunk {
+    uint32_t R = 0, RT = 0;                  // owned ranges / ranges whose job slice this rank computes, in this chunk
+    uint64_t nh_main = 0, nh_skip = 0, nh_all = 0;
+    hipStream_t main = nullptr, side = nullptr, xchg = nullptr, copy = nullptr;
+    // inputs
+    uint8_t *headers_all = nullptr, *ranges = nullptr, *latest = nullptr;
+    uint8_t *skip_ranges = nullptr, *skip_ranges_side = nullptr, *validators = nullptr, *trusted = nullptr;
+    uint32_t* target_idx = nullptr;
+    // per-header digests
+    uint8_t *hashes_all = nullptr, *dh_aunts = nullptr, *lb_aunts = nullptr, *paths = nullptr;
+    // map / reduce
+    uint32_t* status = nullptr;              // [0] header, [1] assemble
+    uint8_t *compact = nullptr, *records = nullptr, *partial = nullptr, *red_compact_local = nullptr, *gathered = nullptr;
+    uint8_t *red_compact_top = nullptr, *results = nullptr, *output64 = nullptr;
+    uint32_t* range_status = nullptr;
+    // commit check
+    uint8_t *h = nullptr, *ok = nullptr, *commit_res = nullptr, *trusted_res = nullptr, *keytable = nullptr;
+    uint32_t* skip_status = nullptr;
+    uint8_t *target_hashes_pp[2] = {nullptr, nullptr}, *skip_hashes_pp[2] = {nullptr, nullptr}, *skip_headers_pp[2] = {nullptr, nullptr};
+    // outputs
+    uint64_t *witness_map = nullptr, *witness_red_local = nullptr, *witness_red_top = nullptr, *trees = nullptr;
+    bool witness_map_vmm = false;
+    uint64_t n_map_el = 0, n_red_local_el = 0, n_red_top_el = 0, trees_words = 0;
+    size_t compact_bytes = 0, records_bytes = 0, headers_bytes = 0;
+    // state
+    int parity = 0;
+    bool commit_done_valid[2] = {false, false}, inputs_consumed_valid = false, h2d_pending = false;
+    hipEvent_t ev_sync = nullptr, ev_merkle = nullptr, ev_fill = nullptr, ev_fin = nullptr, ev_inputs_consumed = nullptr, ev_h2d = nullptr;
+    hipEvent_t ev_commit_done[2] = {nullptr, nullptr}, ev_hash_tok = nullptr, ev_expand_tok = nullptr, ev_x_in = nullptr, ev_x_out = nullptr;
+    uint8_t* host_image = nullptr;           // page-locked image of headers_all (input streaming)
+    std::vector<TimingSlot> timing;
+    size_t timing_used = 0;
+};
+
+}  // namespace
+
+struct bsx_pipeline {
+    bsx_ctx* ctx = nullptr;
+    bsx_pipeline_config cfg{};
+    uint32_t J = 0, B = 0, V = 0, R = 0, E = 0, Rc = 0, rank = 0, world = 1, jf = 0, jc = 0;
+    uint64_t hpr = 0, hfr = 0;
+    bool with_witness = false, with_commit = false, with_caps = false, keyed = false, commit_beside_hash = false, fused_hint = true;
+    uint32_t subchain_flags = 0, merkle_wgs = 0;
+    uint32_t leaf_len = 0, cap_height = 0, n_leaves = 0;
+    uint64_t tree_digests = 0;
+    bsx_witness_layout ml{}, rl{};
+    std::vector<Chunk> chunks;
+    std::vector<void*> allocs;               // hipMalloc'ed blocks
+    std::vector<void*> host_allocs;          // hipHostMalloc'ed blocks
+    hipEvent_t hash_token = nullptr, expand_token = nullptr;     // aliases of a chunk's ev_hash_tok / ev_expand_tok
+    Chunk* pending_verify = nullptr;
+    bsx_allgather_fn allgather = nullptr;
+    void* allgather_user = nullptr;
+    bool timing_on = false, streaming = false, uploaded = false;
+};
+
+namespace {
+
+int dalloc(bsx_pipeline* p, size_t bytes, void** out) {
+    if (bytes < 256) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(BSX_ERR_HIP, "bsx_pipeline: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    e = hipMemset(q, 0, bytes);
+    if (e != hipSuccess) { (void)hipFree(q); return fail(BSX_ERR_HIP, "bsx_pipeline: hipMemset: %s", hipGetErrorString(e)); }
+    p->allocs.push_back(q);
+    *out = q;
+    return BSX_OK;
+}
+template <typename T> int dalloc_t(bsx_pipeline* p, size_t bytes, T** out) {
+    void* q = nullptr;
+    RET(dalloc(p, bytes, &q));
+    *out = static_cast<T*>(q);
+    return BSX_OK;
+}
+int new_event(hipEvent_t* e, bool timing = false) {
+    HIPCHK(hipEventCreateWithFlags(e, timing ? hipEventDefault : hipEventDisableTiming));
+    return BSX_OK;
+}
+int new_stream(hipStream_t* s) {
+    HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    return BSX_OK;
+}
+// `waiter` continues only after everything enqueued on `on` so far
+int stream_wait_stream(hipStream_t waiter, hipStream_t on, hipEvent_t scratch) {
+    HIPCHK(hipEventRecord(scratch, on));
+    HIPCHK(hipStreamWaitEvent(waiter, scratch, 0));
+    return BSX_OK;
+}
+
+int create_chunk(bsx_pipeline* p, Chunk& c) {
+    const uint32_t jc = p->jc, V = p->V, world = p->world;
+    c.R = p->Rc;
+    c.RT = p->Rc * world;
+    const uint32_t R = c.R, RT = c.RT;
+    c.nh_main = (uint64_t)RT * p->hpr;
+    c.nh_skip = p->with_commit ? (uint64_t)R * 2 : 0;
+    c.nh_all = c.nh_main + c.nh_skip;
+    RET(new_stream(&c.main));
+    RET(new_stream(&c.side));
+    if (world > 1) RET(new_stream(&c.xchg));
+    for (hipEvent_t* e : {&c.ev_sync, &c.ev_merkle, &c.ev_fill, &c.ev_fin, &c.ev_inputs_consumed, &c.ev_h2d, &c.ev_commit_done[0], &c.ev_commit_done[1],
+                          &c.ev_hash_tok, &c.ev_expand_tok, &c.ev_x_in, &c.ev_x_out})
+        RET(new_event(e));
+    // one header block per step: this rank's slice of every range, then (owned ranges) the trusted and the target header of
+    // the commit check as a 2-header block per range — hashed by ONE k_header_merkle launch
+    c.headers_bytes = c.nh_all * sizeof(bsx_header);
+    RET(dalloc_t(p, c.headers_bytes, &c.headers_all));
+    RET(dalloc_t(p, c.nh_all * 32, &c.hashes_all));
+    RET(dalloc_t(p, c.nh_all * 128, &c.dh_aunts));
+    RET(dalloc_t(p, c.nh_all * 128, &c.lb_aunts));
+    if (p->fused_hint) RET(dalloc_t(p, c.nh_all * BSX_HEADER_PATH_BYTES, &c.paths));
+    RET(dalloc_t(p, (size_t)RT * sizeof(bsx_shared_ctx), &c.ranges));
+    RET(dalloc_t(p, (size_t)RT * 8, &c.latest));
+    RET(dalloc_t(p, 32, &c.status));
+    c.compact_bytes = (size_t)RT * jc * p->ml.compact_stride;
+    RET(dalloc_t(p, c.compact_bytes, &c.compact));
+    c.records_bytes = (size_t)RT * jc * sizeof(bsx_subchain);
+    RET(dalloc_t(p, c.records_bytes, &c.records));
+    RET(dalloc_t(p, (size_t)RT * 128, &c.partial));
+    const size_t n_local_nodes = (size_t)RT * (jc > 1 ? jc - 1 : 0);
+    RET(dalloc_t(p, n_local_nodes * p->rl.compact_stride, &c.red_compact_local));
+    RET(dalloc_t(p, (size_t)world * RT * 128, &c.gathered));
+    RET(dalloc_t(p, (size_t)R * (world - 1) * p->rl.compact_stride, &c.red_compact_top));
+    RET(dalloc_t(p, (size_t)R * 128, &c.results));
+    RET(dalloc_t(p, (size_t)R * 64, &c.output64));
+    RET(dalloc_t(p, (size_t)R * 4, &c.range_status));
+    RET(dalloc_t(p, (size_t)R * sizeof(bsx_shared_ctx), &c.skip_ranges));
+    RET(dalloc_t(p, (size_t)R * sizeof(bsx_shared_ctx), &c.skip_ranges_side));
+    RET(dalloc_t(p, (size_t)R * 4, &c.target_idx));
+    {
+        std::vector<uint32_t> ones(R, 1u);                 // the target is header 1 of each (trusted, target) block
+        HIPCHK(hipMemcpy(c.target_idx, ones.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+    }
+    RET(dalloc_t(p, (size_t)R * V * sizeof(bsx_validator), &c.validators));
+    RET(dalloc_t(p, (size_t)R * V * sizeof(bsx_validator), &c.trusted));
+    RET(dalloc_t(p, (size_t)R * V * 32, &c.h));
+    RET(dalloc_t(p, (size_t)R * V, &c.ok));
+    RET(dalloc_t(p, (size_t)R * sizeof(bsx_commit_result), &c.commit_res));
+    RET(dalloc_t(p, (size_t)R * sizeof(bsx_commit_result), &c.trusted_res));
+    RET(dalloc_t(p, (size_t)R * 4, &c.skip_status));
+    for (int q = 0; q < 2; q++) {
+        RET(dalloc_t(p, (size_t)R * 32, &c.target_hashes_pp[q]));
+        RET(dalloc_t(p, (size_t)R * 64, &c.skip_hashes_pp[q]));
+        RET(dalloc_t(p, (size_t)R * 2 * sizeof(bsx_header), &c.skip_headers_pp[q]));
+    }
+    if (p->with_commit && p->keyed) RET(dalloc_t(p, bsxk_keytable_bytes(V), &c.keytable));   // zeroed: no row to reuse yet
+    c.n_map_el = (uint64_t)RT * jc * p->ml.n_elements;
+    c.n_red_local_el = (uint64_t)n_local_nodes * p->rl.n_elements;
+    c.n_red_top_el = (uint64_t)R * (world - 1) * p->rl.n_elements;
+    if (p->with_witness) {
+        // the map-job image (14.7 GB per chunk at the bench shape) comes from the HIP virtual-memory API: one physical handle,
+        // deterministic placement (bsx_dev_alloc)
+        const uint64_t bytes = (c.n_map_el + 2) * 8;
+        if (bytes >= (64ull << 20)) {
+            void* q = nullptr;
+            RET(bsx_dev_alloc(p->ctx, bytes, &q));
+            c.witness_map = static_cast<uint64_t*>(q);
+            c.witness_map_vmm = true;
+        } else {
+            RET(dalloc_t(p, bytes, &c.witness_map));
+        }
+        RET(dalloc_t(p, (c.n_red_local_el + 2) * 8, &c.witness_red_local));
+        RET(dalloc_t(p, (c.n_red_top_el + 2) * 8, &c.witness_red_top));
+    }
+    if (p->with_caps) {
+        c.trees_words = (uint64_t)RT * jc * p->tree_digests * 4;
+        RET(dalloc_t(p, c.trees_words * 8, &c.trees));
+    }
+    return BSX_OK;
+}
+
+TimingSlot* timing_slot(Chunk& c) {
+    if (c.timing_used == c.timing.size()) {
+        TimingSlot t{};
+        for (auto& e : t.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDefault) != hipSuccess) return nullptr;
+        c.timing.push_back(t);
+    }
+    TimingSlot* t = &c.timing[c.timing_used++];
+    t->sub = t->exp = t->caps = false;
+    return t;
+}
+
+// Stage 3 for the owned ranges on stream `st` (builder.skip, header_range.rs:42-48).
+//   prep:   SHA-512 challenges + per-validator tables (small, memory-latency sensitive) — beside the hashing
+//   verify: signature checks, tallies, skip conditions (integer ALU) — beside the expansion
+int commit_part(bsx_pipeline* p, Chunk& c, hipStream_t st, bool prep, bool verify) {
+    const uint32_t R = c.R, V = p->V;
+    const uint64_t n = (uint64_t)R * V;
+    auto* vals = reinterpret_cast<const bsx_validator*>(c.validators);
+    auto* trs = reinterpret_cast<const bsx_validator*>(c.trusted);
+    if (prep) {
+        HIPCHK(bsxk_sha512_challenge(st, vals, n, c.h, nullptr));
+        if (p->keyed) HIPCHK(bsxk_ed25519_keytable(st, vals, V, c.keytable));
+    }
+    if (!verify) return BSX_OK;
+    if (p->keyed)
+        HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, V, p->ctx->btab, c.ok, nullptr));
+    else
+        HIPCHK(bsxk_ed25519_verify(st, vals, c.h, n, c.ok));
+    auto* cres = reinterpret_cast<bsx_commit_result*>(c.commit_res);
+    auto* tres = reinterpret_cast<bsx_commit_result*>(c.trusted_res);
+    HIPCHK(bsxk_commit_tally(st, trs, R, V, nullptr, nullptr, tres));
+    HIPCHK(bsxk_commit_tally(st, vals, R, V, c.target_hashes_pp[c.parity], c.ok, cres));
+    // streamed inputs: headers_all is overwritten early in the next step while this check may still run -> private copy
+    const uint8_t* skip_headers = p->streaming ? c.skip_headers_pp[c.parity] : c.headers_all + c.nh_main * sizeof(bsx_header);
+    HIPCHK(bsxk_skip_check(st, R, V, reinterpret_cast<const bsx_shared_ctx*>(c.skip_ranges_side), reinterpret_cast<const bsx_header*>(skip_headers), 2,
+                           c.skip_hashes_pp[c.parity], vals, trs, c.ok, cres, tres, c.skip_status, nullptr, c.target_idx,
+                           p->cfg.chain_id_len ? p->cfg.chain_id : nullptr, p->cfg.chain_id_len));
+    HIPCHK(hipEventRecord(c.ev_commit_done[c.parity], st));
+    c.commit_done_valid[c.parity] = true;
+    return BSX_OK;
+}
+
+bool commit_active(const bsx_pipeline* p, const Chunk& c) { return p->with_commit && c.R && c.nh_skip; }
+
+// signature checks, tallies and skip conditions of the chunk's current step on its side stream; after_event (optional)
+// delays them — the other chunk's header-hashing event, so that this ALU work runs beside that chunk's memory-leaning kernels
+int launch_verify(bsx_pipeline* p, Chunk& c, hipEvent_t after_event) {
+    if (!commit_active(p, c) || p->commit_beside_hash) return BSX_OK;
+    HIPCHK(hipStreamWaitEvent(c.side, c.ev_fill, 0));
+    if (after_event) HIPCHK(hipStreamWaitEvent(c.side, after_event, 0));
+    return commit_part(p, c, c.side, false, true);
+}
+
+// stages 1-5 + local fold: everything before the cross-GPU exchange
+int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
+    const uint32_t B = p->B, jc = p->jc, RT = c.RT, R = c.R;
+    hipStream_t st = c.main;
+    if (c.h2d_pending) {                      // streamed inputs: this step's headers arrive on the copy stream
+        HIPCHK(hipStreamWaitEvent(st, c.ev_h2d, 0));
+        c.h2d_pending = false;
+    }
+    HIPCHK(hipMemsetAsync(c.status, 0, 32, st));
+    const bool commit = commit_active(p, c);
+    if (commit && !p->commit_beside_hash) {
+        // challenges + per-validator tables need nothing from this step: start them right away beside the hashing
+        RET(stream_wait_stream(c.side, st, c.ev_sync));
+        RET(commit_part(p, c, c.side, true, false));
+    }
+    HIPCHK(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(c.headers_all), commit ? c.nh_all : c.nh_main, c.hashes_all, c.dh_aunts,
+                              c.lb_aunts, c.paths, c.status, p->merkle_wgs));
+    HIPCHK(hipEventRecord(c.ev_merkle, st));
+    if (commit) {
+        c.parity ^= 1;
+        if (c.commit_done_valid[c.parity]) HIPCHK(hipStreamWaitEvent(st, c.ev_commit_done[c.parity], 0));   // the check two steps ago read these
+        uint8_t* skip_hashes = c.hashes_all + c.nh_main * 32;
+        HIPCHK(bsxk_fill_end_hash(st, R, reinterpret_cast<bsx_shared_ctx*>(c.skip_ranges), skip_hashes, 2, c.target_idx, c.target_hashes_pp[c.parity],
+                                  c.skip_hashes_pp[c.parity]));
+        if (p->streaming)
+            HIPCHK(hipMemcpyAsync(c.skip_headers_pp[c.parity], c.headers_all + c.nh_main * sizeof(bsx_header), (size_t)R * 2 * sizeof(bsx_header),
+                                  hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(c.ev_fill, st));
+        if (p->commit_beside_hash) {
+            RET(stream_wait_stream(c.side, st, c.ev_sync));
+            RET(commit_part(p, c, c.side, true, true));
+        }
+    }
+    HIPCHK(bsxk_assemble_inputs(st, RT, p->J, B, p->jf, jc, B, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), reinterpret_cast<const uint64_t*>(c.latest),
+                                reinterpret_cast<const bsx_header*>(c.headers_all), p->hpr, p->hfr, c.hashes_all, c.dh_aunts, c.lb_aunts, c.compact,
+                                c.status + 1, c.paths, p->ctx->zero_paths));
+    HIPCHK(hipEventRecord(c.ev_inputs_consumed, st));       // headers_all may be overwritten from here on (input streaming)
+    c.inputs_consumed_valid = true;
+    if (ts) { HIPCHK(hipEventRecord(ts->ev[0], st)); }
+    HIPCHK(bsxk_prove_subchain(st, RT, B, jc, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), c.compact, reinterpret_cast<bsx_subchain*>(c.records),
+                               p->subchain_flags));
+    if (ts) { HIPCHK(hipEventRecord(ts->ev[1], st)); ts->sub = true; }
+    HIPCHK(bsxk_reduce(st, RT, jc, reinterpret_cast<const bsx_subchain*>(c.records), jc, 1, reinterpret_cast<bsx_subchain*>(c.partial),
+                       jc > 1 ? c.red_compact_local : nullptr));
+    return BSX_OK;
+}
+
+int stream_inputs(bsx_pipeline* p, Chunk& c) {
+    if (!p->streaming || !c.host_image) return BSX_OK;
+    if (c.inputs_consumed_valid) HIPCHK(hipStreamWaitEvent(c.copy, c.ev_inputs_consumed, 0));
+    HIPCHK(hipMemcpyAsync(c.headers_all, c.host_image, c.headers_bytes, hipMemcpyHostToDevice, c.copy));
+    HIPCHK(hipEventRecord(c.ev_h2d, c.copy));
+    c.h2d_pending = true;
+    return BSX_OK;
+}
+
+int exchange_begin(bsx_pipeline* p, Chunk& c) {
+    if (!p->allgather) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline: world > 1 needs bsx_pipeline_set_allgather before the first step");
+    RET(stream_wait_stream(c.xchg, c.main, c.ev_x_in));
+    if (p->allgather(p->allgather_user, c.partial, c.gathered, (uint64_t)c.RT * 128, c.xchg) != 0)
+        return fail(BSX_ERR_HIP, "bsx_pipeline: the caller's all-gather failed");
+    HIPCHK(hipEventRecord(c.ev_x_out, c.xchg));
+    return BSX_OK;
+}
+// top fold straight from the all-gather layout [rank][range]: record k of owned range r = gathered[k][rank*R + r]
+int exchange_end(bsx_pipeline* p, Chunk& c, const uint8_t** out_results) {
+    HIPCHK(hipStreamWaitEvent(c.main, c.ev_x_out, 0));
+    const uint8_t* own = c.gathered + (size_t)p->rank * c.R * 128;
+    HIPCHK(bsxk_reduce(c.main, c.R, p->world, reinterpret_cast<const bsx_subchain*>(own), 1, c.RT, reinterpret_cast<bsx_subchain*>(c.results),
+                       c.red_compact_top));
+    *out_results = c.results;
+    return BSX_OK;
+}
+
+int finalize(bsx_pipeline* p, Chunk& c, const uint8_t* records) {
+    const uint8_t* own_ranges = p->with_commit ? c.skip_ranges : c.ranges + (size_t)p->rank * c.R * sizeof(bsx_shared_ctx);
+    HIPCHK(bsxk_finalize(c.main, c.R, p->J, p->B, reinterpret_cast<const bsx_shared_ctx*>(own_ranges), reinterpret_cast<const bsx_subchain*>(records),
+                         p->with_commit ? c.target_hashes_pp[c.parity] : nullptr, c.output64, c.range_status));
+    return BSX_OK;
+}
+
+// finalize + (commit verification on the side stream) + witness expansion / Poseidon commitment.
+// result_records == nullptr: the exchange was only begun; top fold, finalize and the top reduce nodes' expansion run behind
+// the map-job expansion, so the collective's latency hides beside this chunk's own expansion.
+int step_final(bsx_pipeline* p, Chunk& c, const uint8_t* result_records, bool do_launch_verify, hipEvent_t wait_before_expand, TimingSlot* ts) {
+    hipStream_t st = c.main;
+    const bool late = result_records == nullptr;
+    if (!late) RET(finalize(p, c, result_records));
+    if (do_launch_verify) {
+        // integer-ALU work: start it beside the HBM-bound expansion (i.e. once finalize is done), not beside the hashing
+        HIPCHK(hipEventRecord(c.ev_fin, st));
+        RET(launch_verify(p, c, c.ev_fin));
+    }
+    if (wait_before_expand) HIPCHK(hipStreamWaitEvent(st, wait_before_expand, 0));
+    if (p->with_witness) {
+        if (ts) HIPCHK(hipEventRecord(ts->ev[2], st));
+        HIPCHK(bsxk_expand_witness(st, &p->ml, c.RT * p->jc, c.compact, c.witness_map));
+        if (ts) { HIPCHK(hipEventRecord(ts->ev[3], st)); ts->exp = true; }
+        if (p->jc > 1) HIPCHK(bsxk_expand_witness(st, &p->rl, c.RT * (p->jc - 1), c.red_compact_local, c.witness_red_local));
+    }
+    if (p->with_caps) {
+        // Poseidon Merkle cap of every map-job witness straight from the compact bytes (elements generated on the fly)
+        if (ts) HIPCHK(hipEventRecord(ts->ev[4], st));
+        HIPCHK(bsxk_leaf_hashes(st, &p->ml, c.RT * p->jc, c.compact, nullptr, p->leaf_len, p->n_leaves, 1, 4 * p->tree_digests, c.trees));
+        HIPCHK(bsxk_merkle_caps(st, c.trees, c.RT * p->jc, 4 * p->tree_digests, p->n_leaves, p->cap_height));
+        if (ts) { HIPCHK(hipEventRecord(ts->ev[5], st)); ts->caps = true; }
+    }
+    if (p->E > 1) {                           // release the other chunk's expansion
+        HIPCHK(hipEventRecord(c.ev_expand_tok, st));
+        p->expand_token = c.ev_expand_tok;
+    }
+    if (late) {
+        const uint8_t* res = nullptr;
+        RET(exchange_end(p, c, &res));
+        RET(finalize(p, c, res));
+    }
+    if (p->with_witness && p->world > 1)
+        HIPCHK(bsxk_expand_witness(st, &p->rl, c.R * (p->world - 1), c.red_compact_top, c.witness_red_top));
+    return BSX_OK;
+}
+
+int join_impl(bsx_pipeline* p) {
+    if (p->pending_verify) {                  // no later chunk to wait for: launch the deferred checks now
+        Chunk* c = p->pending_verify;
+        p->pending_verify = nullptr;
+        RET(launch_verify(p, *c, nullptr));
+    }
+    for (Chunk& c : p->chunks) {
+        HIPCHK(hipStreamSynchronize(c.main));
+        HIPCHK(hipStreamSynchronize(c.side));
+        if (c.xchg) HIPCHK(hipStreamSynchronize(c.xchg));
+        if (c.copy) HIPCHK(hipStreamSynchronize(c.copy));
+    }
+    return BSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeline** out) {
+    RET(use(ctx));
+    if (!cfg || !out) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_create: null pointer");
+    *out = nullptr;
+    const uint32_t J = cfg->nb_map_jobs, B = cfg->batch_size, V = cfg->v_max, world = cfg->world ? cfg->world : 1;
+    if (!pow2(J) || J > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
+    if (!pow2(B) || B > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
+    if (cfg->flags & ~(BSX_PIPE_WITNESS | BSX_PIPE_COMMIT | BSX_PIPE_CAPS | BSX_PIPE_ED_GENERIC | BSX_PIPE_COMMIT_BESIDE_HASH | BSX_PIPE_RECOMPUTE_PATHS))
+        return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_create: unknown flags 0x%x", cfg->flags);
+    if ((cfg->flags & BSX_PIPE_COMMIT) && (V == 0 || (int)V > bsxk_tally_vmax())) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", V, bsxk_tally_vmax());
+    if (!cfg->n_ranges || !cfg->n_chunks || cfg->n_ranges % cfg->n_chunks) return fail(BSX_ERR_BAD_ARG, "n_chunks must divide n_ranges (both > 0)");
+    if (cfg->rank >= world || J % world) return fail(BSX_ERR_BAD_ARG, "world %u must divide NB_MAP_JOBS %u and rank %u be below it", world, J, cfg->rank);
+    if (!pow2(J / world)) return fail(BSX_ERR_BAD_ARG, "each rank needs a power-of-two slice of the map jobs (the local fold is a subtree of the reference's reduce tree)");
+    if (cfg->chain_id_len > 50) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
+    if (cfg->tune_subchain > 2) return fail(BSX_ERR_BAD_ARG, "tune_subchain must be 0, 1 or 2");
+    bsx_pipeline* p = new bsx_pipeline();
+    p->ctx = ctx;
+    p->cfg = *cfg;
+    p->J = J; p->B = B; p->V = V ? V : 1; p->R = cfg->n_ranges; p->E = cfg->n_chunks; p->Rc = p->R / p->E;
+    p->rank = cfg->rank; p->world = world;
+    p->jc = J / world; p->jf = p->rank * p->jc;
+    p->hpr = (uint64_t)p->jc * B + 1;          // headers this rank holds per range: its slice + the next one
+    p->hfr = (uint64_t)p->jf * B;              // height offset of the first of them
+    p->with_witness = cfg->flags & BSX_PIPE_WITNESS;
+    p->with_commit = cfg->flags & BSX_PIPE_COMMIT;
+    p->with_caps = cfg->flags & BSX_PIPE_CAPS;
+    p->commit_beside_hash = cfg->flags & BSX_PIPE_COMMIT_BESIDE_HASH;
+    p->fused_hint = !(cfg->flags & BSX_PIPE_RECOMPUTE_PATHS);
+    // fixed-key tables pay from a handful of commits per chunk on (below, the generic kernel's 256 doublings are hidden anyway)
+    p->keyed = !(cfg->flags & BSX_PIPE_ED_GENERIC) && p->Rc >= 8;
+    p->ml = bsx_map_layout(B);
+    p->rl = bsx_reduce_layout();
+    // Launch forms (measured): beside an expansion the header hashing is held to 2 workgroups per CU and
+    // prove_subchain keeps its stages in separate launches, so that the expansion's waves keep half of the register file;
+    // alone, both take the whole GPU.
+    p->subchain_flags = p->fused_hint ? BSX_SUBCHAIN_PATHS_FROM_HINT : 0;
+    const bool beside_expansion = p->with_witness && p->E > 1;
+    if (beside_expansion && p->fused_hint) p->subchain_flags |= BSX_SUBCHAIN_SEPARATE_LAUNCHES;
+    if (cfg->tune_subchain == 1) p->subchain_flags &= ~BSX_SUBCHAIN_SEPARATE_LAUNCHES;
+    if (cfg->tune_subchain == 2 && p->fused_hint) p->subchain_flags |= BSX_SUBCHAIN_SEPARATE_LAUNCHES;
+    if (cfg->tune_merkle_workgroups) {
+        p->merkle_wgs = cfg->tune_merkle_workgroups == 0xffffffffu ? 0 : cfg->tune_merkle_workgroups;
+    } else if (beside_expansion) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) p->merkle_wgs = 2u * (uint32_t)prop.multiProcessorCount;
+    }
+    if (p->with_caps) {
+        p->leaf_len = cfg->leaf_len ? cfg->leaf_len : 135;
+        p->n_leaves = bsx_witness_leaf_count(p->ml.n_elements, p->leaf_len);
+        uint32_t lg = 0;
+        while ((1u << (lg + 1)) <= p->n_leaves) lg++;
+        p->cap_height = cfg->cap_height || cfg->leaf_len ? cfg->cap_height : 4;
+        if (p->cap_height > lg) p->cap_height = lg;
+        p->tree_digests = bsx_poseidon_tree_digests(p->n_leaves, p->cap_height);
+        if (!p->n_leaves || !p->tree_digests) { delete p; return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_create: bad leaf_len / cap_height"); }
+    }
+    p->chunks.resize(p->E);
+    for (Chunk& c : p->chunks) {
+        const int rc = create_chunk(p, c);
+        if (rc != BSX_OK) {
+            const std::string msg = bsxapi::g_err;
+            bsx_pipeline_destroy(p);
+            bsxapi::g_err = msg;
+            return rc;
+        }
+    }
+    *out = p;
+    return BSX_OK;
+}
+
+void bsx_pipeline_destroy(bsx_pipeline* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    for (Chunk& c : p->chunks) {
+        for (hipStream_t s : {c.main, c.side, c.xchg, c.copy})
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        for (hipEvent_t e : {c.ev_sync, c.ev_merkle, c.ev_fill, c.ev_fin, c.ev_inputs_consumed, c.ev_h2d, c.ev_commit_done[0], c.ev_commit_done[1],
+                             c.ev_hash_tok, c.ev_expand_tok, c.ev_x_in, c.ev_x_out})
+            if (e) (void)hipEventDestroy(e);
+        for (TimingSlot& t : c.timing)
+            for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
+        if (c.witness_map && c.witness_map_vmm) (void)bsx_dev_free(p->ctx, c.witness_map);
+    }
+    for (void* q : p->allocs) (void)hipFree(q);
+    for (void* q : p->host_allocs) (void)hipHostFree(q);
+    delete p;
+}
+
+int bsx_pipeline_set_allgather(bsx_pipeline* p, bsx_allgather_fn fn, void* user) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    p->allgather = fn;
+    p->allgather_user = user;
+    return BSX_OK;
+}
+
+int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
+    if (!p || !in) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_upload: null pointer");
+    RET(use(p->ctx));
+    if (!in->headers || !in->ranges || !in->latest) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_upload: headers / ranges / latest are required");
+    if (p->with_commit && (!in->target_validators || !in->trusted_validators)) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_upload: validator sets are required with BSX_PIPE_COMMIT");
+    const uint64_t HPR = in->headers_per_range;
+    if (HPR < p->hfr + p->hpr) return fail(BSX_ERR_BAD_ARG, "headers_per_range %llu does not cover this rank's slice (needs %llu)", (unsigned long long)HPR,
+                                           (unsigned long long)(p->hfr + p->hpr));
+    RET(join_impl(p));                         // steps in flight read the buffers about to be overwritten
+    const uint32_t R = p->R, Rc = p->Rc, V = p->V;
+    std::vector<bsx_header> sk((size_t)Rc * 2);
+    for (uint32_t e = 0; e < p->E; e++) {
+        Chunk& c = p->chunks[e];
+        hipStream_t st = c.main;
+        for (uint32_t g = 0; g < p->world; g++) {
+            const size_t r0 = (size_t)g * R + (size_t)e * Rc;          // first global range of this (chunk, owner) block
+            const size_t i0 = (size_t)g * Rc;                          // its position inside the chunk
+            HIPCHK(hipMemcpy2DAsync(c.headers_all + i0 * p->hpr * sizeof(bsx_header), p->hpr * sizeof(bsx_header),
+                                    in->headers + r0 * HPR + p->hfr, HPR * sizeof(bsx_header), p->hpr * sizeof(bsx_header), Rc,
+                                    hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c.ranges + i0 * sizeof(bsx_shared_ctx), in->ranges + r0, (size_t)Rc * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c.latest + i0 * 8, in->latest + r0, (size_t)Rc * 8, hipMemcpyHostToDevice, st));
+        }
+        if (p->with_commit) {
+            const size_t r0 = (size_t)p->rank * R + (size_t)e * Rc;    // owned block
+            for (uint32_t k = 0; k < Rc; k++) {
+                const bsx_shared_ctx& rg = in->ranges[r0 + k];
+                const uint64_t ti = rg.end_block - rg.start_block;
+                if (rg.end_block <= rg.start_block || ti >= HPR)
+                    return fail(BSX_ERR_BAD_ARG, "range %zu: target header (end - start = %llu) is not among the %llu supplied headers", r0 + k,
+                                (unsigned long long)ti, (unsigned long long)HPR);
+                sk[2 * k] = in->headers[(r0 + k) * HPR];               // trusted header: height S
+                sk[2 * k + 1] = in->headers[(r0 + k) * HPR + ti];      // target header: height E
+            }
+            HIPCHK(hipMemcpyAsync(c.headers_all + c.nh_main * sizeof(bsx_header), sk.data(), (size_t)Rc * 2 * sizeof(bsx_header), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c.skip_ranges, in->ranges + r0, (size_t)Rc * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c.skip_ranges_side, in->ranges + r0, (size_t)Rc * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c.validators, in->target_validators + r0 * V, (size_t)Rc * V * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c.trusted, in->trusted_validators + r0 * V, (size_t)Rc * V * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));      // `sk` and the caller's buffers are free again
+        if (c.host_image) {                    // keep the streamed image in step with the resident block
+            HIPCHK(hipMemcpyAsync(c.host_image, c.headers_all, c.headers_bytes, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    p->uploaded = true;
+    return BSX_OK;
+}
+
+int bsx_pipeline_enable_input_streaming(bsx_pipeline* p, int on) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    RET(use(p->ctx));
+    RET(join_impl(p));
+    if (!on) {
+        p->streaming = false;
+        for (Chunk& c : p->chunks) c.h2d_pending = false;
+        return BSX_OK;
+    }
+    for (Chunk& c : p->chunks) {
+        if (!c.copy) RET(new_stream(&c.copy));
+        if (!c.host_image) {
+            void* q = nullptr;
+            HIPCHK(hipHostMalloc(&q, c.headers_bytes, hipHostMallocDefault));
+            p->host_allocs.push_back(q);
+            c.host_image = static_cast<uint8_t*>(q);
+        }
+        HIPCHK(hipMemcpy(c.host_image, c.headers_all, c.headers_bytes, hipMemcpyDeviceToHost));
+    }
+    p->streaming = true;
+    return BSX_OK;
+}
+
+// One step over all chunks.  Two tokens keep the chunks in complementary phases: only one chunk hashes at a time and only
+// one expands at a time, so chunk e+1's (ALU-bound) hashing always runs beside chunk e's (HBM-bound) expansion — without the
+// tokens the streams drift into the same phase and the overlap is lost.
+int bsx_pipeline_step(bsx_pipeline* p) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    RET(use(p->ctx));
+    if (!p->uploaded) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_step before bsx_pipeline_upload");
+    const bool multi = p->E > 1;
+    for (Chunk& c : p->chunks) {
+        TimingSlot* ts = p->timing_on ? timing_slot(c) : nullptr;
+        if (multi && p->hash_token) HIPCHK(hipStreamWaitEvent(c.main, p->hash_token, 0));
+        RET(step_local(p, c, ts));
+        RET(stream_inputs(p, c));
+        if (p->pending_verify) {
+            // the previous chunk's signature checks: enqueued now so that they can wait for THIS chunk's k_header_merkle
+            // (both are integer-ALU bound; the rest of this chunk's hashing phase leans on memory)
+            Chunk* pv = p->pending_verify;
+            p->pending_verify = nullptr;
+            RET(launch_verify(p, *pv, c.ev_merkle));
+        }
+        const uint8_t* res = c.partial;       // single GPU: the local fold already is the range result
+        if (p->world > 1) {
+            RET(exchange_begin(p, c));        // collective in flight; finished behind this chunk's expansion
+            res = nullptr;
+        }
+        if (multi) {
+            HIPCHK(hipEventRecord(c.ev_hash_tok, c.main));
+            p->hash_token = c.ev_hash_tok;
+        }
+        const bool defer = multi;             // the commit check is launched with the NEXT chunk's header hashing as its gate
+        RET(step_final(p, c, res, !defer, multi ? p->expand_token : nullptr, ts));
+        if (defer && commit_active(p, c) && !p->commit_beside_hash) p->pending_verify = &c;
+        // the commit check is NOT joined here: its inputs are double-buffered by step parity, so it may run on into the
+        // chunk's next step; bsx_pipeline_join / _get_results wait for it
+    }
+    return BSX_OK;
+}
+
+int bsx_pipeline_join(bsx_pipeline* p) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    RET(use(p->ctx));
+    return join_impl(p);
+}
+
+int bsx_pipeline_get_results(bsx_pipeline* p, bsx_pipeline_results* out) {
+    if (!p || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    RET(use(p->ctx));
+    RET(join_impl(p));
+    out->header_status = out->assemble_status = 0;
+    const uint32_t R = p->R, Rc = p->Rc;
+    for (uint32_t e = 0; e < p->E; e++) {
+        Chunk& c = p->chunks[e];
+        uint32_t st[2] = {0, 0};
+        HIPCHK(hipMemcpy(st, c.status, 8, hipMemcpyDeviceToHost));
+        out->header_status |= st[0];
+        out->assemble_status |= st[1];
+        const size_t k0 = (size_t)e * Rc;
+        if (out->output64) HIPCHK(hipMemcpy(out->output64 + k0 * 64, c.output64, (size_t)Rc * 64, hipMemcpyDeviceToHost));
+        if (out->range_status) HIPCHK(hipMemcpy(out->range_status + k0, c.range_status, (size_t)Rc * 4, hipMemcpyDeviceToHost));
+        if (out->skip_status) {
+            if (p->with_commit) HIPCHK(hipMemcpy(out->skip_status + k0, c.skip_status, (size_t)Rc * 4, hipMemcpyDeviceToHost));
+            else memset(out->skip_status + k0, 0, (size_t)Rc * 4);
+        }
+        if (out->commit) {
+            if (p->with_commit) HIPCHK(hipMemcpy(out->commit + k0, c.commit_res, (size_t)Rc * sizeof(bsx_commit_result), hipMemcpyDeviceToHost));
+            else memset(out->commit + k0, 0, (size_t)Rc * sizeof(bsx_commit_result));
+        }
+        if (out->records)
+            for (uint32_t g = 0; g < p->world; g++)
+                HIPCHK(hipMemcpy(out->records + ((size_t)g * R + k0) * p->jc, c.records + (size_t)g * Rc * p->jc * sizeof(bsx_subchain),
+                                 (size_t)Rc * p->jc * sizeof(bsx_subchain), hipMemcpyDeviceToHost));
+    }
+    return BSX_OK;
+}
+
+int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** out_d_ptr, uint64_t* out_bytes) {
+    if (!p || !out_d_ptr || !out_bytes) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (chunk >= p->E) return fail(BSX_ERR_BAD_ARG, "chunk %u out of range (n_chunks %u)", chunk, p->E);
+    Chunk& c = p->chunks[chunk];
+    void* q = nullptr;
+    uint64_t n = 0;
+    switch (which) {
+    case BSX_PIPE_BUF_WITNESS_MAP: q = c.witness_map; n = c.witness_map ? c.n_map_el * 8 : 0; break;
+    case BSX_PIPE_BUF_WITNESS_REDUCE_LOCAL: q = c.witness_red_local; n = c.witness_red_local ? c.n_red_local_el * 8 : 0; break;
+    case BSX_PIPE_BUF_WITNESS_REDUCE_TOP: q = c.witness_red_top; n = c.witness_red_top ? c.n_red_top_el * 8 : 0; break;
+    case BSX_PIPE_BUF_COMPACT: q = c.compact; n = c.compact_bytes; break;
+    case BSX_PIPE_BUF_TREES: q = c.trees; n = c.trees_words * 8; break;
+    case BSX_PIPE_BUF_PARTIAL: q = c.partial; n = (uint64_t)c.RT * 128; break;
+    case BSX_PIPE_BUF_HEADERS: q = c.headers_all; n = c.headers_bytes; break;
+    case BSX_PIPE_BUF_RECORDS: q = c.records; n = c.records_bytes; break;
+    case BSX_PIPE_BUF_GATHERED: q = c.gathered; n = (uint64_t)p->world * c.RT * 128; break;
+    case BSX_PIPE_BUF_REDUCE_COMPACT_LOCAL: q = c.red_compact_local; n = (uint64_t)c.RT * (p->jc > 1 ? p->jc - 1 : 0) * p->rl.compact_stride; break;
+    case BSX_PIPE_BUF_HASHES: q = c.hashes_all; n = c.nh_all * 32; break;
+    case BSX_PIPE_BUF_DH_AUNTS: q = c.dh_aunts; n = c.nh_all * 128; break;
+    case BSX_PIPE_BUF_LB_AUNTS: q = c.lb_aunts; n = c.nh_all * 128; break;
+    case BSX_PIPE_BUF_PATHS: q = c.paths; n = c.paths ? c.nh_all * BSX_HEADER_PATH_BYTES : 0; break;
+    default: return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_buffer: unknown buffer %u", which);
+    }
+    *out_d_ptr = n ? q : nullptr;
+    *out_bytes = n;
+    return BSX_OK;
+}
+
+int bsx_pipeline_set_timing(bsx_pipeline* p, int on) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    p->timing_on = on != 0;
+    return BSX_OK;
+}
+
+int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out) {
+    if (!p || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    RET(use(p->ctx));
+    RET(join_impl(p));
+    double sub = 0, ex = 0, caps = 0;
+    uint32_t n_sub = 0, n_ex = 0, n_caps = 0;
+    for (Chunk& c : p->chunks) {
+        for (size_t i = 0; i < c.timing_used; i++) {
+            TimingSlot& t = c.timing[i];
+            float ms = 0;
+            if (t.sub) { HIPCHK(hipEventElapsedTime(&ms, t.ev[0], t.ev[1])); sub += ms; n_sub++; }
+            if (t.exp) { HIPCHK(hipEventElapsedTime(&ms, t.ev[2], t.ev[3])); ex += ms; n_ex++; }
+            if (t.caps) { HIPCHK(hipEventElapsedTime(&ms, t.ev[4], t.ev[5])); caps += ms; n_caps++; }
+        }
+        c.timing_used = 0;
+    }
+    out->prove_subchain_ms = n_sub ? sub / n_sub : 0;
+    out->expand_map_ms = n_ex ? ex / n_ex : 0;
+    out->caps_ms = n_caps ? caps / n_caps : 0;
+    out->launches = n_sub;
+    out->_pad = 0;
+    return BSX_OK;
+}
+
+}  // extern "C"

@@ -463,6 +463,30 @@ int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* p
                     uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max,
                     const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit);
 
+/* ------------------------------------------------------------------ mode S: a commit on EVERY header, sharded with the headers
+ * BASELINE configs #4/#5 ("N headers x V validators"): N back-to-back next_header / skip verifications (circuits/next_header.rs:
+ * 25-47 per header; batches are independent: builder.rs:305-336).  One call = the whole commit check of n_commits commits of
+ * v_max validator slots on `stream`: SHA-512 challenges, fixed-key Ed25519 (tables of the first commit's keys in d_keytable —
+ * persistent, bsx_ed25519_keytable_bytes(v_max) bytes, key records zero before the first call — slots whose key differs fall
+ * back to the generic path inside the kernel), batch-inverted encodings, tallies + validator-set hashes, and the FOLD of the
+ * commit results into one 128-byte record.  Across GPUs rank g verifies commits [g*N/world, (g+1)*N/world) of the range and ONE
+ * all-gather of the 128-byte folds tells every rank whether the whole range verified (bench.py --mode S --gpus N).
+ * d_scratch: bsx_dev_verify_commits_scratch_bytes(n_commits, v_max) bytes, 256-byte aligned.  n_commits <= BSX_COMMIT_FOLD_MAX. */
+#define BSX_COMMIT_FOLD_MAX 2048u
+typedef struct bsx_commit_fold {
+    uint8_t root[32];            /* SHA-256 tree over the per-commit digests (kernels_misc.hip k_commit_fold) */
+    uint64_t n_commits;
+    uint64_t n_ok;               /* commits with 2/3 signed and no bad signature / message / power overflow */
+    uint64_t n_signatures_ok;    /* signed validators whose signature verified */
+    uint32_t first_index;        /* global index of this slice's first commit */
+    uint32_t first_failing;      /* lowest global index of a commit that is not ok, or 0xffffffff */
+    uint32_t _pad[16];
+} bsx_commit_fold;               /* sizeof == 128 */
+uint64_t bsx_dev_verify_commits_scratch_bytes(uint32_t n_commits, uint32_t v_max);
+int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits, uint32_t v_max,
+                           const uint8_t* d_header_hashes, uint32_t first_index, void* d_keytable, void* d_scratch, uint8_t* d_ok,
+                           bsx_commit_result* d_results, bsx_commit_fold* d_fold);
+
 /* ------------------------------------------------------------------ operator skip-target search
  * circuits/fetcher.rs:60-87 find_block_to_request: starting at max_end_block, return the first candidate c with
  * is_valid_skip(start set, c's set, c's commit); otherwise halve the distance to start_block; c - start_block == 1 is
@@ -553,6 +577,139 @@ int bsx_dev_witness_leaf_hashes(bsx_ctx* ctx, void* stream, const bsx_witness_la
 /* Upper levels of n_trees trees whose leaf digests are in place, down to the cap (2^cap_height nodes). */
 int bsx_dev_poseidon_merkle_caps(bsx_ctx* ctx, void* stream, uint64_t* d_trees, uint32_t n_trees, uint64_t tree_stride,
                                  uint32_t n_leaves, uint32_t cap_height);
+
+/* ------------------------------------------------------------------ device ceilings for roofline reporting
+ * Measures, in about 50 ms, what THIS device sustains on the bodies the hot path's kernels are made of (the library's own
+ * device functions, alone, 8 waves per SIMD, no memory traffic) and on streaming stores.  A roofline fraction quoted against
+ * these is reproducible on any box; bench.py runs it at start-up.  Rates are per second over the whole device. */
+typedef struct bsx_calibration {
+    double valu_add_u32_lane_ops_per_s;       /* full-rate 2-source 32-bit VALU issue */
+    double valu_mad_u64_u32_lane_ops_per_s;   /* the multiply-add every field multiplication is made of */
+    double valu_alignbit_lane_ops_per_s;      /* every SHA rotate */
+    double sha256_compress_per_s;             /* 64-byte blocks */
+    double sha512_compress_per_s;             /* 128-byte blocks */
+    double fe25519_mul_per_s, fe25519_sq_per_s;   /* GF(2^255 - 19), 10 x 25.5-bit limbs */
+    double goldilocks_mul_per_s;              /* 64 x 64 -> mod 2^64 - 2^32 + 1 */
+    double hbm_store_bytes_per_s;             /* non-temporal 16-byte stores over 1 GiB */
+    uint32_t compute_units, clock_mhz;
+} bsx_calibration;                            /* sizeof == 80 */
+int bsx_calibrate(bsx_ctx* ctx, bsx_calibration* out);
+
+/* ------------------------------------------------------------------ batched pipeline (the throughput path)
+ * R independent header_range instances per step with every input resident in HBM — what a prover farm that keeps a GPU
+ * busy calls instead of one bsx_header_range per proof.  The pipeline object owns its device buffers, HIP streams and
+ * events; nothing here depends on environment variables or on a host language runtime.  One step over the ranges of a chunk:
+ *
+ *   header_merkle (input.rs:175-195,250-261) -> fill_end_hash (header_range.rs:42-55) -> hint of every map job
+ *   (data_commitment.rs:22-44) -> prove_subchain (builder.rs:150-271,305-336) -> reduce (builder.rs:337-395) ->
+ *   [all-gather across GPUs, top fold] -> final asserts + public output (builder.rs:292-297,400-406; header_range.rs:57-58)
+ *   -> witness expansion and/or Poseidon caps; on a side stream the commit check of the target header (builder.skip,
+ *   header_range.rs:42-48): SHA-512 challenges, fixed-key Ed25519, tallies + validator-set hashes, skip conditions.
+ *
+ * n_chunks > 1 cuts the step into chunks on their own streams kept in complementary phases by event tokens: the integer-
+ * ALU-bound hashing of chunk e+1 runs beside the HBM-bound witness expansion of chunk e; consecutive steps pipeline the same
+ * way (steps are NOT joined: commit-check inputs are double-buffered by step parity).  bsx_pipeline_step only enqueues.
+ *
+ * Multi-GPU: rank g of `world` computes map jobs [g*J/world, (g+1)*J/world) of ALL world*n_ranges ranges, folds
+ * them locally, ONE all-gather of a 128-byte record per (range, rank) per chunk, and the owner of a range (range index /
+ * n_ranges) runs the last log2(world) reduce levels, the final assertions and that range's commit check.  The collective
+ * itself is the caller's (RCCL ncclAllGather, torch.distributed, ... — INTEGRATION.md): see bsx_pipeline_set_allgather. */
+typedef struct bsx_pipeline bsx_pipeline;
+
+#define BSX_PIPE_WITNESS 1u             /* materialise the Goldilocks witness (map jobs + reduce nodes) in HBM every step */
+#define BSX_PIPE_COMMIT 2u              /* verify the target commit of every owned range (builder.skip) */
+#define BSX_PIPE_CAPS 4u                /* Poseidon Merkle cap of every map-job witness, hashed straight from the compact bytes
+                                           (plonky2 PoseidonGoldilocksConfig; rows of leaf_len elements, cap_height) */
+#define BSX_PIPE_ED_GENERIC 8u          /* per-signature Ed25519 kernel instead of the fixed-key tables (same verdicts) */
+#define BSX_PIPE_COMMIT_BESIDE_HASH 16u /* run the whole commit check beside the hashing phase instead of beside the expansion */
+#define BSX_PIPE_RECOMPUTE_PATHS 32u    /* prove_subchain re-derives both proof paths per slot (builder.rs:189-199 literally)
+                                           instead of taking the digests the header hashing already produced (same witness) */
+typedef struct bsx_pipeline_config {
+    uint32_t nb_map_jobs, batch_size, v_max;
+    uint32_t n_ranges;                  /* header_range instances this rank OWNS per step */
+    uint32_t n_chunks;                  /* pipelined chunks; must divide n_ranges (1 = no chunking) */
+    uint32_t rank, world;               /* job-slice sharding; world must divide nb_map_jobs into power-of-two slices */
+    uint32_t flags;                     /* BSX_PIPE_* */
+    uint32_t leaf_len, cap_height;      /* BSX_PIPE_CAPS: 0, 0 = plonky2 standard_recursion_config (135 wires, cap height 4) */
+    uint32_t chain_id_len;              /* C::CHAIN_ID_BYTES (header_range.rs:42-43), at most 50 bytes */
+    uint8_t chain_id[52];
+    /* launch forms; results never depend on them.  0 = automatic (the measured choice for the configuration) */
+    uint32_t tune_merkle_workgroups;    /* resident workgroups of the header-hashing kernel; 0xffffffff = one per 64 headers */
+    uint32_t tune_subchain;             /* 1 = prove_subchain as one launch, 2 = its stages in separate launches */
+} bsx_pipeline_config;                  /* sizeof == 104 */
+
+int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeline** out);
+void bsx_pipeline_destroy(bsx_pipeline* p);
+
+/* Inputs of one step in HOST memory, for all world*n_ranges ranges this rank touches, in global order r = g*n_ranges + k
+ * (g = owning rank, k < n_ranges; chunk e takes k in [e*n_ranges/n_chunks, (e+1)*n_ranges/n_chunks) of every g).  The
+ * library takes this rank's header slice of every range and, for the ranges it owns, the (trusted, target) headers and both
+ * validator sets.  Synchronous; the buffers may be reused on return. */
+typedef struct bsx_pipeline_inputs {
+    const bsx_header* headers;          /* [world*n_ranges][headers_per_range]: header k of range r = height S_r + k */
+    uint64_t headers_per_range;         /* >= nb_map_jobs*batch_size + 1 */
+    const bsx_shared_ctx* ranges;       /* [world*n_ranges] (start = trusted block / hash, end = target block; end hash ignored) */
+    const uint64_t* latest;             /* [world*n_ranges] chain head the hint clamps against (input.rs:160-162) */
+    const bsx_validator* target_validators;    /* [world*n_ranges][v_max] — only owned ranges are read (BSX_PIPE_COMMIT) */
+    const bsx_validator* trusted_validators;   /* same */
+} bsx_pipeline_inputs;
+int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in);
+
+/* PCIe-inclusive operation: keep a page-locked host image of the header block and re-upload it on a copy stream EVERY step,
+ * overlapped with the previous step's compute (a caller whose inputs are not resident).  Call after bsx_pipeline_upload. */
+int bsx_pipeline_enable_input_streaming(bsx_pipeline* p, int on);
+
+/* Enqueue one step over all chunks; returns without waiting.  Steps may be issued back to back. */
+int bsx_pipeline_step(bsx_pipeline* p);
+/* Block until everything enqueued has finished (also launches commit checks still deferred). */
+int bsx_pipeline_join(bsx_pipeline* p);
+
+/* The one collective of the multi-GPU path.  fn must perform an all-gather ORDERED ON `stream`: when work enqueued on
+ * `stream` after fn returns runs, d_recv holds [world][bytes_per_rank] (rank-major), block g = rank g's d_send.  With RCCL:
+ * `ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, comm, (hipStream_t)stream)`.  Called once per chunk per step, in
+ * chunk order, on every rank.  Return 0 on success. */
+typedef int (*bsx_allgather_fn)(void* user, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream);
+int bsx_pipeline_set_allgather(bsx_pipeline* p, bsx_allgather_fn fn, void* user);
+
+/* Results of the most recent step (joins first).  Every pointer is optional.  Owned ranges are indexed k < n_ranges. */
+typedef struct bsx_pipeline_results {
+    uint8_t* output64;                  /* [n_ranges][64] target_header_hash ‖ data_commitment (header_range.rs:57-58) */
+    uint32_t* range_status;             /* [n_ranges] OR of failed BSX_A* bits */
+    uint32_t* skip_status;              /* [n_ranges] bsx_status of the skip verification (BSX_PIPE_COMMIT) */
+    bsx_commit_result* commit;          /* [n_ranges] */
+    bsx_subchain* records;              /* [world*n_ranges][nb_map_jobs/world] map-job records of this rank's slice, global range order */
+    uint32_t header_status, assemble_status;   /* out: OR over chunks of the device status words (0 = clean) */
+} bsx_pipeline_results;
+int bsx_pipeline_get_results(bsx_pipeline* p, bsx_pipeline_results* out);
+
+/* Device buffers of a chunk, for in-place consumers (a prover reading the witness from HBM) and tests.  Ranges inside a chunk
+ * are ordered [g][k - e*Rc].  *out_bytes is 0 when the configuration has no such buffer. */
+#define BSX_PIPE_BUF_WITNESS_MAP 0u          /* u64 [ranges][jobs of the slice][layout.n_elements] */
+#define BSX_PIPE_BUF_WITNESS_REDUCE_LOCAL 1u /* u64 [ranges][jobs-1 of the slice][reduce layout n_elements] */
+#define BSX_PIPE_BUF_WITNESS_REDUCE_TOP 2u   /* u64 [owned ranges][world-1][...] */
+#define BSX_PIPE_BUF_COMPACT 3u              /* compact witnesses [ranges][jobs] (bsx_map_witness_layout().compact_stride) */
+#define BSX_PIPE_BUF_TREES 4u                /* BSX_PIPE_CAPS: u64 [map jobs][bsx_poseidon_tree_digests()][4]; the cap is each tree's tail */
+#define BSX_PIPE_BUF_PARTIAL 5u              /* locally folded record of every range, 128 B each (the all-gather's send buffer) */
+#define BSX_PIPE_BUF_HEADERS 6u              /* the chunk's header block */
+#define BSX_PIPE_BUF_RECORDS 7u              /* map-job records [ranges][jobs of the slice] */
+#define BSX_PIPE_BUF_GATHERED 8u             /* the all-gather's receive buffer [world][ranges][128] */
+#define BSX_PIPE_BUF_REDUCE_COMPACT_LOCAL 9u /* compact witnesses of the local reduce nodes [ranges][jobs-1] */
+#define BSX_PIPE_BUF_HASHES 10u              /* header hashes of the chunk's header block, 32 B each */
+#define BSX_PIPE_BUF_DH_AUNTS 11u            /* data_hash proof aunts, 128 B per header */
+#define BSX_PIPE_BUF_LB_AUNTS 12u            /* last_block_id proof aunts, 128 B per header */
+#define BSX_PIPE_BUF_PATHS 13u               /* BSX_HEADER_PATH_BYTES per header (absent with BSX_PIPE_RECOMPUTE_PATHS) */
+int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** out_d_ptr, uint64_t* out_bytes);
+
+/* Kernel timing with HIP events on the launch streams: when on, every step brackets prove_subchain, the map-job witness
+ * expansion and the Poseidon commitment of every chunk.  bsx_pipeline_timing joins, returns the average launch durations
+ * (ms; 0 when not applicable) over the steps since the last call and resets. */
+int bsx_pipeline_set_timing(bsx_pipeline* p, int on);
+typedef struct bsx_pipeline_timing_result {
+    double prove_subchain_ms, expand_map_ms, caps_ms;
+    uint32_t launches;                  /* chunk-steps averaged */
+    uint32_t _pad;
+} bsx_pipeline_timing_result;
+int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out);
 
 #ifdef __cplusplus
 }

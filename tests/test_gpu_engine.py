@@ -1,5 +1,6 @@
-"""GPU suite: the device-resident batched pipeline bench.py times (blobstreamx_amd/engine.py) against the oracle —
-public outputs, per-job records, commit results and the complete Goldilocks witness of every range of a batch."""
+"""GPU suite: the device-resident batched pipeline bench.py times — `bsx_pipeline_*` of the C ABI (csrc/pipeline.hip) through
+its thin ctypes wrapper blobstreamx_amd/engine.py — against the oracle: public outputs, per-job records, commit results and
+the complete Goldilocks witness of every range of a batch."""
 import numpy as np
 import pytest
 
@@ -54,7 +55,7 @@ def _check_pipelined_against_oracle(pe, w, J, B):
     ml, rl = T.map_layout(B), T.reduce_layout()
     nm, nr = J * int(ml["n_elements"]), (J - 1) * int(rl["n_elements"])
     assert res["header_status"] == 0 and res["assemble_status"] == 0
-    wits = [eng.witness_numpy() for eng in pe.engines]
+    wits = [pe.witness_numpy(e) for e in range(pe.E)]
     for r in range(pe.R):
         e, k = divmod(r, pe.Rc)
         rc, out, cres, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
@@ -77,14 +78,13 @@ def _check_pipelined_against_oracle(pe, w, J, B):
 
 
 @pytest.mark.parametrize("J,B,V,R,n_blocks", [(32, 64, 100, 4, 2048), (32, 32, 100, 4, 1024), (8, 32, 20, 6, 131)])
-def test_pipelined_engines_multi_step_vs_oracle(J, B, V, R, n_blocks, monkeypatch):
+def test_pipelined_engines_multi_step_vs_oracle(J, B, V, R, n_blocks):
     """THE object bench.py times: PipelinedEngines with two chunks on separate streams, event tokens, the commit check
     deferred onto side streams and double-buffered by pass parity.  Three consecutive step()s WITHOUT a join in between
     (cross-step races — step i+1's hint / header hashing vs step i's side-stream commit check or expansion — would
     corrupt a status, a record or the witness), then every range is diffed against the oracle.  One tampered range per
     chunk: the per-range verdicts must be the oracle's and must not leak into the neighbours."""
     from blobstreamx_amd.engine import PipelinedEngines
-    monkeypatch.setenv("BSX_PLACEMENT_PROBE", "1")
     w = synth.Workload(4, R, J, B, v=V, n_blocks=n_blocks)
     w.headers[1, 9]["hash"][1][5] ^= 1                     # chunk 0: range 1's chain breaks at header 9
     w.validators[R - 1, 3]["signature"][0] ^= 2            # chunk 1: the last range carries one bad signature
@@ -123,7 +123,7 @@ def test_alternating_pipelines_compact_only_vs_oracle():
         assert res["header_status"] == 0 and res["assemble_status"] == 0
         for r in range(R):
             rc, out, cres, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
-                                                   w.validators[r], w.trusted[r], want_witness=True)
+                                                   w.validators[r], w.trusted[r])
             mine = res["skip_status"][r] if res["skip_status"][r] else (T.ERR_ASSERT if res["range_status"][r] else T.OK)
             assert mine == rc, (r, mine, rc)
             assert res["output64"][r].tobytes() == out, r
@@ -139,18 +139,16 @@ def test_alternating_pipelines_compact_only_vs_oracle():
 
 
 @pytest.mark.parametrize("ed_path,commit_with", [("generic", "expand"), ("keyed", "expand"), ("keyed", "hash"), ("generic", "hash")])
-def test_engine_reports_failures_per_range(ed_path, commit_with, monkeypatch):
+def test_engine_reports_failures_per_range(ed_path, commit_with):
     """Both forms of the signature check (per-signature / per-validator tables) and both placements of the commit
     side stream must report the same per-range verdicts as the oracle."""
     from blobstreamx_amd.engine import HeaderRangeEngine
-    monkeypatch.setenv("BSX_ED_PATH", ed_path)
-    monkeypatch.setenv("BSX_COMMIT_WITH", commit_with)
     J, B, V, R = 4, 8, 12, 4
     w = synth.Workload(6, R, J, B, v=V)
     w.headers[1, 9]["hash"][1][5] ^= 1            # range 1: chain breaks at header 9
     w.validators[2, 3]["signature"][0] ^= 2       # range 2: one bad signature
     w.trusted[3, 0]["voting_power"] += 7          # range 3: trusted set no longer matches the header
-    eng = HeaderRangeEngine(J, B, V, R)
+    eng = HeaderRangeEngine(J, B, V, R, ed_path=ed_path, commit_with=commit_with)
     eng.upload_workload(w)
     eng.step()
     res = eng.download()
@@ -164,44 +162,54 @@ def test_engine_reports_failures_per_range(ed_path, commit_with, monkeypatch):
         assert mine == rc, (r, mine, rc)
 
 
-@pytest.mark.parametrize("world,J,B,R,n_blocks", [(2, 4, 8, 2, 32), (4, 8, 8, 2, 37), (8, 32, 64, 1, 2048), (2, 2, 32, 3, 64)])
-def test_sharded_engines_on_one_gpu(world, J, B, R, n_blocks):
-    """Every rank's engine of an N-GPU run, executed on ONE GPU with the all-gather emulated by concatenating the ranks'
-    partial buffers: job slices + header_first_rel + local fold + top fold + owner's commit/finalize/witness must
-    reproduce the oracle for every range (the real collective is covered over gloo in tests/test_distributed_cpu.py)."""
-    import torch
-    from blobstreamx_amd.engine import HeaderRangeEngine
-    V = 12
+@pytest.mark.parametrize("world,J,B,R,n_blocks,V,E", [(2, 4, 8, 2, 32, 12, 1), (4, 8, 8, 2, 37, 12, 2), (8, 32, 64, 1, 2048, 12, 1), (2, 2, 32, 3, 64, 12, 1),
+                                                      (2, 32, 64, 2, 2048, 100, 2), (8, 32, 64, 1, 2048, 512, 1)])
+def test_sharded_engines_on_one_gpu(world, J, B, R, n_blocks, V, E):
+    """Every rank's pipeline of an N-GPU run, executed on ONE GPU with the all-gather delivered by a callback that hands every
+    rank the concatenation of all ranks' partial buffers (what ncclAllGather returns): job slices + header_first_rel + local
+    fold + exchange stream + top fold + owner's commit/finalize/witness must reproduce the oracle for every range — public
+    output, statuses, commit result, this rank's records and map-job witness of EVERY range, and the owner's top reduce nodes.
+    Includes the BASELINE shapes: config #4 (32x64, V = 100, two pipelined chunks) and #5 (V = 512, world 8).  The real
+    collective is covered over gloo in tests/test_distributed_cpu.py and test_bench_two_ranks_share_one_gpu."""
+    from blobstreamx_amd.engine import PipelinedEngines, run_world_on_one_gpu
     w = synth.Workload(9, R * world, J, B, v=V, n_blocks=n_blocks)
-    engs = [HeaderRangeEngine(J, B, V, R, rank=g, world=world) for g in range(world)]
+    engs = [PipelinedEngines(J, B, V, R, n_engines=E, rank=g, world=world) for g in range(world)]
     for e in engs:
         e.upload_workload(w)
-        e.step_local()
-    torch.cuda.synchronize()
-    gathered = torch.stack([e.partial[:e.RT * 128].clone() for e in engs])          # [world, RT*128] == all_gather_into_tensor
+    run_world_on_one_gpu(engs)
     ml, rl = T.map_layout(B), T.reduce_layout()
     jc = J // world
     nm = jc * int(ml["n_elements"])
+    nt = (world - 1) * int(rl["n_elements"])
+    refs = [oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r],
+                                want_witness=True) for r in range(R * world)]
+    fulls = [oracle.expand_range_witness(J, B, ref[3]) for ref in refs]
+    nmap = J * int(ml["n_elements"])
     for g, e in enumerate(engs):
-        res = e.step_exchange(gathered)
-        e.step_final(res)
-        torch.cuda.current_stream().wait_stream(e.side)
         out = e.download()
-        wm, wrl, wrt = e.witness_numpy()
+        assert out["header_status"] == 0 and out["assemble_status"] == 0
         for k in range(R):
-            r = g * R + k
-            rc, ref_out, cres, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
-                                                        w.validators[r], w.trusted[r], want_witness=True)
+            rc, ref_out, cres, _ = refs[g * R + k]
             assert rc == T.OK
             assert out["output64"][k].tobytes() == ref_out, (g, k)
             assert out["range_status"][k] == 0 and out["skip_status"][k] == 0
-        # map-job witnesses of this rank's slice of EVERY range equal the oracle's jobs [g*jc, (g+1)*jc)
-        for r in range(R * world):
-            rc, ref = oracle.prove_data_commitment(J, B, w.ranges[r:r + 1], w.headers[r], int(w.first_height[r]), int(w.latest[r]),
-                                                   want_witness=True)
-            full = oracle.expand_witness(ml, J, ref["compact"])
-            want = full[g * nm:(g + 1) * nm]
-            assert (wm[r * nm:(r + 1) * nm] == want).all(), (g, r)
+            got = np.array(out["commit"][k]).copy(); got["_pad"] = 0
+            want = np.array(cres).copy(); want["_pad"] = 0
+            assert got.tobytes() == want.tobytes(), (g, k)
+        for c in range(E):
+            wm, _, wrt = e.witness_numpy(c)
+            for i, r in enumerate(e.sel(c)):
+                # map-job witnesses of this rank's slice of EVERY range equal the oracle's jobs [g*jc, (g+1)*jc)
+                assert (wm[i * nm:(i + 1) * nm] == fulls[r][g * nm:(g + 1) * nm]).all(), (g, r)
+                ctx = w.ranges[r:r + 1].copy()
+                ctx["end_header_hash"][0] = np.frombuffer(refs[r][1][:32], np.uint8)
+                _, ref = oracle.prove_data_commitment(J, B, ctx, w.headers[r], int(w.first_height[r]), int(w.latest[r]))
+                assert [_rec(x) for x in out["records"][r]] == [_rec(x) for x in ref["records"][g * jc:(g + 1) * jc]], (g, r)
+            # the owner's top reduce nodes (the last log2(world) levels of the reference's tree) = the tail of the oracle's
+            # reduce section: level order, so the top world-1 nodes are its last world-1 entries
+            for k in range(e.Rc):
+                r = g * R + c * e.Rc + k
+                assert (wrt[k * nt:(k + 1) * nt] == fulls[r][nmap + (J - 1 - (world - 1)) * int(rl["n_elements"]):]).all(), (g, r)
 
 
 def test_bench_two_ranks_share_one_gpu():
@@ -218,7 +226,7 @@ def test_bench_two_ranks_share_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, BSX_DIST_BACKEND="gloo", BSX_BENCH_DEVICE="0", BSX_PLACEMENT_PROBE="1")
+    env = dict(os.environ, BSX_DIST_BACKEND="gloo", BSX_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--ranges", "8", "--no-cpu-baseline", "--no-stress"]

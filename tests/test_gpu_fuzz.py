@@ -61,8 +61,7 @@ def test_engine_fuzz_sharded_shapes(seed):
     per rank, range length (disabled batches, padded slots through the latest-2 clamp), validator count.  Every rank's
     engine runs on the one GPU with the all-gather emulated; public outputs, statuses and the map-job witness of every
     rank's slice must equal the oracle's."""
-    import torch
-    from blobstreamx_amd.engine import HeaderRangeEngine
+    from blobstreamx_amd.engine import HeaderRangeEngine, run_world_on_one_gpu
     rnd = np.random.default_rng(7000 + seed)
     world = int(rnd.choice([1, 2, 4]))
     J = int(rnd.choice([j for j in (2, 4, 8, 16) if j >= world]))
@@ -74,18 +73,13 @@ def test_engine_fuzz_sharded_shapes(seed):
     engs = [HeaderRangeEngine(J, B, V, R, rank=g, world=world) for g in range(world)]
     for e in engs:
         e.upload_workload(w)
-        e.step_local()
-    torch.cuda.synchronize()
-    gathered = torch.stack([e.partial[:e.RT * 128].clone() for e in engs]) if world > 1 else None
+    run_world_on_one_gpu(engs)
     ml = T.map_layout(B)
     jc = J // world
     nm = jc * int(ml["n_elements"])
     refs = [oracle.prove_data_commitment(J, B, w.ranges[r:r + 1], w.headers[r], int(w.first_height[r]), int(w.latest[r]),
                                          want_witness=True) for r in range(R * world)]
     for g, e in enumerate(engs):
-        res = e.step_exchange(gathered)
-        e.step_final(res)
-        e.join_commit()
         out = e.download()
         wm, _, _ = e.witness_numpy()
         assert out["header_status"] == 0 and out["assemble_status"] == 0, (seed, g)

@@ -810,28 +810,27 @@ def test_next_header_vs_oracle(v, v_max):
 
 
 def test_tuning_and_launch_forms_do_not_change_results():
-    """bsx_set_tuning(BSX_TUNE_MERKLE_WORKGROUPS) (grid-strided header hashing) and BSX_SUBCHAIN_SEPARATE_LAUNCHES (prove_subchain
-    as four launches instead of one) are performance knobs: same hashes, proofs, path digests, records and compact witness."""
+    """The launch-form knobs of bsx_pipeline_config (tune_merkle_workgroups: grid-strided header hashing; tune_subchain:
+    prove_subchain as one launch or as separate launches; BSX_PIPE_RECOMPUTE_PATHS) and bsx_set_tuning for the device tier are
+    performance knobs: same hashes, proofs, path digests, records and compact witness."""
     import ctypes as C
-    import torch
     from blobstreamx_amd.engine import HeaderRangeEngine
     J, B, V, R = 8, 32, 10, 3
     w = synth.Workload(21, R, J, B, v=V, n_blocks=J * B - 5)
     L = _lib.lib()
     outs = []
-    for wgs, flags in ((0, 1), (3, 1), (512, 3), (0, 0)):
-        eng = HeaderRangeEngine(J, B, V, R, with_witness=False)
-        _lib.check(L.bsx_set_tuning(eng.ctx, C.c_uint32(T.TUNE_MERKLE_WORKGROUPS), C.c_uint64(wgs)))
-        eng.subchain_flags = flags if eng.fused_hint else 0
+    for wgs, form, fused in ((0, 1, True), (3, 1, True), (512, 2, True), (0xffffffff, 0, False)):
+        eng = HeaderRangeEngine(J, B, V, R, with_witness=False, merkle_workgroups=wgs, subchain_form=form, fused_hint=fused)
         eng.upload_workload(w)
         eng.step()
         res = eng.download()
         outs.append((res["output64"].tobytes(), res["records"].tobytes(), eng.hashes_all.cpu().numpy().tobytes(),
                      eng.dh_aunts.cpu().numpy().tobytes(), eng.paths.cpu().numpy().tobytes() if eng.paths is not None else b"",
                      eng.compact.cpu().numpy().tobytes()))
-    _lib.check(L.bsx_set_tuning(_lib.context(0), C.c_uint32(T.TUNE_MERKLE_WORKGROUPS), C.c_uint64(0)))
     assert outs[0] == outs[1] == outs[2]
-    assert outs[0][:4] == outs[3][:4] and outs[0][5] == outs[3][5]          # flags 0 = paths recomputed from the proofs: same witness
+    assert outs[0][:4] == outs[3][:4] and outs[0][5] == outs[3][5]          # paths recomputed from the proofs: same witness
+    assert L.bsx_set_tuning(_lib.context(0), C.c_uint32(T.TUNE_MERKLE_WORKGROUPS), C.c_uint64(7)) == T.OK
+    assert L.bsx_set_tuning(_lib.context(0), C.c_uint32(T.TUNE_MERKLE_WORKGROUPS), C.c_uint64(0)) == T.OK
     assert L.bsx_set_tuning(_lib.context(0), C.c_uint32(99), C.c_uint64(1)) == T.ERR_BAD_ARG
 
 
