@@ -4,32 +4,40 @@
 A "step" = one pass of the whole hot path (header hashing + hint assembly + prove_subchain + reduce + final
 asserts + target-commit verification + Goldilocks witness expansion) over one batch of R synthetic header_range_2048
 instances (32 map jobs x 64 headers, 100 validators, mode F = one commit per range, exactly what one reference proof
-does) whose inputs are already resident in HBM.  value = N * R * 2048 headers / step time, all ranks, max over ranks.
+does) whose inputs are already resident in HBM.  The timed object is the C-ABI pipeline (`bsx_pipeline_step`,
+csrc/pipeline.hip) — Python only calls it.  value = N * R * 2048 headers / step time, all ranks, max over ranks.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): every rank computes its 32/N-job slice of all
 ranges, one all-gather of 128-byte records per pipelined chunk, the owner finishes its ranges.  --scaling weak (default):
 R ranges per GPU (N * R in total); --scaling strong: R ranges in total, i.e. BASELINE config #4 literally (each
 header_range_2048 split into N sub-ranges of 2048 / N headers).  Every rank re-proves a sample of its owned ranges with
-an un-sharded engine on its own GPU and compares (blobstreamx_amd/engine.py), so a wrong collective cannot go unnoticed.
+an un-sharded pipeline on its own GPU and compares outputs, statuses, commit results, map-job records and a sampled
+witness, so a wrong collective cannot go unnoticed.  --mode S: a commit on EVERY header (BASELINE config #5), the commits
+sharded with their headers, one all-gather of 128-byte folds.
 
-Objects on the JSON line beside the contract's keys (all measured in this run, N = 1 unless noted):
-  roofline            dominant kernel of the headline (witness expansion, HBM-write bound)
+Every `peak` of an ALU-bound roofline is measured in THIS process on THIS device (`bsx_calibrate`, ~50 ms at start-up):
+no constants carried over from another box.
+
+Objects on the JSON line beside the contract's keys (N = 1 unless noted):
+  roofline            dominant kernel of the headline (witness expansion, HBM-write bound); also at N > 1
+  calibration         the device ceilings measured at start-up
   kernels             the SHA kernels' compact-byte rates (never mixed with the expanded figure)
-  cpu_baseline        the C oracle timed on this box's host cores on a bounded sample; also the checker of the timed
-                      engine's outputs AND of the full Goldilocks witness of sampled ranges (config.witness_checked_ranges).
-                      oracle/ is imported only by the cpu_baseline* functions and the `cpu_baseline` legs of stress /
-                      fused_commitment — always as the checker / CPU timing, never on the measured GPU path
+  cpu_baseline        the C oracle timed on this box's host cores on a bounded sample (rank 0; also at N > 1); also the
+                      checker of the timed pipeline's outputs AND of the full Goldilocks witness of sampled ranges
+                      (config.witness_checked_ranges).  oracle/ is imported only by the cpu_baseline* functions and the
+                      `cpu_baseline` legs of stress / fused_commitment — always as the checker / CPU timing, never on the
+                      measured GPU path
   compact_only        the same step without the Goldilocks expansion (fresh process): the ALU-bound rate of the SHA path
-  stress              mode S (a V-validator commit on EVERY header; BASELINE configs #4/#5): Ed25519 + SHA-512 bound, with
-                      its own `roofline` (bound "valu", peak = tools/microbench_alu ceilings) and `cpu_baseline`
-  latency             ONE range through the host tier (bsx_header_range, host pointers in, 64 B out): what a single proof
-                      request sees
+  stress              mode S: Ed25519 + SHA-512 bound, with its own `roofline` (bound "valu") and `cpu_baseline`
+  latency             ONE range through the host tier (bsx_header_range, host pointers in, 64 B out)
   with_input_upload   the headline step with the headers streamed from pinned host memory every step (PCIe inclusive)
-  fused_commitment    Poseidon Merkle caps of the witness straight from the compact bytes (no 64x image), vs materialised
+  fused_commitment    Poseidon Merkle caps of the witness straight from the compact bytes (no 64x image): the pipeline's
+                      BSX_PIPE_CAPS mode (headers/s) and the kernel alone vs the materialised form
   header_range_1024   the metric's other production shape
 """
 import argparse
 import csv
+import ctypes as C
 import json
 import os
 import subprocess
@@ -40,28 +48,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Two pipelined chunks need four independent hardware queues (2 main + 2 commit side streams) beside the default stream,
-# the library's own stream, the input-copy streams and — at N > 1 — RCCL's; HIP's default of 4 maps the second chunk's main
-# stream onto the first chunk's side-stream queue and serialises them (8 and 16 measure the same at N = 1).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-# Measured integer-ALU ceilings of MI355X for the bodies the ALU-bound kernels are made of (tools/microbench.hip,
-# tools/microbench_alu.hip at 8 waves/SIMD; profiles/r1_microbench.txt, profiles/r2_microbench_alu.txt)
-PEAK = {"sha256_compress_per_s": 27.7e9, "sha512_compress_per_s": 6.40e9, "fe25519_mul_per_s": 197e9, "fe25519_sq_per_s": 268.7e9,
-        "poseidon_permute_per_s": 1.835e9, "goldilocks_mul_per_s": 2.05e12}
 # Field operations of ONE fixed-key Ed25519 verification (ed25519.h ed25519_verify_keyed_core: affine tables, 22 radix-4096
 # digits of h for the key, 16 radix-65536 digits of s for B): 38 mixed additions (3 + 4 mul each, the last one 3 + 3), no
-# doubling + encoding.
-# With the batch-inversion scratch (k_ed25519_finish) the encoding costs 5 multiplications per signature plus one
-# inversion (254 sq + 11 mul) per 8 / 16 / 32 signatures — counted at 16.
+# doubling + encoding.  With the batch-inversion scratch (k_ed25519_finish) the encoding costs 5 multiplications per
+# signature plus one inversion (254 sq + 11 mul) per 8 / 16 / 32 signatures — counted at 16.
 FE_MUL_PER_VERIFY = 38 * 7 - 1 + 5 + 11 / 16
 FE_SQ_PER_VERIFY = 254 / 16
-# the ALU ceiling those counts imply: every multiplication at the measured fe_mul rate, every squaring at the fe_sq rate
-PEAK_KEYED_VERIFIES_PER_S = 1.0 / (FE_MUL_PER_VERIFY / PEAK["fe25519_mul_per_s"] + FE_SQ_PER_VERIFY / PEAK["fe25519_sq_per_s"])
+# Goldilocks multiplications of one Poseidon permutation that NO formulation can avoid: the x^7 S-boxes (4 multiplications
+# each: x2, x3 = x2*x, x4 = x2*x2, x7 = x4*x3) of 8 full rounds x 12 lanes + 22 partial rounds x 1 lane.  The MDS layers are
+# multiplications by small constants (shifts/adds here) and are NOT counted: an upper-bound style ceiling, never below truth.
+GL_MUL_PER_PERMUTATION = 4 * (8 * 12 + 22)
 
 
 def parse():
@@ -73,13 +73,13 @@ def parse():
     ap.add_argument("--jobs", type=int, default=32)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--validators", type=int, default=100)
-    ap.add_argument("--engines", type=int, default=2, help="chunks of the step pipelined on separate HIP streams (the ALU-bound hashing "
-                    "of one chunk beside the HBM-bound expansion of the other).  Measured on one box: 83.7 / 90.4 M headers/s at 1 / 2 chunks")
+    ap.add_argument("--engines", type=int, default=2, help="chunks of the step pipelined on separate HIP streams inside the library (the "
+                    "ALU-bound hashing of one chunk beside the HBM-bound expansion of the other)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--mode", choices=["F", "S"], default="F", help="F: one commit per range (a reference proof); S: a commit on every header")
-    ap.add_argument("--event-every", type=int, default=1, help="record the per-kernel HIP events on every n-th timed step")
     ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
-    ap.add_argument("--alternate", type=int, default=1, help="K engine sets over the same ranges stepped in turn (pipelining across steps; the compact-only leg uses 2)")
+    ap.add_argument("--caps", action="store_true", help="Poseidon Merkle caps of the map-job witnesses from the compact bytes (with --no-witness: instead of the expansion)")
+    ap.add_argument("--alternate", type=int, default=1, help="K pipelines over the same ranges stepped in turn (pipelining across steps; the compact-only leg uses 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only: none of the secondary objects")
@@ -113,53 +113,104 @@ def host_threads():
     return n, f"{n} threads of {model} (no CPU quota)"
 
 
+# ---------------------------------------------------------------------------------------------------------------- ceilings
+class Calibration(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("valu_add_u32_lane_ops_per_s", "valu_mad_u64_u32_lane_ops_per_s", "valu_alignbit_lane_ops_per_s",
+                                          "sha256_compress_per_s", "sha512_compress_per_s", "fe25519_mul_per_s", "fe25519_sq_per_s",
+                                          "goldilocks_mul_per_s", "hbm_store_bytes_per_s")] + [("compute_units", C.c_uint32), ("clock_mhz", C.c_uint32)]
+
+
+def calibrate(dev):
+    """bsx_calibrate on this device: the ALU / store ceilings every ALU-bound `roofline.peak` below is priced against."""
+    from blobstreamx_amd import _lib
+    c = Calibration()
+    _lib.check(_lib.lib().bsx_calibrate(_lib.context(dev.index or 0), C.byref(c)))
+    d = {k: getattr(c, k) for k, _ in Calibration._fields_}
+    d["source"] = "bsx_calibrate in this process (library's own device functions alone at 8 waves/SIMD; csrc/calibrate.hip)"
+    return d
+
+
+def keyed_verify_peak(cal):
+    """Ed25519 verifications/s if only the kernel's field multiplications and squarings cost time, at the measured rates."""
+    return 1.0 / (FE_MUL_PER_VERIFY / cal["fe25519_mul_per_s"] + FE_SQ_PER_VERIFY / cal["fe25519_sq_per_s"])
+
+
+def valu_insts(kernel_substr):
+    """Wave-level VALU instructions per unit of work of a kernel, from the committed SQ counter summaries (profiles/
+    valu_insts.json, written by tools/valu_insts.py from `rocprofv3 --pmc SQ_INSTS_VALU` passes).  None if not profiled."""
+    path = os.path.join(ROOT, "profiles", "valu_insts.json")
+    if not os.path.exists(path):
+        return None
+    for k, v in json.load(open(path)).get("kernels", {}).items():
+        if kernel_substr in k:
+            return v
+    return None
+
+
+def valu_issue(cal, kernel_substr, units, seconds):
+    """valu_issue_frac = SQ_INSTS_VALU (wave instructions, scaled to this launch) / (time x the measured v_add_u32 wave-issue
+    rate of the device).  Independent of any body micro-benchmark: how much of the VALU issue bandwidth the kernel used."""
+    v = valu_insts(kernel_substr)
+    if not v or seconds <= 0:
+        return None
+    insts = v["wave_valu_insts_per_unit"] * units
+    rate = cal["valu_add_u32_lane_ops_per_s"] / 64.0
+    return {"valu_issue_frac": insts / (seconds * rate), "wave_valu_insts_per_unit": v["wave_valu_insts_per_unit"], "unit": v["unit"],
+            "wave_issue_rate_per_s": rate, "counter_source": v.get("source")}
+
+
 # ---------------------------------------------------------------------------------------------------------------- checkers
 def cpu_baseline_witness_check(eng, w, J, B, per_chunk=2):
     """Download the Goldilocks witness of `per_chunk` sampled ranges of every pipelined chunk — as the TIMED loop left it in
     HBM — and diff it, element by element, against the oracle's witness of the same range (map jobs of this rank's slice;
     at N = 1 also every reduce node), plus the public output of the owned ones.  Returns the number of ranges checked."""
     import oracle
+    from blobstreamx_amd import engine as E
     from blobstreamx_amd import types as T
     ml, rl = T.map_layout(B), T.reduce_layout()
     nel, rel = int(ml["n_elements"]), int(rl["n_elements"])
     n = 0
-    torch.cuda.synchronize(eng.dev)
-    for e, en in enumerate(eng.engines):
+    eng.join()
+    out64 = eng.download()["output64"]
+    for e in range(eng.E):
         sel = eng.sel(e)
-        picks = sorted({0, en.RT - 1} if per_chunk >= 2 else {0})
+        wm = eng.buffer(e, E.BUF_WITNESS_MAP, i64=True)
+        wr = eng.buffer(e, E.BUF_WITNESS_REDUCE_LOCAL, i64=True)
+        picks = sorted({0, eng.RT - 1} if per_chunk >= 2 else {0})
         for k in picks:
             r = int(sel[k])
             rc, out, _, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
                                                  w.validators[r], w.trusted[r], want_witness=True)
             assert rc == 0, f"oracle status {rc} on range {r}"
             full = oracle.expand_range_witness(J, B, cw)
-            nm = en.jc * nel
-            got = en.witness_map[k * nm:(k + 1) * nm].cpu().numpy().view(np.uint64)
-            want = full[en.jf * nel:(en.jf + en.jc) * nel]
+            nm = eng.jc * nel
+            got = wm[k * nm:(k + 1) * nm].cpu().numpy().view(np.uint64)
+            want = full[eng.jf * nel:(eng.jf + eng.jc) * nel]
             assert (got == want).all(), f"map-job witness of range {r} differs from the oracle"
-            if en.world == 1 and J > 1:
+            if eng.world == 1 and J > 1:
                 nr = (J - 1) * rel
-                gr = en.witness_red_local[k * nr:(k + 1) * nr].cpu().numpy().view(np.uint64)
+                gr = wr[k * nr:(k + 1) * nr].cpu().numpy().view(np.uint64)
                 assert (gr == full[J * nel:]).all(), f"reduce witness of range {r} differs from the oracle"
-            own0 = en.rank * en.R
-            if own0 <= k < own0 + en.R:
-                o = en.output64[(k - own0) * 64:(k - own0 + 1) * 64].cpu().numpy().tobytes()
+            own0 = eng.rank * eng.Rc
+            if own0 <= k < own0 + eng.Rc:
+                o = out64[e * eng.Rc + (k - own0)].tobytes()
                 assert o == out, f"public output of range {r} differs from the oracle"
             n += 1
     return n
 
 
-def cpu_baseline(w, J, B, V, seconds, gpu_out64, n_ranges):
+def cpu_baseline(w, J, B, V, seconds, gpu_out64, n_ranges, first=0):
     """Oracle (oracle/, C) timed on the host cores on a bounded sample of the SAME workload; its outputs double as a
     check of the GPU's public outputs for the sampled ranges."""
     import oracle
     cores, cores_desc = host_threads()
     n = n_ranges
+    sl = slice(first, first + n)
 
     def run(reps):
         t = time.perf_counter()
-        rc, out64, _ = oracle.bench_header_range(J, B, w.ranges[:n], w.headers[:n], w.hpr, w.latest[:n], w.validators[:n],
-                                                 w.trusted[:n], V, True, cores, reps=reps)
+        rc, out64, _ = oracle.bench_header_range(J, B, w.ranges[sl], w.headers[sl], w.hpr, w.latest[sl], w.validators[sl],
+                                                 w.trusted[sl], V, True, cores, reps=reps)
         return time.perf_counter() - t, rc, out64
     r0 = max(1, -(-2 * cores // n))                 # >= 2 tasks per thread for the calibration pass
     dt, rc, out = run(r0)
@@ -175,132 +226,122 @@ def cpu_baseline(w, J, B, V, seconds, gpu_out64, n_ranges):
 
 
 # ---------------------------------------------------------------------------------------------------------------- mode S
-def stress(args, dev, V, cpu_seconds):
+def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     """Mode S (BASELINE configs #4/#5: 'N headers x V validators', i.e. next_header.rs:25-47 per header): every header of one
-    header_range_2048 carries its own V-signature commit: SHA-512 challenges, Ed25519 verifications, validator-set hashes
-    and tallies.  Per-signature ok bits and every commit result are compared with the oracle's (the CPU leg)."""
-    import ctypes as C
-    import oracle
+    header_range_2048 carries its own V-signature commit.  Rank g verifies commits [g*N/world, (g+1)*N/world) through ONE
+    C-ABI call per step (bsx_dev_verify_commits) and ONE all-gather of the 128-byte folds tells every rank the verdict of
+    the whole range.  Per-signature ok bits, every commit result and the fold of this rank's slice are compared with the
+    oracle's (the CPU leg); the gathered folds are compared with the oracle's folds of every slice on rank 0."""
     import synth
     from blobstreamx_amd import _lib
-    from blobstreamx_amd import types as T
+    from blobstreamx_amd.stress import CommitShard, range_verdict
     nh = args.jobs * args.batch
     w = synth.Workload(5 if V > 100 else 4, 1, args.jobs, args.batch, v=V, mode="S")
-    vals = w.validators.reshape(-1)
-    n = vals.size
-    L, ctx, dp = _lib.lib(), _lib.context(dev.index or 0), _lib.dp
-    dv = torch.from_numpy(vals.view(np.uint8).copy()).to(dev)
-    dh = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
-    dok = torch.zeros(n, dtype=torch.uint8, device=dev)
-    dhh = torch.from_numpy(w.commit_hashes.copy()).to(dev).view(-1)
-    dres = torch.zeros(nh * 96, dtype=torch.uint8, device=dev)
+    sh = CommitShard(nh, V, rank=rank, world=world, device=dev)
+    sh.upload(w.validators.reshape(nh, V), w.commit_hashes)
+    n = sh.n * V
+    L, ctx, dp = sh.L, sh.ctx, _lib.dp
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    tab = torch.zeros(int(L.bsx_ed25519_keytable_bytes(C.c_uint32(V))), dtype=torch.uint8, device=dev)
-    scr = torch.zeros(int(L.bsx_ed25519_verify_scratch_bytes(C.c_uint64(n))), dtype=torch.uint8, device=dev)   # batch-inversion slots
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    h_scratch = sh.scratch           # challenge scalars live at the head of the scratch block (bsx.h)
 
-    def once():
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+
+    def staged():
+        """the stages of bsx_dev_verify_commits as separate device-tier calls, bracketed by HIP events on the launch stream"""
+        ed_scr = sh.scratch[((n * 32 + 255) & ~255):]
         ev[0].record()
-        _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(dv), C.c_uint64(n), dp(dh), None))
+        _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(sh.vals), C.c_uint64(n), dp(h_scratch), None))
         ev[1].record()
-        # fixed-key P7: the table call is inside the timed region; rows whose key is unchanged since the previous call are
-        # kept (one compare per row) — `cold` below forces the rebuild
-        _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(V), dp(tab)))
+        _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(sh.vals), C.c_uint32(V), dp(sh.keytable)))
         ev[2].record()
-        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(V), dp(tab), C.c_uint32(V), dp(dok), dp(scr)))
+        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(sh.vals), dp(h_scratch), C.c_uint64(n), C.c_uint32(V), dp(sh.keytable),
+                                                  C.c_uint32(V), dp(sh.ok), dp(ed_scr)))
         ev[3].record()
-        _lib.check(L.bsx_dev_commit_tally(ctx, st, dp(dv), C.c_uint32(nh), C.c_uint32(V), dp(dhh), dp(dok), dp(dres)))
+        _lib.check(L.bsx_dev_commit_tally(ctx, st, dp(sh.vals), C.c_uint32(sh.n), C.c_uint32(V), dp(sh.hh), dp(sh.ok), dp(sh.res)))
         ev[4].record()
         torch.cuda.synchronize(dev)
         return [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
-    cold = once()                                   # first call: every table row is built
-    reps = 5
-    t = np.mean([once() for _ in range(reps)], axis=0)
+    cold = staged()                                 # first call: every table row is built
+    t = np.mean([staged() for _ in range(5)], axis=0)
     t_sha, t_tab, t_ed, t_tally = (float(x) for x in t)
-    tot = float(t.sum())
-    # The same work as a 2-stream software pipeline over the two halves of the commits (K steps back to back): one half's
-    # SHA-512 / tally kernels and the partial last wave round of its signature kernel overlap the other half's kernels
-    # (a single launch of 204,800 signatures is 3.1 waves per SIMD: a quarter of the last round's slots idle).
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-    half = nh // 2
-    K = 6
-
-    def pipelined():
-        cur = torch.cuda.current_stream(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(cur)
-        for s in streams:
-            s.wait_stream(cur)
-        for _ in range(K):
-            with torch.cuda.stream(streams[0]):
-                _lib.check(L.bsx_dev_ed25519_keytable(ctx, C.c_void_p(streams[0].cuda_stream), dp(dv), C.c_uint32(V), dp(tab)))
-                tab_ok = torch.cuda.Event()
-                tab_ok.record(streams[0])
-            streams[1].wait_event(tab_ok)
-            for i, s in enumerate(streams):
-                o, ns = i * half, half * V
-                with torch.cuda.stream(s):
-                    sp = C.c_void_p(s.cuda_stream)
-                    _lib.check(L.bsx_dev_sha512_challenge(ctx, sp, dp(dv[o * V * 256:]), C.c_uint64(ns), dp(dh[o * V * 32:]), None))
-                    _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, sp, dp(dv[o * V * 256:]), dp(dh[o * V * 32:]), C.c_uint64(ns), C.c_uint32(V),
-                                                              dp(tab), C.c_uint32(V), dp(dok[o * V:]), dp(scr[o * V * 160:])))
-                    _lib.check(L.bsx_dev_commit_tally(ctx, sp, dp(dv[o * V * 256:]), C.c_uint32(half), C.c_uint32(V), dp(dhh[o * 32:]),
-                                                      dp(dok[o * V:]), dp(dres[o * 96:])))
-        for s in streams:
-            cur.wait_stream(s)
-        e1.record(cur)
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / K
-    dok.zero_(); dres.zero_()
-    pipelined()
-    t_pipe = min(pipelined() for _ in range(3))
-    gpu_ok = dok.cpu().numpy().reshape(nh, V)
-    gpu_res = dres.cpu().numpy().view(T.COMMIT_RESULT)
-    # CPU leg = checker: the oracle's verify_commit of EVERY commit on all host threads, repeated to fill ~cpu_seconds
-    cores, cores_desc = host_threads()
+    # the timed object: K steps of the ONE composite call + the fold all-gather, barrier on both sides, max over ranks
+    sh.step()
+    folds = sh.gather()
+    K = 5
+    barrier()
     t0 = time.perf_counter()
-    res, ok = oracle.bench_verify_commits(w.validators.reshape(nh, V), w.commit_hashes, cores, reps=1)
-    dt = time.perf_counter() - t0
-    creps = int(max(1, min(32, round(cpu_seconds / max(dt, 1e-3)))))
+    for _ in range(K):
+        sh.step()
+        folds = sh.gather()
+    barrier()
+    dt = (time.perf_counter() - t0) / K
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    tot = dt * 1e3
+    gpu_ok, gpu_res, gpu_fold = sh.download()
+    verdict = range_verdict(folds)
+    out = {"workload": f"mode S: {nh} headers x {V} validators = {nh * V} signatures (one header_range_{nh}, a commit per header)"
+                       + (f", sharded {world} x {sh.n} commits, one all-gather of 128-byte folds" if world > 1 else ""),
+           "headers_per_s": nh / dt, "verifies_per_s_all_stages": nh * V / dt, "ms": tot,
+           "verifies_per_s_incl_table": n / (t_ed + t_tab) * 1e3, "signatures": nh * V, "signatures_this_rank": n,
+           "range_verdict": verdict,
+           "stage_ms": {"sha512_challenge": t_sha, "keytable": t_tab, "ed25519_verify_keyed": t_ed, "tally_validator_hash": t_tally,
+                        "keytable_cold_build": cold[1]},
+           "ed25519_path": "fixed-key affine tables: 22 radix-4096 digits of h for every validator key (5.8 MB per key), 16 radix-65536 digits of "
+                           "s for B (64 MB) = 38 mixed additions, no doubling; table rows reused while the validator set is unchanged; "
+                           "encodings through per-lane Montgomery batch inversion (8 / 16 / 32 signatures per inversion)"}
+    ver_per_s = n / (t_ed * 1e-3)
+    peak = keyed_verify_peak(cal)
+    out["roofline"] = {"kernel": "k_ed25519_verify_keyed", "bound": "valu", "unit": "M Ed25519 verifications/s",
+                       "achieved": ver_per_s / 1e6, "peak": peak / 1e6, "frac": min(1.0, ver_per_s / peak),
+                       "avg_launch_ms": t_ed, "traffic": None,
+                       "field_ops_per_verification": {"mul": FE_MUL_PER_VERIFY, "sq": FE_SQ_PER_VERIFY},
+                       "achieved_G_field_ops_per_s": ver_per_s * (FE_MUL_PER_VERIFY + FE_SQ_PER_VERIFY) / 1e9,
+                       "valu_issue": valu_issue(cal, "k_ed25519_verify_keyed", n, t_ed * 1e-3),
+                       "note": "peak = the time the kernel's GF(2^255-19) multiplications and squarings would take at the fe_mul / fe_sq "
+                               f"rates measured in this run ({cal['fe25519_mul_per_s'] / 1e9:.0f} / {cal['fe25519_sq_per_s'] / 1e9:.0f} G/s); additions, "
+                               "table selection, recoding and the launch's partial last wave round are what is left; ALU bound, bytes are "
+                               "not the limiter (96 B in per signature)",
+                       "sha512_challenge": {"avg_launch_ms": t_sha, "compressions_per_s": 2 * n / t_sha * 1e3,
+                                            "frac_of_measured_peak": min(1.0, 2 * n / t_sha * 1e3 / cal["sha512_compress_per_s"]),
+                                            "algorithmic_GBps": n * 237 / t_sha / 1e6}}
+    if not check:
+        return out
+    # CPU leg = checker: the oracle's verify_commit of this rank's commits on all host threads, repeated to fill ~cpu_seconds
+    import oracle
+    cores, cores_desc = host_threads()
+    vv = w.validators.reshape(nh, V)[sh.first:sh.first + sh.n]
+    hh = w.commit_hashes[sh.first:sh.first + sh.n]
+    t0 = time.perf_counter()
+    res, ok = oracle.bench_verify_commits(vv, hh, cores, reps=1)
+    dtc = time.perf_counter() - t0
+    creps = int(max(1, min(32, round(cpu_seconds / max(dtc, 1e-3)))))
     if creps > 1:
         t0 = time.perf_counter()
-        res, ok = oracle.bench_verify_commits(w.validators.reshape(nh, V), w.commit_hashes, cores, reps=creps)
-        dt = time.perf_counter() - t0
+        res, ok = oracle.bench_verify_commits(vv, hh, cores, reps=creps)
+        dtc = time.perf_counter() - t0
     assert (gpu_ok == ok).all(), "mode S: per-signature verdicts differ from the oracle"
     a, b = gpu_res.copy(), res.copy()
     a["_pad"] = 0; b["_pad"] = 0
     if a.tobytes() != b.tobytes():
-        bad = [c for c in range(nh) if a[c].tobytes() != b[c].tobytes()]
+        bad = [c for c in range(sh.n) if a[c].tobytes() != b[c].tobytes()]
         raise AssertionError(f"mode S: commit results differ from the oracle at {len(bad)} commits, first {bad[:4]}: {a[bad[0]]} vs {b[bad[0]]}")
     assert int(gpu_ok.sum()) == n
-    ver_per_s = n / (t_ed * 1e-3)
-    return {"workload": f"mode S: {nh} headers x {V} validators = {n} signatures (one header_range_{nh}, a commit per header)",
-            "headers_per_s": nh / tot * 1e3, "verifies_per_s_incl_table": n / (t_ed + t_tab) * 1e3, "ms": tot,
-            "pipelined": {"ms_per_step": t_pipe, "headers_per_s": nh / t_pipe * 1e3, "verifies_per_s_all_stages": n / t_pipe * 1e3,
-                          "note": "2 streams x half of the commits, 6 steps back to back; every stage (challenge, table check, verify, "
-                                  "tally + validator hashes) inside; the verdicts compared with the oracle are the ones this run left"},
-            "signatures": n, "checked_against_oracle": {"sig_ok_bits": n, "commit_results": nh},
-            "stage_ms": {"sha512_challenge": t_sha, "keytable": t_tab, "ed25519_verify_keyed": t_ed, "tally_validator_hash": t_tally,
-                         "keytable_cold_build": cold[1]},
-            "ed25519_path": "fixed-key affine tables: 22 radix-4096 digits of h for every validator key (5.8 MB per key), 16 radix-65536 digits of "
-                            "s for B (64 MB) = 38 mixed additions, no doubling; table rows reused while the validator set is unchanged; "
-                            "encodings through per-lane Montgomery batch inversion (8 / 16 / 32 signatures per inversion)",
-            "roofline": {"kernel": "k_ed25519_verify_keyed", "bound": "valu", "unit": "M Ed25519 verifications/s",
-                         "achieved": ver_per_s / 1e6, "peak": PEAK_KEYED_VERIFIES_PER_S / 1e6, "frac": ver_per_s / PEAK_KEYED_VERIFIES_PER_S,
-                         "avg_launch_ms": t_ed, "traffic": None,
-                         "field_ops_per_verification": {"mul": FE_MUL_PER_VERIFY, "sq": FE_SQ_PER_VERIFY},
-                         "achieved_G_field_ops_per_s": ver_per_s * (FE_MUL_PER_VERIFY + FE_SQ_PER_VERIFY) / 1e9,
-                         "note": "peak = the time the kernel's GF(2^255-19) multiplications and squarings would take at the measured "
-                                 f"fe_mul ({PEAK['fe25519_mul_per_s'] / 1e9:.0f} G/s) and fe_sq ({PEAK['fe25519_sq_per_s'] / 1e9:.0f} G/s) rates "
-                                 "(bodies alone at 8 waves/SIMD, tools/microbench_alu.hip); additions, table selection, recoding and the "
-                                 "launch's partial last wave round (204,800 signatures = 3.1 waves per SIMD) are what is left; ALU bound, "
-                                 "bytes are not the limiter (96 B in per signature)",
-                         "sha512_challenge": {"avg_launch_ms": t_sha, "compressions_per_s": 2 * n / t_sha * 1e3,
-                                              "frac_of_measured_peak": 2 * n / t_sha * 1e3 / PEAK["sha512_compress_per_s"],
-                                              "algorithmic_GBps": n * 237 / t_sha / 1e6}},
-            "cpu_baseline": {"value": nh * creps / dt, "unit": "headers/s", "verifies_per_s": n * creps / dt, "cores": cores, "kind": "port",
-                             "sample": f"oracle verify_commit of all {nh} commits x {creps} repetitions, {dt:.1f} s wall on {cores_desc}; "
-                                       "every verdict and commit result compared with the GPU's"}}
+    ofold = oracle.commit_fold(res, sh.first)
+    assert gpu_fold.tobytes() == ofold.tobytes(), "mode S: this rank's fold differs from the oracle's fold of the oracle's results"
+    assert folds[rank].tobytes() == ofold.tobytes(), "mode S: the gathered fold of this rank is not the one it sent"
+    assert verdict["all_ok"] and verdict["commits"] == nh, verdict
+    out["checked_against_oracle"] = {"sig_ok_bits": n, "commit_results": sh.n, "fold": 1, "gathered_folds": int(len(folds))}
+    out["cpu_baseline"] = {"value": sh.n * creps / dtc, "unit": "headers/s", "verifies_per_s": n * creps / dtc, "cores": cores, "kind": "port",
+                           "sample": f"oracle verify_commit of this rank's {sh.n} commits x {creps} repetitions, {dtc:.1f} s wall on {cores_desc}; "
+                                     "every verdict, commit result and the fold compared with the GPU's"}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------- other legs
@@ -329,46 +370,60 @@ def latency_leg(dev, J, B, V):
 
 def upload_leg(eng, args, steps):
     """The headline step with the header block (headers + skip headers, 512 B each) streamed from pinned host memory EVERY
-    step on a copy stream, overlapped with the previous step's compute: the PCIe-inclusive rate of a caller whose inputs
-    are not resident."""
-    for en in eng.engines:
-        en.enable_input_streaming()
+    step on a copy stream inside the library (bsx_pipeline_enable_input_streaming), overlapped with the previous step's
+    compute: the PCIe-inclusive rate of a caller whose inputs are not resident."""
+    from blobstreamx_amd import engine as E
+    eng.enable_input_streaming(True)
     for _ in range(2):
         eng.step()
     eng.join()
-    torch.cuda.synchronize(eng.dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.step()
     eng.join()
-    torch.cuda.synchronize(eng.dev)
     dt = (time.perf_counter() - t0) / steps
-    for en in eng.engines:
-        en._h2d = None
-        en._h2d_done = None
-    nbytes = sum(en.headers_all.numel() for en in eng.engines)
+    eng.enable_input_streaming(False)
+    nbytes = sum(eng.buffer(e, E.BUF_HEADERS).numel() for e in range(eng.E))
     return {"value": eng.R * args.jobs * args.batch / dt, "unit": "headers/s", "ms_per_step": dt * 1e3, "steps": steps,
             "h2d_bytes_per_step": nbytes, "h2d_GBps": nbytes / dt / 1e9,
             "note": "inputs streamed H2D from pinned memory on a copy stream each step, overlapped with compute; the witness stays on the device"}
 
 
-def commitment_leg(dev, J, B, V, R=32, leaf_len=135, cap_height=4):
-    """Poseidon (plonky2 PoseidonGoldilocksConfig) Merkle caps of every map job's witness: fused (elements generated on the
-    fly from the compact bytes, the 64x image never exists) vs materialised (expand to HBM, then hash)."""
-    import ctypes as C
+def commitment_leg(dev, J, B, V, cal, R=32, leaf_len=135, cap_height=4):
+    """Poseidon (plonky2 PoseidonGoldilocksConfig) Merkle caps of every map job's witness.  (1) the pipeline's BSX_PIPE_CAPS
+    mode: the whole step (hashing, hint, prove_subchain, reduce, commit check) + caps straight from the compact bytes, no
+    64x image — headers/s, three un-joined steps, caps of two jobs checked against the oracle's own witness + Poseidon;
+    (2) the commitment kernels alone: fused vs materialised (expand to HBM, then hash)."""
     import oracle
     import synth
     from blobstreamx_amd import _lib
-    from blobstreamx_amd.engine import HeaderRangeEngine
+    from blobstreamx_amd import engine as E
     from blobstreamx_amd.poseidon import WitnessCommitter
     w = synth.Workload(4, R, J, B, v=V)
-    eng = HeaderRangeEngine(J, B, V, R, device=dev)
+    pe = E.PipelinedEngines(J, B, V, R, n_engines=2, device=dev, with_witness=False, with_caps=True, leaf_len=leaf_len, cap_height=cap_height)
+    pe.upload_workload(w)
+    pe.step()
+    pe.join()
+    pe.set_timing(True)
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pe.step()
+    pe.join()
+    dt_pipe = (time.perf_counter() - t0) / steps
+    tm = pe.timing()
+    _, caps0 = pe.caps_numpy(0)
+    res = pe.download()
+    assert not res["range_status"].any() and not res["skip_status"].any()
+    del pe
+    eng = E.HeaderRangeEngine(J, B, V, R, device=dev)
     eng.upload_workload(w)
     eng.step()
-    torch.cuda.synchronize(dev)
+    eng.join()
     n_jobs = R * J
     wc = WitnessCommitter(eng.ml, n_jobs, leaf_len, cap_height, device=dev)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    compact, wmap = eng.compact, eng.witness_map
 
     def timed(fn, reps=3):
         fn()
@@ -379,15 +434,17 @@ def commitment_leg(dev, J, B, V, R=32, leaf_len=135, cap_height=4):
         ev[1].record()
         torch.cuda.synchronize(dev)
         return ev[0].elapsed_time(ev[1]) / reps
-    t_fused = timed(lambda: wc.commit_compact(eng.compact))
+    t_fused = timed(lambda: wc.commit_compact(compact))
     caps_fused = wc.caps_numpy().copy()
 
     def materialised():
         _lib.check(eng.L.bsx_dev_expand_witness(eng.ctx, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), _lib.p(eng._ml),
-                                                C.c_uint32(n_jobs), _lib.dp(eng.compact), _lib.dp(eng.witness_map)))
-        wc.commit_materialised(eng.witness_map)
+                                                C.c_uint32(n_jobs), _lib.dp(compact), _lib.dp(wmap)))
+        wc.commit_materialised(wmap)
     t_mat = timed(materialised)
     assert (wc.caps_numpy() == caps_fused).all(), "fused and materialised commitments differ"
+    # the pipeline's chunk 0 holds ranges 0 .. R/2: its caps are the stand-alone committer's
+    assert (caps0 == caps_fused[:caps0.shape[0]]).all(), "the pipeline's BSX_PIPE_CAPS output differs from the stand-alone commitment"
     # oracle check of two jobs: its own witness, its own Poseidon
     rc, _, _, cw = oracle.header_range(J, B, w.input48(0), w.headers[0], int(w.first_height[0]), int(w.latest[0]), w.validators[0],
                                        w.trusted[0], want_witness=True)
@@ -396,15 +453,22 @@ def commitment_leg(dev, J, B, V, R=32, leaf_len=135, cap_height=4):
         _, cap = oracle.poseidon_merkle_tree(full[j * wc.nel:(j + 1) * wc.nel], leaf_len, wc.n_leaves, wc.cap_height)
         assert (caps_fused[j] == cap).all(), "witness commitment differs from the oracle"
     perms = n_jobs * wc.perms_per_job
+    perm_per_s = perms / t_fused * 1e3
+    peak = cal["goldilocks_mul_per_s"] / GL_MUL_PER_PERMUTATION
     return {"workload": f"{R} x header_range_{J * B}: {n_jobs} map-job witnesses of {wc.nel} elements, rows of {leaf_len}, "
                         f"{wc.n_leaves} leaves, cap height {wc.cap_height}",
+            "pipeline_caps_mode": {"headers_per_s": R * J * B / dt_pipe, "ms_per_step": dt_pipe * 1e3, "steps": steps, "caps_launch_ms": tm["caps_ms"],
+                                   "note": "bsx_pipeline with BSX_PIPE_CAPS (no expansion): the whole step incl. commit check + Poseidon caps of every "
+                                           "map-job witness from the compact bytes; steps not joined"},
             "fused_ms": t_fused, "materialised_ms": t_mat, "headers_per_s_fused": R * J * B / t_fused * 1e3,
             "permutations": perms, "checked_against_oracle_jobs": 2,
             "roofline": {"kernel": "k_leaf_hashes<fused> + k_merkle_level", "bound": "valu", "unit": "G Poseidon permutations/s",
-                         "achieved": perms / t_fused / 1e6, "peak": PEAK["poseidon_permute_per_s"] / 1e9,
-                         "frac": perms / t_fused * 1e3 / PEAK["poseidon_permute_per_s"], "traffic": None,
-                         "note": "peak = the permutation body alone at 8 waves/SIMD (tools/microbench_alu.hip); one permutation "
-                                 "absorbs 8 elements = 1 compact byte: bytes are irrelevant"},
+                         "achieved": perm_per_s / 1e9, "peak": peak / 1e9, "frac": min(1.0, perm_per_s / peak), "traffic": None,
+                         "valu_issue": valu_issue(cal, "k_leaf_hashes<true>", n_jobs * wc.n_rows * (-(-leaf_len // 8)), t_fused * 1e-3),
+                         "note": f"peak = the {GL_MUL_PER_PERMUTATION} Goldilocks multiplications of a permutation's x^7 S-boxes at the gl_mul rate measured in "
+                                 f"this run ({cal['goldilocks_mul_per_s'] / 1e12:.2f} T/s) — the MDS layers' shift/add arithmetic is not counted, so this "
+                                 "is an upper-bound style ceiling (an independent one: not the permutation's own micro-benchmark); "
+                                 "valu_issue_frac = counted VALU wave-instructions / (time x measured v_add_u32 wave-issue rate)"},
             "hbm_bytes_not_written_per_header": int(8 * wc.nel / B)}
 
 
@@ -421,7 +485,7 @@ def subprocess_leg(args, extra, timeout=900):
 def pmc_traffic(n_jobs, B):
     """HBM bytes of one k_expand_witness launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.csv +
     .meta.json written by the profiling command), scaled per map job.  None when no profile of this shape is committed."""
-    for tag in ("r2", "r1"):
+    for tag in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.csv")
         meta = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.meta.json")
         if not os.path.exists(path):
@@ -451,6 +515,39 @@ def memory_partition_mode():
     return None
 
 
+def sharded_self_check(eng, w, J, B, V, R, rank, dev, res):
+    """N > 1 must prove itself: re-prove a sample of the owned ranges with an UN-SHARDED pipeline (world = 1, all map jobs,
+    no collective) on this rank's own GPU and compare public output, final status, commit result, this rank's map-job
+    records and — for one range — this rank's slice of the Goldilocks witness."""
+    from blobstreamx_amd import engine as E
+    from blobstreamx_amd import types as T
+    ks = sorted({0, R // 2, R - 1})
+    solo = E.HeaderRangeEngine(J, B, V, len(ks), device=dev, with_witness=eng.with_witness)
+    solo.upload_workload(w, np.array([rank * R + k for k in ks]))
+    solo.step()
+    sres = solo.download()
+    for i, k in enumerate(ks):
+        assert sres["output64"][i].tobytes() == res["output64"][k].tobytes(), f"rank {rank}: sharded output of owned range {k} differs from the un-sharded pipeline"
+        assert sres["range_status"][i] == res["range_status"][k] and sres["skip_status"][i] == res["skip_status"][k]
+        a, b = np.array(sres["commit"][i]).copy(), np.array(res["commit"][k]).copy()
+        a["_pad"] = 0; b["_pad"] = 0
+        assert a.tobytes() == b.tobytes()
+        mine = res["records"][rank * R + k].copy()
+        ref = sres["records"][i][eng.jf:eng.jf + eng.jc].copy()
+        mine["_pad"] = 0; ref["_pad"] = 0
+        assert mine.tobytes() == ref.tobytes(), f"rank {rank}: map-job records of owned range {k} differ from the un-sharded pipeline"
+    checked_w = 0
+    if eng.with_witness:
+        nel = int(T.map_layout(B)["n_elements"])
+        sw = solo.witness_map[eng.jf * nel:(eng.jf + eng.jc) * nel]          # un-sharded range ks[0], jobs of this rank's slice
+        i0 = eng.rank * eng.Rc                                               # owned range 0 = chunk 0, position rank*Rc
+        mw = eng.buffer(0, E.BUF_WITNESS_MAP, i64=True)[i0 * eng.jc * nel:(i0 + 1) * eng.jc * nel]
+        assert torch.equal(sw, mw), f"rank {rank}: sharded map-job witness of owned range 0 differs from the un-sharded pipeline"
+        checked_w = 1
+    del solo
+    return {"ranges": len(ks), "fields": "output64, statuses, commit result, map-job records", "witness_ranges": checked_w}
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -463,6 +560,8 @@ def main():
     # gloo process group; the driver's multi-GPU runs use neither (one rank per GPU over RCCL)
     if os.environ.get("BSX_BENCH_DEVICE") is not None:
         local = int(os.environ["BSX_BENCH_DEVICE"])
+    from blobstreamx_amd import _lib
+    _lib.lib()                     # loads libbsx.so before the first HIP call (its constructor raises GPU_MAX_HW_QUEUES)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     backend = None
@@ -476,16 +575,23 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import synth
-    from blobstreamx_amd.engine import HeaderRangeEngine, PipelinedEngines
+    from blobstreamx_amd import engine as E
 
+    cal = calibrate(dev)
     J, B, V = args.jobs, args.batch, args.validators
     if args.mode == "S":
-        # mode S as the primary object (N = 1): the `stress` leg on its own
-        out = stress(args, dev, V, args.cpu_seconds)
-        print(json.dumps({"metric": "headers/sec, mode S (a commit on every header)", "value": out["headers_per_s"], "unit": "headers/s",
-                          "n_gpus": 1, "steps": 5, "warmup": 1, "ms_per_step": out["ms"], "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": out["workload"]},
-                          "roofline": out["roofline"], "cpu_baseline": out["cpu_baseline"], "stress": out}))
+        # mode S as the primary object: commits sharded with their headers across the ranks
+        out = stress(args, dev, V, args.cpu_seconds, cal, rank=rank, world=world)
+        if rank == 0:
+            print(json.dumps({"metric": "headers/sec, mode S (a commit on every header)", "value": out["headers_per_s"], "unit": "headers/s",
+                              "n_gpus": world, "steps": 5, "warmup": 1, "ms_per_step": out["ms"], "higher_is_better": True, "scaling": "strong",
+                              "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                              "config": {"workload": out["workload"], "nccl_ranks": world, "dist_backend": backend,
+                                         "parallelism": f"{world} x {args.jobs * args.batch // world} commits, 1 all-gather of 128-byte folds per step"},
+                              "roofline": out["roofline"], "cpu_baseline": out.get("cpu_baseline"), "calibration": cal, "stress": out}))
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
     strong = args.scaling == "strong" and world > 1
     R = args.ranges // world if strong else args.ranges          # ranges OWNED per rank
@@ -493,13 +599,11 @@ def main():
     t0 = time.perf_counter()
     w = synth.Workload(4, R * world, J, B, v=V)          # config #4 seed; identical on every rank
     t_gen = time.perf_counter() - t0
-    E = args.engines
-    if args.alternate > 1:
-        from blobstreamx_amd.engine import AlternatingPipelines
-        eng = AlternatingPipelines(args.alternate, J, B, V, R, n_engines=E, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
-    else:
-        eng = PipelinedEngines(J, B, V, R, n_engines=E, rank=rank, world=world, device=dev, with_witness=not args.no_witness)
+    Ech = args.engines
+    kw = dict(n_engines=Ech, rank=rank, world=world, device=dev, with_witness=not args.no_witness, with_caps=args.caps)
+    eng = E.AlternatingPipelines(args.alternate, J, B, V, R, **kw) if args.alternate > 1 else E.PipelinedEngines(J, B, V, R, **kw)
     eng.upload_workload(w)
+    p0 = eng.sets[0] if args.alternate > 1 else eng
 
     # correctness gate before timing: statuses clean, public output = (target header hash, commitment) for every owned range
     eng.step()
@@ -509,23 +613,7 @@ def main():
     assert not res["range_status"].any() and not res["skip_status"].any(), (res["range_status"], res["skip_status"])
     assert (res["output64"][:, :32] == w.hashes[own, w.n_blocks]).all(), "target header hash mismatch"
     gpu_out64 = res["output64"].copy()
-    self_check = None
-    if world > 1:
-        # N > 1 must prove itself: re-prove a sample of the owned ranges with an UN-SHARDED engine (world = 1, all 32 map
-        # jobs, no collective) on this rank's own GPU and compare public output, final record status and commit result
-        ks = sorted({0, R // 2, R - 1})
-        solo = HeaderRangeEngine(J, B, V, len(ks), device=dev, with_witness=False)
-        solo.upload_workload(w, np.array([rank * R + k for k in ks]))
-        solo.step()
-        sres = solo.download()
-        for i, k in enumerate(ks):
-            assert sres["output64"][i].tobytes() == res["output64"][k].tobytes(), f"rank {rank}: sharded output of owned range {k} differs from the un-sharded engine"
-            assert sres["range_status"][i] == res["range_status"][k] and sres["skip_status"][i] == res["skip_status"][k]
-            a, b = np.array(sres["commit"][i]).copy(), np.array(res["commit"][k]).copy()
-            a["_pad"] = 0; b["_pad"] = 0
-            assert a.tobytes() == b.tobytes()
-        self_check = len(ks)
-        del solo
+    self_check = sharded_self_check(p0, w, J, B, V, R, rank, dev, res) if world > 1 else None
 
     def barrier():
         eng.join()
@@ -536,25 +624,15 @@ def main():
     for _ in range(args.warmup):
         eng.step()
     barrier()
-    t_sub = t_exp = 0.0
+    eng.set_timing(True)             # HIP events on the launch streams, inside the library
     t0 = time.perf_counter()
-    pending = []
     for i in range(args.steps):
-        if i % args.event_every == 0:
-            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(E)]
-            eng.step(time_kernels=True, events=evs)
-            pending.append(evs)
-        else:
-            eng.step()
+        eng.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    for step_evs in pending:             # HIP events on the launch stream of each engine; per-launch averages
-        for evs in step_evs:
-            t_sub += evs[0].elapsed_time(evs[1])
-            if not args.no_witness:
-                t_exp += evs[2].elapsed_time(evs[3])
-    t_sub /= len(pending) * E
-    t_exp /= len(pending) * E
+    tm = eng.timing()
+    eng.set_timing(False)
+    t_sub, t_exp = tm["prove_subchain_ms"], tm["expand_map_ms"]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -563,14 +641,13 @@ def main():
     headers_per_step = world * R * J * B
     value = headers_per_step / (elapsed / args.steps)
     # the witness the TIMED loop left in HBM, against the oracle (every rank checks its own buffers)
-    n_checked = cpu_baseline_witness_check(eng, w, J, B) if not args.no_witness else 0
+    n_checked = cpu_baseline_witness_check(p0, w, J, B) if not args.no_witness else 0
     res2 = eng.download()
     assert (res2["output64"] == gpu_out64).all() and not res2["range_status"].any() and not res2["skip_status"].any(), "outputs changed during the timed loop"
 
     if rank == 0:
-        e0 = eng.engines[0]
-        ml = e0.ml
-        n_jobs = e0.RT * e0.jc           # map jobs per launch (one engine = 1/E of the step)
+        ml = p0.ml
+        n_jobs = p0.RT * p0.jc           # map jobs per launch (one chunk = 1/E of the step)
         # algorithmic bytes: expansion reads the compact witness once and writes 8 B per element
         exp_bytes = n_jobs * (int(ml["n_bytes"]) + 4 * int(ml["n_words"]) + int(ml["n_bools"]) + 8 * int(ml["n_elements"]))
         slots = n_jobs * B
@@ -581,29 +658,30 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"header_range_{J * B} ({J} map jobs x {B} headers), {V} validators, mode F (one target commit per range), "
-                                   f"{R} ranges per GPU per step, Goldilocks witness {'off' if args.no_witness else 'materialised'}",
-                       "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": E, "alternating_engine_sets": args.alternate,
+                                   f"{R} ranges per GPU per step, Goldilocks witness {'off' if args.no_witness else 'materialised'}"
+                                   + (", Poseidon caps from the compact bytes" if args.caps else ""),
+                       "timed_entry": "bsx_pipeline_step (C ABI, csrc/pipeline.hip)",
+                       "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": Ech, "alternating_pipelines": args.alternate,
                        "parallelism": (f"{world} x ({J // world} of {J} map jobs = {J * B // world} headers of every range), 1 all-gather of 128-B "
                                        f"records per chunk; {'strong: ' + str(R * world) + ' ranges in total' if strong else 'weak: ' + str(R) + ' ranges per GPU'}")
                        if world > 1 else "1 GPU",
                        "nccl_ranks": torch.distributed.get_world_size() if world > 1 else 1, "dist_backend": backend,
-                       "sharded_vs_unsharded_ranges_checked_per_rank": self_check,
+                       "sharded_vs_unsharded_self_check_per_rank": self_check,
                        "witness_checked_ranges": n_checked,
-                       "witness_bytes_per_step_per_gpu": int(E * n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
+                       "witness_bytes_per_step_per_gpu": int(Ech * n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
                        "input_generation_s": round(t_gen, 2),
-                       "ed25519_path": e0.ed_path, "commit_beside": e0.commit_with,
-                       "witness_placement": e0.placement_probe, "memory_partition": memory_partition_mode()},
+                       "ed25519_path": p0.ed_path, "commit_beside": p0.commit_with, "memory_partition": memory_partition_mode()},
+            "calibration": cal,
         }
         if not args.no_witness:
             # the same kernel alone on an idle GPU (after the timed region): what the overlap with the other chunk's hashing costs it
-            import ctypes as C
-            from blobstreamx_amd import _lib
             iso = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            compact, wmap = p0.buffer(0, E.BUF_COMPACT), p0.buffer(0, E.BUF_WITNESS_MAP, i64=True)
             t_iso = 0.0
             for _ in range(5):
                 iso[0].record()
-                _lib.check(e0.L.bsx_dev_expand_witness(e0.ctx, st, _lib.p(e0._ml), C.c_uint32(n_jobs), _lib.dp(e0.compact), _lib.dp(e0.witness_map)))
+                _lib.check(p0.L.bsx_dev_expand_witness(p0.ctx, st, _lib.p(p0._ml), C.c_uint32(n_jobs), _lib.dp(compact), _lib.dp(wmap)))
                 iso[1].record()
                 torch.cuda.synchronize(dev)
                 t_iso += iso[0].elapsed_time(iso[1]) / 5
@@ -611,54 +689,63 @@ def main():
             out["roofline"] = {"kernel": "k_expand_witness (map-job section)", "bound": "hbm", "achieved": exp_bytes / t_exp / 1e6,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exp_bytes / t_exp / 1e6 / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_source": traffic_src,
-                               "avg_launch_ms": t_exp, "algorithmic_bytes_per_launch": exp_bytes,
+                               "avg_launch_ms": t_exp, "algorithmic_bytes_per_launch": exp_bytes, "launches_timed": tm["launches"],
+                               "measured_store_ceiling_GBps": cal["hbm_store_bytes_per_s"] / 1e9,
+                               "frac_of_measured_store_ceiling": min(1.0, exp_bytes / t_exp * 1e3 / cal["hbm_store_bytes_per_s"]),
                                "isolated": {"avg_launch_ms": t_iso, "achieved": exp_bytes / t_iso / 1e6, "frac": exp_bytes / t_iso / 1e6 / HBM_PEAK_GBS},
                                "note": "expanded (witness-emitting) byte count: 8 B written per Goldilocks element + the compact read; "
-                                       "`achieved` is measured inside the timed region where the kernel co-runs with the other chunk's "
-                                       "ALU-bound hashing; `isolated` is the same launch alone; `traffic` = PMC bytes per launch read from "
-                                       "the committed profile at run time (null when no profile of this shape exists)"}
-        fused = bool(e0.fused_hint)
+                                       "`achieved` is measured with HIP events on the launch stream inside the timed region where the kernel "
+                                       "co-runs with the other chunk's ALU-bound hashing; `isolated` is the same launch alone; `traffic` = PMC "
+                                       "bytes per launch read from the committed profile at run time (null when no profile of this shape exists)"}
+        else:
+            out["roofline"] = None
+        fused = bool(p0.fused_hint)
         exec_per_slot = (2 + 2 * (B - 1) / B) if fused else (21 + 2 * (B - 1) / B)     # tuple leaf + tree (+ both proof paths)
         comp_s = slots * exec_per_slot / t_sub * 1e3
-        one_launch = fused and not (e0.subchain_flags & 2)
+        one_launch = fused and not (p0.with_witness and p0.E > 1)
         out["kernels"] = [{"kernel": "prove_subchain (k_batch_finish<fused>: tuple leaf hashes + every tree level + predicates in one launch)" if one_launch
                            else "prove_subchain (k_slot_hashes + k_tree_level x n + k_batch_finish)", "avg_launch_ms": t_sub, "slots_per_launch": slots,
                            "compact_bytes_per_slot": 874, "achieved_GBps": sub_bytes / t_sub / 1e6,
                            "frac_of_hbm_peak": sub_bytes / t_sub / 1e6 / HBM_PEAK_GBS,
                            "fused_hint": fused, "sha256_compressions_executed_per_slot": exec_per_slot,
-                           "sha256_compressions_per_s": comp_s, "frac_of_measured_alu_peak": comp_s / PEAK["sha256_compress_per_s"],
+                           "sha256_compressions_per_s": comp_s, "frac_of_measured_alu_peak": min(1.0, comp_s / cal["sha256_compress_per_s"]),
                            "reference_equivalent_compressions_per_s": slots * 23 / t_sub * 1e3,
-                           "note": "compact bytes (362 B proofs in + 512 B digests/tuple out per slot); integer-ALU bound.  With the fused hint the "
-                                   "19 path compressions per slot the reference's circuit performs (builder.rs:189-199) are NOT executed: their "
-                                   "digests are nodes of the header trees k_header_merkle hashed (41 compressions/header) and are copied, so "
-                                   "`reference_equivalent` counts the reference's 23/slot over the same time; in-region = beside the other chunk's expansion"}]
+                           "note": "compact bytes (362 B proofs in + 512 B digests/tuple out per slot); integer-ALU bound; peak = the SHA-256 compression "
+                                   "rate measured in this run.  With the fused hint the 19 path compressions per slot the reference's circuit performs "
+                                   "(builder.rs:189-199) are NOT executed: their digests are nodes of the header trees k_header_merkle hashed (41 "
+                                   "compressions/header) and are copied, so `reference_equivalent` counts the reference's 23/slot over the same time; "
+                                   "in-region = beside the other chunk's expansion"}]
+        if args.no_witness:
+            per_header = 41 + exec_per_slot
+            out["compact_step"] = {"sha256_compressions_executed_per_header": per_header, "sha256_compressions_per_s_whole_step": value * per_header,
+                                   "frac_of_measured_alu_peak_whole_step": min(1.0, value * per_header / cal["sha256_compress_per_s"]),
+                                   "measured_sha256_ceiling_per_s": cal["sha256_compress_per_s"]}
+        # rank 0 keeps the CPU baseline at every N (north_star: GPU throughput next to the CPU path, core count stated);
+        # the other legs are N = 1 only
+        if not args.no_legs and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, J, B, V, args.cpu_seconds, gpu_out64, min(R, 256), first=rank * R)
         legs = world == 1 and not args.no_legs
-        if legs and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, J, B, V, args.cpu_seconds, gpu_out64, min(R, 256))
         if legs and not args.no_witness:
-            out["with_input_upload"] = upload_leg(eng, args, max(5, args.steps // 2))
-        del eng
+            out["with_input_upload"] = upload_leg(p0, args, max(5, args.steps // 2))
+        del eng, p0
         torch.cuda.empty_cache()
         if legs:
             out["latency"] = latency_leg(dev, J, B, V)
-            out["fused_commitment"] = commitment_leg(dev, J, B, V)
+            out["fused_commitment"] = commitment_leg(dev, J, B, V, cal)
             if not args.no_stress:
-                out["stress"] = {"v100": stress(args, dev, 100, 6.0), "v512": stress(args, dev, 512, 6.0)}
+                out["stress"] = {"v100": stress(args, dev, 100, 6.0, cal), "v512": stress(args, dev, 512, 6.0, cal)}
             # one chunk per step: without an expansion to run beside there is nothing to pipeline against, and a chunk of 256
             # ranges quantises better (8196 header groups on 4096 wave slots) than two of 128
-            # ... and two engine sets stepped in turn: step i + 1 starts while step i's chain of small kernels drains
+            # ... and two pipelines stepped in turn: step i + 1 starts while step i's chain of small kernels drains
             d, err = subprocess_leg(args, ["--no-witness", "--engines", "1", "--alternate", "2"])
             out["compact_only"] = {"error": err} if d is None else {
                 "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                 "prove_subchain_ms": d["kernels"][0]["avg_launch_ms"], "sha256_compressions_per_s_prove_subchain": d["kernels"][0]["sha256_compressions_per_s"],
                 "frac_of_measured_alu_peak_prove_subchain": d["kernels"][0]["frac_of_measured_alu_peak"],
-                "sha256_compressions_executed_per_header": 41 + d["kernels"][0]["sha256_compressions_executed_per_slot"],
-                "sha256_compressions_per_s_whole_step": d["value"] * (41 + d["kernels"][0]["sha256_compressions_executed_per_slot"]),
-                "frac_of_measured_alu_peak_whole_step": d["value"] * (41 + d["kernels"][0]["sha256_compressions_executed_per_slot"]) / PEAK["sha256_compress_per_s"],
+                **d["compact_step"],
                 "reference_equivalent_compressions_per_s_whole_step": d["value"] * (41 + 23),
-                "note": "no Goldilocks expansion, one chunk per step, two engine sets stepped in turn: header hashing (41 compressions/header) + prove_subchain + commit check "
-                        "(Ed25519, SHA-512) on the side stream; fractions are of the measured 27.7 G/s SHA-256 ceiling; the step is bounded by "
-                        "the commit check's latency chain, not by the ALUs (DESIGN.md)"}
+                "note": "no Goldilocks expansion, one chunk per step, two pipelines stepped in turn: header hashing (41 compressions/header) + prove_subchain + commit check "
+                        "(Ed25519, SHA-512) on the side stream; fractions are of the SHA-256 ceiling measured in that process"}
             if (J, B) == (32, 64):
                 a1024 = argparse.Namespace(**vars(args))
                 a1024.batch = 32

@@ -1,0 +1,94 @@
+"""Mode S (BASELINE configs #4/#5: "N headers x V validators"): a V-validator commit on EVERY header of a range, i.e. N
+back-to-back next_header / skip verifications (circuits/next_header.rs:25-47 per header; batches are independent,
+circuits/builder.rs:305-336), sharded with the headers across GPUs.
+
+CommitShard is a thin wrapper over ONE C-ABI call per step — `bsx_dev_verify_commits` (include/bsx.h): SHA-512 challenges,
+fixed-key Ed25519, tallies + validator-set hashes and the 128-byte fold of the slice — plus the one collective of the mode:
+an all-gather of the ranks' folds (torch.distributed: RCCL on GPUs, gloo in the CPU tests).  PyTorch owns the device buffers
+and the collective; no arithmetic happens here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import types as T
+
+
+def commit_slice(n_commits, rank, world):
+    """Commits [first, first + count) of the range that `rank` verifies: contiguous, equal slices (2048 / N headers each)."""
+    assert n_commits % world == 0, "world size must divide the number of headers"
+    count = n_commits // world
+    return rank * count, count
+
+
+def all_gather_folds(fold_bytes, world):
+    """THE collective of mode S: every rank's 128-byte bsx_commit_fold -> uint8 [world][128] on every rank."""
+    import torch
+    import torch.distributed as dist
+    flat = fold_bytes[:128].contiguous()
+    if world == 1:
+        return flat.clone().view(1, 128)
+    if flat.is_cuda and dist.get_backend() == "gloo":          # tests: ranks sharing one GPU
+        g = torch.empty(world * 128, dtype=torch.uint8)
+        dist.all_gather_into_tensor(g, flat.cpu())
+        return g.view(world, 128).to(flat.device)
+    out = torch.empty(world * 128, dtype=torch.uint8, device=flat.device)
+    dist.all_gather_into_tensor(out, flat)
+    return out.view(world, 128)
+
+
+def range_verdict(folds):
+    """folds: COMMIT_FOLD[world] -> dict: did every commit of the whole range verify, first failing global index, checksum."""
+    import hashlib
+    f = np.asarray(folds, T.COMMIT_FOLD)
+    ff = f["first_failing"][f["first_failing"] != 0xffffffff]
+    return {"commits": int(f["n_commits"].sum()), "ok": int(f["n_ok"].sum()), "signatures_ok": int(f["n_signatures_ok"].sum()),
+            "all_ok": bool(f["n_ok"].sum() == f["n_commits"].sum()), "first_failing": int(ff.min()) if ff.size else None,
+            "root_of_roots": hashlib.sha256(b"".join(bytes(x["root"]) for x in f)).hexdigest()}
+
+
+class CommitShard:
+    def __init__(self, n_commits_total, v_max, rank=0, world=1, device=None):
+        import torch
+        self.N, self.V, self.rank, self.world = n_commits_total, v_max, rank, world
+        self.first, self.n = commit_slice(n_commits_total, rank, world)
+        self.dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.ctx = _lib.context(self.dev.index if self.dev.index is not None else 0)
+        self.L = _lib.lib()
+        n, V, d = self.n, v_max, self.dev
+        z = lambda nbytes: torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=d)
+        self.vals = z(n * V * 256)
+        self.hh = z(n * 32)
+        self.ok = z(n * V)
+        self.res = z(n * 96)
+        self.fold = z(128)
+        self.keytable = z(int(self.L.bsx_ed25519_keytable_bytes(C.c_uint32(V))))
+        self.scratch = z(int(self.L.bsx_dev_verify_commits_scratch_bytes(C.c_uint32(n), C.c_uint32(V))))
+
+    def upload(self, validators, header_hashes):
+        """validators [N, V] VALIDATOR and header_hashes [N, 32] of the WHOLE range; this rank keeps its slice."""
+        import torch
+        v = np.ascontiguousarray(validators, T.VALIDATOR).reshape(self.N, self.V)[self.first:self.first + self.n]
+        h = np.ascontiguousarray(header_hashes, np.uint8).reshape(self.N, 32)[self.first:self.first + self.n]
+        self.vals[:v.nbytes].copy_(torch.from_numpy(np.ascontiguousarray(v).view(np.uint8).reshape(-1)))
+        self.hh[:h.nbytes].copy_(torch.from_numpy(np.ascontiguousarray(h).reshape(-1)))
+        torch.cuda.synchronize(self.dev)
+
+    def step(self, stream=None):
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        dp = _lib.dp
+        _lib.check(self.L.bsx_dev_verify_commits(self.ctx, C.c_void_p(st.cuda_stream), dp(self.vals), C.c_uint32(self.n), C.c_uint32(self.V),
+                                                 dp(self.hh), C.c_uint32(self.first), dp(self.keytable), dp(self.scratch), dp(self.ok),
+                                                 dp(self.res), dp(self.fold)))
+
+    def gather(self):
+        """All ranks' folds -> COMMIT_FOLD[world] (host)."""
+        return all_gather_folds(self.fold, self.world).cpu().numpy().reshape(-1).view(T.COMMIT_FOLD).copy()
+
+    def download(self):
+        import torch
+        torch.cuda.synchronize(self.dev)
+        return (self.ok[:self.n * self.V].cpu().numpy().reshape(self.n, self.V), self.res[:self.n * 96].cpu().numpy().view(T.COMMIT_RESULT).copy(),
+                self.fold.cpu().numpy().view(T.COMMIT_FOLD)[0].copy())

@@ -66,6 +66,9 @@ WITNESS_LAYOUT = np.dtype([("batch_size", "<u4"), ("n_bytes", "<u4"), ("n_words"
                            ("compact_stride", "<u4"), ("off_words", "<u4"), ("off_bools", "<u4"), ("_pad", "<u4"),
                            ("n_elements", "<u8")])
 
+COMMIT_FOLD = np.dtype([("root", "u1", 32), ("n_commits", "<u8"), ("n_ok", "<u8"), ("n_signatures_ok", "<u8"), ("first_index", "<u4"),
+                        ("first_failing", "<u4"), ("_pad", "<u4", 16)])      # bsx_commit_fold, 128 B
+assert COMMIT_FOLD.itemsize == 128
 assert HEADER.itemsize == 512
 assert DH_PROOF.itemsize == 162 and LB_PROOF.itemsize == 200
 assert SHARED_CTX.itemsize == 80 and SUBCHAIN.itemsize == 128

@@ -344,6 +344,14 @@ def poseidon_merkle_tree(elements, leaf_len, n_leaves, cap_height):
     return tree, tree[-(1 << cap_height):]
 
 
+def commit_fold(results, first_index=0):
+    """checker twin of bsx_dev_verify_commits' fold: COMMIT_RESULT[n] -> COMMIT_FOLD record."""
+    r = np.ascontiguousarray(results, T.COMMIT_RESULT).reshape(-1)
+    out = np.zeros(1, T.COMMIT_FOLD)
+    lib().orc_commit_fold(_p(r), C.c_uint32(r.size), C.c_uint32(first_index), _p(out))
+    return out[0]
+
+
 def bench_verify_commits(validators, header_hashes, n_threads, reps=1):
     """mode S driver: validators [n_commits, v_max] VALIDATOR, header_hashes [n_commits, 32] -> (results, sig_ok)."""
     v = np.ascontiguousarray(validators, T.VALIDATOR)

@@ -428,3 +428,40 @@ int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, co
     memcpy(output64 + 32, dc, 32);                                 /* :45 */
     return st ? st : rc;
 }
+
+/* ---------------------------------------------------------------- mode-S fold (checker of bsx_dev_verify_commits' d_fold)
+ * The unit of the mode-S all-gather: a rank's slice of per-header commit results (next_header.rs:25-47 per header) folded
+ * into one 128-byte record.  digest(c) = inner(leaf(result bytes 0..64), leaf(result bytes 64..84 ‖ u32 LE index ‖ 40 zero
+ * bytes)); root = binary tree of inner nodes over the digests padded with all-zero digests to a power of two. */
+void orc_commit_fold(const bsx_commit_result* res, uint32_t n, uint32_t first_index, bsx_commit_fold* out) {
+    uint32_t P = 1;
+    while (P < n) P *= 2;
+    uint8_t* d = calloc((size_t)P, 32);
+    memset(out, 0, sizeof *out);
+    out->first_failing = 0xffffffffu;
+    for (uint32_t c = 0; c < n; c++) {
+        const uint8_t* p = (const uint8_t*)&res[c];
+        uint8_t a[32], b[32], t[64];
+        orc_leaf_hash(p, 64, a);
+        memset(t, 0, sizeof t);
+        memcpy(t, p + 64, 20);
+        const uint32_t idx = first_index + c;
+        memcpy(t + 20, &idx, 4);
+        orc_leaf_hash(t, 64, b);
+        orc_inner_hash(a, b, d + 32 * (size_t)c);
+        const int good = res[c].two_thirds_ok && !res[c].n_bad_signature && !res[c].n_bad_message && !res[c].power_overflow;
+        out->n_ok += good ? 1 : 0;
+        out->n_signatures_ok += res[c].n_signed - res[c].n_bad_signature;
+        if (!good && out->first_failing == 0xffffffffu) out->first_failing = idx;
+    }
+    for (uint32_t w = P / 2; w >= 1; w /= 2)
+        for (uint32_t i = 0; i < w; i++) {
+            uint8_t nd[32];
+            orc_inner_hash(d + 64 * (size_t)i, d + 64 * (size_t)i + 32, nd);
+            memcpy(d + 32 * (size_t)i, nd, 32);
+        }
+    memcpy(out->root, d, 32);
+    out->n_commits = n;
+    out->first_index = first_index;
+    free(d);
+}

@@ -88,6 +88,8 @@ void orc_sha512_challenge(const bsx_validator* v, uint8_t h[32], uint8_t digest[
 int orc_validator_leaf(const uint8_t pk[32], uint64_t power, uint8_t out[BSX_VALIDATOR_LEAF_MAX]);
 void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t header_hash[32],
                        bsx_commit_result* out, uint8_t* sig_ok);
+/* mode-S fold of a slice of commit results (checker of bsx_dev_verify_commits' d_fold; include/bsx.h bsx_commit_fold) */
+void orc_commit_fold(const bsx_commit_result* res, uint32_t n, uint32_t first_index, bsx_commit_fold* out);
 int orc_header_range(uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const bsx_header* headers,
                      uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,

@@ -102,3 +102,85 @@ def test_job_slice_rules():
         job_slice(32, 0, 3)
     with pytest.raises(AssertionError):
         job_slice(24, 0, 4)     # 6 jobs per rank is not a power-of-two subtree
+
+
+# ------------------------------------------------------------------------------------------------ mode S across ranks
+def _worker_s(rank, world, port, nh, V, bad_commit, q):
+    """Mode S sharded (BASELINE config #5): rank g verifies commits [g*nh/world, (g+1)*nh/world) — the oracle stands
+    in for bsx_dev_verify_commits' kernels here, the product's slicing, fold layout and collective are the real ones."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from blobstreamx_amd.stress import all_gather_folds, commit_slice, range_verdict
+        w = synth.Workload(5, 1, 2, nh // 2, v=V, mode="S")
+        vals = w.validators.reshape(nh, V).copy()
+        if bad_commit is not None:
+            vals[bad_commit, 1]["signature"][3] ^= 1
+        first, n = commit_slice(nh, rank, world)
+        res = np.zeros(n, T.COMMIT_RESULT)
+        for c in range(n):
+            res[c], _ = oracle.verify_commit(vals[first + c], w.commit_hashes[first + c].tobytes())
+        fold = oracle.commit_fold(res, first)
+        folds = all_gather_folds(torch.from_numpy(np.frombuffer(fold.tobytes(), np.uint8).copy()), world)
+        folds = folds.numpy().reshape(-1).view(T.COMMIT_FOLD)
+        q.put((rank, folds.tobytes(), range_verdict(folds)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bad_commit", [(2, None), (2, 11), (4, 5)])
+def test_mode_s_commits_shard_with_their_headers(world, bad_commit):
+    nh, V = 16, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_s, args=(rk, world, port, nh, V, bad_commit, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: every slice's fold from the oracle's verify_commit of the whole range
+    from blobstreamx_amd.stress import commit_slice
+    w = synth.Workload(5, 1, 2, nh // 2, v=V, mode="S")
+    vals = w.validators.reshape(nh, V).copy()
+    if bad_commit is not None:
+        vals[bad_commit, 1]["signature"][3] ^= 1
+    res = np.zeros(nh, T.COMMIT_RESULT)
+    for c in range(nh):
+        res[c], _ = oracle.verify_commit(vals[c], w.commit_hashes[c].tobytes())
+    want = b"".join(oracle.commit_fold(res[f:f + n], f).tobytes() for f, n in (commit_slice(nh, g, world) for g in range(world)))
+    for rank, folds, verdict in got:
+        assert folds == want, rank                           # every rank holds every slice's fold after the one collective
+        assert verdict["commits"] == nh and verdict["all_ok"] == (bad_commit is None)
+        assert verdict["first_failing"] == bad_commit
+        assert verdict["ok"] == nh - (0 if bad_commit is None else 1)
+    assert len({v["root_of_roots"] for _, _, v in got}) == 1
+
+
+def test_commit_fold_is_sensitive_to_every_field_and_index():
+    """The fold is a checksum of checksums: any bit of any commit result, the commit's position, or the slice offset moves it."""
+    w = synth.Workload(5, 1, 2, 4, v=4, mode="S")
+    res = np.zeros(8, T.COMMIT_RESULT)
+    for c in range(8):
+        res[c], _ = oracle.verify_commit(w.validators.reshape(8, 4)[c], w.commit_hashes[c].tobytes())
+    res[1]["trusted_signed_power"] += 1          # the synthetic commits are signed by one set: make one result distinct for the swap below
+    base = oracle.commit_fold(res, 0)
+    assert base["n_commits"] == 8 and base["n_ok"] == 8 and base["first_failing"] == 0xffffffff and base["n_signatures_ok"] == 32
+    seen = {bytes(base["root"])}
+    for field in ("validators_hash", "total_power", "signed_power", "trusted_signed_power", "n_enabled", "n_signed", "n_bad_signature",
+                  "first_bad_signature", "n_bad_message", "two_thirds_ok", "power_overflow"):
+        r2 = res.copy()
+        if field == "validators_hash":
+            r2[3][field][7] ^= 1
+        else:
+            r2[3][field] ^= 1
+        seen.add(bytes(oracle.commit_fold(r2, 0)["root"]))
+    seen.add(bytes(oracle.commit_fold(res, 8)["root"]))                      # same results at another offset
+    seen.add(bytes(oracle.commit_fold(res[[1, 0, 2, 3, 4, 5, 6, 7]], 0)["root"]))  # swapped
+    seen.add(bytes(oracle.commit_fold(res[:7], 0)["root"]))                  # padded slice
+    assert len(seen) == 15
+    r2 = res.copy(); r2[5]["_pad"] = 7
+    assert bytes(oracle.commit_fold(r2, 0)["root"]) == bytes(base["root"])    # padding bytes are not part of the record

@@ -273,3 +273,107 @@ def test_expansion_kernel_variants_agree():
         assert out.returncode == 0, (chunk, nt, cap, out.stderr[-2000:])
         got = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("WITNESS")]
         assert got == [want.hexdigest()], (chunk, nt, cap)
+
+
+def test_pipeline_driven_from_cpp_without_python(tmp_path):
+    """the batched pipeline is behind the C ABI.  tests/hostcheck/pipeline_driver.cpp — a plain C++ program that
+    includes include/bsx.h only and links libbsx.so — creates a 2-chunk pipeline with witness + commit check, uploads, enqueues
+    three steps WITHOUT joins and fetches the results; they must be the oracle's for every range (one tampered range per chunk)."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "hostcheck"), "pipeline_driver"], check=True, capture_output=True)
+    J, B, V, R, E, steps = 8, 32, 20, 4, 2, 3
+    w = synth.Workload(41, R, J, B, v=V)
+    w.headers[1, 9]["hash"][1][5] ^= 1
+    w.validators[R - 1, 3]["signature"][0] ^= 2
+    outs, rs, ss = [], [], []
+    for r in range(R):
+        rc, out, _, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])
+        outs.append(out)
+        ss.append(rc if rc in (T.ERR_BAD_SIGNATURE, T.ERR_VOTING_POWER, T.ERR_BAD_ARG) else 0)
+        rs.append(1 if rc == T.ERR_ASSERT else 0)
+    assert rs == [0, 1, 0, 0] and ss[R - 1] == T.ERR_BAD_SIGNATURE
+    cid = b"celestia"
+    case = tmp_path / "case.bin"
+    with open(case, "wb") as f:
+        f.write(struct.pack("<10I56s", 0x42535850, J, B, V, R, E, w.hpr, steps, 1 | 2, len(cid), cid))
+        for a in (w.headers[:R], w.ranges[:R], np.ascontiguousarray(w.latest[:R], np.uint64), w.validators[:R], w.trusted[:R]):
+            f.write(np.ascontiguousarray(a).tobytes())
+        f.write(b"".join(outs))
+        f.write(np.array(rs, np.uint32).tobytes())
+        f.write(np.array(ss, np.uint32).tobytes())
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([os.path.join(root, "tests", "hostcheck", "pipeline_driver"), str(case)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "PIPELINE_DRIVER_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
+    assert f"ranges={R} steps={steps} chunks={E}" in out.stdout
+
+
+@pytest.mark.parametrize("J,B,V,R,leaf_len,cap_h", [(8, 32, 20, 4, 135, 4), (32, 64, 100, 2, 135, 4), (4, 16, 6, 6, 80, 2)])
+def test_pipeline_caps_mode_multi_step_vs_oracle(J, B, V, R, leaf_len, cap_h):
+    """BSX_PIPE_CAPS: the pipeline commits to every map-job witness with a Poseidon Merkle cap hashed STRAIGHT
+    FROM THE COMPACT BYTES inside the step (no 64x image; here together with the materialised witness so that both can be
+    compared).  Three un-joined steps over two chunks, then every cap node of every job against the oracle's own witness
+    hashed by the oracle's own Poseidon, and the usual outputs / statuses."""
+    from blobstreamx_amd.engine import PipelinedEngines
+    w = synth.Workload(44, R, J, B, v=V)
+    w.headers[1, 5]["hash"][1][9] ^= 4
+    pe = PipelinedEngines(J, B, V, R, n_engines=2, with_witness=True, with_caps=True, leaf_len=leaf_len, cap_height=cap_h)
+    pe.upload_workload(w)
+    for _ in range(3):
+        pe.step()
+    res = pe.download()
+    ml = T.map_layout(B)
+    nel = int(ml["n_elements"])
+    for e in range(pe.E):
+        trees, caps = pe.caps_numpy(e)
+        wm, _, _ = pe.witness_numpy(e)
+        n_leaves = (trees.shape[1] + caps.shape[1]) // 2
+        for i, r in enumerate(pe.sel(e)):
+            rc, out, _, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r],
+                                                 want_witness=True)
+            assert res["output64"][r].tobytes() == out and (res["range_status"][r] != 0) == (rc == T.ERR_ASSERT)
+            full = oracle.expand_range_witness(J, B, cw)
+            assert (wm[i * J * nel:(i + 1) * J * nel] == full[:J * nel]).all()
+            for j in range(J):
+                tree, cap = oracle.poseidon_merkle_tree(full[j * nel:(j + 1) * nel], leaf_len, n_leaves, min(cap_h, n_leaves.bit_length() - 1))
+                assert (trees[i * J + j] == tree).all(), (r, j)
+                assert (caps[i * J + j] == cap).all(), (r, j)
+    assert res["range_status"][1] != 0 and not res["range_status"][[r for r in range(R) if r != 1]].any()
+
+
+def test_rccl_all_gather_on_an_external_stream_world_1():
+    """The collective the N > 1 pipeline hands to torch.distributed runs over RCCL on a stream the LIBRARY owns (wrapped as a
+    torch ExternalStream).  One GPU cannot host two RCCL ranks, but a world of ONE exercises the same calls: process group
+    over "nccl" (= RCCL), all_gather_into_tensor enqueued behind work on the external stream, results visible to work
+    enqueued after it — both for the pipeline's record exchange and for mode S's folds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from blobstreamx_amd import _lib\n"
+        "from blobstreamx_amd.engine import torch_allgather\n"
+        "from blobstreamx_amd.stress import all_gather_folds\n"
+        "_lib.lib(); torch.cuda.set_device(0); dev = torch.device('cuda:0')\n"
+        "os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ.setdefault('MASTER_PORT', '29517')\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "s = torch.cuda.Stream(device=dev)                      # stands in for the pipeline's exchange stream\n"
+        "send = torch.zeros(4096 * 128, dtype=torch.uint8, device=dev); recv = torch.full_like(send, 0xEE)\n"
+        "with torch.cuda.stream(s):\n"
+        "    torch.cuda._sleep(20_000_000)                      # the collective must wait for this stream's earlier work\n"
+        "    send.copy_((torch.arange(send.numel(), device=dev) % 251).to(torch.uint8))\n"
+        "torch_allgather(dev, 1)(send, recv, s.cuda_stream)\n"
+        "with torch.cuda.stream(s):\n"
+        "    after = recv.clone()                               # enqueued after the callback returned: must see the gathered data\n"
+        "s.synchronize()\n"
+        "assert torch.equal(after, send) and int(after[250]) == 250\n"
+        "f = all_gather_folds(send[:128], 1)\n"
+        "assert f.shape == (1, 128) and torch.equal(f[0], send[:128])\n"
+        "print('RCCL_WORLD1_OK', dist.get_backend())\n"
+        "dist.destroy_process_group()\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_WORLD1_OK nccl" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])

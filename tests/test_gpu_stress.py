@@ -1,0 +1,92 @@
+"""GPU suite: mode S (a V-validator commit on EVERY header — BASELINE configs #4/#5; circuits/next_header.rs:25-47 per header)
+through ONE C-ABI call per step, `bsx_dev_verify_commits`, and its sharding across ranks (SURVEY §8e "in S mode commits shard
+with their headers"): per-signature verdicts, every commit result and the 128-byte fold of every rank's slice against the
+oracle; the all-gather itself over gloo with two ranks on the one GPU of the box."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from blobstreamx_amd import types as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean(r):
+    r = np.array(r).copy()
+    r["_pad"] = 0
+    return r.tobytes()
+
+
+@pytest.mark.parametrize("world,J,B,V,tamper", [(1, 2, 16, 12, False), (2, 4, 16, 33, True), (4, 8, 8, 7, True), (8, 32, 64, 100, False), (1, 32, 64, 100, True)])
+def test_commit_shards_vs_oracle(world, J, B, V, tamper):
+    """Every rank's CommitShard of an N-GPU mode-S run on ONE GPU: its slice's ok bits, commit results and fold equal the
+    oracle's; the concatenation of the folds (= the all-gather's result) gives the range verdict, incl. the global index of a
+    tampered commit and a nil/absent mix."""
+    import torch
+    from blobstreamx_amd.stress import CommitShard, range_verdict
+    nh = J * B
+    w = synth.Workload(5, 1, J, B, v=V, mode="S", nil_permille=100 if tamper else 0, absent_permille=50 if tamper else 0)
+    vals = w.validators.reshape(nh, V).copy()
+    bad = None
+    if tamper:
+        bad = nh // 2 + 3
+        k = int(np.nonzero(vals[bad]["is_signed"])[0][0])
+        vals[bad, k]["signature"][9] ^= 8
+    ref = [oracle.verify_commit(vals[c], w.commit_hashes[c].tobytes()) for c in range(nh)]
+    folds = []
+    for g in range(world):
+        sh = CommitShard(nh, V, rank=g, world=world)
+        sh.upload(vals, w.commit_hashes)
+        sh.step()
+        sh.step()                                   # warm tables, same answer
+        ok, res, fold = sh.download()
+        for c in range(sh.n):
+            rres, rok = ref[sh.first + c]
+            assert (ok[c] == rok).all(), (g, c)
+            assert _clean(res[c]) == _clean(rres), (g, c)
+        want = oracle.commit_fold(np.array([ref[sh.first + c][0] for c in range(sh.n)], T.COMMIT_RESULT), sh.first)
+        assert fold.tobytes() == want.tobytes(), g
+        assert sh.gather().tobytes() == fold.tobytes() if world == 1 else True
+        folds.append(fold)
+        del sh
+        torch.cuda.empty_cache()
+    v = range_verdict(np.array(folds, T.COMMIT_FOLD))
+    # expected verdict from the oracle's results (with nil / absent votes a commit may also miss the 2/3 rule)
+    good = [bool(r["two_thirds_ok"]) and not r["n_bad_signature"] and not r["n_bad_message"] and not r["power_overflow"] for r, _ in ref]
+    assert v["commits"] == nh and v["ok"] == sum(good)
+    assert v["first_failing"] == (good.index(False) if False in good else None)
+    assert v["signatures_ok"] == sum(int(r["n_signed"]) - int(r["n_bad_signature"]) for r, _ in ref)
+    if tamper:
+        assert not good[bad] and ref[bad][0]["n_bad_signature"] == 1
+    else:
+        assert v["all_ok"] and v["signatures_ok"] == nh * V
+
+
+def test_bench_mode_s_two_ranks_share_one_gpu():
+    """bench.py --mode S --gpus 2 end to end over gloo with both ranks on the one GPU: commit slices, one all-gather of folds per
+    step, barriers, max-over-ranks timing, oracle checks on every rank's slice, ONE JSON line from rank 0."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BSX_DIST_BACKEND="gloo", BSX_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "S", "--jobs", "8", "--batch", "32",
+           "--validators", "40", "--cpu-seconds", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] <= 1.0 and d["cpu_baseline"]["value"] > 0
+    s = d["stress"]
+    assert s["signatures"] == 8 * 32 * 40 and s["signatures_this_rank"] == 4 * 32 * 40
+    assert s["range_verdict"]["all_ok"] and s["range_verdict"]["commits"] == 256
+    assert s["checked_against_oracle"]["gathered_folds"] == 2
