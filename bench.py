@@ -79,7 +79,9 @@ def parse():
     ap.add_argument("--mode", choices=["F", "S"], default="F", help="F: one commit per range (a reference proof); S: a commit on every header")
     ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
     ap.add_argument("--caps", action="store_true", help="Poseidon Merkle caps of the map-job witnesses from the compact bytes (with --no-witness: instead of the expansion)")
-    ap.add_argument("--alternate", type=int, default=1, help="K pipelines over the same ranges stepped in turn (pipelining across steps; the compact-only leg uses 2)")
+    ap.add_argument("--alternate", type=int, default=1, help="K buffer sets inside the pipeline, step i on set i mod K (pipelining across steps; the compact-only leg uses 2)")
+    ap.add_argument("--merkle-wgs", type=int, default=0, help="bsx_pipeline_config.tune_merkle_workgroups (experiments; 0 = automatic)")
+    ap.add_argument("--no-commit", action="store_true", help="experiments: no target-commit verification (not a valid headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only: none of the secondary objects")
@@ -600,18 +602,19 @@ def main():
     w = synth.Workload(4, R * world, J, B, v=V)          # config #4 seed; identical on every rank
     t_gen = time.perf_counter() - t0
     Ech = args.engines
-    kw = dict(n_engines=Ech, rank=rank, world=world, device=dev, with_witness=not args.no_witness, with_caps=args.caps)
+    kw = dict(n_engines=Ech, rank=rank, world=world, device=dev, with_witness=not args.no_witness, with_caps=args.caps, merkle_workgroups=args.merkle_wgs,
+              with_commit=not args.no_commit)
     eng = E.AlternatingPipelines(args.alternate, J, B, V, R, **kw) if args.alternate > 1 else E.PipelinedEngines(J, B, V, R, **kw)
     eng.upload_workload(w)
-    p0 = eng.sets[0] if args.alternate > 1 else eng
+    p0 = eng
 
     # correctness gate before timing: statuses clean, public output = (target header hash, commitment) for every owned range
     eng.step()
     res = eng.download()
     own = slice(rank * R, (rank + 1) * R)
     assert res["header_status"] == 0 and res["assemble_status"] == 0, res
-    assert not res["range_status"].any() and not res["skip_status"].any(), (res["range_status"], res["skip_status"])
-    assert (res["output64"][:, :32] == w.hashes[own, w.n_blocks]).all(), "target header hash mismatch"
+    assert not res["range_status"].any() and (args.no_commit or not res["skip_status"].any()), (res["range_status"], res.get("skip_status"))
+    assert args.no_commit or (res["output64"][:, :32] == w.hashes[own, w.n_blocks]).all(), "target header hash mismatch"
     gpu_out64 = res["output64"].copy()
     self_check = sharded_self_check(p0, w, J, B, V, R, rank, dev, res) if world > 1 else None
 
@@ -643,7 +646,7 @@ def main():
     # the witness the TIMED loop left in HBM, against the oracle (every rank checks its own buffers)
     n_checked = cpu_baseline_witness_check(p0, w, J, B) if not args.no_witness else 0
     res2 = eng.download()
-    assert (res2["output64"] == gpu_out64).all() and not res2["range_status"].any() and not res2["skip_status"].any(), "outputs changed during the timed loop"
+    assert (res2["output64"] == gpu_out64).all() and not res2["range_status"].any() and (args.no_commit or not res2["skip_status"].any()), "outputs changed during the timed loop"
 
     if rank == 0:
         ml = p0.ml
@@ -661,7 +664,7 @@ def main():
                                    f"{R} ranges per GPU per step, Goldilocks witness {'off' if args.no_witness else 'materialised'}"
                                    + (", Poseidon caps from the compact bytes" if args.caps else ""),
                        "timed_entry": "bsx_pipeline_step (C ABI, csrc/pipeline.hip)",
-                       "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": Ech, "alternating_pipelines": args.alternate,
+                       "ranges_per_gpu": R, "headers_per_step": headers_per_step, "pipelined_chunks": Ech, "buffer_sets": args.alternate,
                        "parallelism": (f"{world} x ({J // world} of {J} map jobs = {J * B // world} headers of every range), 1 all-gather of 128-B "
                                        f"records per chunk; {'strong: ' + str(R * world) + ' ranges in total' if strong else 'weak: ' + str(R) + ' ranges per GPU'}")
                        if world > 1 else "1 GPU",
@@ -737,14 +740,14 @@ def main():
             # one chunk per step: without an expansion to run beside there is nothing to pipeline against, and a chunk of 256
             # ranges quantises better (8196 header groups on 4096 wave slots) than two of 128
             # ... and two pipelines stepped in turn: step i + 1 starts while step i's chain of small kernels drains
-            d, err = subprocess_leg(args, ["--no-witness", "--engines", "1", "--alternate", "2"])
+            d, err = subprocess_leg(args, ["--no-witness", "--engines", "1", "--alternate", "3"])
             out["compact_only"] = {"error": err} if d is None else {
                 "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                 "prove_subchain_ms": d["kernels"][0]["avg_launch_ms"], "sha256_compressions_per_s_prove_subchain": d["kernels"][0]["sha256_compressions_per_s"],
                 "frac_of_measured_alu_peak_prove_subchain": d["kernels"][0]["frac_of_measured_alu_peak"],
                 **d["compact_step"],
                 "reference_equivalent_compressions_per_s_whole_step": d["value"] * (41 + 23),
-                "note": "no Goldilocks expansion, one chunk per step, two pipelines stepped in turn: header hashing (41 compressions/header) + prove_subchain + commit check "
+                "note": "no Goldilocks expansion, one chunk per step, three buffer sets stepped in turn inside the pipeline (one header hashing at a time): header hashing (41 compressions/header) + prove_subchain + commit check "
                         "(Ed25519, SHA-512) on the side stream; fractions are of the SHA-256 ceiling measured in that process"}
             if (J, B) == (32, 64):
                 a1024 = argparse.Namespace(**vars(args))

@@ -36,6 +36,7 @@ SYMBOLS = [
     "bsx_pipeline_create", "bsx_pipeline_destroy", "bsx_pipeline_upload", "bsx_pipeline_enable_input_streaming", "bsx_pipeline_step",
     "bsx_pipeline_join", "bsx_pipeline_set_allgather", "bsx_pipeline_get_results", "bsx_pipeline_buffer", "bsx_pipeline_set_timing",
     "bsx_pipeline_timing", "bsx_calibrate", "bsx_dev_verify_commits", "bsx_dev_verify_commits_scratch_bytes",
+    "bsx_ed25519_decoded_r_bytes", "bsx_dev_ed25519_decode_r", "bsx_dev_ed25519_verify_keyed_r",
 ]
 
 
@@ -79,6 +80,7 @@ def lib():
             L.bsx_ingest_last_error.restype = C.c_char_p
             L.bsx_pipeline_destroy.restype = None
             L.bsx_dev_verify_commits_scratch_bytes.restype = C.c_uint64
+            L.bsx_ed25519_decoded_r_bytes.restype = C.c_uint64
             for s in SYMBOLS:
                 getattr(L, s)   # AttributeError here = header/library drift
             _lib = L

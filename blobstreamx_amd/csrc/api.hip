@@ -26,7 +26,7 @@ static_assert(sizeof(bsx_shared_ctx) == 80 && sizeof(bsx_subchain) == 128, "reco
 static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "commit");
 static_assert(sizeof(bsx_witness_layout) == 40, "layout");
 static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
-static_assert(sizeof(bsx_commit_fold) == 128 && sizeof(bsx_pipeline_config) == 104 && sizeof(bsx_calibration) == 80, "pipeline / fold / calibration");
+static_assert(sizeof(bsx_commit_fold) == 128 && sizeof(bsx_pipeline_config) == 112 && sizeof(bsx_calibration) == 80, "pipeline / fold / calibration");
 
 namespace bsxapi {
 thread_local std::string g_err;
@@ -221,7 +221,7 @@ int bsx_dev_header_merkle(bsx_ctx* ctx, void* stream, const bsx_header* d_header
                           uint8_t* d_dh_aunts, uint8_t* d_lb_aunts, uint8_t* d_paths, uint32_t* d_status) {
     DEV_ENTER();
     if (n && !d_headers) return fail(BSX_ERR_BAD_ARG, "null headers");
-    HIPCHK(bsxk_header_merkle(S(ctx, stream), d_headers, n, d_hashes, d_dh_aunts, d_lb_aunts, d_paths, d_status, ctx->merkle_wgs));
+    HIPCHK(bsxk_header_merkle(S(ctx, stream), d_headers, n, d_hashes, d_dh_aunts, d_lb_aunts, d_paths, d_status, ctx->merkle_wgs, 0));
     return BSX_OK;
 }
 
@@ -329,7 +329,28 @@ int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
     if ((uintptr_t)d_table & 127) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
     if ((uintptr_t)d_scratch & 15) return fail(BSX_ERR_BAD_ARG, "scratch must be 16-byte aligned");
-    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch));
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch, nullptr));
+    return BSX_OK;
+}
+
+uint64_t bsx_ed25519_decoded_r_bytes(uint64_t n) { return bsxk_ed25519_rdec_bytes(n); }
+
+int bsx_dev_ed25519_decode_r(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n, void* d_decoded_r) {
+    DEV_ENTER();
+    if (n && (!d_validators || !d_decoded_r)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if ((uintptr_t)d_decoded_r & 15) return fail(BSX_ERR_BAD_ARG, "decoded-R buffer must be 16-byte aligned");
+    HIPCHK(bsxk_ed25519_decode_r(S(ctx, stream), d_validators, n, d_decoded_r));
+    return BSX_OK;
+}
+
+int bsx_dev_ed25519_verify_keyed_r(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n,
+                                   uint32_t v_max, const void* d_table, uint32_t n_keys, const void* d_decoded_r, uint8_t* d_ok) {
+    DEV_ENTER();
+    if (n && (!d_validators || !d_h || !d_ok || !d_decoded_r)) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
+    if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
+    if ((uintptr_t)d_table & 127) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, nullptr, d_decoded_r));
     return BSX_OK;
 }
 
@@ -386,7 +407,7 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     uint8_t* d_fs = d_ed + ((bsxk_ed25519_scratch_bytes(n) + 255) & ~255ull);
     HIPCHK(bsxk_sha512_challenge(st, d_validators, n, d_h, nullptr));
     HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable)));
-    HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed));
+    HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed, nullptr));
     HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results));
     HIPCHK(bsxk_commit_fold(st, d_results, n_commits, first_index, d_fs, d_fold));
     return BSX_OK;
@@ -419,7 +440,7 @@ static int ctx_keytable(bsx_ctx* ctx, uint32_t v_max, uint8_t** out, hipStream_t
 // signature check of n = n_commits * v_max slots: keyed (table of the first commit's keys, kept in the context) or, when the
 // table could not be allocated, generic
 static int ctx_verify(bsx_ctx* ctx, hipStream_t st, const bsx_validator* dv, const uint8_t* dh, uint64_t n, uint32_t v_max, uint8_t* dok,
-                      void* dscratch) {
+                      void* dscratch, void* drdec) {
     uint8_t* tab = nullptr;
     RET(ctx_keytable(ctx, v_max, &tab, st));
     if (!tab) {
@@ -427,7 +448,9 @@ static int ctx_verify(bsx_ctx* ctx, hipStream_t st, const bsx_validator* dv, con
         return BSX_OK;
     }
     HIPCHK(bsxk_ed25519_keytable(st, dv, v_max, tab));
-    HIPCHK(bsxk_ed25519_verify_keyed(st, dv, dh, n, v_max, tab, v_max, ctx->btab, dok, dscratch));
+    // small batches (a proof request): R decoded ahead, 16 lanes per signature, projective comparison — no inversion on the chain
+    if (drdec && !dscratch) HIPCHK(bsxk_ed25519_decode_r(st, dv, n, drdec));
+    HIPCHK(bsxk_ed25519_verify_keyed(st, dv, dh, n, v_max, tab, v_max, ctx->btab, dok, dscratch, dscratch ? nullptr : drdec));
     return BSX_OK;
 }
 
@@ -522,7 +545,7 @@ int bsx_header_hashes(bsx_ctx* ctx, const bsx_header* headers, uint64_t n, uint8
     uint8_t* d_lb = d_dh + n * 128;
     H2D(dh.p, headers, n * sizeof(bsx_header));
     HIPCHK(hipMemsetAsync(dst.p, 0, 4, st));
-    HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, nullptr, dst.as<uint32_t>(), 0));
+    HIPCHK(bsxk_header_merkle(st, dh.as<bsx_header>(), n, d_hash, d_dh, d_lb, nullptr, dst.as<uint32_t>(), 0, 0));
     std::vector<uint8_t> tmp(n * 288);
     uint32_t hs = 0;
     StagedD2H back(ctx, st);
@@ -610,7 +633,7 @@ static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers,
         HIPCHK(hipMemsetAsync(rd.astatus.p, 0, 4, st));
     }
     HIPCHK(bsxk_header_merkle(st, rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
-                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>(), 0));
+                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>(), 0, 0));
     (void)ctx;
     return BSX_OK;
 }
@@ -919,9 +942,10 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
     {
         // per-key tables from the first commit's slots (kept in the context between calls); slots whose key differs fall
         // back to the generic path inside bsxk_ed25519_verify_keyed: same accept set for any input
-        DBuf dscr;                                  // batch inversion pays from a few thousand signatures on (one more launch)
-        if (n >= 4096) RET(dscr.alloc(bsxk_ed25519_scratch_bytes(n)));
-        RET(ctx_verify(ctx, st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dok.as<uint8_t>(), dscr.p));
+        DBuf dscr, drd;                             // batch inversion pays from tens of thousands of signatures on; below: the latency form
+        if (n >= 65536) RET(dscr.alloc(bsxk_ed25519_scratch_bytes(n)));
+        else RET(drd.alloc(bsxk_ed25519_rdec_bytes(n)));
+        RET(ctx_verify(ctx, st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dok.as<uint8_t>(), dscr.p, drd.p));
     }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     StagedD2H back(ctx, st);
@@ -1001,7 +1025,9 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     HIPCHK(hipEventRecord(ctx->ev_a, st));
     const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
     HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
-    RET(ctx_verify(ctx, sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, dok.as<uint8_t>(), nullptr));
+    DBuf drd;
+    RET(drd.alloc(bsxk_ed25519_rdec_bytes(v_max)));
+    RET(ctx_verify(ctx, sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, dok.as<uint8_t>(), nullptr, drd.p));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) + trusted tally from `st`
     HIPCHK(bsxk_commit_tally(sb, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
     HIPCHK(bsxk_skip_check(sb, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),

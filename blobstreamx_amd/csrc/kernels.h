@@ -6,7 +6,7 @@
 #include "../../include/bsx.h"
 
 extern "C" {
-hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t);
+hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t, uint32_t);
 hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
 hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
@@ -20,7 +20,13 @@ hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, ui
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
 uint64_t bsxk_keytable_bytes(uint32_t);
 hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
-hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*);
+hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*, const void*);
+// sentinel for bsxk_ed25519_verify_keyed's last argument: no decoded R, and (with a scratch) prefer the form with the least total work
+#ifndef BSXK_ED_THROUGHPUT
+#define BSXK_ED_THROUGHPUT (reinterpret_cast<const void*>(static_cast<uintptr_t>(1)))
+#endif
+uint64_t bsxk_ed25519_rdec_bytes(uint64_t);
+hipError_t bsxk_ed25519_decode_r(hipStream_t, const bsx_validator*, uint64_t, void*);
 hipError_t bsxk_ed25519_btable(hipStream_t, uint8_t*);
 uint64_t bsxk_ed25519_btable_bytes();
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t);

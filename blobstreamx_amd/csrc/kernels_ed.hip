@@ -26,6 +26,9 @@
 #include "sha256.h"
 #include "sha512.h"
 
+// see kernels.h
+#define BSXK_ED_THROUGHPUT (reinterpret_cast<const void*>(static_cast<uintptr_t>(1)))
+
 namespace bsx {
 
 // ------------------------------------------------------------------------------------------------ k_sha512_challenge
@@ -98,9 +101,11 @@ template <bool ONLY_DEFERRED>
 __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validator* __restrict__ vals,
                                                                const uint8_t* __restrict__ hs, uint64_t n,
                                                                uint8_t* __restrict__ ok_out) {
-    const uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
-    if (me >= n) return;
-    if (ONLY_DEFERRED && ok_out[me] != ED_DEFERRED) return;
+    // ONLY_DEFERRED: a SMALL grid strides over the markers (the launcher caps it): normally nothing is deferred, and a launch of
+    // one wave per 64 slots that only reads a byte each still has to be dispatched through a GPU full of hashing waves (0.17 ms
+    // per 25,600 slots beside k_header_merkle); 64 workgroups scan the same bytes in one round
+    for (uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x; me < n; me += (uint64_t)gridDim.x * ED_THREADS) {
+    if (ONLY_DEFERRED && ok_out[me] != ED_DEFERRED) continue;
     const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
     const uint4 flags = rec[14];                    // bytes 224..239: voting_power (8), enabled, is_signed, present, pad
     const bool active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validat
         ok = ed25519_verify_core(pk, sr, ss, h);
     }
     ok_out[me] = ok ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ fixed-key tables
@@ -479,6 +485,99 @@ __global__ __launch_bounds__(128) void k_ed25519_verify_keyed_small(const bsx_va
 #pragma unroll
     for (int i = 0; i < 10; i++) { nx.v[i] = rdec[sub][i]; ry.v[i] = rdec[sub][10 + i]; }
     const bool rok = rdec[sub][20] != 0;
+    const bool same_x = !fe_isnonzero(fe_add(p.X, fe_mul(nx, p.Z)));      // X - x_R Z, with nx = -x_R
+    const bool same_y = !fe_isnonzero(fe_sub(p.Y, fe_mul(ry, p.Z)));
+    ok_out[me] = (decodes && sc_is_canonical(ss) && rok && same_x && same_y) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ the latency form (mode F)
+// One proof verifies ONE commit (<= 100 signatures), a pipelined chunk a few thousand: every signature lane sits on its own
+// SIMD and the launch takes as long as ONE signature's dependent chain.  In the forms above that chain is 12-48 additions
+// followed by a field inversion (254 squarings) for the encoding.  Here
+//   * R is DECODED ahead of time (k_ed25519_decode_r: strict RFC 8032 decoding, a square-root chain as long as the inversion
+//     but independent of h and of the point arithmetic) — the pipeline runs it with the challenges, beside the header hashing,
+//     off the commit check's critical path;
+//   * the 38 table entries of a signature are summed by SPLIT = 8 or 16 lanes (2-5 mixed additions each) and joined by a
+//     log2(SPLIT)-level butterfly of full additions through wave shuffles;
+//   * the comparison is projective: (X : Y : Z) == (x_R, y_R)  <=>  X = x_R Z and Y = y_R Z — no inversion anywhere.
+// Same accept set: encodings are canonical, so "encode(P) == R bytes" holds exactly when R decodes strictly and decodes to P.
+// Dependent chain per signature: 3 + 4 (SPLIT 16) or 5 + 3 (SPLIT 8) additions and two multiplications, instead of
+// 14 additions + an inversion: 0.35 ms -> ~0.05 ms per pipelined chunk's 12,800 signatures.
+constexpr uint32_t ED_RDEC_I32 = 24;     // per signature: -x_R (10 limbs), y_R (10), decodes flag, 3 pad = 96 bytes
+__global__ __launch_bounds__(ED_THREADS) void k_ed25519_decode_r(const bsx_validator* __restrict__ vals, uint64_t n, int32_t* __restrict__ rdec) {
+    const uint64_t me = (uint64_t)blockIdx.x * ED_THREADS + threadIdx.x;
+    if (me >= n) return;
+    const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
+    const uint4 flags = rec[14];
+    const bool active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
+    int32_t* d = rdec + me * ED_RDEC_I32;
+    if (!active) { d[20] = 0; return; }
+    const uint4 r0 = rec[2], r1 = rec[3];
+    const uint32_t sr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    ge_p3 nr;
+    const bool rok = ge_frombytes_negate(nr, sr);
+#pragma unroll
+    for (int i = 0; i < 10; i++) { d[i] = nr.X.v[i]; d[10 + i] = nr.Y.v[i]; }
+    d[20] = rok ? 1 : 0;
+}
+
+template <int SPLIT>
+__global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed_proj(const bsx_validator* __restrict__ vals, const uint8_t* __restrict__ hs,
+                                                                          uint64_t n, uint32_t v_max, const uint8_t* __restrict__ table,
+                                                                          uint32_t n_keys, const int32_t* __restrict__ b_tab,
+                                                                          const int32_t* __restrict__ rdec, uint8_t* __restrict__ ok_out) {
+    constexpr uint32_t SIGS = ED_THREADS / SPLIT;
+    const uint32_t sub = threadIdx.x / SPLIT, part0 = threadIdx.x % SPLIT;
+    const uint64_t me = (uint64_t)blockIdx.x * SIGS + sub;
+    if (me >= n) return;                        // whole groups of SPLIT lanes leave together (every test below is per signature)
+    const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
+    const uint4 flags = rec[14];
+    const bool active = ((flags.z & 0xffu) != 0) && (((flags.z >> 8) & 0xffu) != 0);
+    if (!active) {
+        if (part0 == 0) ok_out[me] = 0;
+        return;
+    }
+    uint32_t pk[8], ss[8], h[8];
+    load_pk(vals + me, pk);
+    const uint4 s0 = rec[4], s1 = rec[5];
+    ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
+    const uint4* hp = reinterpret_cast<const uint4*>(hs + me * 32);
+    const uint4 h0 = hp[0], h1 = hp[1];
+    h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
+    const uint32_t slot = (uint32_t)(me % v_max);
+    bool keyed = slot < n_keys;
+    bool decodes = false;
+    if (keyed) {
+        const uint4* kr = reinterpret_cast<const uint4*>(table + (uint64_t)slot * KT_REC_BYTES);
+        const uint4 k0 = kr[0], k1 = kr[1];
+        keyed = k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] && k1.x == pk[4] && k1.y == pk[5] &&
+                k1.z == pk[6] && k1.w == pk[7];
+        decodes = kr[2].x != 0;
+    }
+    if (!keyed) {
+        if (part0 == 0) ok_out[me] = ED_DEFERRED;   // left to k_ed25519_verify<true>, launched right behind on the same stream
+        return;
+    }
+    const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
+    ge_p3 p = ed25519_keyed_partial<SPLIT>(kt, b_tab, ss, h, (int)part0);
+#pragma unroll
+    for (int m = 1; m < SPLIT; m <<= 1) {
+        ge_p3 o;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            o.X.v[i] = __shfl_xor(p.X.v[i], m, 64);
+            o.Y.v[i] = __shfl_xor(p.Y.v[i], m, 64);
+            o.Z.v[i] = __shfl_xor(p.Z.v[i], m, 64);
+            o.T.v[i] = __shfl_xor(p.T.v[i], m, 64);
+        }
+        p = p1p1_to_p3(ge_add(p, p3_to_cached(o)));
+    }
+    if (part0 != 0) return;
+    const int32_t* d = rdec + me * ED_RDEC_I32;
+    fe nx, ry;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { nx.v[i] = d[i]; ry.v[i] = d[10 + i]; }
+    const bool rok = d[20] != 0;
     const bool same_x = !fe_isnonzero(fe_add(p.X, fe_mul(nx, p.Z)));      // X - x_R Z, with nx = -x_R
     const bool same_y = !fe_isnonzero(fe_sub(p.Y, fe_mul(ry, p.Z)));
     ok_out[me] = (decodes && sc_is_canonical(ss) && rok && same_x && same_y) ? 1 : 0;
@@ -920,10 +1019,32 @@ hipError_t bsxk_ed25519_btable(hipStream_t s, uint8_t* table) {
     return hipGetLastError();
 }
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t n) { return n * ED_SLOT_I32 * 4; }
+static inline uint32_t deferred_grid(uint64_t n) {
+    const uint64_t wgs = (n + ED_THREADS - 1) / ED_THREADS;
+    return (uint32_t)(wgs < 64 ? wgs : 64);
+}
+uint64_t bsxk_ed25519_rdec_bytes(uint64_t n) { return n * ED_RDEC_I32 * 4; }
+hipError_t bsxk_ed25519_decode_r(hipStream_t s, const bsx_validator* vals, uint64_t n, void* rdec) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_ed25519_decode_r, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, static_cast<int32_t*>(rdec));
+    return hipGetLastError();
+}
+// rdec (optional, from bsxk_ed25519_decode_r over the same records): batches below ED_SPLIT_BELOW signatures without a
+// batch-inversion scratch take the latency form (k_ed25519_verify_keyed_proj)
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
-                                     const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch) {
+                                     const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch, const void* rdec) {
     if (n == 0) return hipSuccess;
     const int32_t* b_tab = reinterpret_cast<const int32_t*>(btable + bt_entries_off());
+    if (rdec && rdec != BSXK_ED_THROUGHPUT && !scratch && n < ED_SPLIT_BELOW) {
+        // BSX_ED_PROJ_SPLIT (experiments): 8 / 16 lanes per signature; default 16 while the launch is a single wave round anyway
+        static const long env_ps = getenv("BSX_ED_PROJ_SPLIT") ? atol(getenv("BSX_ED_PROJ_SPLIT")) : 0;
+        const bool s16 = env_ps ? env_ps == 16 : n <= 8192;
+        const int32_t* rd = static_cast<const int32_t*>(rdec);
+        if (s16) hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<16>, dim3((uint32_t)((n + 3) / 4)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
+        else hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<8>, dim3((uint32_t)((n + 7) / 8)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
+        hipLaunchKernelGGL(k_ed25519_verify<true>, dim3(deferred_grid(n)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
+        return hipGetLastError();
+    }
     int32_t* scr = static_cast<int32_t*>(scratch);
     const uint64_t n_commits = (n + v_max - 1) / v_max;
     // BSX_ED_BY_KEY (experiments): 0 / 1 forces the lane order; default: by key from 32 commits on (waves at least half full)
@@ -931,7 +1052,11 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     // BSX_ED_SPLIT (experiments): 1 / 4 lanes per signature; default: 4 while the batch cannot fill the GPU's wave slots
     // anyway (latency is what counts) or fills them so barely that finer units balance better, 1 above (20 % less work)
     static const long env_split = getenv("BSX_ED_SPLIT") ? atol(getenv("BSX_ED_SPLIT")) : -1;
-    const bool split4 = env_split >= 0 ? env_split == 4 : n < ED_SPLIT_BELOW;
+    // rdec == BSXK_ED_THROUGHPUT (with a scratch): the caller has a whole step of slack and an ALU-bound GPU (the compact
+    // pipeline) — one lane per signature + batch inversion is the form with the least total work (280 multiplications per
+    // signature against 421 on four lanes and 761 in the latency form), whatever the batch size
+    const bool throughput = rdec == BSXK_ED_THROUGHPUT && scratch;
+    const bool split4 = env_split >= 0 ? env_split == 4 : (n < ED_SPLIT_BELOW && !throughput);
     const uint32_t sigs = split4 ? ED_THREADS / 4 : ED_THREADS;               // signatures per workgroup
     const bool by_key = env_by_key >= 0 ? env_by_key != 0 : n_commits >= sigs / 2;
     dim3 grid;
@@ -962,7 +1087,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
         const uint64_t lanes = (n + K - 1) / K;
         hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
     }
-    hipLaunchKernelGGL(k_ed25519_verify<true>, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
+    hipLaunchKernelGGL(k_ed25519_verify<true>, dim3(deferred_grid(n)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
     return hipGetLastError();
 }
 hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,

@@ -146,8 +146,10 @@ constexpr uint32_t HM_PATH_BYTES = 7 * 32;
 __global__ __launch_bounds__(HM_THREADS, 4) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
                                                               uint8_t* __restrict__ lb_aunts, uint8_t* __restrict__ paths,
-                                                              uint32_t* __restrict__ status) {
-    BSX_CHAIN_PRIO();
+                                                              uint32_t* __restrict__ status, uint32_t low_prio) {
+    // beside an expansion: above the commit check's waves (BSX_CHAIN_PRIO).  In the compact pipeline this kernel is the bulk
+    // ALU work that the OTHER buffer set's short chain kernels (hint, prove_subchain, reduce, ...) must get through: it yields
+    if (!low_prio) BSX_CHAIN_PRIO();
     // double-buffered by pass parity: the joining wave of pass p reads buffer p & 1 while the other three waves already
     // write pass p + 1's sub-tree roots into the other one; pass p + 2 reuses buffer p & 1 only behind the barrier of pass
     // p + 1, which the joining wave of pass p reaches after its reads
@@ -936,7 +938,7 @@ extern "C" {
 using namespace bsx;
 
 hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint8_t* paths,
-                              uint32_t* status, uint32_t max_wgs) {
+                              uint32_t* status, uint32_t max_wgs, uint32_t low_prio) {
     if (!n) return hipSuccess;
     uint32_t grid = (uint32_t)((n + HM_GROUP - 1) / HM_GROUP);
     // cap on the grid (the workgroups then stride over the header groups): the context's BSX_TUNE_MERKLE_WORKGROUPS, or the
@@ -944,7 +946,8 @@ hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, 
     static const long env_cap = getenv("BSX_MERKLE_WGS") ? atol(getenv("BSX_MERKLE_WGS")) : -1;
     const long cap = env_cap >= 0 ? env_cap : (long)max_wgs;
     if (cap > 0 && grid > (uint32_t)cap) grid = (uint32_t)cap;
-    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status);
+    static const long env_lp = getenv("BSX_MERKLE_LOW_PRIO") ? atol(getenv("BSX_MERKLE_LOW_PRIO")) : -1;       // experiments
+    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status, env_lp >= 0 ? (uint32_t)env_lp : low_prio);
     return hipGetLastError();
 }
 hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {

@@ -9,6 +9,7 @@
 //
 // Host code only: buffer ownership, stream/event choreography, argument validation.  All arithmetic is in kernels_*.hip.
 // No environment variables, no Python, no torch: a Rust caller binds exactly this.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,7 +44,7 @@ struct Chunk {
     uint8_t *red_compact_top = nullptr, *results = nullptr, *output64 = nullptr;
     uint32_t* range_status = nullptr;
     // commit check
-    uint8_t *h = nullptr, *ok = nullptr, *commit_res = nullptr, *trusted_res = nullptr, *keytable = nullptr;
+    uint8_t *h = nullptr, *ok = nullptr, *commit_res = nullptr, *trusted_res = nullptr, *keytable = nullptr, *rdec = nullptr, *ed_scratch = nullptr;
     uint32_t* skip_status = nullptr;
     uint8_t *target_hashes_pp[2] = {nullptr, nullptr}, *skip_hashes_pp[2] = {nullptr, nullptr}, *skip_headers_pp[2] = {nullptr, nullptr};
     // outputs
@@ -66,7 +67,9 @@ struct Chunk {
 struct bsx_pipeline {
     bsx_ctx* ctx = nullptr;
     bsx_pipeline_config cfg{};
-    uint32_t J = 0, B = 0, V = 0, R = 0, E = 0, Rc = 0, rank = 0, world = 1, jf = 0, jc = 0;
+    uint32_t J = 0, B = 0, V = 0, R = 0, E = 0, K = 1, Rc = 0, rank = 0, world = 1, jf = 0, jc = 0;
+    uint64_t step_index = 0;                 // steps enqueued so far: step i runs on buffer set i % K
+    uint32_t last_set = 0;
     uint64_t hpr = 0, hfr = 0;
     bool with_witness = false, with_commit = false, with_caps = false, keyed = false, commit_beside_hash = false, fused_hint = true;
     uint32_t subchain_flags = 0, merkle_wgs = 0;
@@ -77,10 +80,11 @@ struct bsx_pipeline {
     std::vector<void*> allocs;               // hipMalloc'ed blocks
     std::vector<void*> host_allocs;          // hipHostMalloc'ed blocks
     hipEvent_t hash_token = nullptr, expand_token = nullptr;     // aliases of a chunk's ev_hash_tok / ev_expand_tok
+    hipEvent_t merkle_token = nullptr;       // compact mode: the previous k_header_merkle launch (any chunk, any set)
     Chunk* pending_verify = nullptr;
     bsx_allgather_fn allgather = nullptr;
     void* allgather_user = nullptr;
-    bool timing_on = false, streaming = false, uploaded = false;
+    bool timing_on = false, streaming = false, uploaded = false, compact_tokens = false;
 };
 
 namespace {
@@ -107,7 +111,13 @@ int new_event(hipEvent_t* e, bool timing = false) {
     HIPCHK(hipEventCreateWithFlags(e, timing ? hipEventDefault : hipEventDisableTiming));
     return BSX_OK;
 }
-int new_stream(hipStream_t* s) {
+int new_stream(hipStream_t* s, bool high_priority = false) {
+    if (high_priority) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest));
+        return BSX_OK;
+    }
     HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
     return BSX_OK;
 }
@@ -127,7 +137,11 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
     c.nh_skip = p->with_commit ? (uint64_t)R * 2 : 0;
     c.nh_all = c.nh_main + c.nh_skip;
     RET(new_stream(&c.main));
-    RET(new_stream(&c.side));
+    // BSX_PIPE_SIDE_PRIORITY=1 (experiment, off): the commit check's stream on a high-priority queue.  Measured: no effect on the
+    // compact step (369 vs 366 M headers/s), and beside an expansion it costs 12 % (78 vs 89 M headers/s: its waves then
+    // pre-empt the store stream's dispatch)
+    static const bool side_hi = getenv("BSX_PIPE_SIDE_PRIORITY") && atoi(getenv("BSX_PIPE_SIDE_PRIORITY")) == 1;
+    RET(new_stream(&c.side, side_hi));
     if (world > 1) RET(new_stream(&c.xchg));
     for (hipEvent_t* e : {&c.ev_sync, &c.ev_merkle, &c.ev_fill, &c.ev_fin, &c.ev_inputs_consumed, &c.ev_h2d, &c.ev_commit_done[0], &c.ev_commit_done[1],
                           &c.ev_hash_tok, &c.ev_expand_tok, &c.ev_x_in, &c.ev_x_out})
@@ -174,7 +188,11 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
         RET(dalloc_t(p, (size_t)R * 64, &c.skip_hashes_pp[q]));
         RET(dalloc_t(p, (size_t)R * 2 * sizeof(bsx_header), &c.skip_headers_pp[q]));
     }
-    if (p->with_commit && p->keyed) RET(dalloc_t(p, bsxk_keytable_bytes(V), &c.keytable));   // zeroed: no row to reuse yet
+    if (p->with_commit && p->keyed) {
+        RET(dalloc_t(p, bsxk_keytable_bytes(V), &c.keytable));   // zeroed: no row to reuse yet
+        if (p->with_witness) RET(dalloc_t(p, bsxk_ed25519_rdec_bytes((uint64_t)R * V), &c.rdec));
+        else RET(dalloc_t(p, bsxk_ed25519_scratch_bytes((uint64_t)R * V), &c.ed_scratch));
+    }
     c.n_map_el = (uint64_t)RT * jc * p->ml.n_elements;
     c.n_red_local_el = (uint64_t)n_local_nodes * p->rl.n_elements;
     c.n_red_top_el = (uint64_t)R * (world - 1) * p->rl.n_elements;
@@ -220,18 +238,23 @@ int commit_part(bsx_pipeline* p, Chunk& c, hipStream_t st, bool prep, bool verif
     const uint64_t n = (uint64_t)R * V;
     auto* vals = reinterpret_cast<const bsx_validator*>(c.validators);
     auto* trs = reinterpret_cast<const bsx_validator*>(c.trusted);
-    if (prep) {
-        HIPCHK(bsxk_sha512_challenge(st, vals, n, c.h, nullptr));
-        if (p->keyed) HIPCHK(bsxk_ed25519_keytable(st, vals, V, c.keytable));
-    }
-    if (!verify) return BSX_OK;
-    if (p->keyed)
-        HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, V, p->ctx->btab, c.ok, nullptr));
-    else
-        HIPCHK(bsxk_ed25519_verify(st, vals, c.h, n, c.ok));
     auto* cres = reinterpret_cast<bsx_commit_result*>(c.commit_res);
     auto* tres = reinterpret_cast<bsx_commit_result*>(c.trusted_res);
-    HIPCHK(bsxk_commit_tally(st, trs, R, V, nullptr, nullptr, tres));
+    if (prep) {
+        // everything that needs nothing from this step's hashing: challenges, R decoded for the projective comparison, the
+        // key-table check, the trusted set's hash and power sum — off the critical chain (verify -> tally -> skip conditions)
+        HIPCHK(bsxk_sha512_challenge(st, vals, n, c.h, nullptr));
+        if (p->keyed) {
+            if (c.rdec) HIPCHK(bsxk_ed25519_decode_r(st, vals, n, c.rdec));
+            HIPCHK(bsxk_ed25519_keytable(st, vals, V, c.keytable));
+        }
+        HIPCHK(bsxk_commit_tally(st, trs, R, V, nullptr, nullptr, tres));
+    }
+    if (!verify) return BSX_OK;
+    if (p->keyed)   // latency form beside an expansion (ALU to spare, one step to finish in); least-work form in the compact pipeline
+        HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, V, p->ctx->btab, c.ok, c.ed_scratch, c.rdec ? c.rdec : BSXK_ED_THROUGHPUT));
+    else
+        HIPCHK(bsxk_ed25519_verify(st, vals, c.h, n, c.ok));
     HIPCHK(bsxk_commit_tally(st, vals, R, V, c.target_hashes_pp[c.parity], c.ok, cres));
     // streamed inputs: headers_all is overwritten early in the next step while this check may still run -> private copy
     const uint8_t* skip_headers = p->streaming ? c.skip_headers_pp[c.parity] : c.headers_all + c.nh_main * sizeof(bsx_header);
@@ -269,9 +292,15 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
         RET(stream_wait_stream(c.side, st, c.ev_sync));
         RET(commit_part(p, c, c.side, true, false));
     }
+    // Without an expansion to hide behind, the step is one ALU-bound kernel (k_header_merkle: 41 of the 45 compressions per
+    // header) and a chain of short, latency-bound ones.  Chunks / buffer sets left to themselves drift into the same phase
+    // (two header hashings sharing the GPU, then two chains leaving it idle); the token lets exactly ONE header hashing run
+    // at a time, back to back across chunks, sets and steps, with the other chunks' chains filling in beside it.
+    if (p->compact_tokens && p->merkle_token) HIPCHK(hipStreamWaitEvent(st, p->merkle_token, 0));
     HIPCHK(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(c.headers_all), commit ? c.nh_all : c.nh_main, c.hashes_all, c.dh_aunts,
-                              c.lb_aunts, c.paths, c.status, p->merkle_wgs));
+                              c.lb_aunts, c.paths, c.status, p->merkle_wgs, p->compact_tokens ? 1u : 0u));
     HIPCHK(hipEventRecord(c.ev_merkle, st));
+    if (p->compact_tokens) p->merkle_token = c.ev_merkle;
     if (commit) {
         c.parity ^= 1;
         if (c.commit_done_valid[c.parity]) HIPCHK(hipStreamWaitEvent(st, c.ev_commit_done[c.parity], 0));   // the check two steps ago read these
@@ -409,10 +438,12 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     if (!pow2(J / world)) return fail(BSX_ERR_BAD_ARG, "each rank needs a power-of-two slice of the map jobs (the local fold is a subtree of the reference's reduce tree)");
     if (cfg->chain_id_len > 50) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     if (cfg->tune_subchain > 2) return fail(BSX_ERR_BAD_ARG, "tune_subchain must be 0, 1 or 2");
+    if (cfg->n_sets > 8) return fail(BSX_ERR_BAD_ARG, "n_sets must be in 0..8");
     bsx_pipeline* p = new bsx_pipeline();
     p->ctx = ctx;
     p->cfg = *cfg;
     p->J = J; p->B = B; p->V = V ? V : 1; p->R = cfg->n_ranges; p->E = cfg->n_chunks; p->Rc = p->R / p->E;
+    p->K = cfg->n_sets ? cfg->n_sets : 1;
     p->rank = cfg->rank; p->world = world;
     p->jc = J / world; p->jf = p->rank * p->jc;
     p->hpr = (uint64_t)p->jc * B + 1;          // headers this rank holds per range: its slice + the next one
@@ -450,7 +481,8 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
         p->tree_digests = bsx_poseidon_tree_digests(p->n_leaves, p->cap_height);
         if (!p->n_leaves || !p->tree_digests) { delete p; return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_create: bad leaf_len / cap_height"); }
     }
-    p->chunks.resize(p->E);
+    p->compact_tokens = !p->with_witness && (p->E > 1 || p->K > 1);
+    p->chunks.resize((size_t)p->E * p->K);
     for (Chunk& c : p->chunks) {
         const int rc = create_chunk(p, c);
         if (rc != BSX_OK) {
@@ -458,6 +490,15 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
             bsx_pipeline_destroy(p);
             bsxapi::g_err = msg;
             return rc;
+        }
+    }
+    // the allocations were zeroed with null-stream memsets, which the pipeline's non-blocking streams do not wait for: drain
+    // them here, or an upload enqueued right away could be overtaken and wiped by a memset still pending
+    {
+        const hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            bsx_pipeline_destroy(p);
+            return fail(BSX_ERR_HIP, "bsx_pipeline_create: %s", hipGetErrorString(e));
         }
     }
     *out = p;
@@ -500,8 +541,9 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
     RET(join_impl(p));                         // steps in flight read the buffers about to be overwritten
     const uint32_t R = p->R, Rc = p->Rc, V = p->V;
     std::vector<bsx_header> sk((size_t)Rc * 2);
-    for (uint32_t e = 0; e < p->E; e++) {
-        Chunk& c = p->chunks[e];
+    for (uint32_t ce = 0; ce < p->E * p->K; ce++) {
+        const uint32_t e = ce % p->E;                                  // every buffer set holds the same inputs
+        Chunk& c = p->chunks[ce];
         hipStream_t st = c.main;
         for (uint32_t g = 0; g < p->world; g++) {
             const size_t r0 = (size_t)g * R + (size_t)e * Rc;          // first global range of this (chunk, owner) block
@@ -570,9 +612,13 @@ int bsx_pipeline_step(bsx_pipeline* p) {
     RET(use(p->ctx));
     if (!p->uploaded) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_step before bsx_pipeline_upload");
     const bool multi = p->E > 1;
-    for (Chunk& c : p->chunks) {
+    const uint32_t set = (uint32_t)(p->step_index % p->K);
+    p->step_index++;
+    p->last_set = set;
+    for (uint32_t e = 0; e < p->E; e++) {
+        Chunk& c = p->chunks[(size_t)set * p->E + e];
         TimingSlot* ts = p->timing_on ? timing_slot(c) : nullptr;
-        if (multi && p->hash_token) HIPCHK(hipStreamWaitEvent(c.main, p->hash_token, 0));
+        if (multi && !p->compact_tokens && p->hash_token) HIPCHK(hipStreamWaitEvent(c.main, p->hash_token, 0));
         RET(step_local(p, c, ts));
         RET(stream_inputs(p, c));
         if (p->pending_verify) {
@@ -613,7 +659,7 @@ int bsx_pipeline_get_results(bsx_pipeline* p, bsx_pipeline_results* out) {
     out->header_status = out->assemble_status = 0;
     const uint32_t R = p->R, Rc = p->Rc;
     for (uint32_t e = 0; e < p->E; e++) {
-        Chunk& c = p->chunks[e];
+        Chunk& c = p->chunks[(size_t)p->last_set * p->E + e];
         uint32_t st[2] = {0, 0};
         HIPCHK(hipMemcpy(st, c.status, 8, hipMemcpyDeviceToHost));
         out->header_status |= st[0];
@@ -639,7 +685,7 @@ int bsx_pipeline_get_results(bsx_pipeline* p, bsx_pipeline_results* out) {
 
 int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** out_d_ptr, uint64_t* out_bytes) {
     if (!p || !out_d_ptr || !out_bytes) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    if (chunk >= p->E) return fail(BSX_ERR_BAD_ARG, "chunk %u out of range (n_chunks %u)", chunk, p->E);
+    if (chunk >= p->E * p->K) return fail(BSX_ERR_BAD_ARG, "chunk %u out of range (n_sets x n_chunks = %u)", chunk, p->E * p->K);
     Chunk& c = p->chunks[chunk];
     void* q = nullptr;
     uint64_t n = 0;

@@ -39,7 +39,7 @@ class _Config(C.Structure):
     _fields_ = [("nb_map_jobs", C.c_uint32), ("batch_size", C.c_uint32), ("v_max", C.c_uint32), ("n_ranges", C.c_uint32),
                 ("n_chunks", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32), ("flags", C.c_uint32),
                 ("leaf_len", C.c_uint32), ("cap_height", C.c_uint32), ("chain_id_len", C.c_uint32), ("chain_id", C.c_uint8 * 52),
-                ("tune_merkle_workgroups", C.c_uint32), ("tune_subchain", C.c_uint32)]
+                ("tune_merkle_workgroups", C.c_uint32), ("tune_subchain", C.c_uint32), ("n_sets", C.c_uint32), ("_reserved", C.c_uint32)]
 
 
 class _Inputs(C.Structure):
@@ -57,7 +57,7 @@ class _Timing(C.Structure):
                 ("_pad", C.c_uint32)]
 
 
-assert C.sizeof(_Config) == 104 and C.sizeof(_Inputs) == 48 and C.sizeof(_Results) == 48 and C.sizeof(_Timing) == 32
+assert C.sizeof(_Config) == 112 and C.sizeof(_Inputs) == 48 and C.sizeof(_Results) == 48 and C.sizeof(_Timing) == 32
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
@@ -144,7 +144,7 @@ class Pipeline:
 
     def __init__(self, nb_map_jobs, batch_size, v_max, n_ranges_local, n_chunks=1, rank=0, world=1, device=None, with_witness=True,
                  with_commit=True, with_caps=False, chain_id=b"celestia", ed_path=None, commit_with="expand", fused_hint=True,
-                 leaf_len=0, cap_height=0, merkle_workgroups=0, subchain_form=0):
+                 leaf_len=0, cap_height=0, merkle_workgroups=0, subchain_form=0, n_sets=1):
         import torch
         self.J, self.B, self.V = nb_map_jobs, batch_size, v_max
         self.R, self.E, self.Rc = n_ranges_local, n_chunks, n_ranges_local // n_chunks
@@ -173,7 +173,8 @@ class Pipeline:
         self.commit_with = commit_with
         cid = bytes(chain_id)
         cfg = _Config(nb_map_jobs, batch_size, v_max, n_ranges_local, n_chunks, rank, world, flags, leaf_len, cap_height, len(cid),
-                      (C.c_uint8 * 52)(*cid[:52]), merkle_workgroups, subchain_form)
+                      (C.c_uint8 * 52)(*cid[:52]), merkle_workgroups, subchain_form, n_sets, 0)
+        self.K = n_sets
         self._h = C.c_void_p()
         _lib.check(self.L.bsx_pipeline_create(self.ctx, C.byref(cfg), C.byref(self._h)))
         self._cb = None
@@ -261,7 +262,8 @@ class Pipeline:
         return out
 
     def buffer(self, chunk, which, i64=False):
-        """Zero-copy torch view of a device buffer of chunk `chunk` (bsx_pipeline_buffer)."""
+        """Zero-copy torch view of a device buffer of chunk `chunk` (bsx_pipeline_buffer; with buffer sets the index is
+        set * n_chunks + chunk)."""
         ptr, n = C.c_void_p(), C.c_uint64()
         _lib.check(self.L.bsx_pipeline_buffer(self._h, C.c_uint32(chunk), C.c_uint32(which), C.byref(ptr), C.byref(n)))
         return _view(ptr.value, n.value, self.dev, i64)
@@ -318,50 +320,13 @@ class PipelinedEngines(Pipeline):
         super().__init__(nb_map_jobs, batch_size, v_max, n_ranges_local, n_chunks=n_engines, rank=rank, world=world, device=device, **kw)
 
 
-class AlternatingPipelines:
-    """K pipelines over the SAME ranges, stepped in turn: software pipelining ACROSS steps (step i + 1 starts on its own
-    buffers while step i's chain of small kernels drains).  The form for the compact-only path, whose step is a serial chain
-    (header hashing, hint, prove_subchain, reduce, finalize) with nothing HBM-bound to hide behind.  With the witness it does
-    not pay (the expansions of two steps share HBM) and doubles the 29 GB image."""
+class AlternatingPipelines(Pipeline):
+    """K buffer sets inside ONE bsx_pipeline (bsx_pipeline_config.n_sets): step i runs on set i mod K, so step i + 1 starts on
+    its own buffers while step i's chain of short kernels drains, and a token lets exactly one header hashing run at a time.
+    The form for the compact-only path; with the witness it does not pay (two expansions share HBM, twice the 29 GB image)."""
 
-    def __init__(self, k, *args, **kw):
-        self.sets = [PipelinedEngines(*args, **kw) for _ in range(k)]
-        self.K, self.i = k, 0
-        s0 = self.sets[0]
-        self.dev, self.R, self.E, self.Rc, self.world, self.rank = s0.dev, s0.R, s0.E, s0.Rc, s0.world, s0.rank
-
-    def sel(self, e):
-        return self.sets[0].sel(e)
-
-    def upload_workload(self, w):
-        for s in self.sets:
-            s.upload_workload(w)
-
-    def step(self):
-        self.sets[self.i % self.K].step()
-        self.i += 1
-
-    def join(self):
-        for s in self.sets:
-            s.join()
-
-    def set_timing(self, on=True):
-        for s in self.sets:
-            s.set_timing(on)
-
-    def timing(self):
-        ts = [s.timing() for s in self.sets]
-        n = sum(t["launches"] for t in ts) or 1
-        out = {k: sum(t[k] * t["launches"] for t in ts) / n for k in ("prove_subchain_ms", "expand_map_ms", "caps_ms")}
-        out["launches"] = sum(t["launches"] for t in ts)
-        return out
-
-    def download(self):
-        """Results of the most recent step; every set that has stepped must hold the same public outputs."""
-        outs = [s.download() for s in self.sets[:min(self.i, self.K)]]
-        for o in outs[1:]:
-            assert (o["output64"] == outs[0]["output64"]).all() and (o["range_status"] == outs[0]["range_status"]).all()
-        return outs[(self.i - 1) % self.K if self.i else 0]
+    def __init__(self, k, nb_map_jobs, batch_size, v_max, n_ranges_local, n_engines=1, rank=0, world=1, device=None, **kw):
+        super().__init__(nb_map_jobs, batch_size, v_max, n_ranges_local, n_chunks=n_engines, rank=rank, world=world, device=device, n_sets=k, **kw)
 
 
 def run_world_on_one_gpu(engines):

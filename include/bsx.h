@@ -447,6 +447,16 @@ int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_
 int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
                                  uint64_t n, uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok,
                                  void* d_scratch);
+/* P7, latency form for small batches (one proof: <= 100 signatures; a pipelined chunk: a few thousand), where a launch takes
+ * as long as ONE signature's dependent chain.  bsx_dev_ed25519_decode_r decodes every R strictly (RFC 8032 §5.1.3) into
+ * d_decoded_r (bsx_ed25519_decoded_r_bytes(n) bytes, 16-byte aligned) — independent of the challenges, so a caller runs it
+ * early, off the critical path; bsx_dev_ed25519_verify_keyed_r then sums the 38 table entries of a signature on 8-16 lanes
+ * and compares projectively with the decoded R: no field inversion in the chain (0.35 -> ~0.05 ms per 12,800 signatures).
+ * Same verdicts as bsx_dev_ed25519_verify for any input (slots whose key differs from their table row fall back). */
+uint64_t bsx_ed25519_decoded_r_bytes(uint64_t n);
+int bsx_dev_ed25519_decode_r(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n, void* d_decoded_r);
+int bsx_dev_ed25519_verify_keyed_r(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n,
+                                   uint32_t v_max, const void* d_table, uint32_t n_keys, const void* d_decoded_r, uint8_t* d_ok);
 /* d_scratch (optional, bsx_ed25519_verify_scratch_bytes(n) bytes, 16-byte aligned): with it the signature lanes stop
  * before the point encoding (a field inversion, a third of a verification) and a second kernel encodes 8 results per lane
  * with ONE inversion (Montgomery's trick); the verdicts are identical.  NULL: every lane inverts for itself. */
@@ -636,7 +646,13 @@ typedef struct bsx_pipeline_config {
     /* launch forms; results never depend on them.  0 = automatic (the measured choice for the configuration) */
     uint32_t tune_merkle_workgroups;    /* resident workgroups of the header-hashing kernel; 0xffffffff = one per 64 headers */
     uint32_t tune_subchain;             /* 1 = prove_subchain as one launch, 2 = its stages in separate launches */
-} bsx_pipeline_config;                  /* sizeof == 104 */
+    /* Buffer sets (0 / 1 = one): with K sets step i runs on set i mod K, so step i + 1 starts on its own buffers while step i's
+     * chain of short kernels drains — software pipelining ACROSS steps, the form for the compact path (no BSX_PIPE_WITNESS),
+     * whose step has nothing HBM-bound to hide behind.  Every set holds the same uploaded inputs; results / buffers are those
+     * of the set of the most recent step (bsx_pipeline_buffer: chunk index = set * n_chunks + chunk). */
+    uint32_t n_sets;
+    uint32_t _reserved;
+} bsx_pipeline_config;                  /* sizeof == 112 */
 
 int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeline** out);
 void bsx_pipeline_destroy(bsx_pipeline* p);

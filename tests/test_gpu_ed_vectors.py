@@ -7,7 +7,9 @@ v1.0.0; host twin circuits/fetcher.rs:76-80): nothing under /root/reference pins
 
 Every kernel form of the signature check sees every vector: the host tier's small fixed-key form (< 8 commits), the 4-lanes-
 per-signature fixed-key kernel with batch inversion (>= 8 commits), the one-lane-per-signature by-key layout (>= 32 commits),
-slots whose key differs from their table row (generic fall-back inside the keyed kernel) and the generic kernel itself."""
+slots whose key differs from their table row (generic fall-back inside the keyed kernel), the generic kernel itself, and the
+latency form (R decoded ahead, 16 / 8 lanes per signature, projective comparison: bsx_dev_ed25519_decode_r + _verify_keyed_r) that
+the host tier takes below 65,536 signatures (16 lanes up to 8,192 signatures: 300 commits x 28 slots = 8,400 take 8)."""
 import ctypes as C
 import hashlib
 import json
@@ -44,7 +46,7 @@ def _slots(vectors):
 WANT = np.array([e["valid"] for e in ALL], np.uint8)
 
 
-@pytest.mark.parametrize("n_commits", [1, 3, 8, 40])
+@pytest.mark.parametrize("n_commits", [1, 3, 8, 40, 300])
 def test_public_vectors_through_verify_commits_parity_unpinned_by_reference(n_commits):
     """bsx_verify_commits (host tier): commit c holds the vectors rotated by c slots, so from the second commit on every slot's
     key differs from its table row (built from commit 0) — the keyed kernel's generic fall-back judges them — while commit 0 is
@@ -60,7 +62,7 @@ def test_public_vectors_through_verify_commits_parity_unpinned_by_reference(n_co
         assert res[c]["signed_power"] == 0
 
 
-@pytest.mark.parametrize("n_commits", [1, 9, 33])
+@pytest.mark.parametrize("n_commits", [1, 9, 33, 300, 2400])
 def test_public_vectors_same_keys_every_commit_parity_unpinned_by_reference(n_commits):
     """The fixed-key tables judge EVERY slot (all commits carry the vectors in the same order): small form, 4-lane form with
     batch inversion, by-key layout."""
@@ -98,3 +100,36 @@ def test_public_vectors_device_tier_parity_unpinned_by_reference():
     assert (dok.cpu().numpy() == WANT).all(), [ALL[i]["name"] for i in np.nonzero(dok.cpu().numpy() != WANT)[0]]
     # FIPS 180-4: SHA-512("abc") is the message of RFC 8032's TEST SHA(abc)
     assert hashlib.sha512(b"abc").hexdigest() == VEC["rfc8032"][3]["message"]
+
+
+def test_latency_form_device_tier_parity_unpinned_by_reference():
+    """bsx_dev_ed25519_decode_r + bsx_dev_ed25519_verify_keyed_r directly (what the pipeline's commit check runs): every vector,
+    at sizes on both sides of the 16 / 8 lanes-per-signature switch, against the expected verdicts AND against the
+    inversion-based form (bsx_dev_ed25519_verify_keyed) on the same inputs."""
+    import torch
+    base = _slots(ALL)
+    V = base.size
+    L, ctx, dp = _lib.lib(), _lib.context(0), _lib.dp
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    tab = torch.zeros(int(L.bsx_ed25519_keytable_bytes(C.c_uint32(V))), dtype=torch.uint8, device=dev)
+    for n_commits in (1, 5, 293, 400):
+        vals = np.stack([base] * n_commits)
+        vals[n_commits // 2] = np.roll(base, 3)                      # one commit whose keys differ from the table rows
+        n = n_commits * V
+        dv = torch.from_numpy(vals.view(np.uint8).reshape(-1).copy()).to(dev)
+        dh = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+        rd = torch.zeros(int(L.bsx_ed25519_decoded_r_bytes(C.c_uint64(n))), dtype=torch.uint8, device=dev)
+        ok_new = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        ok_old = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(dv), C.c_uint64(n), dp(dh), None))
+        _lib.check(L.bsx_dev_ed25519_decode_r(ctx, st, dp(dv), C.c_uint64(n), dp(rd)))
+        _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(V), dp(tab)))
+        _lib.check(L.bsx_dev_ed25519_verify_keyed_r(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(V), dp(tab), C.c_uint32(V), dp(rd), dp(ok_new)))
+        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(V), dp(tab), C.c_uint32(V), dp(ok_old), None))
+        torch.cuda.synchronize()
+        want = np.stack([WANT] * n_commits)
+        want[n_commits // 2] = np.roll(WANT, 3)
+        got = ok_new.cpu().numpy().reshape(n_commits, V)
+        assert (got == want).all(), (n_commits, np.argwhere(got != want)[:5])
+        assert torch.equal(ok_new, ok_old), n_commits

@@ -105,37 +105,44 @@ def test_pipelined_engines_multi_step_vs_oracle(J, B, V, R, n_blocks):
     assert not res["range_status"].any() and not res["skip_status"].any()
 
 
-def test_alternating_pipelines_compact_only_vs_oracle():
-    """The compact-only leg's object: two single-chunk engine sets over the same ranges stepped in turn WITHOUT joins
-    (step i + 1 starts while step i's kernels drain), one-launch prove_subchain, no witness.  Public outputs, statuses, commit
-    results and per-job records of every range against the oracle, from both sets, with one tampered range."""
+@pytest.mark.parametrize("n_engines", [1, 2])
+def test_alternating_pipelines_compact_only_vs_oracle(n_engines):
+    """The compact-only leg's object: ONE bsx_pipeline with two buffer sets (bsx_pipeline_config.n_sets = 2; step i on set i mod 2)
+    stepped WITHOUT joins (step i + 1 starts while step i's kernels drain; a token serialises the header hashings), one-launch
+    prove_subchain, no witness.  Public outputs, statuses, commit results and per-job records of every range against the oracle,
+    after an odd and after an even number of steps (= from both sets), with one tampered range."""
     from blobstreamx_amd.engine import AlternatingPipelines
     J, B, V, R, n_blocks = 32, 64, 100, 4, 2048
     w = synth.Workload(4, R, J, B, v=V, n_blocks=n_blocks)
     w.headers[2, 700]["hash"][1][5] ^= 1
-    ap = AlternatingPipelines(2, J, B, V, R, n_engines=1, with_witness=False)
+    ap = AlternatingPipelines(2, J, B, V, R, n_engines=n_engines, with_witness=False)
     ap.upload_workload(w)
-    for _ in range(5):                                    # set 0 runs steps 0, 2, 4; set 1 runs 1, 3
-        ap.step()
-    ap.join()
-    for s in ap.sets:
-        res = s.download()
+    refs = []
+    for r in range(R):
+        rc, out, cres, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])
+        ctx = w.ranges[r:r + 1].copy()
+        ctx["end_header_hash"][0] = np.frombuffer(out[:32], np.uint8)
+        _, ref = oracle.prove_data_commitment(J, B, ctx, w.headers[r], int(w.first_height[r]), int(w.latest[r]))
+        refs.append((rc, out, cres, ref))
+    outs = []
+    for n_steps in (5, 2):                                # steps 0..4: the last ran on set 0; one more below, then steps 6, 7: set 1
+        for _ in range(n_steps):
+            ap.step()
+        res = ap.download()
+        outs.append(res)
         assert res["header_status"] == 0 and res["assemble_status"] == 0
         for r in range(R):
-            rc, out, cres, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
-                                                   w.validators[r], w.trusted[r])
+            rc, out, cres, ref = refs[r]
             mine = res["skip_status"][r] if res["skip_status"][r] else (T.ERR_ASSERT if res["range_status"][r] else T.OK)
             assert mine == rc, (r, mine, rc)
             assert res["output64"][r].tobytes() == out, r
             got = np.array(res["commit"][r]).copy(); got["_pad"] = 0
             want = np.array(cres).copy(); want["_pad"] = 0
             assert got.tobytes() == want.tobytes(), r
-            ctx = w.ranges[r:r + 1].copy()
-            ctx["end_header_hash"][0] = np.frombuffer(out[:32], np.uint8)
-            _, ref = oracle.prove_data_commitment(J, B, ctx, w.headers[r], int(w.first_height[r]), int(w.latest[r]))
             assert [_rec(x) for x in res["records"][r]] == [_rec(x) for x in ref["records"]], r
         assert res["range_status"][2] != 0 and not res["range_status"][[0, 1, 3]].any()
-    assert ap.download()["output64"].tobytes() == ap.sets[0].download()["output64"].tobytes()
+        ap.step()                                         # one more: the next download reads the OTHER set
+    assert outs[0]["output64"].tobytes() == outs[1]["output64"].tobytes()
 
 
 @pytest.mark.parametrize("ed_path,commit_with", [("generic", "expand"), ("keyed", "expand"), ("keyed", "hash"), ("generic", "hash")])
@@ -192,7 +199,7 @@ def test_sharded_engines_on_one_gpu(world, J, B, R, n_blocks, V, E):
             rc, ref_out, cres, _ = refs[g * R + k]
             assert rc == T.OK
             assert out["output64"][k].tobytes() == ref_out, (g, k)
-            assert out["range_status"][k] == 0 and out["skip_status"][k] == 0
+            assert out["range_status"][k] == 0 and out["skip_status"][k] == 0, (g, k, out["range_status"], out["skip_status"], out["commit"][k])
             got = np.array(out["commit"][k]).copy(); got["_pad"] = 0
             want = np.array(cres).copy(); want["_pad"] = 0
             assert got.tobytes() == want.tobytes(), (g, k)
