@@ -26,9 +26,25 @@ struct bsx_vmm_block {
     size_t size;
     hipMemGenericAllocationHandle_t handle;
 };
+// shape of a bsx_header_range request: everything its launch sequence depends on (a captured graph is replayed only for an
+// identical key, including the addresses the arena / staging / key table handed out)
+struct HrGraphKey {
+    uint32_t J, B, V, chain_id_len;
+    uint64_t hpr, span;
+    uint8_t chain_id[56];
+    void *arena_base, *hstage, *keytab;
+    size_t arena_cap;
+};
 struct bsx_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t stream3 = nullptr;       // host tier: work the commit check needs but need not wait for in line
+    hipEvent_t ev_d = nullptr;
+    bool graphs_enabled = false;         // BSX_TUNE_HOST_GRAPHS (off: ROCm 7.2 runs a graph's parallel branches one after the other)
+    bool hr_seen = false;                // the previous bsx_header_range request was graphable, with key hr_seen_key
+    HrGraphKey hr_seen_key{}, hr_key{};
+    hipGraphExec_t hr_exec = nullptr;    // captured launch sequence of bsx_header_range for hr_key
+    void* hr_d_headers = nullptr;        // where that sequence reads the range's headers
     hipStream_t stream2 = nullptr;       // host tier: the commit check of a header_range runs beside its hashing chain
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bsx_arena arena;

@@ -28,6 +28,7 @@ MAX_BATCH = 256
 OK, ERR_NO_DEVICE, ERR_HIP, ERR_BAD_ARG, ERR_RANGE_TOO_LONG, ERR_BAD_HEADER, ERR_ASSERT, ERR_BAD_SIGNATURE, \
     ERR_VOTING_POWER, ERR_UNSUPPORTED = range(10)
 TUNE_MERKLE_WORKGROUPS = 1      # bsx_set_tuning key (bsx.h)
+TUNE_HOST_GRAPHS = 2
 STATUS_NAMES = ["OK", "ERR_NO_DEVICE", "ERR_HIP", "ERR_BAD_ARG", "ERR_RANGE_TOO_LONG", "ERR_BAD_HEADER", "ERR_ASSERT",
                 "ERR_BAD_SIGNATURE", "ERR_VOTING_POWER", "ERR_UNSUPPORTED"]
 

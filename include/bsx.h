@@ -345,6 +345,12 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr);
  *   beside the hashing of the next (blobstreamx_amd/engine.py) sets 512 = 2 workgroups per CU, which leaves half of the
  *   register file to the expansion's waves: +2 % whole-step throughput on MI355X. */
 #define BSX_TUNE_MERKLE_WORKGROUPS 1u
+/* BSX_TUNE_HOST_GRAPHS (default 0): 1 = bsx_header_range captures its launch sequence into a hipGraph the second time a shape
+ *   (circuit sizes, range length, chain id) is requested and replays it from then on: one graph launch per proof request
+ *   instead of ~25 kernel launches and 8 event operations.  Off by default: measured on ROCm 7.2 / MI355X the replay takes
+ *   0.56 ms against 0.33 ms for the direct launches — the runtime executes the graph's three parallel branches (hashing chain,
+ *   commit check, R decoding + trusted tally) one after the other, so the request pays the SUM of the chains. */
+#define BSX_TUNE_HOST_GRAPHS 2u
 int bsx_set_tuning(bsx_ctx* ctx, uint32_t key, uint64_t value);
 
 /* P5: four lanes (of four waves) per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be

@@ -869,3 +869,45 @@ def test_status_priority_with_several_faults_matches_the_oracle():
     assert run(w, cid=b"mocha-4") == T.ERR_ASSERT                       # wrong chain id outranks the bad signature
     w.trusted[0, 0]["voting_power"] += 1
     assert run(w) == T.ERR_BAD_SIGNATURE                                # bad signature outranks the trusted-set hash
+
+
+def test_header_range_graph_replay_vs_oracle():
+    """bsx_header_range replays a captured hipGraph from the fourth request of a shape on (the request's bytes travel through
+    the staging block and the header buffer).  Twelve requests over different inputs of one shape — valid ranges, a broken chain,
+    a bad signature — then a different range length (new key: direct launches, new capture) and back, and the same sequence
+    with graphs disabled: every public output, status and commit result must be the oracle's."""
+    import ctypes as C
+    J, B, V, R = 4, 16, 10, 6
+    w = synth.Workload(77, R, J, B, v=V)
+    w.headers[2, 9]["hash"][1][5] ^= 1
+    w.validators[4, 3]["signature"][0] ^= 2
+    w2 = synth.Workload(78, 2, J, B, v=V, n_blocks=J * B - 7)
+    L = _lib.lib()
+
+    def one(ws, r):
+        S = int(ws.first_height[r])
+        want_rc, want_out, want_res, _ = oracle.header_range(J, B, ws.input48(r), ws.headers[r], S, int(ws.latest[r]), ws.validators[r], ws.trusted[r])
+        circ = CombinedSkipCircuit(V, J, B)
+        try:
+            out, res, _ = circ.prove(ws.input48(r), InputDataFetcher(ws.headers[r], S, int(ws.latest[r])), ws.validators[r], ws.trusted[r])
+            rc = T.OK
+            assert out == want_out, r
+            a, b = np.array(res).copy(), np.array(want_res).copy()
+            a["_pad"] = 0; b["_pad"] = 0
+            assert a.tobytes() == b.tobytes(), r
+        except _lib.BsxError as e:
+            rc = e.status
+        assert rc == want_rc, (r, rc, want_rc)
+        return rc
+
+    for graphs in (1, 0, 1):
+        _lib.check(L.bsx_set_tuning(_lib.context(0), C.c_uint32(T.TUNE_HOST_GRAPHS), C.c_uint64(graphs)))
+        seen = []
+        for i in range(12):
+            seen.append(one(w, i % R))
+        for i in range(5):
+            one(w2, i % 2)
+        for i in range(5):
+            seen.append(one(w, (i + 1) % R))
+        assert T.ERR_ASSERT in seen and T.ERR_BAD_SIGNATURE in seen and seen.count(T.OK) >= 8
+    _lib.check(L.bsx_set_tuning(_lib.context(0), C.c_uint32(T.TUNE_HOST_GRAPHS), C.c_uint64(1)))
