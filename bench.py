@@ -305,7 +305,7 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
                        "avg_launch_ms": t_ed, "traffic": None,
                        "field_ops_per_verification": {"mul": FE_MUL_PER_VERIFY, "sq": FE_SQ_PER_VERIFY},
                        "achieved_G_field_ops_per_s": ver_per_s * (FE_MUL_PER_VERIFY + FE_SQ_PER_VERIFY) / 1e9,
-                       "valu_issue": valu_issue(cal, "k_ed25519_verify_keyed", n, t_ed * 1e-3),
+                       "valu_issue": valu_issue(cal, "k_ed25519_verify_keyed<true, true, 4>" if n < 300000 else "k_ed25519_verify_keyed<true, true, 1>", n, t_ed * 1e-3),
                        "note": "peak = the time the kernel's GF(2^255-19) multiplications and squarings would take at the fe_mul / fe_sq "
                                f"rates measured in this run ({cal['fe25519_mul_per_s'] / 1e9:.0f} / {cal['fe25519_sq_per_s'] / 1e9:.0f} G/s); additions, "
                                "table selection, recoding and the launch's partial last wave round are what is left; ALU bound, bytes are "
