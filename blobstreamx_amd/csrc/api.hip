@@ -96,6 +96,7 @@ int bsx_init(int device, bsx_ctx** out) {
     e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_d, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_e, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming);
@@ -123,6 +124,7 @@ void bsx_shutdown(bsx_ctx* ctx) {
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_d) (void)hipEventDestroy(ctx->ev_d);
+    if (ctx->ev_e) (void)hipEventDestroy(ctx->ev_e);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
@@ -1068,8 +1070,9 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     uint8_t* tab = nullptr;
     RET(ctx_keytable(ctx, v_max, &tab, sb));
     if (tab) HIPCHK(bsxk_ed25519_decode_r(s3, dv.as<bsx_validator>(), v_max, drd.p));
+    HIPCHK(hipEventRecord(ctx->ev_d, s3));                              // the signature check waits for this ...
     HIPCHK(bsxk_commit_tally(s3, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
-    HIPCHK(hipEventRecord(ctx->ev_d, s3));
+    HIPCHK(hipEventRecord(ctx->ev_e, s3));                              // ... only the skip conditions for this
     const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
     HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
     if (tab) {
@@ -1082,6 +1085,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     }
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) from `st`
     HIPCHK(bsxk_commit_tally(sb, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_e, 0));
     HIPCHK(bsxk_skip_check(sb, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
                            dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth2.as<uint8_t>(), nullptr, chain_id, chain_id_len));

@@ -39,7 +39,7 @@ struct bsx_ctx {
     int device;
     hipStream_t stream;
     hipStream_t stream3 = nullptr;       // host tier: work the commit check needs but need not wait for in line
-    hipEvent_t ev_d = nullptr;
+    hipEvent_t ev_d = nullptr, ev_e = nullptr;
     bool graphs_enabled = false;         // BSX_TUNE_HOST_GRAPHS (off: ROCm 7.2 runs a graph's parallel branches one after the other)
     bool hr_seen = false;                // the previous bsx_header_range request was graphable, with key hr_seen_key
     HrGraphKey hr_seen_key{}, hr_key{};
