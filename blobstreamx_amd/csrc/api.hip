@@ -165,6 +165,7 @@ int bsx_reduce_witness_layout(bsx_witness_layout* out) {
 int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr) {
     DEV_ENTER();
     if (!out_ptr || !bytes) return fail(BSX_ERR_BAD_ARG, "bsx_dev_alloc: null out / zero size");
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mu);      // ctx->vmm (pipelines of several threads may share a context)
     *out_ptr = nullptr;
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
@@ -198,6 +199,7 @@ int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr) {
 
 int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
     DEV_ENTER();
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mu);
     for (size_t i = 0; i < ctx->vmm.size(); i++)
         if (ctx->vmm[i].va == ptr) {
             // the block stays registered until its teardown has succeeded: a failure here leaves it to bsx_shutdown

@@ -630,6 +630,8 @@ int bsx_calibrate(bsx_ctx* ctx, bsx_calibration* out);
  * them locally, ONE all-gather of a 128-byte record per (range, rank) per chunk, and the owner of a range (range index /
  * n_ranges) runs the last log2(world) reduce levels, the final assertions and that range's commit check.  The collective
  * itself is the caller's (RCCL ncclAllGather, torch.distributed, ... — INTEGRATION.md): see bsx_pipeline_set_allgather. */
+/* Threading: one pipeline = one caller at a time (its calls are not re-entrant); different pipelines — on one context or on
+ * several — may be driven by different threads concurrently. */
 typedef struct bsx_pipeline bsx_pipeline;
 
 #define BSX_PIPE_WITNESS 1u             /* materialise the Goldilocks witness (map jobs + reduce nodes) in HBM every step */

@@ -378,6 +378,13 @@ def test_rccl_all_gather_on_an_external_stream_world_1():
         "    after = recv.clone()                               # enqueued after the callback returned: must see the gathered data\n"
         "s.synchronize()\n"
         "assert torch.equal(after, send) and int(after[250]) == 250\n"
+        "# the pipeline's own buffers (library allocations, not torch's): the tensors the callback really sees at N > 1\n"
+        "from blobstreamx_amd import engine as E\n"
+        "pe = E.HeaderRangeEngine(2, 4, 4, 2, with_witness=False)\n"
+        "ps, pr = pe.buffer(0, E.BUF_PARTIAL), pe.buffer(0, E.BUF_GATHERED)\n"
+        "ps.copy_((torch.arange(ps.numel(), device=dev) % 199).to(torch.uint8)); pr.zero_(); torch.cuda.synchronize()\n"
+        "torch_allgather(dev, 1)(ps, pr, s.cuda_stream); s.synchronize()\n"
+        "assert torch.equal(ps, pr)\n"
         "f = all_gather_folds(send[:128], 1)\n"
         "assert f.shape == (1, 128) and torch.equal(f[0], send[:128])\n"
         "print('RCCL_WORLD1_OK', dist.get_backend())\n"
