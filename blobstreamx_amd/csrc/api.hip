@@ -306,7 +306,7 @@ int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_sha
                           uint64_t headers_per_range, const uint32_t* d_target_index, uint8_t* d_target_hashes, uint8_t* d_hashes_copy) {
     DEV_ENTER();
     if (!d_ranges || !d_hashes) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_fill_end_hash(S(ctx, stream), n_ranges, d_ranges, d_hashes, headers_per_range, d_target_index, d_target_hashes, d_hashes_copy));
+    HIPCHK(bsxk_fill_end_hash(S(ctx, stream), n_ranges, d_ranges, d_hashes, headers_per_range, d_target_index, d_target_hashes, d_hashes_copy, 0));
     return BSX_OK;
 }
 
@@ -1061,7 +1061,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     RET(dth.alloc(32));
     RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd, &io, capture));
     // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash (and the first output half)
-    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, dth.as<uint8_t>(), nullptr));
+    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, dth.as<uint8_t>(), nullptr, 0));
     RET(dh.alloc((size_t)v_max * 32));
     RET(dok.alloc(v_max));
     RET(dtres.alloc(sizeof(bsx_commit_result)));

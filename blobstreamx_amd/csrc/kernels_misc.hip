@@ -67,10 +67,14 @@ __global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_has
 }
 
 __global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
-                                const uint32_t* target_idx, uint8_t* target_out, uint8_t* hashes_copy) {
+                                const uint32_t* target_idx, uint8_t* target_out, uint8_t* hashes_copy, uint64_t first_rel) {
     const uint32_t r = blockIdx.x, t = threadIdx.x;   // 32 lanes
     if (r >= n_ranges) return;
-    const uint64_t idx = (uint64_t)r * hpr + (target_idx ? (uint64_t)target_idx[r] : ranges[r].end_block - ranges[r].start_block);
+    // first_rel: the range's header block starts at height S + first_rel (a rank that holds only its job slice): ranges whose
+    // target header lies outside the block keep their end hash (no slot of this rank's slice can be the range's last block)
+    const uint64_t rel = target_idx ? (uint64_t)target_idx[r] : ranges[r].end_block - ranges[r].start_block - first_rel;
+    if (!target_idx && (ranges[r].end_block - ranges[r].start_block < first_rel || rel >= hpr)) return;
+    const uint64_t idx = (uint64_t)r * hpr + rel;
     const uint8_t b = hashes[idx * 32 + t];
     ranges[r].end_header_hash[t] = b;
     if (target_out) target_out[(uint64_t)r * 32 + t] = b;   // dense copy for the commit tally / finalize
@@ -184,9 +188,9 @@ hipError_t bsxk_data_commitment(hipStream_t s, const uint8_t* data_hashes, uint3
     return hipGetLastError();
 }
 hipError_t bsxk_fill_end_hash(hipStream_t s, uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
-                              const uint32_t* target_idx, uint8_t* target_out, uint8_t* hashes_copy) {
+                              const uint32_t* target_idx, uint8_t* target_out, uint8_t* hashes_copy, uint64_t first_rel) {
     if (!n_ranges) return hipSuccess;
-    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr, target_idx, target_out, hashes_copy);
+    hipLaunchKernelGGL(k_fill_end_hash, dim3(n_ranges), dim3(32), 0, s, n_ranges, ranges, hashes, hpr, target_idx, target_out, hashes_copy, first_rel);
     return hipGetLastError();
 }
 }

@@ -306,7 +306,7 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
         if (c.commit_done_valid[c.parity]) HIPCHK(hipStreamWaitEvent(st, c.ev_commit_done[c.parity], 0));   // the check two steps ago read these
         uint8_t* skip_hashes = c.hashes_all + c.nh_main * 32;
         HIPCHK(bsxk_fill_end_hash(st, R, reinterpret_cast<bsx_shared_ctx*>(c.skip_ranges), skip_hashes, 2, c.target_idx, c.target_hashes_pp[c.parity],
-                                  c.skip_hashes_pp[c.parity]));
+                                  c.skip_hashes_pp[c.parity], 0));
         if (p->streaming)
             HIPCHK(hipMemcpyAsync(c.skip_headers_pp[c.parity], c.headers_all + c.nh_main * sizeof(bsx_header), (size_t)R * 2 * sizeof(bsx_header),
                                   hipMemcpyDeviceToDevice, st));
@@ -316,6 +316,9 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
             RET(commit_part(p, c, c.side, true, true));
         }
     }
+    // ctx.end_header_hash of every range := the hash of its target header (what builder.skip hands to prove_data_commitment,
+    // header_range.rs:42-55) wherever that header lies in this rank's slice: the caller's value is not trusted
+    HIPCHK(bsxk_fill_end_hash(st, RT, reinterpret_cast<bsx_shared_ctx*>(c.ranges), c.hashes_all, p->hpr, nullptr, nullptr, nullptr, p->hfr));
     HIPCHK(bsxk_assemble_inputs(st, RT, p->J, B, p->jf, jc, B, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), reinterpret_cast<const uint64_t*>(c.latest),
                                 reinterpret_cast<const bsx_header*>(c.headers_all), p->hpr, p->hfr, c.hashes_all, c.dh_aunts, c.lb_aunts, c.compact,
                                 c.status + 1, c.paths, p->ctx->zero_paths));
@@ -703,6 +706,7 @@ int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** 
     case BSX_PIPE_BUF_HASHES: q = c.hashes_all; n = c.nh_all * 32; break;
     case BSX_PIPE_BUF_DH_AUNTS: q = c.dh_aunts; n = c.nh_all * 128; break;
     case BSX_PIPE_BUF_LB_AUNTS: q = c.lb_aunts; n = c.nh_all * 128; break;
+    case BSX_PIPE_BUF_RANGES: q = p->with_commit && p->world == 1 ? c.skip_ranges : c.ranges; n = (uint64_t)(p->with_commit && p->world == 1 ? c.R : c.RT) * sizeof(bsx_shared_ctx); break;
     case BSX_PIPE_BUF_PATHS: q = c.paths; n = c.paths ? c.nh_all * BSX_HEADER_PATH_BYTES : 0; break;
     default: return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_buffer: unknown buffer %u", which);
     }

@@ -32,7 +32,7 @@ from . import types as T
 # bsx.h
 PIPE_WITNESS, PIPE_COMMIT, PIPE_CAPS, PIPE_ED_GENERIC, PIPE_COMMIT_BESIDE_HASH, PIPE_RECOMPUTE_PATHS = 1, 2, 4, 8, 16, 32
 (BUF_WITNESS_MAP, BUF_WITNESS_REDUCE_LOCAL, BUF_WITNESS_REDUCE_TOP, BUF_COMPACT, BUF_TREES, BUF_PARTIAL, BUF_HEADERS, BUF_RECORDS,
- BUF_GATHERED, BUF_REDUCE_COMPACT_LOCAL, BUF_HASHES, BUF_DH_AUNTS, BUF_LB_AUNTS, BUF_PATHS) = range(14)
+ BUF_GATHERED, BUF_REDUCE_COMPACT_LOCAL, BUF_HASHES, BUF_DH_AUNTS, BUF_LB_AUNTS, BUF_PATHS, BUF_RANGES) = range(15)
 
 
 class _Config(C.Structure):

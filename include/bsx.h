@@ -672,7 +672,11 @@ void bsx_pipeline_destroy(bsx_pipeline* p);
 typedef struct bsx_pipeline_inputs {
     const bsx_header* headers;          /* [world*n_ranges][headers_per_range]: header k of range r = height S_r + k */
     uint64_t headers_per_range;         /* >= nb_map_jobs*batch_size + 1 */
-    const bsx_shared_ctx* ranges;       /* [world*n_ranges] (start = trusted block / hash, end = target block; end hash ignored) */
+    const bsx_shared_ctx* ranges;       /* [world*n_ranges] start = trusted block / hash, end = target block.  end_header_hash: at world 1
+                                           ignored — every step sets it to the hash of the target header it has just hashed, as
+                                           builder.skip hands it to prove_data_commitment (header_range.rs:42-55); at world > 1 a
+                                           rank whose job slice does not contain the target header works with the caller's value
+                                           (the owner's final assertions reject a wrong one) */
     const uint64_t* latest;             /* [world*n_ranges] chain head the hint clamps against (input.rs:160-162) */
     const bsx_validator* target_validators;    /* [world*n_ranges][v_max] — only owned ranges are read (BSX_PIPE_COMMIT) */
     const bsx_validator* trusted_validators;   /* same */
@@ -722,6 +726,7 @@ int bsx_pipeline_get_results(bsx_pipeline* p, bsx_pipeline_results* out);
 #define BSX_PIPE_BUF_DH_AUNTS 11u            /* data_hash proof aunts, 128 B per header */
 #define BSX_PIPE_BUF_LB_AUNTS 12u            /* last_block_id proof aunts, 128 B per header */
 #define BSX_PIPE_BUF_PATHS 13u               /* BSX_HEADER_PATH_BYTES per header (absent with BSX_PIPE_RECOMPUTE_PATHS) */
+#define BSX_PIPE_BUF_RANGES 14u              /* bsx_shared_ctx of the chunk's ranges (end_header_hash filled by the step) */
 int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** out_d_ptr, uint64_t* out_bytes);
 
 /* Kernel timing with HIP events on the launch streams: when on, every step brackets prove_subchain, the map-job witness

@@ -391,3 +391,27 @@ def test_rccl_all_gather_on_an_external_stream_world_1():
         "dist.destroy_process_group()\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_WORLD1_OK nccl" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_pipeline_does_not_trust_the_callers_end_header_hash():
+    """ctx.end_header_hash is an OUTPUT of builder.skip (header_range.rs:42-55), not an input of the proof request: the pipeline
+    sets it from the target header it hashed.  Garbage in the uploaded ranges' end hashes must change nothing (world 1)."""
+    from blobstreamx_amd.engine import PipelinedEngines
+    J, B, V, R = 8, 32, 20, 4
+    w = synth.Workload(52, R, J, B, v=V, n_blocks=201)
+    good = w.ranges.copy()
+    w.ranges["end_header_hash"] = np.random.default_rng(1).integers(0, 256, size=w.ranges["end_header_hash"].shape, dtype=np.uint8)
+    for kw in (dict(with_witness=True), dict(with_witness=False, with_commit=False)):
+        pe = PipelinedEngines(J, B, V, R, n_engines=2, **kw)
+        pe.upload_workload(w)
+        pe.step(); pe.step()
+        res = pe.download()
+        assert not res["range_status"].any() and res["header_status"] == 0
+        for r in range(R):
+            rc, out, _, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])
+            assert rc == T.OK
+            if kw.get("with_commit", True):
+                assert res["output64"][r].tobytes() == out, r
+            else:
+                assert res["output64"][r, 32:].tobytes() == out[32:], r          # the commitment; no skip -> first half is ctx.end_header_hash
+                assert res["output64"][r, :32].tobytes() == bytes(good[r]["end_header_hash"]), r
