@@ -150,7 +150,8 @@ class Pipeline:
         self.R, self.E, self.Rc = n_ranges_local, n_chunks, n_ranges_local // n_chunks
         self.rank, self.world = rank, world
         self.RT = self.Rc * world                   # ranges per chunk
-        self.jf, self.jc = job_slice(nb_map_jobs, rank, world)
+        self.jc = nb_map_jobs // world if world else 0            # the library validates the shape (bsx_pipeline_create)
+        self.jf = rank * self.jc
         self.with_witness, self.with_commit, self.with_caps = with_witness, with_commit, with_caps
         self.dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.dev_index = self.dev.index if self.dev.index is not None else 0

@@ -415,3 +415,54 @@ def test_pipeline_does_not_trust_the_callers_end_header_hash():
             else:
                 assert res["output64"][r, 32:].tobytes() == out[32:], r          # the commitment; no skip -> first half is ctx.end_header_hash
                 assert res["output64"][r, :32].tobytes() == bytes(good[r]["end_header_hash"]), r
+
+
+def test_pipeline_argument_errors():
+    """bsx_pipeline_* report misuse with a status code and a message, never abort: bad shapes, unknown flags, a step before the
+    upload, a multi-GPU step without the all-gather callback, inputs that do not cover the rank's slice, a target outside the
+    supplied headers, unknown buffer ids."""
+    import ctypes as C
+    from blobstreamx_amd import _lib
+    from blobstreamx_amd import engine as E
+    with pytest.raises(_lib.BsxError) as e:
+        E.Pipeline(3, 8, 4, 2)                                         # NB_MAP_JOBS not a power of two
+    assert e.value.status == T.ERR_BAD_ARG
+    with pytest.raises(_lib.BsxError):
+        E.Pipeline(4, 8, 4, 3, n_chunks=2)                             # chunks do not divide the ranges
+    with pytest.raises(_lib.BsxError):
+        E.Pipeline(4, 8, 600, 2)                                       # v_max beyond what one tally workgroup folds
+    with pytest.raises(_lib.BsxError):
+        E.Pipeline(4, 8, 4, 2, subchain_form=9)
+    with pytest.raises(_lib.BsxError):
+        E.Pipeline(4, 8, 4, 2, rank=0, world=3)                        # world must divide the map jobs
+    with pytest.raises(_lib.BsxError):
+        E.Pipeline(4, 8, 4, 2, rank=2, world=2)                        # rank out of range
+    L = _lib.lib()
+    cfg = E._Config(4, 8, 4, 2, 1, 0, 1, 1 << 20, 0, 0, 0, (C.c_uint8 * 52)(), 0, 0, 1, 0)
+    h = C.c_void_p()
+    assert L.bsx_pipeline_create(_lib.context(0), C.byref(cfg), C.byref(h)) == T.ERR_BAD_ARG and b"unknown flags" in L.bsx_last_error()
+    p = E.Pipeline(4, 8, 4, 2)
+    with pytest.raises(_lib.BsxError) as e:
+        p.step()
+    assert "before bsx_pipeline_upload" in str(e.value)
+    w = synth.Workload(3, 2, 4, 8, v=4)
+    with pytest.raises(_lib.BsxError):
+        p.upload(w.headers[:, :20], w.ranges, w.latest, w.validators, w.trusted)      # 20 headers per range < J*B + 1
+    bad = w.ranges.copy()
+    bad["end_block"][1] = bad["start_block"][1] + 40                                  # target header beyond the 33 supplied
+    with pytest.raises(_lib.BsxError):
+        p.upload(w.headers, bad, w.latest, w.validators, w.trusted)
+    with pytest.raises(_lib.BsxError):
+        p.upload(w.headers, w.ranges, w.latest)                                       # BSX_PIPE_COMMIT needs the validator sets
+    with pytest.raises(_lib.BsxError):
+        p.buffer(0, 99)
+    with pytest.raises(_lib.BsxError):
+        p.buffer(5, E.BUF_COMPACT)
+    p.upload_workload(w)
+    p.step()
+    assert not p.download()["range_status"].any()
+    p2 = E.Pipeline(4, 8, 4, 1, rank=1, world=2)                                      # no process group: no callback registered
+    p2.upload_workload(synth.Workload(3, 2, 4, 8, v=4))
+    with pytest.raises(_lib.BsxError) as e:
+        p2.step()
+    assert "bsx_pipeline_set_allgather" in str(e.value)
