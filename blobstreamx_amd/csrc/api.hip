@@ -7,6 +7,7 @@
 // status words into bsx_status codes.  There is NO CPU compute path: without a GPU bsx_init fails.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -978,6 +979,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                      const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness) {
     HOST_ENTER();
+    const auto t_entry = std::chrono::steady_clock::now();
     if (!input48 || !headers || !target_validators || !trusted_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     if (!pow2(nb_map_jobs) || nb_map_jobs > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
@@ -1096,6 +1098,8 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     RET(run_data_commitment(ctx, st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, nullptr, nullptr, nullptr, witness, nullptr, &io));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_b, 0));
     HIPCHK(hipMemcpyAsync(io.h + io.out_off, io.dout(0), SmallIO::OUT_BYTES, hipMemcpyDeviceToHost, st));
+    static const bool trace_host = getenv("BSX_TRACE_HOST") != nullptr;       // experiments: host enqueue time vs wait for the GPU
+    const auto t_enq = std::chrono::steady_clock::now();
     if (capture) {
         hipGraph_t g = nullptr;
         cap_guard.active = false;
@@ -1110,6 +1114,9 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         HIPCHK(hipGraphLaunch(ctx->hr_exec, st));
     }
     SYNC();
+    if (trace_host)
+        fprintf(stderr, "bsx_header_range: enqueue %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(t_enq - t_entry).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count());
     }
     bsx_subchain result;
     bsx_commit_result cr;
