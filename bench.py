@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-autotune", action="store_true", help="keep the pipeline's default stream assignment")
     ap.add_argument("--ranges", type=int, default=256, help="header_range instances per GPU per step (R); with --scaling strong: in total")
     ap.add_argument("--jobs", type=int, default=32)
     ap.add_argument("--batch", type=int, default=64)
@@ -624,6 +625,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    # one-time, before the warm-up: which hardware queues the chunks' streams overlap best on (bsx_pipeline_autotune; real steps)
+    tune = eng.autotune(0) if not args.no_autotune else None
     for _ in range(args.warmup):
         eng.step()
     barrier()
@@ -672,7 +675,7 @@ def main():
                        "sharded_vs_unsharded_self_check_per_rank": self_check,
                        "witness_checked_ranges": n_checked,
                        "witness_bytes_per_step_per_gpu": int(Ech * n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
-                       "input_generation_s": round(t_gen, 2),
+                       "input_generation_s": round(t_gen, 2), "stream_autotune": tune,
                        "ed25519_path": p0.ed_path, "commit_beside": p0.commit_with, "memory_partition": memory_partition_mode()},
             "calibration": cal,
         }

@@ -9,6 +9,8 @@
 //
 // Host code only: buffer ownership, stream/event choreography, argument validation.  All arithmetic is in kernels_*.hip.
 // No environment variables, no Python, no torch: a Rust caller binds exactly this.
+#include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -22,6 +24,8 @@ using bsxapi::pow2;
 using bsxapi::use;
 
 namespace {
+
+constexpr size_t PIPE_POOL = 16;             // GPU_MAX_HW_QUEUES: more streams than that share queues anyway
 
 struct TimingSlot {
     hipEvent_t ev[6];       // prove_subchain [0,1], map expansion [2,3], Poseidon commitment [4,5]
@@ -77,6 +81,11 @@ struct bsx_pipeline {
     uint64_t tree_digests = 0;
     bsx_witness_layout ml{}, rl{};
     std::vector<Chunk> chunks;
+    // Every stream a chunk's hashing / expansion (main) and commit check (side) may run on, created AND used once at
+    // bsx_pipeline_create, in this order: HIP binds a stream to a hardware queue at its first command, and WHICH queues the hot
+    // streams sit on decides how well the chunks' phases overlap (bsx_pipeline_autotune)
+    std::vector<hipStream_t> pool;
+    std::vector<uint32_t> assign;            // pool index of chunk i's main (2 i) and side (2 i + 1) stream
     std::vector<void*> allocs;               // hipMalloc'ed blocks
     std::vector<void*> host_allocs;          // hipHostMalloc'ed blocks
     hipEvent_t hash_token = nullptr, expand_token = nullptr;     // aliases of a chunk's ev_hash_tok / ev_expand_tok
@@ -136,12 +145,11 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
     c.nh_main = (uint64_t)RT * p->hpr;
     c.nh_skip = p->with_commit ? (uint64_t)R * 2 : 0;
     c.nh_all = c.nh_main + c.nh_skip;
-    RET(new_stream(&c.main));
-    // BSX_PIPE_SIDE_PRIORITY=1 (experiment, off): the commit check's stream on a high-priority queue.  Measured: no effect on the
-    // compact step (369 vs 366 M headers/s), and beside an expansion it costs 12 % (78 vs 89 M headers/s: its waves then
-    // pre-empt the store stream's dispatch)
-    static const bool side_hi = getenv("BSX_PIPE_SIDE_PRIORITY") && atoi(getenv("BSX_PIPE_SIDE_PRIORITY")) == 1;
-    RET(new_stream(&c.side, side_hi));
+    {
+        const size_t idx = (size_t)(&c - p->chunks.data());
+        c.main = p->pool[p->assign[2 * idx]];
+        c.side = p->pool[p->assign[2 * idx + 1]];
+    }
     if (world > 1) RET(new_stream(&c.xchg));
     for (hipEvent_t* e : {&c.ev_sync, &c.ev_merkle, &c.ev_fill, &c.ev_fin, &c.ev_inputs_consumed, &c.ev_h2d, &c.ev_commit_done[0], &c.ev_commit_done[1],
                           &c.ev_hash_tok, &c.ev_expand_tok, &c.ev_x_in, &c.ev_x_out})
@@ -486,6 +494,23 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     }
     p->compact_tokens = !p->with_witness && (p->E > 1 || p->K > 1);
     p->chunks.resize((size_t)p->E * p->K);
+    {
+        const size_t hot = 2 * p->chunks.size();
+        const size_t n_pool = hot > PIPE_POOL ? hot : PIPE_POOL;
+        void* touch = nullptr;
+        if (hipMalloc(&touch, 256) != hipSuccess) { bsx_pipeline_destroy(p); return fail(BSX_ERR_HIP, "bsx_pipeline_create: out of device memory"); }
+        p->allocs.push_back(touch);
+        for (size_t i = 0; i < n_pool; i++) {
+            hipStream_t st = nullptr;
+            const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e != hipSuccess) { bsx_pipeline_destroy(p); return fail(BSX_ERR_HIP, "bsx_pipeline_create: hipStreamCreate: %s", hipGetErrorString(e)); }
+            p->pool.push_back(st);
+            (void)hipMemsetAsync(touch, 0, 256, st);                   // first command: binds the stream's hardware queue, in creation order
+            (void)hipStreamSynchronize(st);
+        }
+        p->assign.resize(hot);
+        for (size_t i = 0; i < hot; i++) p->assign[i] = (uint32_t)i;   // default: consecutive queues
+    }
     for (Chunk& c : p->chunks) {
         const int rc = create_chunk(p, c);
         if (rc != BSX_OK) {
@@ -512,7 +537,9 @@ void bsx_pipeline_destroy(bsx_pipeline* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     for (Chunk& c : p->chunks) {
-        for (hipStream_t s : {c.main, c.side, c.xchg, c.copy})
+        for (hipStream_t s : {c.main, c.side})
+            if (s) (void)hipStreamSynchronize(s);
+        for (hipStream_t s : {c.xchg, c.copy})
             if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
         for (hipEvent_t e : {c.ev_sync, c.ev_merkle, c.ev_fill, c.ev_fin, c.ev_inputs_consumed, c.ev_h2d, c.ev_commit_done[0], c.ev_commit_done[1],
                              c.ev_hash_tok, c.ev_expand_tok, c.ev_x_in, c.ev_x_out})
@@ -521,6 +548,7 @@ void bsx_pipeline_destroy(bsx_pipeline* p) {
             for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
         if (c.witness_map && c.witness_map_vmm) (void)bsx_dev_free(p->ctx, c.witness_map);
     }
+    for (hipStream_t st : p->pool) (void)hipStreamDestroy(st);
     for (void* q : p->allocs) (void)hipFree(q);
     for (void* q : p->host_allocs) (void)hipHostFree(q);
     delete p;
@@ -645,6 +673,70 @@ int bsx_pipeline_step(bsx_pipeline* p) {
         if (defer && commit_active(p, c) && !p->commit_beside_hash) p->pending_verify = &c;
         // the commit check is NOT joined here: its inputs are double-buffered by step parity, so it may run on into the
         // chunk's next step; bsx_pipeline_join / _get_results wait for it
+    }
+    return BSX_OK;
+}
+
+// Which hardware queues the chunks' streams sit on decides how well their phases overlap: the same pipeline measured 77 .. 98 M
+// headers/s (header_range_2048, two chunks, one box) by nothing but the position of its four hot streams among the process's
+// queues — the command processor serves queues that share a dispatch pipe one kernel at a time, and a kernel with more
+// workgroups than the GPU holds (every large launch here) keeps its pipe busy for its whole duration.  The mapping of HSA
+// queues to pipes is the driver's, so it is measured: every candidate assignment of pool streams (consecutive quartets at each
+// offset, mains-then-sides at each offset) runs `steps_per_trial` real steps; the fastest stays.
+int bsx_pipeline_autotune(bsx_pipeline* p, uint32_t steps_per_trial, bsx_pipeline_autotune_result* out) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    RET(use(p->ctx));
+    if (!p->uploaded) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_autotune before bsx_pipeline_upload");
+    const bool auto_steps = steps_per_trial == 0;
+    const size_t nc = p->chunks.size(), hot = 2 * nc, P = p->pool.size();
+    std::vector<std::vector<uint32_t>> cand;
+    cand.push_back(p->assign);                                        // trial 0: what the pipeline was created with
+    for (size_t base = 0; base + hot <= P; base++)
+        for (int pattern = 0; pattern < 2; pattern++) {
+            std::vector<uint32_t> a(hot);
+            for (size_t i = 0; i < nc; i++) {
+                a[2 * i] = (uint32_t)(base + (pattern ? i : 2 * i));
+                a[2 * i + 1] = (uint32_t)(base + (pattern ? nc + i : 2 * i + 1));
+            }
+            if (std::find(cand.begin(), cand.end(), a) == cand.end()) cand.push_back(a);
+        }
+    auto apply = [&](const std::vector<uint32_t>& a) {
+        p->assign = a;
+        for (size_t i = 0; i < nc; i++) { p->chunks[i].main = p->pool[a[2 * i]]; p->chunks[i].side = p->pool[a[2 * i + 1]]; }
+    };
+    const bool timing_was = p->timing_on;
+    p->timing_on = false;
+    double best_ms = 1e30, worst_ms = 0, first_ms = 0;
+    size_t best = 0;
+    for (size_t t = 0; t < cand.size(); t++) {
+        RET(join_impl(p));                                            // streams are swapped only while nothing is in flight
+        apply(cand[t]);
+        const auto tw = std::chrono::steady_clock::now();
+        RET(bsx_pipeline_step(p));                                    // one untimed step: first launches on these queues
+        RET(join_impl(p));
+        if (auto_steps && t == 0) {                                   // ~20 ms of steps per trial, 3 .. 32
+            const double one = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+            const double want = 20.0 / (one > 0.05 ? one : 0.05);
+            steps_per_trial = want < 3 ? 3 : want > 32 ? 32 : (uint32_t)want;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t k = 0; k < steps_per_trial; k++) RET(bsx_pipeline_step(p));
+        RET(join_impl(p));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps_per_trial;
+        if (t == 0) first_ms = ms;
+        if (ms < best_ms) { best_ms = ms; best = t; }
+        if (ms > worst_ms) worst_ms = ms;
+    }
+    apply(cand[best]);
+    p->timing_on = timing_was;
+    for (Chunk& c : p->chunks) c.timing_used = 0;
+    if (out) {
+        memset(out, 0, sizeof *out);
+        out->n_trials = (uint32_t)cand.size();
+        out->best_trial = (uint32_t)best;
+        out->steps_per_trial = steps_per_trial;
+        out->initial_ms = first_ms; out->best_ms = best_ms; out->worst_ms = worst_ms;
+        for (size_t i = 0; i < hot && i < 16; i++) out->assignment[i] = cand[best][i];
     }
     return BSX_OK;
 }

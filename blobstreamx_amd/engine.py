@@ -57,6 +57,12 @@ class _Timing(C.Structure):
                 ("_pad", C.c_uint32)]
 
 
+class _Autotune(C.Structure):
+    _fields_ = [("n_trials", C.c_uint32), ("best_trial", C.c_uint32), ("steps_per_trial", C.c_uint32), ("_pad", C.c_uint32),
+                ("initial_ms", C.c_double), ("best_ms", C.c_double), ("worst_ms", C.c_double), ("assignment", C.c_uint32 * 16)]
+
+
+assert C.sizeof(_Autotune) == 104
 assert C.sizeof(_Config) == 112 and C.sizeof(_Inputs) == 48 and C.sizeof(_Results) == 48 and C.sizeof(_Timing) == 32
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
@@ -240,6 +246,13 @@ class Pipeline:
 
     def join(self):
         _lib.check(self.L.bsx_pipeline_join(self._h))
+
+    def autotune(self, steps_per_trial=0):
+        """bsx_pipeline_autotune: measure which hardware queues the chunks' streams overlap best on; keeps the fastest."""
+        r = _Autotune()
+        _lib.check(self.L.bsx_pipeline_autotune(self._h, C.c_uint32(steps_per_trial), C.byref(r)))
+        return {"n_trials": r.n_trials, "best_trial": r.best_trial, "steps_per_trial": r.steps_per_trial, "initial_ms": r.initial_ms,
+                "best_ms": r.best_ms, "worst_ms": r.worst_ms, "assignment": list(r.assignment)[:2 * self.E * getattr(self, "K", 1)]}
 
     def set_timing(self, on=True):
         _lib.check(self.L.bsx_pipeline_set_timing(self._h, C.c_int(1 if on else 0)))

@@ -687,6 +687,20 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in);
  * overlapped with the previous step's compute (a caller whose inputs are not resident).  Call after bsx_pipeline_upload. */
 int bsx_pipeline_enable_input_streaming(bsx_pipeline* p, int on);
 
+/* One-time tuning of WHERE the pipeline's streams run.  HIP binds a stream to a hardware queue; queues that share a dispatch pipe
+ * of the command processor are served one kernel at a time, and which queues share is the driver's business — measured on
+ * MI355X the same pipeline runs at 77 .. 98 M headers/s by nothing but the position of its four hot streams among the process's
+ * queues.  The pipeline therefore owns a pool of 16 streams (bound to their queues in creation order at bsx_pipeline_create) and
+ * this call times every candidate assignment with `steps_per_trial` (0 = about 20 ms worth, 3 .. 32) real steps each — results stay valid, steps are
+ * steps — and keeps the fastest (~0.5 s at the bench shape).  Optional; without it the first streams of the pool are used.
+ * Call after bsx_pipeline_upload. */
+typedef struct bsx_pipeline_autotune_result {
+    uint32_t n_trials, best_trial, steps_per_trial, _pad;
+    double initial_ms, best_ms, worst_ms;      /* per step: the assignment the pipeline had, the one it keeps, the slowest tried */
+    uint32_t assignment[16];                   /* pool index of chunk i's main (2 i) and side (2 i + 1) stream */
+} bsx_pipeline_autotune_result;                /* sizeof == 104 */
+int bsx_pipeline_autotune(bsx_pipeline* p, uint32_t steps_per_trial, bsx_pipeline_autotune_result* out);
+
 /* Enqueue one step over all chunks; returns without waiting.  Steps may be issued back to back. */
 int bsx_pipeline_step(bsx_pipeline* p);
 /* Block until everything enqueued has finished (also launches commit checks still deferred). */

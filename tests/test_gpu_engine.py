@@ -417,6 +417,38 @@ def test_pipeline_does_not_trust_the_callers_end_header_hash():
                 assert res["output64"][r, :32].tobytes() == bytes(good[r]["end_header_hash"]), r
 
 
+@pytest.mark.parametrize("J,B,V,R,n_engines,n_sets,witness", [(8, 32, 20, 4, 2, 1, True), (32, 64, 100, 2, 2, 1, True), (8, 32, 20, 3, 1, 3, False)])
+def test_pipeline_autotune_keeps_results(J, B, V, R, n_engines, n_sets, witness):
+    """bsx_pipeline_autotune moves the chunks' main / side streams over the pipeline's stream pool between joined trials: the
+    steps it runs are real steps, so after it (and after further un-joined steps on the assignment it kept) every range must
+    still equal the oracle's, tampered range included; it fails before an upload."""
+    from blobstreamx_amd import _lib
+    from blobstreamx_amd.engine import Pipeline
+    w = synth.Workload(7, R, J, B, v=V)
+    w.validators[R - 1, 2]["signature"][3] ^= 4
+    p = Pipeline(J, B, V, R, n_chunks=n_engines, n_sets=n_sets, with_witness=witness)
+    with pytest.raises(_lib.BsxError) as e:
+        p.autotune()
+    assert "before bsx_pipeline_upload" in str(e.value)
+    p.upload_workload(w)
+    p.step()
+    tune = p.autotune(2)
+    hot = 2 * n_engines * n_sets
+    assert tune["n_trials"] == 2 * (17 - hot) and tune["best_ms"] <= tune["initial_ms"] <= tune["worst_ms"]
+    assert len(set(tune["assignment"])) == hot and max(tune["assignment"]) < 16
+    for _ in range(3):
+        p.step()
+    if witness:
+        res = _check_pipelined_against_oracle(p, w, J, B)
+    else:
+        res = p.download()
+        for r in range(R):
+            rc, out, _, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])
+            mine = res["skip_status"][r] if res["skip_status"][r] else (T.ERR_ASSERT if res["range_status"][r] else T.OK)
+            assert mine == rc and res["output64"][r].tobytes() == out, r
+    assert res["skip_status"][R - 1] == T.ERR_BAD_SIGNATURE and not res["skip_status"][:R - 1].any()
+
+
 def test_pipeline_argument_errors():
     """bsx_pipeline_* report misuse with a status code and a message, never abort: bad shapes, unknown flags, a step before the
     upload, a multi-GPU step without the all-gather callback, inputs that do not cover the rank's slice, a target outside the
