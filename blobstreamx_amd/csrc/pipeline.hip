@@ -706,26 +706,42 @@ int bsx_pipeline_autotune(bsx_pipeline* p, uint32_t steps_per_trial, bsx_pipelin
     };
     const bool timing_was = p->timing_on;
     p->timing_on = false;
-    double best_ms = 1e30, worst_ms = 0, first_ms = 0;
-    size_t best = 0;
-    for (size_t t = 0; t < cand.size(); t++) {
-        RET(join_impl(p));                                            // streams are swapped only while nothing is in flight
-        apply(cand[t]);
-        const auto tw = std::chrono::steady_clock::now();
-        RET(bsx_pipeline_step(p));                                    // one untimed step: first launches on these queues
-        RET(join_impl(p));
-        if (auto_steps && t == 0) {                                   // ~20 ms of steps per trial, 3 .. 32
-            const double one = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-            const double want = 20.0 / (one > 0.05 ? one : 0.05);
-            steps_per_trial = want < 3 ? 3 : want > 32 ? 32 : (uint32_t)want;
-        }
+    int rc = BSX_OK;
+    // `n` steps on assignment `a`, joined on both sides; ms per step (< 0: a step failed, rc holds the status)
+    auto run = [&](const std::vector<uint32_t>& a, uint32_t n) -> double {
+        if ((rc = join_impl(p)) != BSX_OK) return -1;                 // streams are swapped only while nothing is in flight
+        apply(a);
+        if ((rc = bsx_pipeline_step(p)) != BSX_OK || (rc = join_impl(p)) != BSX_OK) return -1;   // untimed: first launches on these queues
         const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t k = 0; k < steps_per_trial; k++) RET(bsx_pipeline_step(p));
-        RET(join_impl(p));
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps_per_trial;
-        if (t == 0) first_ms = ms;
-        if (ms < best_ms) { best_ms = ms; best = t; }
-        if (ms > worst_ms) worst_ms = ms;
+        for (uint32_t k = 0; k < n; k++)
+            if ((rc = bsx_pipeline_step(p)) != BSX_OK) return -1;
+        if ((rc = join_impl(p)) != BSX_OK) return -1;
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
+    };
+    std::vector<double> ms(cand.size(), 0.0);
+    double worst_ms = 0;
+    if (auto_steps) {                                                 // ~20 ms of steps per trial, 3 .. 32
+        const double one = run(cand[0], 3);                           // also the warm-up of the whole exercise
+        if (one < 0) { p->timing_on = timing_was; return rc; }
+        const double want = 20.0 / (one > 0.05 ? one : 0.05);
+        steps_per_trial = want < 3 ? 3 : want > 32 ? 32 : (uint32_t)want;
+    }
+    for (size_t t = 0; t < cand.size(); t++) {
+        ms[t] = run(cand[t], steps_per_trial);
+        if (ms[t] < 0) { p->timing_on = timing_was; return rc; }
+        if (ms[t] > worst_ms) worst_ms = ms[t];
+    }
+    // the three fastest once more, twice as long: a trial is short, and the winner's margin is often within its noise
+    std::vector<size_t> order(cand.size());
+    for (size_t t = 0; t < order.size(); t++) order[t] = t;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return ms[x] < ms[y]; });
+    const double first_ms = ms[0];
+    size_t best = order[0];
+    double best_ms = 1e30;
+    for (size_t k = 0; k < 3 && k < order.size(); k++) {
+        const double m = run(cand[order[k]], 2 * steps_per_trial);
+        if (m < 0) { p->timing_on = timing_was; return rc; }
+        if (m < best_ms) { best_ms = m; best = order[k]; }
     }
     apply(cand[best]);
     p->timing_on = timing_was;

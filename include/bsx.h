@@ -696,7 +696,8 @@ int bsx_pipeline_enable_input_streaming(bsx_pipeline* p, int on);
  * Call after bsx_pipeline_upload. */
 typedef struct bsx_pipeline_autotune_result {
     uint32_t n_trials, best_trial, steps_per_trial, _pad;
-    double initial_ms, best_ms, worst_ms;      /* per step: the assignment the pipeline had, the one it keeps, the slowest tried */
+    double initial_ms, best_ms, worst_ms;      /* per step: the assignment the pipeline had, the one it keeps (re-timed twice as long
+                                                  with the two runners-up), the slowest tried */
     uint32_t assignment[16];                   /* pool index of chunk i's main (2 i) and side (2 i + 1) stream */
 } bsx_pipeline_autotune_result;                /* sizeof == 104 */
 int bsx_pipeline_autotune(bsx_pipeline* p, uint32_t steps_per_trial, bsx_pipeline_autotune_result* out);

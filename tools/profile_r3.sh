@@ -6,7 +6,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3prof; mkdir -p $O
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
-HEAD="python bench.py --no-legs --steps 10 --warmup 2"
+HEAD="python bench.py --no-legs --no-autotune --steps 10 --warmup 2"   # traced runs keep the default stream assignment: the autotune trials would sit in the trace
 kt() { find $1 -name "*kernel_trace.csv" | head -1; }
 # 1. kernel trace + stats of the headline command
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- $HEAD > $O/kt.log 2>&1
@@ -15,12 +15,12 @@ cp $(find $O/kt -name "bench_kernel_stats.csv" | head -1) $O/r3_rocprofv3_kernel
 python tools/timeline2.py $(kt $O/kt) > $O/r3_timeline_steady_state.txt
 # 2. HBM traffic PMC passes (separate runs)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o bench -- python bench.py --no-legs --steps 3 --warmup 1 > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o bench -- python bench.py --no-legs --no-autotune --steps 3 --warmup 1 > $O/pmc_$c.log 2>&1
 done
 python tools/pmc_summary.py $(find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE -name "*counter_collection.csv") > $O/r3_pmc_hbm_traffic.csv
-echo '{"jobs_per_launch": 4096, "batch": 64, "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-legs --steps 3 --warmup 1"}' > $O/r3_pmc_hbm_traffic.meta.json
+echo '{"jobs_per_launch": 4096, "batch": 64, "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-legs --no-autotune --steps 3 --warmup 1"}' > $O/r3_pmc_hbm_traffic.meta.json
 # 3. SQ counters of the headline
-rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmcSQ -o bench -- python bench.py --no-legs --steps 3 --warmup 1 > $O/pmcSQ.log 2>&1
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmcSQ -o bench -- python bench.py --no-legs --no-autotune --steps 3 --warmup 1 > $O/pmcSQ.log 2>&1
 python tools/pmc_summary.py $(find $O/pmcSQ -name "*counter_collection.csv") > $O/r3_pmc_sq.csv
 # 4. mode S (2048 x 512 and 2048 x 100): kernel trace + SQ counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktS -o bench -- python bench.py --mode S --validators 512 --cpu-seconds 1 > $O/ktS.log 2>&1
@@ -35,7 +35,7 @@ python tools/kernel_avg.py $(kt $O/ktP) > $O/r3_poseidon_kernel_avg.txt
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmcP -o bench -- python tools/poseidon_bench.py 8 > $O/pmcP.log 2>&1
 python tools/pmc_summary.py $(find $O/pmcP -name "*counter_collection.csv") > $O/r3_poseidon_pmc_sq.csv
 # 6. compact-only pipeline (3 buffer sets): kernel averages + timeline
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktC -o bench -- python bench.py --no-legs --no-witness --engines 1 --alternate 3 --steps 12 --warmup 2 > $O/ktC.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktC -o bench -- python bench.py --no-legs --no-autotune --no-witness --engines 1 --alternate 3 --steps 12 --warmup 2 > $O/ktC.log 2>&1
 python tools/kernel_avg.py $(kt $O/ktC) > $O/r3_compact_kernel_avg_steady_state.txt
 python tools/timeline3.py $(kt $O/ktC) 6 2 > $O/r3_compact_timeline.txt
 # 7. one host-tier call (bsx_header_range)
