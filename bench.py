@@ -371,12 +371,13 @@ def latency_leg(dev, J, B, V):
     return out
 
 
-def upload_leg(eng, args, steps):
+def upload_leg(eng, args, steps, tune_streams=True):
     """The headline step with the header block (headers + skip headers, 512 B each) streamed from pinned host memory EVERY
     step on a copy stream inside the library (bsx_pipeline_enable_input_streaming), overlapped with the previous step's
     compute: the PCIe-inclusive rate of a caller whose inputs are not resident."""
     from blobstreamx_amd import engine as E
     eng.enable_input_streaming(True)
+    tune = eng.autotune(0) if tune_streams else None        # the copy streams take queues too: place the chunks' streams for THIS mode
     for _ in range(2):
         eng.step()
     eng.join()
@@ -389,6 +390,7 @@ def upload_leg(eng, args, steps):
     nbytes = sum(eng.buffer(e, E.BUF_HEADERS).numel() for e in range(eng.E))
     return {"value": eng.R * args.jobs * args.batch / dt, "unit": "headers/s", "ms_per_step": dt * 1e3, "steps": steps,
             "h2d_bytes_per_step": nbytes, "h2d_GBps": nbytes / dt / 1e9,
+            "stream_autotune": tune,
             "note": "inputs streamed H2D from pinned memory on a copy stream each step, overlapped with compute; the witness stays on the device"}
 
 
