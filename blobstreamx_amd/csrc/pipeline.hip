@@ -86,6 +86,7 @@ struct bsx_pipeline {
     // streams sit on decides how well the chunks' phases overlap (bsx_pipeline_autotune)
     std::vector<hipStream_t> pool;
     std::vector<uint32_t> assign;            // pool index of chunk i's main (2 i) and side (2 i + 1) stream
+    uint8_t* touch = nullptr;                // 256 B the pool's first commands write + 8 B per rank (autotune's agreement on a step count)
     std::vector<void*> allocs;               // hipMalloc'ed blocks
     std::vector<void*> host_allocs;          // hipHostMalloc'ed blocks
     hipEvent_t hash_token = nullptr, expand_token = nullptr;     // aliases of a chunk's ev_hash_tok / ev_expand_tok
@@ -498,8 +499,9 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
         const size_t hot = 2 * p->chunks.size();
         const size_t n_pool = hot > PIPE_POOL ? hot : PIPE_POOL;
         void* touch = nullptr;
-        if (hipMalloc(&touch, 256) != hipSuccess) { bsx_pipeline_destroy(p); return fail(BSX_ERR_HIP, "bsx_pipeline_create: out of device memory"); }
+        if (hipMalloc(&touch, 256 + 8 * (size_t)world) != hipSuccess) { bsx_pipeline_destroy(p); return fail(BSX_ERR_HIP, "bsx_pipeline_create: out of device memory"); }
         p->allocs.push_back(touch);
+        p->touch = static_cast<uint8_t*>(touch);
         for (size_t i = 0; i < n_pool; i++) {
             hipStream_t st = nullptr;
             const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -687,6 +689,7 @@ int bsx_pipeline_autotune(bsx_pipeline* p, uint32_t steps_per_trial, bsx_pipelin
     if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
     RET(use(p->ctx));
     if (!p->uploaded) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_autotune before bsx_pipeline_upload");
+    if (p->world > 1 && !p->allgather) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline: world > 1 needs bsx_pipeline_set_allgather before bsx_pipeline_autotune");
     const bool auto_steps = steps_per_trial == 0;
     const size_t nc = p->chunks.size(), hot = 2 * nc, P = p->pool.size();
     std::vector<std::vector<uint32_t>> cand;
@@ -725,6 +728,24 @@ int bsx_pipeline_autotune(bsx_pipeline* p, uint32_t steps_per_trial, bsx_pipelin
         if (one < 0) { p->timing_on = timing_was; return rc; }
         const double want = 20.0 / (one > 0.05 ? one : 0.05);
         steps_per_trial = want < 3 ? 3 : want > 32 ? 32 : (uint32_t)want;
+        if (p->world > 1) {
+            // every step holds a collective: all ranks must run the SAME number of steps.  Agree on the smallest count through
+            // the caller's own all-gather (8 bytes per rank)
+            uint64_t mine = steps_per_trial;
+            std::vector<uint64_t> all(p->world);
+            hipStream_t xs = p->chunks[0].xchg;
+            hipError_t e = hipMemcpyAsync(p->touch, &mine, 8, hipMemcpyHostToDevice, xs);
+            if (e == hipSuccess) e = hipStreamSynchronize(xs);
+            if (e != hipSuccess) { p->timing_on = timing_was; return fail(BSX_ERR_HIP, "bsx_pipeline_autotune: %s", hipGetErrorString(e)); }
+            if (p->allgather(p->allgather_user, p->touch, p->touch + 256, 8, xs) != 0) {
+                p->timing_on = timing_was;
+                return fail(BSX_ERR_HIP, "bsx_pipeline_autotune: the all-gather callback failed");
+            }
+            e = hipStreamSynchronize(xs);
+            if (e == hipSuccess) e = hipMemcpy(all.data(), p->touch + 256, 8 * (size_t)p->world, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { p->timing_on = timing_was; return fail(BSX_ERR_HIP, "bsx_pipeline_autotune: %s", hipGetErrorString(e)); }
+            for (uint64_t v : all) if (v >= 1 && v < steps_per_trial) steps_per_trial = (uint32_t)v;
+        }
     }
     for (size_t t = 0; t < cand.size(); t++) {
         ms[t] = run(cand[t], steps_per_trial);

@@ -692,8 +692,10 @@ int bsx_pipeline_enable_input_streaming(bsx_pipeline* p, int on);
  * MI355X the same pipeline runs at 77 .. 98 M headers/s by nothing but the position of its four hot streams among the process's
  * queues.  The pipeline therefore owns a pool of 16 streams (bound to their queues in creation order at bsx_pipeline_create) and
  * this call times every candidate assignment with `steps_per_trial` (0 = about 20 ms worth, 3 .. 32) real steps each — results stay valid, steps are
- * steps — and keeps the fastest (~0.5 s at the bench shape).  Optional; without it the first streams of the pool are used.
- * Call after bsx_pipeline_upload. */
+ * steps — and keeps the fastest (~0.7 s at the bench shape).  Optional; without it the first streams of the pool are used.
+ * Call after bsx_pipeline_upload.  With world > 1 it is COLLECTIVE: every rank calls it (each step holds the all-gather); the
+ * ranks run the same number of steps (with steps_per_trial 0 they agree on one through the all-gather callback) and each keeps
+ * its own best assignment. */
 typedef struct bsx_pipeline_autotune_result {
     uint32_t n_trials, best_trial, steps_per_trial, _pad;
     double initial_ms, best_ms, worst_ms;      /* per step: the assignment the pipeline had, the one it keeps (re-timed twice as long

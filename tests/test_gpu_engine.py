@@ -244,6 +244,8 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["ranges_per_gpu"] == 8 and d["config"]["headers_per_step"] == 2 * 8 * 2048
+    # bsx_pipeline_autotune ran as a collective: both ranks agreed on the steps per trial through the all-gather callback
+    assert d["config"]["stream_autotune"]["n_trials"] == 26 and d["config"]["stream_autotune"]["steps_per_trial"] >= 3
 
 
 def test_expansion_kernel_variants_agree():
