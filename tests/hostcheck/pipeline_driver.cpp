@@ -57,6 +57,9 @@ int main(int argc, char** argv) {
     in.headers = headers.data(); in.headers_per_range = HPR; in.ranges = ranges.data(); in.latest = latest.data();
     in.target_validators = tv.data(); in.trusted_validators = rv.data();
     if (bsx_pipeline_upload(p, &in) != BSX_OK) { fprintf(stderr, "bsx_pipeline_upload: %s\n", bsx_last_error()); return 3; }
+    bsx_pipeline_autotune_result tune;
+    if (bsx_pipeline_autotune(p, 2, &tune) != BSX_OK) { fprintf(stderr, "bsx_pipeline_autotune: %s\n", bsx_last_error()); return 3; }
+    fprintf(stderr, "autotune: %u placements tried, %.3f -> %.3f ms per step\n", tune.n_trials, tune.initial_ms, tune.best_ms);
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t s = 0; s < h.steps; s++)
         if (bsx_pipeline_step(p) != BSX_OK) { fprintf(stderr, "bsx_pipeline_step: %s\n", bsx_last_error()); return 3; }
