@@ -24,7 +24,7 @@ SYMBOLS = [
     "bsx_encode_data_root_tuple", "bsx_get_data_commitment", "bsx_header_hashes", "bsx_data_commitment_inputs",
     "bsx_prove_subchain", "bsx_reduce", "bsx_prove_data_commitment", "bsx_prove_next_header_data_commitment",
     "bsx_verify_commits", "bsx_header_range", "bsx_next_header",
-    "bsx_dev_alloc", "bsx_dev_free", "bsx_set_tuning", "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_reduce_strided", "bsx_dev_finalize",
+    "bsx_dev_alloc", "bsx_dev_free", "bsx_set_tuning", "bsx_trim", "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_reduce_strided", "bsx_dev_finalize",
     "bsx_dev_expand_witness", "bsx_dev_fill_end_hash", "bsx_dev_sha512_challenge", "bsx_dev_ed25519_verify",
     "bsx_dev_commit_tally", "bsx_dev_skip_check",
     "bsx_ed25519_keytable_bytes", "bsx_dev_ed25519_keytable", "bsx_dev_ed25519_verify_keyed", "bsx_ed25519_verify_scratch_bytes",

@@ -215,6 +215,21 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
     return fail(BSX_ERR_BAD_ARG, "bsx_dev_free: pointer was not returned by bsx_dev_alloc on this context");
 }
 
+int bsx_trim(bsx_ctx* ctx, uint64_t* freed_bytes) {
+    if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mu);
+    RET(use(ctx));
+    if (ctx->arena.depth) return fail(BSX_ERR_BAD_ARG, "bsx_trim inside a host-tier call");
+    HIPCHK(hipDeviceSynchronize());
+    uint64_t freed = 0;
+    if (ctx->hr_exec) { (void)hipGraphExecDestroy(ctx->hr_exec); ctx->hr_exec = nullptr; }   // it holds arena / key-table addresses
+    ctx->hr_seen = false;
+    if (ctx->arena.base) { freed += ctx->arena.cap; (void)hipFree(ctx->arena.base); ctx->arena.base = nullptr; ctx->arena.cap = 0; }
+    if (ctx->keytab) { freed += bsxk_keytable_bytes(ctx->keytab_rows); (void)hipFree(ctx->keytab); ctx->keytab = nullptr; ctx->keytab_rows = 0; }
+    if (freed_bytes) *freed_bytes = freed;
+    return BSX_OK;
+}
+
 int bsx_set_tuning(bsx_ctx* ctx, uint32_t key, uint64_t value) {
     if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");
     switch (key) {

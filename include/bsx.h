@@ -353,6 +353,12 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr);
 #define BSX_TUNE_HOST_GRAPHS 2u
 int bsx_set_tuning(bsx_ctx* ctx, uint32_t key, uint64_t value);
 
+/* Give back what the host tier keeps between calls: the scratch arena (grown to the largest call seen, e.g. 115 MB after a
+ * witness download), the persistent fixed-key Ed25519 table (5.8 MB per validator slot) and a captured launch graph.  The next
+ * host-tier call re-creates what it needs (one cold key-table build, ~2 ms at V = 100).  Waits for the device.  Returns the
+ * bytes of device memory released in *freed_bytes (may be NULL). */
+int bsx_trim(bsx_ctx* ctx, uint64_t* freed_bytes);
+
 /* P5: four lanes (of four waves) per header. d_hashes n*32; d_dh_aunts / d_lb_aunts n*128 (4 aunts, leaf-adjacent first); any may be
  * NULL.  d_status (1 u32, optional): bit0 = a header violates the field-size rules.
  * d_paths (optional, n * BSX_HEADER_PATH_BYTES): the 7 distinct digests of the two inclusion-proof paths of each header

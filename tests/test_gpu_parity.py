@@ -911,3 +911,36 @@ def test_header_range_graph_replay_vs_oracle():
             seen.append(one(w, (i + 1) % R))
         assert T.ERR_ASSERT in seen and T.ERR_BAD_SIGNATURE in seen and seen.count(T.OK) >= 8
     _lib.check(L.bsx_set_tuning(_lib.context(0), C.c_uint32(T.TUNE_HOST_GRAPHS), C.c_uint64(1)))
+
+
+def test_trim_releases_host_tier_state_and_the_next_call_rebuilds_it():
+    """bsx_trim gives the scratch arena (grown by a witness request), the persistent key table and a captured graph back; the
+    next requests — with and without graph replay — re-create them and still equal the oracle; misuse (null context) is an error."""
+    import ctypes as C
+    J, B, V = 4, 16, 10
+    w = synth.Workload(79, 2, J, B, v=V)
+    L, ctx = _lib.lib(), _lib.context(0)
+    circ = CombinedSkipCircuit(V, J, B)
+
+    def one(r, want_witness=False):
+        S = int(w.first_height[r])
+        _, want_out, _, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], S, int(w.latest[r]), w.validators[r], w.trusted[r], want_witness=want_witness)
+        out, _, wit = circ.prove(w.input48(r), InputDataFetcher(w.headers[r], S, int(w.latest[r])), w.validators[r], w.trusted[r], want_witness=want_witness)
+        assert out == want_out
+        if want_witness:
+            full = oracle.expand_range_witness(J, B, cw)
+            assert np.asarray(wit).shape == full.shape and (np.asarray(wit) == full).all()
+
+    one(0, want_witness=True)
+    freed = C.c_uint64(0)
+    _lib.check(L.bsx_trim(ctx, C.byref(freed)))
+    assert freed.value >= J * int(T.map_layout(B)["n_elements"]) * 8       # at least the witness the arena held
+    _lib.check(L.bsx_set_tuning(ctx, C.c_uint32(T.TUNE_HOST_GRAPHS), C.c_uint64(1)))
+    for i in range(6):                                                      # capture + replays on the re-created state
+        one(i % 2)
+    _lib.check(L.bsx_trim(ctx, C.byref(freed)))                             # drops the captured graph too
+    assert freed.value > 0
+    _lib.check(L.bsx_set_tuning(ctx, C.c_uint32(T.TUNE_HOST_GRAPHS), C.c_uint64(0)))
+    one(1)
+    _lib.check(L.bsx_trim(ctx, None))
+    assert L.bsx_trim(None, None) == T.ERR_BAD_ARG
