@@ -121,13 +121,7 @@ int new_event(hipEvent_t* e, bool timing = false) {
     HIPCHK(hipEventCreateWithFlags(e, timing ? hipEventDefault : hipEventDisableTiming));
     return BSX_OK;
 }
-int new_stream(hipStream_t* s, bool high_priority = false) {
-    if (high_priority) {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest));
-        return BSX_OK;
-    }
+int new_stream(hipStream_t* s) {
     HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
     return BSX_OK;
 }
