@@ -34,8 +34,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktP -o bench -- pytho
 python tools/kernel_avg.py $(kt $O/ktP) > $O/r3_poseidon_kernel_avg.txt
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmcP -o bench -- python tools/poseidon_bench.py 8 > $O/pmcP.log 2>&1
 python tools/pmc_summary.py $(find $O/pmcP -name "*counter_collection.csv") > $O/r3_poseidon_pmc_sq.csv
-# 6. compact-only pipeline (3 buffer sets): kernel averages + timeline
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktC -o bench -- python bench.py --no-legs --no-autotune --no-witness --engines 1 --alternate 3 --steps 12 --warmup 2 > $O/ktC.log 2>&1
+# 6. compact-only pipeline (2 buffer sets): kernel averages + timeline
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktC -o bench -- python bench.py --no-legs --no-autotune --no-witness --engines 1 --alternate 2 --steps 12 --warmup 2 > $O/ktC.log 2>&1
 python tools/kernel_avg.py $(kt $O/ktC) > $O/r3_compact_kernel_avg_steady_state.txt
 python tools/timeline3.py $(kt $O/ktC) 6 2 > $O/r3_compact_timeline.txt
 # 7. one host-tier call (bsx_header_range)
