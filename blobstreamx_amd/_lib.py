@@ -37,6 +37,8 @@ SYMBOLS = [
     "bsx_pipeline_join", "bsx_pipeline_set_allgather", "bsx_pipeline_get_results", "bsx_pipeline_buffer", "bsx_pipeline_set_timing",
     "bsx_pipeline_timing", "bsx_pipeline_autotune", "bsx_calibrate", "bsx_dev_verify_commits", "bsx_dev_verify_commits_scratch_bytes",
     "bsx_ed25519_decoded_r_bytes", "bsx_dev_ed25519_decode_r", "bsx_dev_ed25519_verify_keyed_r",
+    "bsx_witness_manifest_section", "bsx_commit_witness_layout", "bsx_skip_witness_layout", "bsx_step_witness_layout",
+    "bsx_header_range_witness_elements", "bsx_next_header_witness_elements",
 ]
 
 
@@ -81,6 +83,8 @@ def lib():
             L.bsx_pipeline_destroy.restype = None
             L.bsx_dev_verify_commits_scratch_bytes.restype = C.c_uint64
             L.bsx_ed25519_decoded_r_bytes.restype = C.c_uint64
+            L.bsx_header_range_witness_elements.restype = C.c_uint64
+            L.bsx_next_header_witness_elements.restype = C.c_uint64
             for s in SYMBOLS:
                 getattr(L, s)   # AttributeError here = header/library drift
             _lib = L

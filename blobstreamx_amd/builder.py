@@ -162,8 +162,9 @@ class DataCommitmentBuilder:
         return out.tobytes()
 
 
-def verify_commits(validators, header_hashes, device=0):
-    """validators: ndarray[n_commits, v_max] of VALIDATOR; header_hashes: [n_commits, 32] -> (results, sig_ok)."""
+def verify_commits(validators, header_hashes, device=0, want_witness=False):
+    """validators: ndarray[n_commits, v_max] of VALIDATOR; header_hashes: [n_commits, 32] -> (results, sig_ok[, witness]).
+    witness: u64 [n_commits, commit_layout(v_max).n_elements] — one COMMIT unit per commit (include/bsx_layout.h)."""
     v = np.ascontiguousarray(validators, T.VALIDATOR)
     if v.ndim == 1:
         v = v.reshape(1, -1)
@@ -171,9 +172,10 @@ def verify_commits(validators, header_hashes, device=0):
     hh = np.ascontiguousarray(header_hashes, np.uint8).reshape(n, 32)
     res = np.zeros(n, T.COMMIT_RESULT)
     ok = np.zeros((n, vmax), np.uint8)
+    wit = np.zeros((n, int(T.commit_layout(vmax)["n_elements"])), np.uint64) if want_witness else None
     _lib.check(_lib.lib().bsx_verify_commits(_lib.context(device), _lib.p(v), C.c_uint32(n), C.c_uint32(vmax), _lib.p(hh),
-                                             _lib.p(res), _lib.p(ok)))
-    return res, ok
+                                             _lib.p(res), _lib.p(ok), _lib.p(wit)))
+    return (res, ok, wit) if want_witness else (res, ok)
 
 
 class CombinedStepCircuit:
@@ -185,8 +187,10 @@ class CombinedStepCircuit:
         circuits/config.rs:6-28: celestia / mocha-4)."""
         self.V, self.device, self.chain_id = max_validator_set_size, device, bytes(chain_id)
 
-    def prove(self, input40, prev_header, next_header, latest_block, next_validators):
-        """40-byte EVM-packed input (prev_block_number ‖ prev_header_hash) -> (64-byte output, commit result)."""
+    def prove(self, input40, prev_header, next_header, latest_block, next_validators, want_witness=False, allow=()):
+        """40-byte EVM-packed input (prev_block_number ‖ prev_header_hash) -> (64-byte output, commit result[, witness]).
+        witness: u64 [next_header_witness_elements(V)] = the COMMIT unit of the next header's commit, then the STEP unit.
+        allow: status codes that do not raise (then `self.last_rc` says which) — a failing request still has a witness."""
         if len(input40) != 40:
             raise ValueError("input must be 40 bytes: uint64 prev_block_number ‖ bytes32 prev_header_hash")
         ph = np.ascontiguousarray(prev_header, T.HEADER).reshape(1)
@@ -198,10 +202,11 @@ class CombinedStepCircuit:
         out = np.zeros(64, np.uint8)
         res = np.zeros(1, T.COMMIT_RESULT)
         cid = np.frombuffer(self.chain_id, np.uint8).copy() if self.chain_id else None
-        _lib.check(_lib.lib().bsx_next_header(_lib.context(self.device), _lib.p(inp), _lib.p(ph), _lib.p(nh), C.c_uint64(latest_block),
-                                              _lib.p(nv), C.c_uint32(self.V), _lib.p(cid), C.c_uint32(len(self.chain_id)), _lib.p(out),
-                                              _lib.p(res)))
-        return out.tobytes(), res[0]
+        wit = np.zeros(T.next_header_witness_elements(self.V), np.uint64) if want_witness else None
+        self.last_rc = _lib.check(_lib.lib().bsx_next_header(_lib.context(self.device), _lib.p(inp), _lib.p(ph), _lib.p(nh), C.c_uint64(latest_block),
+                                                             _lib.p(nv), C.c_uint32(self.V), _lib.p(cid), C.c_uint32(len(self.chain_id)), _lib.p(out),
+                                                             _lib.p(res), _lib.p(wit)), allow=allow)
+        return (out.tobytes(), res[0], wit) if want_witness else (out.tobytes(), res[0])
 
 
 def find_block_to_request(start_block, max_end_block, start_validators, candidate_heights, candidate_validators, device=0):
@@ -257,9 +262,11 @@ class CombinedSkipCircuit:
             self._wit_pinned = buf
         return buf.numpy().view(np.uint64)
 
-    def prove(self, input48, fetcher, target_validators, trusted_validators, want_witness=False):
+    def prove(self, input48, fetcher, target_validators, trusted_validators, want_witness=False, allow=()):
         """48-byte EVM-packed input -> 64-byte output (target_header_hash ‖ data_commitment).  want_witness: also the
-        Goldilocks witness, as a view of a page-locked buffer that the next prove() of this object overwrites (copy it to keep it)."""
+        Goldilocks witness of the WHOLE circuit (map jobs, reduce nodes, the COMMIT unit of the target commit, the SKIP unit;
+        T.header_range_witness_elements), as a view of a page-locked buffer that the next prove() of this object overwrites
+        (copy it to keep it).  allow: status codes that do not raise (`self.last_rc`)."""
         tv = np.ascontiguousarray(target_validators, T.VALIDATOR).reshape(-1)
         rv = np.ascontiguousarray(trusted_validators, T.VALIDATOR).reshape(-1)
         if tv.size != self.V or rv.size != self.V:
@@ -268,24 +275,29 @@ class CombinedSkipCircuit:
         res = np.zeros(1, T.COMMIT_RESULT)
         wit = None
         if want_witness:
-            ml, rl = T.map_layout(self.B), T.reduce_layout()
-            wit = self._witness_buffer(self.J * int(ml["n_elements"]) + (self.J - 1) * int(rl["n_elements"]))
-        _lib.check(_lib.lib().bsx_header_range(
+            wit = self._witness_buffer(T.header_range_witness_elements(self.J, self.B, self.V))
+        self.last_rc = _lib.check(_lib.lib().bsx_header_range(
             _lib.context(self.device), C.c_uint32(self.J), C.c_uint32(self.B), _lib.p(_b(input48, 48)), _lib.p(fetcher.headers),
             C.c_uint64(fetcher.first_height), C.c_uint64(fetcher.headers.size), C.c_uint64(fetcher.latest_block), _lib.p(tv),
             _lib.p(rv), C.c_uint32(self.V), _lib.p(np.frombuffer(self.chain_id, np.uint8).copy()) if self.chain_id else None,
-            C.c_uint32(len(self.chain_id)), _lib.p(out), _lib.p(res), _lib.p(wit)))
+            C.c_uint32(len(self.chain_id)), _lib.p(out), _lib.p(res), _lib.p(wit)), allow=allow)
         return out.tobytes(), res[0], wit
 
 
 def witness_manifest(batch_size):
     """bsx_witness_manifest -> ndarray[MANIFEST_ENTRY]: the variable groups of one map job's witness (batch_size = 0: of one
     reduce node) with their element offsets; `witness_view` slices a witness by group name."""
+    return witness_manifest_section(T.SECTION_MAP if batch_size else T.SECTION_REDUCE, batch_size)
+
+
+def witness_manifest_section(section, param=0):
+    """bsx_witness_manifest_section -> ndarray[MANIFEST_ENTRY] of one unit: T.SECTION_MAP (param = BATCH_SIZE), SECTION_REDUCE,
+    SECTION_COMMIT / SECTION_SKIP (param = validator slots), SECTION_STEP."""
     L = _lib.lib()
     n = C.c_uint32(0)
-    _lib.check(L.bsx_witness_manifest(C.c_uint32(batch_size), None, C.c_uint32(0), C.byref(n)))
+    _lib.check(L.bsx_witness_manifest_section(C.c_uint32(section), C.c_uint32(param), None, C.c_uint32(0), C.byref(n)))
     ent = np.zeros(n.value, T.MANIFEST_ENTRY)
-    _lib.check(L.bsx_witness_manifest(C.c_uint32(batch_size), _lib.p(ent), C.c_uint32(n.value), C.byref(n)))
+    _lib.check(L.bsx_witness_manifest_section(C.c_uint32(section), C.c_uint32(param), _lib.p(ent), C.c_uint32(n.value), C.byref(n)))
     return ent
 
 

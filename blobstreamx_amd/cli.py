@@ -64,9 +64,8 @@ def main(argv=None):
     V, J, B = a.validators or V, a.jobs or J, a.batch or B
     if a.command == "build":
         # the reference compiles circuits here; the witness engine has nothing to build beyond its layout
-        ml, rl = T.map_layout(B), T.reduce_layout()
-        print(json.dumps({"circuit": a.circuit, "max_validators": V, "nb_map_jobs": J, "batch_size": B,
-                          "witness_elements": int(J * int(ml["n_elements"]) + (J - 1) * int(rl["n_elements"]))}))
+        nel = T.next_header_witness_elements(V) if a.circuit.startswith("next_header") else T.header_range_witness_elements(J, B, V)
+        print(json.dumps({"circuit": a.circuit, "max_validators": V, "nb_map_jobs": J, "batch_size": B, "witness_elements": int(nel)}))
         return 0
     if not a.input or not a.fixtures:
         ap.error("prove needs input.json and --fixtures")
@@ -103,22 +102,25 @@ def main(argv=None):
         blocks = {h: fx.signed_block(h) for h in (prev, prev + 1)}
         headers = np.array([blocks[prev]["header"], blocks[prev + 1]["header"]], dtype=T.HEADER)
         # CombinedStepCircuit::define (circuits/next_header.rs:25-46) behind the C ABI (bsx_next_header)
-        out, _ = CombinedStepCircuit(blocks[prev + 1]["validators"].size, chain_id=chain_id).prove(inp, headers[0], headers[1], a.latest or prev + 3,
-                                                                               blocks[prev + 1]["validators"])
-        wit = None
+        out, _, wit = CombinedStepCircuit(blocks[prev + 1]["validators"].size, chain_id=chain_id).prove(
+            inp, headers[0], headers[1], a.latest or prev + 3, blocks[prev + 1]["validators"], want_witness=True)
+        V = blocks[prev + 1]["validators"].size
     json.dump({"type": "res_bytes", "data": {"output": "0x" + out.hex()}}, open(a.output, "w"))
     if a.witness and wit is not None:
         wit.astype("<u8").tofile(a.witness)
     if a.caps and wit is not None:
-        # what the prover commits to first: Merkle caps of the witness columns
+        # what the prover commits to first: Merkle caps of the witness columns, one per unit of the witness
         from .poseidon import witness_leaf_count, witness_merkle_caps
-        ml, rl = T.map_layout(B), T.reduce_layout()
-        nm = J * int(ml["n_elements"])
         hexd = lambda caps_: [["0x" + "".join(f"{int(x):016x}" for x in d) for d in c] for c in caps_]
         ch = lambda lay: min(4, witness_leaf_count(int(lay["n_elements"]), 135).bit_length() - 1)
-        caps = {"leaf_len": 135, "cap_height": {"map_jobs": ch(ml), "reduce_nodes": ch(rl)},
-                "map_jobs": hexd(witness_merkle_caps(ml, wit[:nm], J, 135, ch(ml))),
-                "reduce_nodes": hexd(witness_merkle_caps(rl, wit[nm:], J - 1, 135, ch(rl))) if J > 1 else []}
+        units = ([("map_jobs", T.map_layout(B), J), ("reduce_nodes", T.reduce_layout(), J - 1), ("commit", T.commit_layout(V), 1),
+                  ("skip", T.skip_layout(V), 1)] if a.circuit.startswith("header_range") else [("commit", T.commit_layout(V), 1), ("step", T.step_layout(), 1)])
+        caps, off = {"leaf_len": 135, "cap_height": {}}, 0
+        for uname, lay, n in units:
+            nel = n * int(lay["n_elements"])
+            caps["cap_height"][uname] = ch(lay)
+            caps[uname] = hexd(witness_merkle_caps(lay, wit[off:off + nel], n, 135, ch(lay))) if n else []
+            off += nel
         json.dump(caps, open(a.caps, "w"))
     print("0x" + out.hex())
     return 0

@@ -156,6 +156,30 @@ int bsx_reduce_witness_layout(bsx_witness_layout* out) {
     *out = bsx_reduce_layout();
     return BSX_OK;
 }
+int bsx_commit_witness_layout(uint32_t v_max, bsx_witness_layout* out) {
+    if (!out || v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_BAD_ARG, "v_max must be in 1..%d", bsxk_tally_vmax());
+    *out = bsx_commit_layout(v_max);
+    return BSX_OK;
+}
+int bsx_skip_witness_layout(uint32_t v_max, bsx_witness_layout* out) {
+    if (!out || v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_BAD_ARG, "v_max must be in 1..%d", bsxk_tally_vmax());
+    *out = bsx_skip_layout(v_max);
+    return BSX_OK;
+}
+int bsx_step_witness_layout(bsx_witness_layout* out) {
+    if (!out) return fail(BSX_ERR_BAD_ARG, "null out");
+    *out = bsx_step_layout();
+    return BSX_OK;
+}
+uint64_t bsx_header_range_witness_elements(uint32_t J, uint32_t B, uint32_t v_max) {
+    if (!pow2(J) || J > 256 || !pow2(B) || B > BSX_MAX_BATCH || v_max == 0 || (int)v_max > bsxk_tally_vmax()) return 0;
+    return (uint64_t)J * bsx_map_layout(B).n_elements + (uint64_t)(J - 1) * bsx_reduce_layout().n_elements + bsx_commit_layout(v_max).n_elements +
+           bsx_skip_layout(v_max).n_elements;
+}
+uint64_t bsx_next_header_witness_elements(uint32_t v_max) {
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return 0;
+    return bsx_commit_layout(v_max).n_elements + bsx_step_layout().n_elements;
+}
 
 // ------------------------------------------------------------------------------------------------ device tier
 #define DEV_ENTER() RET(use(ctx))
@@ -305,7 +329,7 @@ int bsx_dev_finalize(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t nb_
                      uint8_t* d_output64, uint32_t* d_status) {
     DEV_ENTER();
     if (!d_ranges || !d_results) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_finalize(S(ctx, stream), n_ranges, nb_map_jobs, batch_size, d_ranges, d_results, d_target_hashes, d_output64, d_status));
+    HIPCHK(bsxk_finalize(S(ctx, stream), n_ranges, nb_map_jobs, batch_size, d_ranges, d_results, d_target_hashes, d_output64, d_status, nullptr, 0));
     return BSX_OK;
 }
 
@@ -329,7 +353,7 @@ int bsx_dev_fill_end_hash(bsx_ctx* ctx, void* stream, uint32_t n_ranges, bsx_sha
 int bsx_dev_sha512_challenge(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint64_t n, uint8_t* d_h, uint8_t* d_digest) {
     DEV_ENTER();
     if (n && (!d_validators || !d_h)) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_sha512_challenge(S(ctx, stream), d_validators, n, d_h, d_digest));
+    HIPCHK(bsxk_sha512_challenge(S(ctx, stream), d_validators, n, d_h, d_digest, 1, nullptr));
     return BSX_OK;
 }
 
@@ -398,7 +422,7 @@ int bsx_dev_commit_tally(bsx_ctx* ctx, void* stream, const bsx_validator* d_vali
     DEV_ENTER();
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
     if (n_commits && (!d_validators || !d_results)) return fail(BSX_ERR_BAD_ARG, "null pointer");
-    HIPCHK(bsxk_commit_tally(S(ctx, stream), d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results));
+    HIPCHK(bsxk_commit_tally(S(ctx, stream), d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results, nullptr));
     return BSX_OK;
 }
 
@@ -413,7 +437,7 @@ int bsx_dev_skip_check(bsx_ctx* ctx, void* stream, uint32_t n_ranges, uint32_t v
         return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
     HIPCHK(bsxk_skip_check(S(ctx, stream), n_ranges, v_max, d_ranges, d_headers, headers_per_range, d_hashes, d_target, d_trusted,
-                           d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes, d_target_index, chain_id, chain_id_len));
+                           d_target_ok, d_target_res, d_trusted_res, d_skip_status, d_target_hashes, d_target_index, chain_id, chain_id_len, nullptr));
     return BSX_OK;
 }
 
@@ -424,7 +448,7 @@ uint64_t bsx_dev_verify_commits_scratch_bytes(uint32_t n_commits, uint32_t v_max
 
 int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits, uint32_t v_max,
                            const uint8_t* d_header_hashes, uint32_t first_index, void* d_keytable, void* d_scratch, uint8_t* d_ok,
-                           bsx_commit_result* d_results, bsx_commit_fold* d_fold) {
+                           bsx_commit_result* d_results, bsx_commit_fold* d_fold, uint8_t* d_commit_compact) {
     DEV_ENTER();
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
     if (!n_commits || n_commits > BSX_COMMIT_FOLD_MAX) return fail(BSX_ERR_UNSUPPORTED, "n_commits %u not in 1..%u", n_commits, BSX_COMMIT_FOLD_MAX);
@@ -435,10 +459,13 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     uint8_t* d_h = static_cast<uint8_t*>(d_scratch);
     uint8_t* d_ed = d_h + ((n * 32 + 255) & ~255ull);
     uint8_t* d_fs = d_ed + ((bsxk_ed25519_scratch_bytes(n) + 255) & ~255ull);
-    HIPCHK(bsxk_sha512_challenge(st, d_validators, n, d_h, nullptr));
+    if (d_commit_compact && ((uintptr_t)d_commit_compact & 15)) return fail(BSX_ERR_BAD_ARG, "d_commit_compact must be 16-byte aligned");
+    const bsx_witness_layout CL = bsx_commit_layout(v_max);
+    const bsxk_unit_dst cw = bsxk_unit(d_commit_compact, CL);
+    HIPCHK(bsxk_sha512_challenge(st, d_validators, n, d_h, nullptr, v_max, d_commit_compact ? &cw : nullptr));
     HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable)));
     HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed, nullptr));
-    HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results));
+    HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results, d_commit_compact ? &cw : nullptr));
     HIPCHK(bsxk_commit_fold(st, d_results, n_commits, first_index, d_fs, d_fold));
     return BSX_OK;
 }
@@ -823,7 +850,7 @@ static int run_data_commitment(bsx_ctx* ctx, hipStream_t st, uint32_t J, uint32_
     HIPCHK(bsxk_prove_subchain(st, 1, B, J, rd.ranges.as<bsx_shared_ctx>(), cw.as<uint8_t>(), recs.as<bsx_subchain>(),
                                BSX_SUBCHAIN_PATHS_FROM_HINT));
     HIPCHK(bsxk_reduce(st, 1, J, recs.as<bsx_subchain>(), J, 1, res.as<bsx_subchain>(), rcw.as<uint8_t>()));
-    HIPCHK(bsxk_finalize(st, 1, J, B, rd.ranges.as<bsx_shared_ctx>(), res.as<bsx_subchain>(), d_target_hashes, o64.as<uint8_t>(), stw.as<uint32_t>()));
+    HIPCHK(bsxk_finalize(st, 1, J, B, rd.ranges.as<bsx_shared_ctx>(), res.as<bsx_subchain>(), d_target_hashes, o64.as<uint8_t>(), stw.as<uint32_t>(), nullptr, 0));
     if (witness) {
         const size_t nmap = (size_t)J * L.n_elements, nred = (size_t)(J - 1) * R.n_elements;
         RET(wit.alloc((nmap + nred) * 8 + 16));
@@ -954,7 +981,7 @@ int bsx_find_block_to_request(bsx_ctx* ctx, uint64_t start_block, uint64_t max_e
 }
 
 int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,
-                       bsx_commit_result* out_results, uint8_t* out_sig_ok) {
+                       bsx_commit_result* out_results, uint8_t* out_sig_ok, uint64_t* witness) {
     HOST_ENTER();
     if (!validators || !header_hashes || !out_results) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
@@ -969,7 +996,18 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
     RET(dres.alloc((size_t)n_commits * sizeof(bsx_commit_result)));
     H2D(dv.p, validators, n * sizeof(bsx_validator));
     H2D(dhh.p, header_hashes, (size_t)n_commits * 32);
-    HIPCHK(bsxk_sha512_challenge(st, dv.as<bsx_validator>(), n, dh.as<uint8_t>(), nullptr));
+    // witness (optional): one COMMIT unit per commit (include/bsx_layout.h), written by the kernels of the chain as they go
+    const bsx_witness_layout CL = bsx_commit_layout(v_max);
+    DBuf dcw, dwit;
+    bsxk_unit_dst cwd = bsxk_unit(nullptr, CL);
+    if (witness) {
+        RET(dcw.alloc((size_t)n_commits * CL.compact_stride));
+        RET(dwit.alloc((size_t)n_commits * CL.n_elements * 8 + 16));
+        HIPCHK(hipMemsetAsync(dcw.p, 0, (size_t)n_commits * CL.compact_stride, st));
+        cwd.base = dcw.as<uint8_t>();
+    }
+    const bsxk_unit_dst* cwp = witness ? &cwd : nullptr;
+    HIPCHK(bsxk_sha512_challenge(st, dv.as<bsx_validator>(), n, dh.as<uint8_t>(), nullptr, v_max, cwp));
     {
         // per-key tables from the first commit's slots (kept in the context between calls); slots whose key differs fall
         // back to the generic path inside bsxk_ed25519_verify_keyed: same accept set for any input
@@ -978,7 +1016,11 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
         else RET(drd.alloc(bsxk_ed25519_rdec_bytes(n)));
         RET(ctx_verify(ctx, st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dok.as<uint8_t>(), dscr.p, drd.p));
     }
-    HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
+    HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(), cwp));
+    if (witness) {
+        HIPCHK(bsxk_expand_witness(st, &CL, n_commits, dcw.as<uint8_t>(), dwit.as<uint64_t>()));
+        D2H(witness, dwit.p, (size_t)n_commits * CL.n_elements * 8);
+    }
     StagedD2H back(ctx, st);
     RET(back.copy(out_results, dres.p, (size_t)n_commits * sizeof(bsx_commit_result)));
     if (out_sig_ok) RET(back.copy(out_sig_ok, dok.p, n));
@@ -1067,6 +1109,22 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         hipStream_t s; bool active;
         ~EndCaptureOnError() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } }
     } cap_guard{st, capture};
+    // witness: the COMMIT unit of the target commit and the SKIP unit (include/bsx_layout.h), written by the kernels of the commit
+    // chain into these compact images; expanded behind both chains
+    const bsx_witness_layout CL = bsx_commit_layout(v_max), SL = bsx_skip_layout(v_max);
+    DBuf dccw, dscw;
+    bsxk_unit_dst cwd = bsxk_unit(nullptr, CL), swd = bsxk_unit(nullptr, SL), swd_t = bsxk_unit(nullptr, SL, 1);
+    if (witness) {
+        RET(dccw.alloc(CL.compact_stride));
+        RET(dscw.alloc(SL.compact_stride));
+        cwd.base = dccw.as<uint8_t>();
+        swd.base = swd_t.base = dscw.as<uint8_t>();
+    }
+    const bsxk_unit_dst *cwp = witness ? &cwd : nullptr, *swp = witness ? &swd : nullptr, *swtp = witness ? &swd_t : nullptr;
+    if (witness) {                                                      // unit bytes no kernel writes (alignment gaps) must be zero
+        HIPCHK(hipMemsetAsync(dccw.p, 0, CL.compact_stride, st));
+        HIPCHK(hipMemsetAsync(dscw.p, 0, SL.compact_stride, st));
+    }
     HIPCHK(hipMemcpyAsync(io.d, io.h, io.out_off + SmallIO::OUT_BYTES, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(ctx->ev_c, st));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_c, 0));                       // the commit check's inputs
@@ -1090,10 +1148,21 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     RET(ctx_keytable(ctx, v_max, &tab, sb));
     if (tab) HIPCHK(bsxk_ed25519_decode_r(s3, dv.as<bsx_validator>(), v_max, drd.p));
     HIPCHK(hipEventRecord(ctx->ev_d, s3));                              // the signature check waits for this ...
-    HIPCHK(bsxk_commit_tally(s3, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>()));
+    HIPCHK(bsxk_commit_tally(s3, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>(), swtp));
+    if (witness) {
+        // header-field inclusion proofs of the target (chain id, height, validators_hash) and the trusted header (validators_hash)
+        bsxk_field_proofs_args fa{};
+        fa.n_items = 1; fa.headers = rd.headers.as<bsx_header>(); fa.headers_per_item = rd.hpr; fa.ranges = rd.ranges.as<bsx_shared_ctx>();
+        fa.unit = swd; fa.n_proofs = BSX_SK_N_PROOFS; fa.zero_paths = ctx->zero_paths;
+        static const uint8_t hsel[BSX_SK_N_PROOFS] = {1, 1, 1, 0}, fld[BSX_SK_N_PROOFS] = {1, BSX_BLOCK_HEIGHT_INDEX, 7, 7};
+        for (uint32_t k = 0; k < BSX_SK_N_PROOFS; k++)
+            fa.proofs[k] = bsxk_proof_spec{hsel[k], fld[k], (uint16_t)bsx_sk_proof_cap(k), bsx_sk_off_proof(v_max, k), BSX_SK_W_LEAF_LEN + k, 0u};
+        HIPCHK(hipStreamWaitEvent(s3, ctx->ev_a, 0));                   // the range's headers are uploaded on `st`
+        HIPCHK(bsxk_field_proofs(s3, &fa));
+    }
     HIPCHK(hipEventRecord(ctx->ev_e, s3));                              // ... only the skip conditions for this
     const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
-    HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr));
+    HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr, v_max, cwp));
     if (tab) {
         HIPCHK(bsxk_ed25519_keytable(sb, dv.as<bsx_validator>(), v_max, tab));
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_d, 0));
@@ -1103,15 +1172,28 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_d, 0));
     }
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) from `st`
-    HIPCHK(bsxk_commit_tally(sb, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>()));
+    HIPCHK(bsxk_commit_tally(sb, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>(), cwp));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_e, 0));
     HIPCHK(bsxk_skip_check(sb, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
-                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth2.as<uint8_t>(), nullptr, chain_id, chain_id_len));
+                           dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth2.as<uint8_t>(), nullptr, chain_id, chain_id_len, swp));
     HIPCHK(hipEventRecord(ctx->ev_b, sb));
     // prove_data_commitment (header_range.rs:50-55) and the public output (:57-58); results stay in the block
     RET(run_data_commitment(ctx, st, nb_map_jobs, batch_size, rd, dth.as<uint8_t>(), nullptr, nullptr, nullptr, nullptr, witness, nullptr, &io));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_b, 0));
+    DBuf dwc, dws;
+    if (witness) {
+        // both chains are done: the data commitment joins the SKIP unit's public outputs (header_range.rs:58), then the two units are
+        // expanded behind the map jobs and reduce nodes
+        const size_t nmr = (size_t)nb_map_jobs * bsx_map_layout(batch_size).n_elements + (size_t)(nb_map_jobs - 1) * bsx_reduce_layout().n_elements;
+        HIPCHK(hipMemcpyAsync(dscw.as<uint8_t>() + 64, io.dout(0) + 32, 32, hipMemcpyDeviceToDevice, st));
+        RET(dwc.alloc(CL.n_elements * 8 + 16));
+        RET(dws.alloc(SL.n_elements * 8 + 16));
+        HIPCHK(bsxk_expand_witness(st, &CL, 1, dccw.as<uint8_t>(), dwc.as<uint64_t>()));
+        HIPCHK(bsxk_expand_witness(st, &SL, 1, dscw.as<uint8_t>(), dws.as<uint64_t>()));
+        D2H(witness + nmr, dwc.p, CL.n_elements * 8);
+        D2H(witness + nmr + CL.n_elements, dws.p, SL.n_elements * 8);
+    }
     HIPCHK(hipMemcpyAsync(io.h + io.out_off, io.dout(0), SmallIO::OUT_BYTES, hipMemcpyDeviceToHost, st));
     static const bool trace_host = getenv("BSX_TRACE_HOST") != nullptr;       // experiments: host enqueue time vs wait for the GPU
     const auto t_enq = std::chrono::steady_clock::now();
@@ -1153,59 +1235,115 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     return rc;
 }
 
-// CombinedStepCircuit::define (circuits/next_header.rs:25-46): built from the host tier above — every hash, signature
-// check and tally runs in the kernels those calls launch; the host only compares 32-byte values and decodes statuses.
+// CombinedStepCircuit::define (circuits/next_header.rs:25-46) as ONE enqueue: header hashes, the commit check of the next
+// header's validator set (challenges, fixed-key Ed25519, tally + validator-set hash), the header-field inclusion proofs, the step
+// conditions and prove_next_header_data_commitment (k_step_check) all run on the device; the host decodes two status words.
+// witness (optional): the COMMIT unit then the STEP unit (include/bsx_layout.h), bsx_next_header_witness_elements(v_max) u64.
 int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
                     uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
-                    uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit) {
+                    uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness) {
     HOST_ENTER();
     if (!input40 || !prev_header || !next_header || !next_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (chain_id_len > 50 || (chain_id_len && !chain_id)) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
+    if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
     uint64_t prev_block = 0;                                                    // next_header.rs:26 evm_read u64 (big endian)
     for (int i = 0; i < 8; i++) prev_block = prev_block << 8 | input40[i];
-    const uint8_t* prev_hash = input40 + 8;                                     // :27
     const uint64_t next_block = prev_block + 1;                                 // :29-30
-    bsx_header two[2] = {*prev_header, *next_header};
-    uint8_t hashes[64];
-    RET(bsx_header_hashes(ctx, two, 2, hashes, nullptr, nullptr));
-    // builder.step (:32-36) [UPSTREAM tendermintx v1.0.0]
+    hipStream_t st = ctx->stream;
+    const bsx_witness_layout CL = bsx_commit_layout(v_max), TL = bsx_step_layout();
+    const size_t vbytes = (size_t)v_max * sizeof(bsx_validator);
+    // one staged block each way: [2 headers][input40 (64)][flags (64)][validators]
+    const size_t in_bytes = 2 * sizeof(bsx_header) + 128 + vbytes;
+    DBuf din, dhash, dst_, dh, dok, dres, dout, dccw, dscw, drd, dscr, dwit;
+    uint8_t* hs = nullptr;
+    RET(ctx_hstage(ctx, in_bytes, &hs));
+    memcpy(hs, prev_header, sizeof(bsx_header));
+    memcpy(hs + sizeof(bsx_header), next_header, sizeof(bsx_header));
+    memset(hs + 2 * sizeof(bsx_header), 0, 128);
+    memcpy(hs + 2 * sizeof(bsx_header), input40, 40);
+    // builder.rs:415-423: the MAX_LEAVES = 1 hint returns a real data_hash proof iff prev < min(next, latest - 2) (input.rs:160-172)
+    const uint64_t req_end = next_block < latest_block - 2 ? next_block : latest_block - 2;
+    const uint32_t flags = prev_block < req_end ? 0u : 1u;
+    memcpy(hs + 2 * sizeof(bsx_header) + 64, &flags, 4);
+    memcpy(hs + 2 * sizeof(bsx_header) + 128, next_validators, vbytes);
+    RET(din.alloc(in_bytes));
+    RET(dhash.alloc(64));
+    RET(dst_.alloc(16));
+    RET(dh.alloc((size_t)v_max * 32));
+    RET(dok.alloc(v_max));
+    RET(dres.alloc(sizeof(bsx_commit_result)));
+    RET(dout.alloc(64));
+    RET(dccw.alloc(CL.compact_stride));
+    RET(dscw.alloc(TL.compact_stride));
+    RET(drd.alloc(bsxk_ed25519_rdec_bytes(v_max)));
+    H2D(din.p, hs, in_bytes);
+    HIPCHK(hipMemsetAsync(dst_.p, 0, 16, st));
+    HIPCHK(hipMemsetAsync(dccw.p, 0, CL.compact_stride, st));
+    HIPCHK(hipMemsetAsync(dscw.p, 0, TL.compact_stride, st));
+    const bsx_header* d_hdr = din.as<bsx_header>();
+    const uint8_t* d_in40 = din.as<uint8_t>() + 2 * sizeof(bsx_header);
+    const uint32_t* d_flags = reinterpret_cast<const uint32_t*>(d_in40 + 64);
+    const bsx_validator* d_val = reinterpret_cast<const bsx_validator*>(d_in40 + 128);
+    uint32_t* d_st = dst_.as<uint32_t>();                                       // [0] header status, [1] step status, [2] A10
+    const bsxk_unit_dst cwd = bsxk_unit(dccw.as<uint8_t>(), CL), swd = bsxk_unit(dscw.as<uint8_t>(), TL);
+    HIPCHK(bsxk_header_merkle(st, d_hdr, 2, dhash.as<uint8_t>(), nullptr, nullptr, nullptr, d_st, 0, 0));
+    // builder.step (:32-36) [UPSTREAM tendermintx v1.0.0]: the commit of the next header
+    HIPCHK(bsxk_sha512_challenge(st, d_val, v_max, dh.as<uint8_t>(), nullptr, v_max, &cwd));
+    RET(ctx_verify(ctx, st, d_val, dh.as<uint8_t>(), v_max, v_max, dok.as<uint8_t>(), nullptr, drd.p));
+    HIPCHK(bsxk_commit_tally(st, d_val, 1, v_max, dhash.as<uint8_t>() + 32, dok.as<uint8_t>(), dres.as<bsx_commit_result>(), &cwd));
+    {
+        bsxk_field_proofs_args fa{};
+        fa.n_items = 1; fa.headers = d_hdr; fa.headers_per_item = 2; fa.flags = d_flags;
+        fa.unit = swd; fa.n_proofs = BSX_ST_N_PROOFS; fa.zero_paths = ctx->zero_paths;
+        static const uint8_t hsel[BSX_ST_N_PROOFS] = {1, 1, 1, 1, 0, 0};
+        static const uint8_t fld[BSX_ST_N_PROOFS] = {1, BSX_BLOCK_HEIGHT_INDEX, 7, BSX_LAST_BLOCK_ID_INDEX, 8, BSX_DATA_HASH_INDEX};
+        for (uint32_t k = 0; k < BSX_ST_N_PROOFS; k++)
+            fa.proofs[k] = bsxk_proof_spec{hsel[k], fld[k], (uint16_t)bsx_st_proof_cap(k), bsx_st_off_proof(k), BSX_ST_W_LEAF_LEN + k, k == 5 ? 1u : 0u};
+        HIPCHK(bsxk_field_proofs(st, &fa));
+    }
+    {
+        bsxk_step_args sa{};
+        sa.headers = d_hdr; sa.hashes = dhash.as<uint8_t>(); sa.input40 = d_in40; sa.commit = dres.as<bsx_commit_result>();
+        sa.step_status = d_st + 1; sa.dc_status = d_st + 2; sa.output64 = dout.as<uint8_t>(); sa.unit = swd;
+        sa.chain_id_len = chain_id_len;
+        if (chain_id_len) memcpy(sa.chain_id, chain_id, chain_id_len);
+        HIPCHK(bsxk_step_check(st, &sa));
+    }
+    if (witness) {
+        RET(dwit.alloc((CL.n_elements + TL.n_elements) * 8 + 32));
+        RET(dscr.alloc(TL.n_elements * 8 + 16));
+        HIPCHK(bsxk_expand_witness(st, &CL, 1, dccw.as<uint8_t>(), dwit.as<uint64_t>()));
+        HIPCHK(bsxk_expand_witness(st, &TL, 1, dscw.as<uint8_t>(), dscr.as<uint64_t>()));
+        D2H(witness, dwit.p, CL.n_elements * 8);
+        D2H(witness + CL.n_elements, dscr.p, TL.n_elements * 8);
+    }
+    uint8_t o64[64];
     bsx_commit_result cr;
-    std::vector<uint8_t> sig_ok(v_max);
-    RET(bsx_verify_commits(ctx, next_validators, 1, v_max, hashes + 32, &cr, sig_ok.data()));
+    uint32_t stw[4] = {0, 0, 0, 0};
+    StagedD2H back(ctx, st);
+    RET(back.copy(o64, dout.p, 64));
+    RET(back.copy(&cr, dres.p, sizeof cr));
+    RET(back.copy(stw, dst_.p, 16));
+    RET(back.sync());
+    if (stw[0] & 1u) return fail(BSX_ERR_BAD_HEADER, "a packed header violates the field-size rules of bsx_header");
     if (out_commit) *out_commit = cr;
-    int st = BSX_OK;
-    const char* why = "";
-    if (memcmp(hashes, prev_hash, 32) != 0) { st = BSX_ERR_ASSERT; why = "prev header does not hash to prev_header_hash"; }
-    uint8_t hf[12];                                                             // height leaf of the next header: 08 varint(prev + 1)
-    int hn = 0;
-    hf[hn++] = 0x08;
-    for (uint64_t hv = next_block;; hv >>= 7) { if (hv >= 0x80) hf[hn++] = (uint8_t)(hv | 0x80); else { hf[hn++] = (uint8_t)hv; break; } }
-    if (!st && (next_header->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(next_header->height, hf, (size_t)hn) != 0)) {
-        st = BSX_ERR_ASSERT; why = "next header's height is not prev_block_number + 1";
+    if (cr.power_overflow)
+        return fail(BSX_ERR_BAD_ARG, "commit 0: the voting powers add up to more than MaxTotalVotingPower (MaxInt64 / 8); tallies are meaningless");
+    if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
+    memcpy(output64, o64, 64);                                                  // :44-45
+    const int stc = (int)(stw[1] & 0xffu);
+    if (stc) {
+        static const char* why[] = {"", "voting power overflow", "prev header does not hash to prev_header_hash", "next header's height is not prev_block_number + 1",
+                                    "next header's chain id is not the circuit's CHAIN_ID_BYTES", "a signed validator's signature or message is bad",
+                                    "validator set does not hash to the next header's validators_hash",
+                                    "validator set does not hash to the prev header's next_validators_hash",
+                                    "next header's last_block_id does not point at the prev header", "less than 2/3 of the voting power signed"};
+        const uint32_t w = (stw[1] >> 8) & 0xffu;
+        return fail(stc, "step verification failed: %s", w < 10 ? why[w] : "");
     }
-    if (!st && (next_header->len[1] != chain_id_len + 2 || next_header->chain_id[0] != 0x0a || next_header->chain_id[1] != chain_id_len ||
-                memcmp(next_header->chain_id + 2, chain_id, chain_id_len) != 0)) {
-        st = BSX_ERR_ASSERT; why = "next header's chain id is not the circuit's CHAIN_ID_BYTES";
-    }
-    if (!st && (cr.n_bad_signature || cr.n_bad_message)) { st = BSX_ERR_BAD_SIGNATURE; why = "a signed validator's signature or message is bad"; }
-    if (!st && (next_header->len[7] != 34 || memcmp(next_header->hash[2] + 2, cr.validators_hash, 32) != 0)) {
-        st = BSX_ERR_ASSERT; why = "validator set does not hash to the next header's validators_hash";
-    }
-    if (!st && (prev_header->len[8] != 34 || memcmp(prev_header->hash[3] + 2, cr.validators_hash, 32) != 0)) {
-        st = BSX_ERR_ASSERT; why = "validator set does not hash to the prev header's next_validators_hash";
-    }
-    if (!st && (next_header->len[BSX_LAST_BLOCK_ID_INDEX] < 34 || memcmp(next_header->last_block_id + 2, hashes, 32) != 0)) {
-        st = BSX_ERR_ASSERT; why = "next header's last_block_id does not point at the prev header";
-    }
-    if (!st && !cr.two_thirds_ok) { st = BSX_ERR_VOTING_POWER; why = "less than 2/3 of the voting power signed"; }
-    // prove_next_header_data_commitment (:38-42) and the public output (:44-45)
-    uint8_t dc[32];
-    const int rc = bsx_prove_next_header_data_commitment(ctx, prev_block, prev_hash, next_block, prev_header, latest_block, dc);
-    if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
-    memcpy(output64, hashes + 32, 32);
-    memcpy(output64 + 32, dc, 32);
-    if (st) return fail(st, "step verification failed: %s", why);
-    return rc;
+    if (stw[2])
+        return fail(BSX_ERR_ASSERT, "prove_next_header_data_commitment: data_hash proof root != prev_header_hash (A10, builder.rs:434)");
+    return BSX_OK;
 }
 
 }  // extern "C"

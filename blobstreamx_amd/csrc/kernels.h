@@ -5,6 +5,17 @@
 
 #include "../../include/bsx.h"
 
+// Where a kernel of the commit chain leaves the witness variables it holds (include/bsx_layout.h): unit c at base + c * stride
+// (COMMIT units: c = commit; SKIP / STEP units: c = range); base == nullptr: no witness.  mode (k_commit_tally): 0 = the COMMIT
+// unit's own validator set, 1 = the trusted set inside a SKIP unit.
+struct bsxk_unit_dst {
+    uint8_t* base;
+    uint32_t stride, off_words, off_bools, mode;
+};
+inline bsxk_unit_dst bsxk_unit(uint8_t* base, const bsx_witness_layout& L, uint32_t mode = 0) {
+    return bsxk_unit_dst{base, L.compact_stride, L.off_words, L.off_bools, mode};
+}
+
 extern "C" {
 hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t, uint32_t);
 hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
@@ -14,9 +25,9 @@ hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint3
 hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*, uint32_t);
 hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
 hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_subchain*, const uint8_t*,
-                         uint8_t*, uint32_t*);
+                         uint8_t*, uint32_t*, uint8_t*, uint32_t);
 hipError_t bsxk_expand_witness(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, uint64_t*);
-hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, uint8_t*, uint8_t*);
+hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, uint8_t*, uint8_t*, uint32_t, const bsxk_unit_dst*);
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
 uint64_t bsxk_keytable_bytes(uint32_t);
 hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
@@ -30,10 +41,46 @@ hipError_t bsxk_ed25519_decode_r(hipStream_t, const bsx_validator*, uint64_t, vo
 hipError_t bsxk_ed25519_btable(hipStream_t, uint8_t*);
 uint64_t bsxk_ed25519_btable_bytes();
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t);
-hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*);
+hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*, const bsxk_unit_dst*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
                            const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
-                           uint32_t*, uint8_t*, const uint32_t*, const uint8_t*, uint32_t);
+                           uint32_t*, uint8_t*, const uint32_t*, const uint8_t*, uint32_t, const bsxk_unit_dst*);
+// header-field inclusion proofs (tendermintx *ProofVariable: aunts, path digests, leaf, leaf length) of the SKIP / STEP units
+struct bsxk_proof_spec {
+    uint8_t header;       // which of the item's headers (0 / 1)
+    uint8_t field;        // header field index (<= 11)
+    uint16_t cap;         // leaf capacity in the record
+    uint32_t off;         // byte offset of the proof record inside the unit
+    uint32_t len_word;    // index of the leaf-length word
+    uint32_t zero_if;     // bit set in flags[item] -> the proof is the hint's all-zero padding (leaf length = cap_zero_len)
+};
+struct bsxk_field_proofs_args {
+    uint32_t n_items;
+    const bsx_header* headers;       // item r: headers[r * headers_per_item + index(r, h)]
+    uint64_t headers_per_item;
+    const bsx_shared_ctx* ranges;    // optional: header 1 of item r is at index end_block - start_block (header 0 at index 0)
+    const uint32_t* target_idx;      // optional: overrides that index
+    const uint32_t* flags;           // optional, per item
+    bsxk_unit_dst unit;
+    uint32_t n_proofs;
+    bsxk_proof_spec proofs[6];
+    const uint8_t* zero_paths;       // the all-zero data_hash proof's path digests (ctx->zero_paths)
+};
+hipError_t bsxk_field_proofs(hipStream_t, const bsxk_field_proofs_args*);
+// step conditions of CombinedStepCircuit (next_header.rs:25-46) + prove_next_header_data_commitment (builder.rs:411-443), one item
+struct bsxk_step_args {
+    const bsx_header* headers;       // [prev, next]
+    const uint8_t* hashes;           // their hashes, 64 bytes
+    const uint8_t* input40;          // device copy of the public input
+    const bsx_commit_result* commit; // the next header's commit
+    uint32_t* step_status;           // out: bsx_status of the step verification
+    uint32_t* dc_status;             // out: 0 or BSX_A10_NEXT_HEADER
+    uint8_t* output64;               // out
+    bsxk_unit_dst unit;              // STEP unit (required: the data-hash proof is read from it)
+    uint32_t chain_id_len;
+    uint8_t chain_id[52];
+};
+hipError_t bsxk_step_check(hipStream_t, const bsxk_step_args*);
 hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
 hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
 hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*, uint8_t*, uint8_t*, uint64_t);

@@ -22,12 +22,12 @@
 #include <cstdlib>
 
 #include "../../include/bsx.h"
+#include "../../include/bsx_layout.h"
 #include "ed25519.h"
+#include "kernels.h"
 #include "sha256.h"
 #include "sha512.h"
 
-// see kernels.h
-#define BSXK_ED_THROUGHPUT (reinterpret_cast<const void*>(static_cast<uintptr_t>(1)))
 
 namespace bsx {
 
@@ -39,8 +39,11 @@ namespace bsx {
 // kernel to 2.5 waves per SIMD).
 constexpr int CH_THREADS = 128;
 
+// wit (COMMIT units, include/bsx_layout.h): slot me = validator me % v_max of commit me / v_max — the lane also leaves the digest, the
+// reduced challenge and the hint's validator record (pubkey, signature, message: the first 220 bytes of bsx_validator as they are)
 __global__ __launch_bounds__(CH_THREADS) void k_sha512_challenge(const bsx_validator* __restrict__ vals, uint64_t n,
-                                                                 uint8_t* __restrict__ out_h, uint8_t* __restrict__ out_digest) {
+                                                                 uint8_t* __restrict__ out_h, uint8_t* __restrict__ out_digest,
+                                                                 uint32_t v_max, bsxk_unit_dst wit) {
     const uint64_t me = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
     if (me >= n) return;
     const uint4* rec = reinterpret_cast<const uint4*>(vals + me);       // pubkey 0, R 32, s 64, message 96..219, message_len 220
@@ -88,6 +91,24 @@ __global__ __launch_bounds__(CH_THREADS) void k_sha512_challenge(const bsx_valid
         uint4* od = reinterpret_cast<uint4*>(out_digest + me * 64);
 #pragma unroll
         for (int k = 0; k < 4; k++) od[k] = make_uint4(dig[4 * k], dig[4 * k + 1], dig[4 * k + 2], dig[4 * k + 3]);
+    }
+    if (wit.base) {
+        const uint32_t c = (uint32_t)(me / v_max), v = (uint32_t)(me % v_max);
+        uint8_t* cw = wit.base + (uint64_t)c * wit.stride;
+        uint4* od = reinterpret_cast<uint4*>(cw + bsx_cm_off_digest(v_max) + 64 * v);
+#pragma unroll
+        for (int k = 0; k < 4; k++) od[k] = make_uint4(dig[4 * k], dig[4 * k + 1], dig[4 * k + 2], dig[4 * k + 3]);
+        uint4* oc = reinterpret_cast<uint4*>(cw + bsx_cm_off_challenge(v_max) + 32 * v);
+        oc[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        oc[1] = make_uint4(h[4], h[5], h[6], h[7]);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(cw + bsx_cm_off_validators(v_max) + BSX_CM_VAL_BYTES * v);   // 4-byte aligned
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const uint4 q = rec[k];
+            dst[4 * k] = q.x; dst[4 * k + 1] = q.y; dst[4 * k + 2] = q.z; dst[4 * k + 3] = q.w;
+        }
+        const uint4 q = rec[13];
+        dst[52] = q.x; dst[53] = q.y; dst[54] = q.z;                  // dword 55 of the record is message_len
     }
 }
 
@@ -671,10 +692,14 @@ __device__ __forceinline__ int validator_leaf(const uint32_t pk[8], uint64_t pow
     return 36 + (power ? 1 + nvar : 0);
 }
 
+// wit: where the validator set's variables go (include/bsx_layout.h) — mode 0: the COMMIT unit of commit c (every slot's words and
+// bools, leaves, the masked tree, sums, verdicts); mode 1: the trusted set inside the SKIP unit of range c (pubkeys, leaves, tree,
+// enabled bools, total power; signed_target / overlap are k_skip_check's).  Every byte of the groups named here is written on
+// every launch, so a resident unit never needs clearing.
 __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator* __restrict__ vals, uint32_t v_max,
                                                              const uint8_t* __restrict__ header_hashes,
                                                              const uint8_t* __restrict__ ok_in,
-                                                             bsx_commit_result* __restrict__ results) {
+                                                             bsx_commit_result* __restrict__ results, bsxk_unit_dst wit) {
     // dynamic LDS sized by the padded validator count P (launcher): nodes[2][P * 8] u32, then en[2][P] u8 — 8.4 KB at
     // V = 100 instead of the 33 KB of the 512-slot maximum, so that 2048 commits are resident at once (mode S)
     extern __shared__ uint32_t tl_lds[];
@@ -694,6 +719,19 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     uint32_t hh[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) hh[k] = header_hashes ? reinterpret_cast<const uint32_t*>(header_hashes + 32 * (uint64_t)c)[k] : 0u;
+    // witness destinations of this unit
+    const bool w_on = wit.base != nullptr, w_commit = w_on && wit.mode == 0;
+    uint8_t* const cw = w_on ? wit.base + (uint64_t)c * wit.stride : nullptr;
+    uint32_t* const WW = w_on ? reinterpret_cast<uint32_t*>(cw + wit.off_words) : nullptr;
+    uint8_t* const WB = w_on ? cw + wit.off_bools : nullptr;
+    const uint32_t o_leaf = w_commit ? bsx_cm_off_leaf(v_max) : bsx_sk_off_leaf(v_max);
+    const uint32_t o_lh = w_commit ? bsx_cm_off_leaf_hash(v_max) : bsx_sk_off_leaf_hash(v_max);
+    const uint32_t o_inner = w_commit ? bsx_cm_off_inner(v_max) : bsx_sk_off_inner(v_max);
+    const uint32_t o_node = w_commit ? bsx_cm_off_node(v_max) : bsx_sk_off_node(v_max);
+    const uint32_t o_root = w_commit ? bsx_cm_off_root(v_max) : bsx_sk_off_root(v_max);
+    const uint32_t b_leaf_en = w_commit ? bsx_cm_b_leaf_enabled(v_max) : bsx_sk_b_leaf_enabled(v_max);
+    const uint32_t b_node_en = w_commit ? bsx_cm_b_node_enabled(v_max) : bsx_sk_b_node_enabled(v_max);
+    if (w_commit && tid < 8) reinterpret_cast<uint32_t*>(cw + bsx_cm_off_header_hash())[tid] = hh[tid];
 
     uint64_t total = 0, signedp = 0, trusted = 0;
     uint64_t total_hi = 0, total_lo = 0;     // exact sum in two halves: the u64 `total` may wrap
@@ -709,32 +747,50 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
             power = (uint64_t)fl.x | ((uint64_t)fl.y << 32);
             enabled = (fl.z & 0xffu) != 0;
             const bool is_signed = ((fl.z >> 8) & 0xffu) != 0, present = ((fl.z >> 16) & 0xffu) != 0;
+            bool sig = false, msg = false, has_round = false;
+            uint32_t mlen = 0;
+            if ((enabled && is_signed) || w_commit) {
+                // the signed message must carry the header hash at offset 16 (25 with a round field); evaluated for every slot
+                // when the witness is emitted (static circuit), only where it counts otherwise
+                const uint32_t* mw = reinterpret_cast<const uint32_t*>(cv[v].message);
+                mlen = cv[v].message_len;
+                has_round = mlen > 12 && (mw[3] & 0xffu) == 0x19u;
+                const uint32_t off = has_round ? 25u : 16u;
+                msg = mlen <= BSX_VALIDATOR_MSG_MAX && mlen >= off + 32;
+                uint32_t diff = 0;
+                if (has_round) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) diff |= funnel_r(mw[7 + k], mw[6 + k], 8) ^ hh[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) diff |= mw[4 + k] ^ hh[k];
+                }
+                msg = msg && diff == 0;
+            }
             if (enabled) {
                 nen++;
                 total += power;
                 total_hi += power >> 32; total_lo += power & 0xffffffffull;
                 if (is_signed) {
                     nsig++;
-                    const bool sig = ok_in ? (ok_in[(uint64_t)c * v_max + v] != 0) : false;
-                    // the signed message must carry the header hash at offset 16 (25 with a round field)
-                    const uint32_t* mw = reinterpret_cast<const uint32_t*>(cv[v].message);
-                    const uint32_t mlen = cv[v].message_len;
-                    const bool has_round = mlen > 12 && (mw[3] & 0xffu) == 0x19u;
-                    const uint32_t off = has_round ? 25u : 16u;
-                    bool msg = mlen <= BSX_VALIDATOR_MSG_MAX && mlen >= off + 32;
-                    uint32_t diff = 0;
-                    if (has_round) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) diff |= funnel_r(mw[7 + k], mw[6 + k], 8) ^ hh[k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) diff |= mw[4 + k] ^ hh[k];
-                    }
-                    msg = msg && diff == 0;
+                    sig = ok_in ? (ok_in[(uint64_t)c * v_max + v] != 0) : false;
                     if (!sig) { nbad++; atomicMin(&s_firstbad, v); }
                     if (!msg) nbadmsg++;
                     if (sig && msg) { signedp += power; if (present) trusted += power; }
                 }
+            }
+            if (w_commit) {
+                uint32_t* ws = WW + BSX_CM_SLOT_WORDS * v;
+                ws[0] = mlen; ws[2] = (uint32_t)power; ws[3] = (uint32_t)(power >> 32);
+                uint8_t* b = WB + BSX_CM_SLOT_BOOLS * v;
+                b[0] = enabled; b[1] = is_signed; b[2] = present; b[3] = sig; b[4] = has_round; b[5] = msg;
+                b[6] = enabled && is_signed && sig && msg;
+            } else if (w_on) {
+                uint32_t* ws = WW + BSX_SK_W_SLOTS + 3 * v;
+                ws[1] = (uint32_t)power; ws[2] = (uint32_t)(power >> 32);
+                WB[2 * v] = enabled;
+                uint4* pkd = reinterpret_cast<uint4*>(cw + bsx_sk_off_pubkeys(v_max) + 32 * v);
+                pkd[0] = p0; pkd[1] = p1;
             }
         } else {
 #pragma unroll
@@ -747,6 +803,18 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
 #pragma unroll
             for (int k = 0; k < 8; k++) nodes(0, v * 8 + k) = lh.w[k];
             en(0, v) = enabled ? 1 : 0;
+            if (w_on) {
+                if (v < v_max) {
+                    // the leaf's bytes beyond its length are zero by construction (validator_leaf fills static positions)
+                    uint4* ld = reinterpret_cast<uint4*>(cw + o_leaf + 48 * v);
+                    ld[0] = make_uint4(d[0], d[1], d[2], d[3]); ld[1] = make_uint4(d[4], d[5], d[6], d[7]); ld[2] = make_uint4(d[8], d[9], d[10], d[11]);
+                    WW[w_commit ? BSX_CM_SLOT_WORDS * v + 1 : BSX_SK_W_SLOTS + 3 * v] = (uint32_t)len;
+                }
+                uint4* hd = reinterpret_cast<uint4*>(cw + o_lh + 32 * v);
+                hd[0] = make_uint4(bswap32(lh.w[0]), bswap32(lh.w[1]), bswap32(lh.w[2]), bswap32(lh.w[3]));
+                hd[1] = make_uint4(bswap32(lh.w[4]), bswap32(lh.w[5]), bswap32(lh.w[6]), bswap32(lh.w[7]));
+                WB[b_leaf_en + v] = enabled ? 1 : 0;
+            }
         }
     }
     // wave-level reduction, then one LDS atomic per wave
@@ -761,6 +829,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     }
     __syncthreads();
     int cur = 0;
+    uint32_t level_off = 0;
     for (uint32_t width = P / 2; width >= 1; width /= 2) {
         for (uint32_t t = tid; t < width; t += nthreads) {
             Digest l, r;
@@ -772,10 +841,21 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
 #pragma unroll
             for (int k = 0; k < 8; k++) nodes(cur ^ 1, t * 8 + k) = node.w[k];
             en(cur ^ 1, t) = (el || er) ? 1 : 0;
+            if (w_on) {
+                uint4* di = reinterpret_cast<uint4*>(cw + o_inner + 32 * (level_off + t));
+                di[0] = make_uint4(bswap32(in.w[0]), bswap32(in.w[1]), bswap32(in.w[2]), bswap32(in.w[3]));
+                di[1] = make_uint4(bswap32(in.w[4]), bswap32(in.w[5]), bswap32(in.w[6]), bswap32(in.w[7]));
+                uint4* dn = reinterpret_cast<uint4*>(cw + o_node + 32 * (level_off + t));
+                dn[0] = make_uint4(bswap32(node.w[0]), bswap32(node.w[1]), bswap32(node.w[2]), bswap32(node.w[3]));
+                dn[1] = make_uint4(bswap32(node.w[4]), bswap32(node.w[5]), bswap32(node.w[6]), bswap32(node.w[7]));
+                WB[b_node_en + level_off + t] = (el || er) ? 1 : 0;
+            }
         }
         __syncthreads();
         cur ^= 1;
+        level_off += width;
     }
+    if (w_on && tid < 8) reinterpret_cast<uint32_t*>(cw + o_root)[tid] = bswap32(nodes(cur, tid));
     if (tid == 0) {
         bsx_commit_result* o = results + c;
 #pragma unroll
@@ -784,9 +864,21 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
         o->n_enabled = s_nen; o->n_signed = s_nsig; o->n_bad_signature = s_nbad; o->first_bad_signature = s_firstbad;
         o->n_bad_message = s_nbadmsg;
         const bool overflow = (((unsigned __int128)s_total_hi << 32) + s_total_lo) > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER;
-        o->two_thirds_ok = (!overflow && (unsigned __int128)s_signed * 3 > (unsigned __int128)s_total * 2) ? 1u : 0u;
+        const bool two_thirds = !overflow && (unsigned __int128)s_signed * 3 > (unsigned __int128)s_total * 2;
+        o->two_thirds_ok = two_thirds ? 1u : 0u;
         o->power_overflow = overflow ? 1u : 0u;
         o->_pad[0] = o->_pad[1] = o->_pad[2] = 0;
+        if (w_commit) {
+            uint32_t* wt = WW + bsx_cm_w_total(v_max);
+            wt[0] = (uint32_t)s_total; wt[1] = (uint32_t)(s_total >> 32);
+            wt[2] = (uint32_t)s_signed; wt[3] = (uint32_t)(s_signed >> 32);
+            wt[4] = (uint32_t)s_trusted; wt[5] = (uint32_t)(s_trusted >> 32);
+            uint8_t* t = WB + bsx_cm_b_tail(v_max);
+            t[0] = two_thirds; t[1] = overflow; t[2] = (s_nbad == 0 && s_nbadmsg == 0);
+        } else if (w_on) {
+            uint32_t* wt = WW + bsx_sk_w_total(v_max);
+            wt[0] = (uint32_t)s_total; wt[1] = (uint32_t)(s_total >> 32);
+        }
     }
 #undef nodes
 #undef en
@@ -810,6 +902,7 @@ struct SkipArgs {
     const uint32_t* target_idx;         // optional: index of the target header inside the range's header block (default E - S)
     uint32_t chain_id_len;              // C::CHAIN_ID_BYTES (header_range.rs:42-43): the target header's field 1 must be 0a len bytes
     uint8_t chain_id[52];
+    bsxk_unit_dst wit;                  // SKIP units (include/bsx_layout.h): public inputs, target hash, signed_target bools, overlap, check bools
 };
 __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
     __shared__ uint32_t tpk[TL_VMAX * 8];
@@ -827,8 +920,12 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
         tsig[k] = (tv[k].enabled && tv[k].is_signed && a.target_ok[(uint64_t)r * V + k]) ? 1 : 0;
     }
     __syncthreads();
+    uint8_t* const scw = a.wit.base ? a.wit.base + (uint64_t)r * a.wit.stride : nullptr;
+    uint32_t* const SW = scw ? reinterpret_cast<uint32_t*>(scw + a.wit.off_words) : nullptr;
+    uint8_t* const SB = scw ? scw + a.wit.off_bools : nullptr;
     uint64_t ov = 0;
     for (uint32_t i = tid; i < V; i += 256) {
+        if (SB) SB[2 * i + 1] = 0;
         if (!rv[i].enabled) continue;
         const uint32_t* p = reinterpret_cast<const uint32_t*>(rv[i].pubkey);
         uint32_t pk[8];
@@ -843,6 +940,7 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
             found = d == 0;
         }
         if (found) ov += rv[i].voting_power;
+        if (SB && found) SB[2 * i + 1] = 1;
     }
     ov = wave_sum_u64(ov);
     if ((tid & 63) == 0) atomicAdd(&s_overlap, (unsigned long long)ov);
@@ -896,6 +994,7 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
         const bool veq = (l_tv == 34) && __ballot(b_tvh != b_cvh) == 0;
         const bool treq = (l_rv == 34) && __ballot(b_rvh != b_tcvh) == 0;
         if (a.target_hashes && tid < 32) a.target_hashes[32 * (uint64_t)r + q] = b_thash;
+        if (scw && tid < 32) { scw[q] = rg.start_header_hash[q]; scw[32 + q] = b_thash; }      // header_range.rs:34, :57
         if (tid == 0) {
             uint32_t st = BSX_OK;
             if (overflow) st = BSX_ERR_BAD_ARG;          // voting powers beyond MaxTotalVotingPower: the tallies cannot be trusted
@@ -910,6 +1009,15 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
             if (!st && !(overlap * 3 > ttotal)) st = BSX_ERR_VOTING_POWER;
             cr->trusted_signed_power = s_overlap;
             a.skip_status[r] = st;
+            if (scw) {
+                SW[BSX_SK_W_TRUSTED_BLOCK] = (uint32_t)S; SW[BSX_SK_W_TRUSTED_BLOCK + 1] = (uint32_t)(S >> 32);
+                SW[BSX_SK_W_TARGET_BLOCK] = (uint32_t)E; SW[BSX_SK_W_TARGET_BLOCK + 1] = (uint32_t)(E >> 32);
+                uint32_t* wt = SW + bsx_sk_w_total(V);
+                wt[2] = (uint32_t)s_overlap; wt[3] = (uint32_t)(s_overlap >> 32);
+                uint8_t* c = SB + bsx_sk_b_checks(V);
+                c[0] = eq_trusted; c[1] = heq; c[2] = ceq; c[3] = !(n_bad_sig || n_bad_msg); c[4] = veq; c[5] = treq; c[6] = two_thirds != 0;
+                c[7] = overlap * 3 > ttotal; c[8] = overflow != 0;
+            }
         }
     }
 }
@@ -984,9 +1092,12 @@ __global__ __launch_bounds__(256) void k_skip_eval(const bsx_validator* __restri
 
 extern "C" {
 using namespace bsx;
-hipError_t bsxk_sha512_challenge(hipStream_t s, const bsx_validator* vals, uint64_t n, uint8_t* h, uint8_t* digest) {
+hipError_t bsxk_sha512_challenge(hipStream_t s, const bsx_validator* vals, uint64_t n, uint8_t* h, uint8_t* digest, uint32_t v_max,
+                                 const bsxk_unit_dst* wit) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_sha512_challenge, dim3((uint32_t)((n + CH_THREADS - 1) / CH_THREADS)), dim3(CH_THREADS), 0, s, vals, n, h, digest);
+    const bsxk_unit_dst w = wit ? *wit : bsxk_unit_dst{nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_sha512_challenge, dim3((uint32_t)((n + CH_THREADS - 1) / CH_THREADS)), dim3(CH_THREADS), 0, s, vals, n, h, digest,
+                       v_max ? v_max : 1u, w);
     return hipGetLastError();
 }
 hipError_t bsxk_ed25519_verify(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint8_t* ok) {
@@ -1091,24 +1202,25 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     return hipGetLastError();
 }
 hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,
-                             const uint8_t* ok, bsx_commit_result* results) {
+                             const uint8_t* ok, bsx_commit_result* results, const bsxk_unit_dst* wit) {
     if (!n_commits) return hipSuccess;
     uint32_t P = 1;
     while (P < v_max) P *= 2;
     // a commit of <= 128 validator slots is two waves' worth of leaves: a 128-thread workgroup (and 8.4 KB of LDS) lets twice
     // as many commits be resident; the tree is a latency chain either way
     const uint32_t threads = P <= 128 ? 128 : TL_THREADS;
-    hipLaunchKernelGGL(k_commit_tally, dim3(n_commits), dim3(threads), 2 * P * 8 * 4 + 2 * P, s, vals, v_max, header_hashes, ok, results);
+    const bsxk_unit_dst w = wit ? *wit : bsxk_unit_dst{nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_commit_tally, dim3(n_commits), dim3(threads), 2 * P * 8 * 4 + 2 * P, s, vals, v_max, header_hashes, ok, results, w);
     return hipGetLastError();
 }
 hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* ranges, const bsx_header* headers,
                            uint64_t hpr, const uint8_t* hashes, const bsx_validator* target, const bsx_validator* trusted,
                            const uint8_t* target_ok, bsx_commit_result* target_res, const bsx_commit_result* trusted_res,
                            uint32_t* skip_status, uint8_t* target_hashes, const uint32_t* target_idx, const uint8_t* chain_id,
-                           uint32_t chain_id_len) {
+                           uint32_t chain_id_len, const bsxk_unit_dst* wit) {
     if (!n_ranges) return hipSuccess;
     SkipArgs a{n_ranges, v_max, ranges, headers, hpr, hashes, target, trusted, target_ok, target_res, trusted_res, skip_status, target_hashes, target_idx,
-               chain_id_len, {0}};
+               chain_id_len, {0}, wit ? *wit : bsxk_unit_dst{nullptr, 0, 0, 0, 0}};
     for (uint32_t i = 0; i < chain_id_len && i < 50; i++) a.chain_id[i] = chain_id[i];
     hipLaunchKernelGGL(k_skip_check, dim3(n_ranges), dim3(256), 0, s, a);
     return hipGetLastError();

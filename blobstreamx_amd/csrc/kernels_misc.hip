@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/bsx.h"
+#include "../../include/bsx_layout.h"
+#include "kernels.h"
 #include "sha256.h"
 
 namespace bsx {
@@ -162,10 +164,213 @@ __global__ __launch_bounds__(256) void k_commit_fold(const bsx_commit_result* __
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ k_field_proofs
+// Header-field inclusion proofs of the SKIP / STEP units (include/bsx_layout.h; tendermintx ChainIdProofVariable / HeightProofVariable
+// / HashInclusionProofVariable [UPSTREAM], the hint outputs builder.skip / builder.step verify against the header hash,
+// header_range.rs:42-48, next_header.rs:32-36): one wave per (item, header) hashes the header's 14-leaf tree (tendermint
+// Header::hash: 14 = 8 | 6, 6 = 4 | 2) level by level through LDS and copies out, for every requested field index (<= 11: depth 4),
+// the 4 aunts, the 5 path digests (leaf hash .. header hash), the zero-padded leaf and its length.  Independent of the signatures:
+// runs in the commit check's prep phase.  Latency only (5 dependent hashing steps).
+__device__ __forceinline__ void fp_field(uint32_t i, uint32_t& off, uint32_t& cap) {   // byte offset / capacity of field i in bsx_header
+    if (i == 0) { off = 16; cap = 24; }
+    else if (i == 1) { off = 40; cap = 52; }
+    else if (i == 2) { off = 92; cap = 12; }
+    else if (i == 3) { off = 104; cap = 20; }
+    else if (i == 4) { off = 124; cap = 76; }
+    else if (i <= 12) { off = 200 + 36 * (i - 5); cap = 36; }
+    else { off = 488; cap = 24; }
+}
+__global__ __launch_bounds__(64) void k_field_proofs(bsxk_field_proofs_args a) {
+    __shared__ uint32_t lv[4][16][8];      // level k (0 = leaf hashes): node j
+    __shared__ uint32_t root_w[8];
+    const uint32_t item = blockIdx.x >> 1, hsel = blockIdx.x & 1, lane = threadIdx.x;
+    bool any = false;
+    for (uint32_t q = 0; q < a.n_proofs; q++) any = any || a.proofs[q].header == hsel;
+    if (!any) return;                      // block-uniform
+    uint64_t hidx = 0;
+    if (hsel) hidx = a.target_idx ? (uint64_t)a.target_idx[item] : a.ranges ? a.ranges[item].end_block - a.ranges[item].start_block : 1;
+    const uint32_t* rec = reinterpret_cast<const uint32_t*>(a.headers + (uint64_t)item * a.headers_per_item + hidx);
+    if (lane < 14) {
+        uint32_t off, cap;
+        fp_field(lane, off, cap);
+        uint32_t len = (rec[lane >> 2] >> (8 * (lane & 3))) & 0xffu;
+        if (len > cap) len = cap;
+        uint32_t d[19];
+#pragma unroll
+        for (uint32_t j = 0; j < 19; j++) d[j] = 4 * j < cap ? rec[off / 4 + j] : 0u;
+        const Digest h = len <= 54 ? leaf_hash_1block(d, (int)len) : leaf_hash_2block(d, (int)len);
+#pragma unroll
+        for (int k = 0; k < 8; k++) lv[0][lane][k] = h.w[k];
+    }
+    __syncthreads();
+    // level 1: 7 pairs; level 2: 3 pairs + the odd node (leaves 12,13) passed up; level 3: 2 pairs; root
+    for (uint32_t level = 1; level <= 3; level++) {
+        const uint32_t pairs = level == 1 ? 7 : level == 2 ? 3 : 2;
+        if (lane < pairs) {
+            Digest l, r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { l.w[k] = lv[level - 1][2 * lane][k]; r.w[k] = lv[level - 1][2 * lane + 1][k]; }
+            const Digest h = inner_hash(l, r);
+#pragma unroll
+            for (int k = 0; k < 8; k++) lv[level][lane][k] = h.w[k];
+        } else if (level == 2 && lane == 3) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) lv[2][3][k] = lv[1][6][k];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        Digest l, r;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { l.w[k] = lv[3][0][k]; r.w[k] = lv[3][1][k]; }
+        const Digest h = inner_hash(l, r);
+#pragma unroll
+        for (int k = 0; k < 8; k++) root_w[k] = h.w[k];
+    }
+    __syncthreads();
+    uint8_t* cw = a.unit.base + (uint64_t)item * a.unit.stride;
+    uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.unit.off_words);
+    const uint32_t fl = a.flags ? a.flags[item] : 0u;
+    for (uint32_t q = 0; q < a.n_proofs; q++) {
+        const bsxk_proof_spec sp = a.proofs[q];
+        if (sp.header != hsel) continue;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(cw + sp.off);
+        const bool zero = (fl & sp.zero_if) != 0;
+        const uint32_t idx = sp.field;
+        uint32_t off, cap;
+        fp_field(idx, off, cap);
+        uint32_t len = (rec[idx >> 2] >> (8 * (idx & 3))) & 0xffu;
+        if (len > cap) len = cap;
+        if (lane < 32) {                                   // aunts: level k's sibling of the path node
+            const uint32_t k = lane >> 3, w = lane & 7;
+            dst[lane] = zero ? 0u : bswap32(lv[k][(idx >> k) ^ 1][w]);
+        }
+        if (lane < 40) {                                   // path: leaf hash, the 4 inner nodes (last = header hash)
+            const uint32_t k = lane >> 3, w = lane & 7;
+            const uint32_t v = k < 4 ? lv[k][idx >> k][w] : root_w[w];
+            dst[32 + lane] = zero ? reinterpret_cast<const uint32_t*>(a.zero_paths)[lane] : bswap32(v);
+        }
+        if (4 * lane < sp.cap) {                           // leaf, zero padded to the record's capacity
+            uint32_t v = 0;
+            if (!zero && 4 * lane < cap && 4 * lane < len) {
+                v = rec[off / 4 + lane];
+                const uint32_t r = len - 4 * lane;
+                if (r < 4) v &= 0xffffffffu >> (32 - 8 * r);
+            }
+            dst[BSX_PROOF_FIXED / 4 + lane] = v;
+        }
+        if (lane == 0) W[sp.len_word] = zero ? BSX_PROTOBUF_HASH_SIZE : len;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_step_check
+// Step conditions of CombinedStepCircuit::define (next_header.rs:25-46; builder.step [UPSTREAM] tendermintx v1.0.0)
+// and prove_next_header_data_commitment (builder.rs:411-443) for one request: one wave.  Status = the FIRST failing condition in the
+// order the oracle uses: power overflow, prev hash, height, chain id, signatures, validators_hash, next_validators_hash,
+// last_block_id, 2/3.  Reads data_hash_proofs[0] (leaf + path) from the STEP unit, where k_field_proofs left it.
+__global__ __launch_bounds__(64) void k_step_check(bsxk_step_args a) {
+    const uint32_t tid = threadIdx.x, q = tid & 31;
+    const bsx_header* ph = a.headers;
+    const bsx_header* nh = a.headers + 1;
+    const bsx_commit_result* cr = a.commit;
+    uint8_t* cw = a.unit.base;
+    uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.unit.off_words);
+    uint8_t* Bo = cw + a.unit.off_bools;
+    uint64_t prev_block = 0;                                               // next_header.rs:26 (big endian)
+    for (int i = 0; i < 8; i++) prev_block = prev_block << 8 | a.input40[i];
+    const uint64_t next_block = prev_block + 1;                            // :29-30
+    const uint8_t b_prev_in = a.input40[8 + q];                            // :27
+    const uint8_t b_hp = a.hashes[q], b_hn = a.hashes[32 + q];
+    const uint8_t b_vh = nh->hash[2][2 + q], b_nvh = ph->hash[3][2 + q], b_cvh = cr->validators_hash[q];
+    const uint8_t b_lb = nh->last_block_id[2 + q];
+    const uint8_t b_height = nh->height[q < 12 ? q : 0];
+    const uint8_t b_chain = nh->chain_id[tid < 52 ? tid : 0];
+    const uint8_t l_chain = nh->len[1], l_height = nh->len[BSX_BLOCK_HEIGHT_INDEX], l_vh = nh->len[7], l_nvh = ph->len[8], l_lb = nh->len[BSX_LAST_BLOCK_ID_INDEX];
+    const uint8_t* dhp = cw + bsx_st_off_proof(5);
+    const uint8_t b_dh_root = dhp[128 + 128 + q];                          // path[4] of data_hash_proofs[0]
+    int hn = 1;
+    uint8_t want = 0x08;
+    {
+        uint64_t hv = next_block;
+        int pos = 1;
+        for (;;) {
+            const bool more = hv >= 0x80;
+            const uint8_t byte = (uint8_t)(more ? (hv | 0x80) : hv);
+            if ((int)q == pos) want = byte;
+            pos++;
+            if (!more) break;
+            hv >>= 7;
+        }
+        hn = pos;
+    }
+    const bool c_prev = __ballot(b_hp != b_prev_in) == 0;
+    const bool c_height = (l_height == hn) && __ballot((int)q < hn && b_height != want) == 0;
+    const uint32_t cl = a.chain_id_len;
+    const uint8_t want_c = tid == 0 ? 0x0a : tid == 1 ? (uint8_t)cl : a.chain_id[tid >= 2 && tid < 52 ? tid - 2 : 0];
+    const bool c_chain = (l_chain == cl + 2) && __ballot(tid < cl + 2 && b_chain != want_c) == 0;
+    const bool c_vh = (l_vh == 34) && __ballot(b_vh != b_cvh) == 0;
+    const bool c_nvh = (l_nvh == 34) && __ballot(b_nvh != b_cvh) == 0;
+    const bool c_lb = (l_lb >= 34) && __ballot(b_lb != b_hp) == 0;
+    const bool c_a10 = __ballot(b_dh_root != b_prev_in) == 0;               // builder.rs:434
+    if (tid < 32) { cw[q] = b_prev_in; cw[32 + q] = b_hn; a.output64[q] = b_hn; }
+    if (tid == 0) {
+        const bool c_sigs = !(cr->n_bad_signature || cr->n_bad_message);
+        const bool two_thirds = cr->two_thirds_ok != 0, overflow = cr->power_overflow != 0;
+        uint32_t st = BSX_OK;
+        if (overflow) st = BSX_ERR_BAD_ARG;
+        if (!st && !c_prev) st = BSX_ERR_ASSERT;
+        if (!st && !c_height) st = BSX_ERR_ASSERT;
+        if (!st && !c_chain) st = BSX_ERR_ASSERT;
+        if (!st && !c_sigs) st = BSX_ERR_BAD_SIGNATURE;
+        if (!st && !c_vh) st = BSX_ERR_ASSERT;
+        if (!st && !c_nvh) st = BSX_ERR_ASSERT;
+        if (!st && !c_lb) st = BSX_ERR_ASSERT;
+        if (!st && !two_thirds) st = BSX_ERR_VOTING_POWER;
+        // which condition failed first, for the host's message: bits 8.. = 1 + index into the list above
+        uint32_t why = 0;
+        if (overflow) why = 1; else if (!c_prev) why = 2; else if (!c_height) why = 3; else if (!c_chain) why = 4; else if (!c_sigs) why = 5;
+        else if (!c_vh) why = 6; else if (!c_nvh) why = 7; else if (!c_lb) why = 8; else if (!two_thirds) why = 9;
+        *a.step_status = st | (why << 8);
+        *a.dc_status = c_a10 ? 0u : BSX_A10_NEXT_HEADER;
+        // data-root tuple (builder.rs:436-439) and its leaf hash (:442)
+        uint32_t t[16];
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = 0;
+        t[6] = (uint32_t)(prev_block >> 32);
+        t[7] = (uint32_t)prev_block;
+        const uint8_t* lf = dhp + BSX_PROOF_FIXED + 2;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[8 + k] = ((uint32_t)lf[4 * k] << 24) | ((uint32_t)lf[4 * k + 1] << 16) | ((uint32_t)lf[4 * k + 2] << 8) | lf[4 * k + 3];
+        const Digest dc = leaf_hash_tuple(t);
+        uint32_t* tp = reinterpret_cast<uint32_t*>(cw + bsx_st_off_tuple());
+#pragma unroll
+        for (int k = 0; k < 16; k++) tp[k] = bswap32(t[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            reinterpret_cast<uint32_t*>(cw + 64)[k] = bswap32(dc.w[k]);
+            reinterpret_cast<uint32_t*>(a.output64 + 32)[k] = bswap32(dc.w[k]);
+        }
+        W[BSX_ST_W_PREV_BLOCK] = (uint32_t)prev_block; W[BSX_ST_W_PREV_BLOCK + 1] = (uint32_t)(prev_block >> 32);
+        W[BSX_ST_W_NEXT_BLOCK] = (uint32_t)next_block; W[BSX_ST_W_NEXT_BLOCK + 1] = (uint32_t)(next_block >> 32);
+        Bo[0] = c_prev; Bo[1] = c_height; Bo[2] = c_chain; Bo[3] = c_sigs; Bo[4] = c_vh; Bo[5] = c_nvh; Bo[6] = c_lb; Bo[7] = two_thirds;
+        Bo[8] = overflow; Bo[9] = c_a10;
+    }
+}
+
 }  // namespace bsx
 
 extern "C" {
 using namespace bsx;
+hipError_t bsxk_field_proofs(hipStream_t s, const bsxk_field_proofs_args* a) {
+    if (!a->n_items || !a->n_proofs) return hipSuccess;
+    hipLaunchKernelGGL(k_field_proofs, dim3(2 * a->n_items), dim3(64), 0, s, *a);
+    return hipGetLastError();
+}
+hipError_t bsxk_step_check(hipStream_t s, const bsxk_step_args* a) {
+    hipLaunchKernelGGL(k_step_check, dim3(1), dim3(64), 0, s, *a);
+    return hipGetLastError();
+}
 // n <= BSX_COMMIT_FOLD_MAX commits; scratch: bsxk_commit_fold_scratch_bytes(n)
 uint64_t bsxk_commit_fold_scratch_bytes(uint32_t n) {
     uint32_t P = 1;

@@ -829,8 +829,11 @@ __global__ __launch_bounds__(128) void k_reduce(ReduceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_finalize
+// dc_units (optional): the SKIP unit of range r (include/bsx_layout.h) starts at dc_units + r * dc_stride; its public output
+// data_commitment (byte 64, header_range.rs:58) is this kernel's to write
 __global__ void k_finalize(uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t batch, const bsx_shared_ctx* ranges,
-                           const bsx_subchain* results, const uint8_t* target_hashes, uint8_t* output64, uint32_t* status) {
+                           const bsx_subchain* results, const uint8_t* target_hashes, uint8_t* output64, uint32_t* status,
+                           uint8_t* dc_units, uint32_t dc_stride) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_ranges) return;
     const bsx_shared_ctx& rg = ranges[r];
@@ -845,6 +848,8 @@ __global__ void k_finalize(uint32_t n_ranges, uint32_t nb_map_jobs, uint32_t bat
         const uint8_t* th = target_hashes ? target_hashes + 32 * (uint64_t)r : rg.end_header_hash;
         for (int q = 0; q < 32; q++) { output64[64 * (uint64_t)r + q] = th[q]; output64[64 * (uint64_t)r + 32 + q] = res.data_merkle_root[q]; }  // header_range.rs:57-58
     }
+    if (dc_units)
+        for (int q = 0; q < 32; q++) dc_units[(uint64_t)r * dc_stride + 64 + q] = res.data_merkle_root[q];
     if (status) status[r] = st;
 }
 
@@ -1013,9 +1018,10 @@ hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_s
     return hipGetLastError();
 }
 hipError_t bsxk_finalize(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, const bsx_shared_ctx* ranges, const bsx_subchain* results,
-                         const uint8_t* target_hashes, uint8_t* output64, uint32_t* status) {
+                         const uint8_t* target_hashes, uint8_t* output64, uint32_t* status, uint8_t* dc_units, uint32_t dc_stride) {
     if (!n_ranges) return hipSuccess;
-    hipLaunchKernelGGL(k_finalize, dim3((n_ranges + 63) / 64), dim3(64), 0, s, n_ranges, J, B, ranges, results, target_hashes, output64, status);
+    hipLaunchKernelGGL(k_finalize, dim3((n_ranges + 63) / 64), dim3(64), 0, s, n_ranges, J, B, ranges, results, target_hashes, output64, status,
+                       dc_units, dc_stride);
     return hipGetLastError();
 }
 hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uint32_t n_jobs, const uint8_t* compact, uint64_t* out) {

@@ -41,10 +41,120 @@ struct Builder {
 };
 }  // namespace
 
-extern "C" int bsx_witness_manifest(uint32_t batch_size, bsx_manifest_entry* entries, uint32_t capacity, uint32_t* out_n) {
+namespace {
+// validator-set tree groups shared by the commit and the skip section
+void tree_groups(Builder& m, const char* prefix, uint32_t V, uint32_t off_leaf, uint32_t off_leaf_hash, uint32_t off_inner, uint32_t off_node,
+                 uint32_t off_root) {
+    const uint32_t P = bsx_pow2_ceil(V);
+    char nm[80];
+    snprintf(nm, sizeof nm, "%sleaf[] (SimpleValidator bytes, zero padded)", prefix);
+    m.bytes(nm, "tendermintx [UPSTREAM]", off_leaf, 48, V, 48);
+    snprintf(nm, sizeof nm, "%sleaf_hash[] (P = pow2 >= V; padding = zero validator)", prefix);
+    m.bytes(nm, "tendermintx [UPSTREAM]", off_leaf_hash, 32, P, 32);
+    if (P > 1) {
+        snprintf(nm, sizeof nm, "%stree.inner[] (levels bottom-up)", prefix);
+        m.bytes(nm, "tendermintx [UPSTREAM]", off_inner, 32, P - 1, 32);
+        snprintf(nm, sizeof nm, "%stree.node[] (select(both enabled, inner, left))", prefix);
+        m.bytes(nm, "tendermintx [UPSTREAM]", off_node, 32, P - 1, 32);
+    }
+    snprintf(nm, sizeof nm, "%svalidators_hash", prefix);
+    m.bytes(nm, "tendermintx [UPSTREAM]", off_root, 32);
+}
+void proof_groups(Builder& m, const char* name, const char* ref, uint32_t off, uint32_t cap) {
+    char nm[80];
+    snprintf(nm, sizeof nm, "%s.proof (4 aunts)", name);
+    m.bytes(nm, ref, off, 128);
+    snprintf(nm, sizeof nm, "%s.path (leaf hash, 4 nodes; last = header hash)", name);
+    m.bytes(nm, ref, off + 128, 160);
+    snprintf(nm, sizeof nm, "%s.leaf (zero padded to the field capacity)", name);
+    m.bytes(nm, ref, off + BSX_PROOF_FIXED, cap);
+}
+}  // namespace
+
+extern "C" int bsx_witness_manifest_section(uint32_t section, uint32_t param, bsx_manifest_entry* entries, uint32_t capacity, uint32_t* out_n) {
     if (!out_n) return BSX_ERR_BAD_ARG;
     Builder m;
-    if (batch_size == 0) {   // one reduce node (circuits/builder.rs:337-395)
+    if (section == BSX_SECTION_COMMIT) {          // one commit of V = param validator slots (builder.skip / builder.step inner loop)
+        const uint32_t V = param;
+        if (V == 0 || V > 512) return BSX_ERR_BAD_ARG;
+        const uint32_t P = bsx_pow2_ceil(V);
+        const bsx_witness_layout L = bsx_commit_layout(V);
+        const char* ref = "header_range.rs:42-48";
+        m.words0 = 8ull * L.n_bytes;
+        m.bools0 = m.words0 + L.n_words;
+        m.bytes("header_hash", ref, bsx_cm_off_header_hash(), 32);
+        m.bytes("validator[].sha512_digest (SHA512(R|A|M))", ref, bsx_cm_off_digest(V), 64, V, 64);
+        m.bytes("validator[].challenge (digest mod L, little endian)", ref, bsx_cm_off_challenge(V), 32, V, 32);
+        tree_groups(m, "", V, bsx_cm_off_leaf(V), bsx_cm_off_leaf_hash(V), bsx_cm_off_inner(V), bsx_cm_off_node(V), bsx_cm_off_root(V));
+        m.bytes("validator[].pubkey", ref, bsx_cm_off_validators(V), 32, V, BSX_CM_VAL_BYTES);
+        m.bytes("validator[].signature (R | s)", ref, bsx_cm_off_validators(V) + 32, 64, V, BSX_CM_VAL_BYTES);
+        m.bytes("validator[].message (CanonicalVote sign bytes, zero padded)", ref, bsx_cm_off_validators(V) + 96, 124, V, BSX_CM_VAL_BYTES);
+        m.words("validator[].message_byte_length", ref, 0, 1, V, BSX_CM_SLOT_WORDS);
+        m.words("validator[].validator_byte_length", ref, 1, 1, V, BSX_CM_SLOT_WORDS);
+        m.words("validator[].voting_power", ref, 2, 2, V, BSX_CM_SLOT_WORDS);
+        m.words("total_voting_power", ref, bsx_cm_w_total(V), 2);
+        m.words("signed_voting_power", ref, bsx_cm_w_total(V) + 2, 2);
+        m.words("trusted_signed_voting_power (present_on_trusted_header)", ref, bsx_cm_w_total(V) + 4, 2);
+        static const char* slot_b[BSX_CM_SLOT_BOOLS] = {"validator[].enabled", "validator[].signed", "validator[].present_on_trusted_header",
+                                                       "validator[].signature_valid", "validator[].message_has_round",
+                                                       "validator[].message_carries_header_hash", "validator[].counted"};
+        for (uint32_t k = 0; k < BSX_CM_SLOT_BOOLS; k++) m.bools(slot_b[k], ref, k, 1, V, BSX_CM_SLOT_BOOLS);
+        m.bools("leaf_enabled[]", ref, bsx_cm_b_leaf_enabled(V), 1, P, 1);
+        if (P > 1) m.bools("node_enabled[]", ref, bsx_cm_b_node_enabled(V), 1, P - 1, 1);
+        m.bools("two_thirds_ok (3 * signed > 2 * total)", ref, bsx_cm_b_tail(V), 1);
+        m.bools("power_overflow (total > MaxTotalVotingPower)", ref, bsx_cm_b_tail(V) + 1, 1);
+        m.bools("signatures_ok", ref, bsx_cm_b_tail(V) + 2, 1);
+    } else if (section == BSX_SECTION_SKIP) {     // the rest of CombinedSkipCircuit::define (header_range.rs:32-59)
+        const uint32_t V = param;
+        if (V == 0 || V > 512) return BSX_ERR_BAD_ARG;
+        const uint32_t P = bsx_pow2_ceil(V);
+        const bsx_witness_layout L = bsx_skip_layout(V);
+        const char* ref = "header_range.rs:42-48";
+        m.words0 = 8ull * L.n_bytes;
+        m.bools0 = m.words0 + L.n_words;
+        m.bytes("trusted_header_hash (public input)", "header_range.rs:34", 0, 32);
+        m.bytes("target_header_hash (public output)", "header_range.rs:57", 32, 32);
+        m.bytes("data_commitment (public output)", "header_range.rs:58", 64, 32);
+        tree_groups(m, "trusted.", V, bsx_sk_off_leaf(V), bsx_sk_off_leaf_hash(V), bsx_sk_off_inner(V), bsx_sk_off_node(V), bsx_sk_off_root(V));
+        m.bytes("trusted.validator[].pubkey", ref, bsx_sk_off_pubkeys(V), 32, V, 32);
+        static const char* pn[BSX_SK_N_PROOFS] = {"target.chain_id_proof", "target.height_proof", "target.validators_hash_proof",
+                                                 "trusted.validators_hash_proof"};
+        for (uint32_t k = 0; k < BSX_SK_N_PROOFS; k++) proof_groups(m, pn[k], ref, bsx_sk_off_proof(V, k), bsx_sk_proof_cap(k));
+        m.words("trusted_block (public input)", "header_range.rs:33", BSX_SK_W_TRUSTED_BLOCK, 2);
+        m.words("target_block (public input)", "header_range.rs:35", BSX_SK_W_TARGET_BLOCK, 2);
+        m.words("proof_leaf_byte_length[] (chain_id, height, target vh, trusted vh)", ref, BSX_SK_W_LEAF_LEN, 1, BSX_SK_N_PROOFS, 1);
+        m.words("trusted.validator[].validator_byte_length", ref, BSX_SK_W_SLOTS, 1, V, 3);
+        m.words("trusted.validator[].voting_power", ref, BSX_SK_W_SLOTS + 1, 2, V, 3);
+        m.words("trusted.total_voting_power", ref, bsx_sk_w_total(V), 2);
+        m.words("trusted.overlap_voting_power (signed the target)", "fetcher.rs:76-80", bsx_sk_w_total(V) + 2, 2);
+        m.bools("trusted.validator[].enabled", ref, 0, 1, V, 2);
+        m.bools("trusted.validator[].signed_target", ref, 1, 1, V, 2);
+        m.bools("trusted.leaf_enabled[]", ref, bsx_sk_b_leaf_enabled(V), 1, P, 1);
+        if (P > 1) m.bools("trusted.node_enabled[]", ref, bsx_sk_b_node_enabled(V), 1, P - 1, 1);
+        static const char* ck[BSX_SK_CHECK_BOOLS] = {"trusted_hash_ok", "height_ok", "chain_id_ok", "signatures_ok", "target_validators_hash_ok",
+                                                    "trusted_validators_hash_ok", "two_thirds_ok", "one_third_ok", "power_overflow"};
+        for (uint32_t k = 0; k < BSX_SK_CHECK_BOOLS; k++) m.bools(ck[k], ref, bsx_sk_b_checks(V) + k, 1);
+    } else if (section == BSX_SECTION_STEP) {     // the rest of CombinedStepCircuit::define (next_header.rs:25-46)
+        const bsx_witness_layout L = bsx_step_layout();
+        const char* ref = "next_header.rs:32-36";
+        m.words0 = 8ull * L.n_bytes;
+        m.bools0 = m.words0 + L.n_words;
+        m.bytes("prev_header_hash (public input)", "next_header.rs:27", 0, 32);
+        m.bytes("next_header_hash (public output)", "next_header.rs:45", 32, 32);
+        m.bytes("data_commitment (public output)", "next_header.rs:46", 64, 32);
+        static const char* pn[BSX_ST_N_PROOFS] = {"next.chain_id_proof", "next.height_proof", "next.validators_hash_proof", "next.last_block_id_proof",
+                                                 "prev.next_validators_hash_proof", "data_hash_proofs[0]"};
+        for (uint32_t k = 0; k < BSX_ST_N_PROOFS; k++)
+            proof_groups(m, pn[k], k == 5 ? "builder.rs:418-433" : ref, bsx_st_off_proof(k), bsx_st_proof_cap(k));
+        m.bytes("data_root_tuple", "builder.rs:436-439", bsx_st_off_tuple(), 64);
+        m.words("prev_block (public input)", "next_header.rs:26", BSX_ST_W_PREV_BLOCK, 2);
+        m.words("next_block", "next_header.rs:29-30", BSX_ST_W_NEXT_BLOCK, 2);
+        m.words("proof_leaf_byte_length[]", ref, BSX_ST_W_LEAF_LEN, 1, BSX_ST_N_PROOFS, 1);
+        static const char* ck[BSX_ST_CHECK_BOOLS] = {"prev_hash_ok", "height_ok", "chain_id_ok", "signatures_ok", "validators_hash_ok",
+                                                    "next_validators_hash_ok", "last_block_id_ok", "two_thirds_ok", "power_overflow",
+                                                    "data_hash_root_ok (A10)"};
+        for (uint32_t k = 0; k < BSX_ST_CHECK_BOOLS; k++) m.bools(ck[k], k == 9 ? "builder.rs:434" : ref, k, 1);
+    } else if (section == BSX_SECTION_REDUCE) {   // one reduce node (circuits/builder.rs:337-395)
         const bsx_witness_layout L = bsx_reduce_layout();
         m.words0 = 8ull * L.n_bytes;
         m.bools0 = m.words0 + L.n_words;
@@ -60,9 +170,9 @@ extern "C" int bsx_witness_manifest(uint32_t batch_size, bsx_manifest_entry* ent
         m.bools("subchains_linked", "builder.rs:351", 3, 1);
         m.bools("link_check", "builder.rs:352", 4, 1);
         m.bools("out.is_enabled", "builder.rs:388", 5, 1);
-    } else {
-        const uint32_t B = batch_size;
-        if ((B & (B - 1)) || B > BSX_MAX_BATCH) return BSX_ERR_BAD_ARG;
+    } else if (section == BSX_SECTION_MAP) {
+        const uint32_t B = param;
+        if (!B || (B & (B - 1)) || B > BSX_MAX_BATCH) return BSX_ERR_BAD_ARG;
         const bsx_witness_layout L = bsx_map_layout(B);
         m.words0 = 8ull * L.n_bytes;
         m.bools0 = m.words0 + L.n_words;
@@ -115,6 +225,8 @@ extern "C" int bsx_witness_manifest(uint32_t batch_size, bsx_manifest_entry* ent
         m.bools("leaf_enabled[]", "builder.rs:119-128", bsx_b_leaf_enabled(B), 1, B, 1);
         if (B > 1) m.bools("node_enabled[]", "builder.rs:144-147", bsx_b_node_enabled(B), 1, B - 1, 1);
         m.bools("record.is_enabled", "builder.rs:263-270", bsx_b_rec_enabled(B), 1);
+    } else {
+        return BSX_ERR_BAD_ARG;
     }
     *out_n = (uint32_t)m.v.size();
     if (entries) {
@@ -122,4 +234,8 @@ extern "C" int bsx_witness_manifest(uint32_t batch_size, bsx_manifest_entry* ent
         memcpy(entries, m.v.data(), m.v.size() * sizeof(bsx_manifest_entry));
     }
     return BSX_OK;
+}
+
+extern "C" int bsx_witness_manifest(uint32_t batch_size, bsx_manifest_entry* entries, uint32_t capacity, uint32_t* out_n) {
+    return bsx_witness_manifest_section(batch_size ? BSX_SECTION_MAP : BSX_SECTION_REDUCE, batch_size, entries, capacity, out_n);
 }

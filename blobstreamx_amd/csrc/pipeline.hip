@@ -55,6 +55,12 @@ struct Chunk {
     uint64_t *witness_map = nullptr, *witness_red_local = nullptr, *witness_red_top = nullptr, *trees = nullptr;
     bool witness_map_vmm = false;
     uint64_t n_map_el = 0, n_red_local_el = 0, n_red_top_el = 0, trees_words = 0;
+    // COMMIT / SKIP units of the owned ranges (builder.skip's variables, include/bsx_layout.h): compact images the commit chain's
+    // kernels fill, their Goldilocks expansion and / or Poseidon trees
+    uint8_t *commit_compact = nullptr, *skip_compact = nullptr;
+    uint64_t *witness_commit = nullptr, *witness_skip = nullptr, *trees_commit = nullptr, *trees_skip = nullptr;
+    bool fin_recorded = false, wit_pending = false, units_done_valid = false;
+    hipEvent_t ev_finalized = nullptr, ev_units_done = nullptr;
     size_t compact_bytes = 0, records_bytes = 0, headers_bytes = 0;
     // state
     int parity = 0;
@@ -79,7 +85,10 @@ struct bsx_pipeline {
     uint32_t subchain_flags = 0, merkle_wgs = 0;
     uint32_t leaf_len = 0, cap_height = 0, n_leaves = 0;
     uint64_t tree_digests = 0;
-    bsx_witness_layout ml{}, rl{};
+    bsx_witness_layout ml{}, rl{}, cl{}, sl{};
+    bool units = false;                      // COMMIT / SKIP units are produced (commit check on, and a witness or caps wanted)
+    uint32_t n_leaves_cm = 0, cap_h_cm = 0, n_leaves_sk = 0, cap_h_sk = 0;
+    uint64_t tree_digests_cm = 0, tree_digests_sk = 0;
     std::vector<Chunk> chunks;
     // Every stream a chunk's hashing / expansion (main) and commit check (side) may run on, created AND used once at
     // bsx_pipeline_create, in this order: HIP binds a stream to a hardware queue at its first command, and WHICH queues the hot
@@ -147,7 +156,7 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
     }
     if (world > 1) RET(new_stream(&c.xchg));
     for (hipEvent_t* e : {&c.ev_sync, &c.ev_merkle, &c.ev_fill, &c.ev_fin, &c.ev_inputs_consumed, &c.ev_h2d, &c.ev_commit_done[0], &c.ev_commit_done[1],
-                          &c.ev_hash_tok, &c.ev_expand_tok, &c.ev_x_in, &c.ev_x_out})
+                          &c.ev_hash_tok, &c.ev_expand_tok, &c.ev_x_in, &c.ev_x_out, &c.ev_finalized, &c.ev_units_done})
         RET(new_event(e));
     // one header block per step: this rank's slice of every range, then (owned ranges) the trusted and the target header of
     // the commit check as a 2-header block per range — hashed by ONE k_header_merkle launch
@@ -218,6 +227,18 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
         c.trees_words = (uint64_t)RT * jc * p->tree_digests * 4;
         RET(dalloc_t(p, c.trees_words * 8, &c.trees));
     }
+    if (p->units) {
+        RET(dalloc_t(p, (size_t)R * p->cl.compact_stride, &c.commit_compact));     // zeroed: bytes no kernel writes stay zero
+        RET(dalloc_t(p, (size_t)R * p->sl.compact_stride, &c.skip_compact));
+        if (p->with_witness) {
+            RET(dalloc_t(p, ((uint64_t)R * p->cl.n_elements + 2) * 8, &c.witness_commit));
+            RET(dalloc_t(p, ((uint64_t)R * p->sl.n_elements + 2) * 8, &c.witness_skip));
+        }
+        if (p->with_caps) {
+            RET(dalloc_t(p, (uint64_t)R * p->tree_digests_cm * 32, &c.trees_commit));
+            RET(dalloc_t(p, (uint64_t)R * p->tree_digests_sk * 32, &c.trees_skip));
+        }
+    }
     return BSX_OK;
 }
 
@@ -236,6 +257,19 @@ TimingSlot* timing_slot(Chunk& c) {
 // Stage 3 for the owned ranges on stream `st` (builder.skip, header_range.rs:42-48).
 //   prep:   SHA-512 challenges + per-validator tables (small, memory-latency sensitive) — beside the hashing
 //   verify: signature checks, tallies, skip conditions (integer ALU) — beside the expansion
+// header-field inclusion proofs of every owned range's target header (chain id, height, validators_hash) and trusted header
+// (validators_hash) into the SKIP units; `skip_headers` = the (trusted, target) header pairs
+int field_proofs(bsx_pipeline* p, Chunk& c, hipStream_t st, const uint8_t* skip_headers) {
+    bsxk_field_proofs_args fa{};
+    fa.n_items = c.R; fa.headers = reinterpret_cast<const bsx_header*>(skip_headers); fa.headers_per_item = 2; fa.target_idx = c.target_idx;
+    fa.unit = bsxk_unit(c.skip_compact, p->sl); fa.n_proofs = BSX_SK_N_PROOFS; fa.zero_paths = p->ctx->zero_paths;
+    static const uint8_t hsel[BSX_SK_N_PROOFS] = {1, 1, 1, 0}, fld[BSX_SK_N_PROOFS] = {1, BSX_BLOCK_HEIGHT_INDEX, 7, 7};
+    for (uint32_t k = 0; k < BSX_SK_N_PROOFS; k++)
+        fa.proofs[k] = bsxk_proof_spec{hsel[k], fld[k], (uint16_t)bsx_sk_proof_cap(k), bsx_sk_off_proof(p->V, k), BSX_SK_W_LEAF_LEN + k, 0u};
+    HIPCHK(bsxk_field_proofs(st, &fa));
+    return BSX_OK;
+}
+
 int commit_part(bsx_pipeline* p, Chunk& c, hipStream_t st, bool prep, bool verify) {
     const uint32_t R = c.R, V = p->V;
     const uint64_t n = (uint64_t)R * V;
@@ -243,29 +277,58 @@ int commit_part(bsx_pipeline* p, Chunk& c, hipStream_t st, bool prep, bool verif
     auto* trs = reinterpret_cast<const bsx_validator*>(c.trusted);
     auto* cres = reinterpret_cast<bsx_commit_result*>(c.commit_res);
     auto* tres = reinterpret_cast<bsx_commit_result*>(c.trusted_res);
+    // with units on, the kernels of the chain leave the variables they hold in the ranges' COMMIT / SKIP units as they go
+    const bsxk_unit_dst cwd = bsxk_unit(c.commit_compact, p->cl), swd = bsxk_unit(c.skip_compact, p->sl), swd_t = bsxk_unit(c.skip_compact, p->sl, 1);
+    const bsxk_unit_dst *cwp = p->units ? &cwd : nullptr, *swp = p->units ? &swd : nullptr, *swtp = p->units ? &swd_t : nullptr;
     if (prep) {
         // everything that needs nothing from this step's hashing: challenges, R decoded for the projective comparison, the
         // key-table check, the trusted set's hash and power sum — off the critical chain (verify -> tally -> skip conditions)
-        HIPCHK(bsxk_sha512_challenge(st, vals, n, c.h, nullptr));
+        HIPCHK(bsxk_sha512_challenge(st, vals, n, c.h, nullptr, V, cwp));
         if (p->keyed) {
             if (c.rdec) HIPCHK(bsxk_ed25519_decode_r(st, vals, n, c.rdec));
             HIPCHK(bsxk_ed25519_keytable(st, vals, V, c.keytable));
         }
-        HIPCHK(bsxk_commit_tally(st, trs, R, V, nullptr, nullptr, tres));
+        HIPCHK(bsxk_commit_tally(st, trs, R, V, nullptr, nullptr, tres, swtp));
+        // resident inputs: the header pairs do not change under the prep phase; streamed inputs: see below
+        if (p->units && !p->streaming) RET(field_proofs(p, c, st, c.headers_all + c.nh_main * sizeof(bsx_header)));
     }
     if (!verify) return BSX_OK;
     if (p->keyed)   // latency form beside an expansion (ALU to spare, one step to finish in); least-work form in the compact pipeline
         HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, V, p->ctx->btab, c.ok, c.ed_scratch, c.rdec ? c.rdec : BSXK_ED_THROUGHPUT));
     else
         HIPCHK(bsxk_ed25519_verify(st, vals, c.h, n, c.ok));
-    HIPCHK(bsxk_commit_tally(st, vals, R, V, c.target_hashes_pp[c.parity], c.ok, cres));
+    HIPCHK(bsxk_commit_tally(st, vals, R, V, c.target_hashes_pp[c.parity], c.ok, cres, cwp));
     // streamed inputs: headers_all is overwritten early in the next step while this check may still run -> private copy
     const uint8_t* skip_headers = p->streaming ? c.skip_headers_pp[c.parity] : c.headers_all + c.nh_main * sizeof(bsx_header);
+    if (p->units && p->streaming) RET(field_proofs(p, c, st, skip_headers));
     HIPCHK(bsxk_skip_check(st, R, V, reinterpret_cast<const bsx_shared_ctx*>(c.skip_ranges_side), reinterpret_cast<const bsx_header*>(skip_headers), 2,
                            c.skip_hashes_pp[c.parity], vals, trs, c.ok, cres, tres, c.skip_status, nullptr, c.target_idx,
-                           p->cfg.chain_id_len ? p->cfg.chain_id : nullptr, p->cfg.chain_id_len));
+                           p->cfg.chain_id_len ? p->cfg.chain_id : nullptr, p->cfg.chain_id_len, swp));
     HIPCHK(hipEventRecord(c.ev_commit_done[c.parity], st));
     c.commit_done_valid[c.parity] = true;
+    c.wit_pending = p->units;
+    return BSX_OK;
+}
+
+// The COMMIT / SKIP units of the chunk's current step are complete once BOTH the commit chain (side stream) and finalize (main
+// stream: the data commitment, header_range.rs:58) are through: expand them / hash them on the side stream, behind both.
+int launch_commit_witness(bsx_pipeline* p, Chunk& c) {
+    if (!p->units || !c.wit_pending || !c.fin_recorded) return BSX_OK;
+    c.wit_pending = false;
+    hipStream_t st = c.side;
+    HIPCHK(hipStreamWaitEvent(st, c.ev_finalized, 0));
+    if (p->with_witness) {
+        HIPCHK(bsxk_expand_witness(st, &p->cl, c.R, c.commit_compact, c.witness_commit));
+        HIPCHK(bsxk_expand_witness(st, &p->sl, c.R, c.skip_compact, c.witness_skip));
+    }
+    if (p->with_caps) {
+        HIPCHK(bsxk_leaf_hashes(st, &p->cl, c.R, c.commit_compact, nullptr, p->leaf_len, p->n_leaves_cm, 1, 4 * p->tree_digests_cm, c.trees_commit));
+        HIPCHK(bsxk_merkle_caps(st, c.trees_commit, c.R, 4 * p->tree_digests_cm, p->n_leaves_cm, p->cap_h_cm));
+        HIPCHK(bsxk_leaf_hashes(st, &p->sl, c.R, c.skip_compact, nullptr, p->leaf_len, p->n_leaves_sk, 1, 4 * p->tree_digests_sk, c.trees_skip));
+        HIPCHK(bsxk_merkle_caps(st, c.trees_skip, c.R, 4 * p->tree_digests_sk, p->n_leaves_sk, p->cap_h_sk));
+    }
+    HIPCHK(hipEventRecord(c.ev_units_done, st));
+    c.units_done_valid = true;
     return BSX_OK;
 }
 
@@ -277,7 +340,8 @@ int launch_verify(bsx_pipeline* p, Chunk& c, hipEvent_t after_event) {
     if (!commit_active(p, c) || p->commit_beside_hash) return BSX_OK;
     HIPCHK(hipStreamWaitEvent(c.side, c.ev_fill, 0));
     if (after_event) HIPCHK(hipStreamWaitEvent(c.side, after_event, 0));
-    return commit_part(p, c, c.side, false, true);
+    RET(commit_part(p, c, c.side, false, true));
+    return launch_commit_witness(p, c);
 }
 
 // stages 1-5 + local fold: everything before the cross-GPU exchange
@@ -289,6 +353,8 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
         c.h2d_pending = false;
     }
     HIPCHK(hipMemsetAsync(c.status, 0, 32, st));
+    c.fin_recorded = false;
+    c.wit_pending = false;
     const bool commit = commit_active(p, c);
     if (commit && !p->commit_beside_hash) {
         // challenges + per-validator tables need nothing from this step: start them right away beside the hashing
@@ -365,8 +431,16 @@ int exchange_end(bsx_pipeline* p, Chunk& c, const uint8_t** out_results) {
 
 int finalize(bsx_pipeline* p, Chunk& c, const uint8_t* records) {
     const uint8_t* own_ranges = p->with_commit ? c.skip_ranges : c.ranges + (size_t)p->rank * c.R * sizeof(bsx_shared_ctx);
+    // the SKIP units of the previous step must have been consumed before this step's data commitments go into them
+    if (p->units && c.units_done_valid) HIPCHK(hipStreamWaitEvent(c.main, c.ev_units_done, 0));
     HIPCHK(bsxk_finalize(c.main, c.R, p->J, p->B, reinterpret_cast<const bsx_shared_ctx*>(own_ranges), reinterpret_cast<const bsx_subchain*>(records),
-                         p->with_commit ? c.target_hashes_pp[c.parity] : nullptr, c.output64, c.range_status));
+                         p->with_commit ? c.target_hashes_pp[c.parity] : nullptr, c.output64, c.range_status,
+                         p->units ? c.skip_compact : nullptr, p->sl.compact_stride));
+    if (p->units) {
+        HIPCHK(hipEventRecord(c.ev_finalized, c.main));
+        c.fin_recorded = true;
+        RET(launch_commit_witness(p, c));
+    }
     return BSX_OK;
 }
 
@@ -463,6 +537,9 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     p->keyed = !(cfg->flags & BSX_PIPE_ED_GENERIC) && p->Rc >= 8;
     p->ml = bsx_map_layout(B);
     p->rl = bsx_reduce_layout();
+    p->cl = bsx_commit_layout(p->V);
+    p->sl = bsx_skip_layout(p->V);
+    p->units = p->with_commit && (p->with_witness || p->with_caps);
     // Launch forms (measured): beside an expansion the header hashing is held to 2 workgroups per CU and
     // prove_subchain keeps its stages in separate launches, so that the expansion's waves keep half of the register file;
     // alone, both take the whole GPU.
@@ -486,6 +563,16 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
         if (p->cap_height > lg) p->cap_height = lg;
         p->tree_digests = bsx_poseidon_tree_digests(p->n_leaves, p->cap_height);
         if (!p->n_leaves || !p->tree_digests) { delete p; return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_create: bad leaf_len / cap_height"); }
+        // the COMMIT / SKIP units' trees: same row length, cap height clipped to each tree's own depth
+        auto tree_of = [&](uint64_t n_elements, uint32_t& n_leaves, uint32_t& cap_h, uint64_t& digests) {
+            n_leaves = bsx_witness_leaf_count(n_elements, p->leaf_len);
+            uint32_t l2 = 0;
+            while ((1u << (l2 + 1)) <= n_leaves) l2++;
+            cap_h = p->cap_height > l2 ? l2 : p->cap_height;
+            digests = bsx_poseidon_tree_digests(n_leaves, cap_h);
+        };
+        tree_of(p->cl.n_elements, p->n_leaves_cm, p->cap_h_cm, p->tree_digests_cm);
+        tree_of(p->sl.n_elements, p->n_leaves_sk, p->cap_h_sk, p->tree_digests_sk);
     }
     p->compact_tokens = !p->with_witness && (p->E > 1 || p->K > 1);
     p->chunks.resize((size_t)p->E * p->K);
@@ -538,7 +625,7 @@ void bsx_pipeline_destroy(bsx_pipeline* p) {
         for (hipStream_t s : {c.xchg, c.copy})
             if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
         for (hipEvent_t e : {c.ev_sync, c.ev_merkle, c.ev_fill, c.ev_fin, c.ev_inputs_consumed, c.ev_h2d, c.ev_commit_done[0], c.ev_commit_done[1],
-                             c.ev_hash_tok, c.ev_expand_tok, c.ev_x_in, c.ev_x_out})
+                             c.ev_hash_tok, c.ev_expand_tok, c.ev_x_in, c.ev_x_out, c.ev_finalized, c.ev_units_done})
             if (e) (void)hipEventDestroy(e);
         for (TimingSlot& t : c.timing)
             for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
@@ -831,6 +918,12 @@ int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** 
     case BSX_PIPE_BUF_LB_AUNTS: q = c.lb_aunts; n = c.nh_all * 128; break;
     case BSX_PIPE_BUF_RANGES: q = p->with_commit && p->world == 1 ? c.skip_ranges : c.ranges; n = (uint64_t)(p->with_commit && p->world == 1 ? c.R : c.RT) * sizeof(bsx_shared_ctx); break;
     case BSX_PIPE_BUF_PATHS: q = c.paths; n = c.paths ? c.nh_all * BSX_HEADER_PATH_BYTES : 0; break;
+    case BSX_PIPE_BUF_WITNESS_COMMIT: q = c.witness_commit; n = c.witness_commit ? (uint64_t)c.R * p->cl.n_elements * 8 : 0; break;
+    case BSX_PIPE_BUF_WITNESS_SKIP: q = c.witness_skip; n = c.witness_skip ? (uint64_t)c.R * p->sl.n_elements * 8 : 0; break;
+    case BSX_PIPE_BUF_COMPACT_COMMIT: q = c.commit_compact; n = c.commit_compact ? (uint64_t)c.R * p->cl.compact_stride : 0; break;
+    case BSX_PIPE_BUF_COMPACT_SKIP: q = c.skip_compact; n = c.skip_compact ? (uint64_t)c.R * p->sl.compact_stride : 0; break;
+    case BSX_PIPE_BUF_TREES_COMMIT: q = c.trees_commit; n = c.trees_commit ? (uint64_t)c.R * p->tree_digests_cm * 32 : 0; break;
+    case BSX_PIPE_BUF_TREES_SKIP: q = c.trees_skip; n = c.trees_skip ? (uint64_t)c.R * p->tree_digests_sk * 32 : 0; break;
     default: return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_buffer: unknown buffer %u", which);
     }
     *out_d_ptr = n ? q : nullptr;

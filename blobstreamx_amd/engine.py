@@ -32,7 +32,8 @@ from . import types as T
 # bsx.h
 PIPE_WITNESS, PIPE_COMMIT, PIPE_CAPS, PIPE_ED_GENERIC, PIPE_COMMIT_BESIDE_HASH, PIPE_RECOMPUTE_PATHS = 1, 2, 4, 8, 16, 32
 (BUF_WITNESS_MAP, BUF_WITNESS_REDUCE_LOCAL, BUF_WITNESS_REDUCE_TOP, BUF_COMPACT, BUF_TREES, BUF_PARTIAL, BUF_HEADERS, BUF_RECORDS,
- BUF_GATHERED, BUF_REDUCE_COMPACT_LOCAL, BUF_HASHES, BUF_DH_AUNTS, BUF_LB_AUNTS, BUF_PATHS, BUF_RANGES) = range(15)
+ BUF_GATHERED, BUF_REDUCE_COMPACT_LOCAL, BUF_HASHES, BUF_DH_AUNTS, BUF_LB_AUNTS, BUF_PATHS, BUF_RANGES, BUF_WITNESS_COMMIT,
+ BUF_WITNESS_SKIP, BUF_COMPACT_COMMIT, BUF_COMPACT_SKIP, BUF_TREES_COMMIT, BUF_TREES_SKIP) = range(21)
 
 
 class _Config(C.Structure):
@@ -287,6 +288,22 @@ class Pipeline:
         self.join()
         return tuple(self.buffer(chunk, b, i64=True).cpu().numpy().view(np.uint64)
                      for b in (BUF_WITNESS_MAP, BUF_WITNESS_REDUCE_LOCAL, BUF_WITNESS_REDUCE_TOP))
+
+    def unit_witness_numpy(self, chunk=0):
+        """BSX_PIPE_WITNESS + BSX_PIPE_COMMIT: (COMMIT units [Rc, n_el], SKIP units [Rc, n_el]) of a chunk's owned ranges — the
+        variables of builder.skip (include/bsx_layout.h) as uint64 (joins first)."""
+        self.join()
+        cl, sl = T.commit_layout(self.V), T.skip_layout(self.V)
+        c = self.buffer(chunk, BUF_WITNESS_COMMIT, i64=True).cpu().numpy().view(np.uint64).reshape(self.Rc, int(cl["n_elements"]))
+        s = self.buffer(chunk, BUF_WITNESS_SKIP, i64=True).cpu().numpy().view(np.uint64).reshape(self.Rc, int(sl["n_elements"]))
+        return c, s
+
+    def unit_caps_numpy(self, chunk=0):
+        """BSX_PIPE_CAPS + BSX_PIPE_COMMIT: the Poseidon trees [Rc][digests][4] of the COMMIT and of the SKIP units (joins first)."""
+        self.join()
+        tc = self.buffer(chunk, BUF_TREES_COMMIT, i64=True).cpu().numpy().view(np.uint64).reshape(self.Rc, -1, 4)
+        ts = self.buffer(chunk, BUF_TREES_SKIP, i64=True).cpu().numpy().view(np.uint64).reshape(self.Rc, -1, 4)
+        return tc, ts
 
     def caps_numpy(self, chunk=0):
         """BSX_PIPE_CAPS: (trees [jobs][digests][4], caps [jobs][2^cap_height][4]) of a chunk's map jobs (joins first)."""

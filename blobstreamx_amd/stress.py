@@ -49,7 +49,10 @@ def range_verdict(folds):
 
 
 class CommitShard:
-    def __init__(self, n_commits_total, v_max, rank=0, world=1, device=None):
+    def __init__(self, n_commits_total, v_max, rank=0, world=1, device=None, with_witness=False, expand=False):
+        """with_witness: every step also leaves the commits' COMMIT units (include/bsx_layout.h: the Goldilocks witness of the
+        per-validator loop, BASELINE config #5) in compact form in `self.compact`; expand: and expands them into `self.witness`
+        (u64 [n][commit_layout(V).n_elements]: 15 MB per commit at V = 512) on the same stream."""
         import torch
         self.N, self.V, self.rank, self.world = n_commits_total, v_max, rank, world
         self.first, self.n = commit_slice(n_commits_total, rank, world)
@@ -65,6 +68,12 @@ class CommitShard:
         self.fold = z(128)
         self.keytable = z(int(self.L.bsx_ed25519_keytable_bytes(C.c_uint32(V))))
         self.scratch = z(int(self.L.bsx_dev_verify_commits_scratch_bytes(C.c_uint32(n), C.c_uint32(V))))
+        self.lay = T.commit_layout(V)
+        self.compact = z(n * int(self.lay["compact_stride"])) if (with_witness or expand) else None
+        self.witness = None
+        if expand:
+            self._wbuf = _lib.DeviceBuffer(n * int(self.lay["n_elements"]) + 2, self.dev.index if self.dev.index is not None else 0)
+            self.witness = self._wbuf.tensor()
 
     def upload(self, validators, header_hashes):
         """validators [N, V] VALIDATOR and header_hashes [N, 32] of the WHOLE range; this rank keeps its slice."""
@@ -81,7 +90,24 @@ class CommitShard:
         dp = _lib.dp
         _lib.check(self.L.bsx_dev_verify_commits(self.ctx, C.c_void_p(st.cuda_stream), dp(self.vals), C.c_uint32(self.n), C.c_uint32(self.V),
                                                  dp(self.hh), C.c_uint32(self.first), dp(self.keytable), dp(self.scratch), dp(self.ok),
-                                                 dp(self.res), dp(self.fold)))
+                                                 dp(self.res), dp(self.fold), dp(self.compact)))
+        if self.witness is not None:
+            lay = np.ascontiguousarray(self.lay).reshape(1)
+            _lib.check(self.L.bsx_dev_expand_witness(self.ctx, C.c_void_p(st.cuda_stream), _lib.p(lay), C.c_uint32(self.n), dp(self.compact),
+                                                     dp(self.witness)))
+
+    def witness_of(self, commits):
+        """Expanded COMMIT units of the given local commit indices -> u64 [len(commits), n_elements] (host)."""
+        import torch
+        torch.cuda.synchronize(self.dev)
+        nel = int(self.lay["n_elements"])
+        return np.stack([self.witness[c * nel:(c + 1) * nel].cpu().numpy().view(np.uint64) for c in commits])
+
+    def compact_of(self, commits):
+        import torch
+        torch.cuda.synchronize(self.dev)
+        cs = int(self.lay["compact_stride"])
+        return np.stack([self.compact[c * cs:(c + 1) * cs].cpu().numpy() for c in commits])
 
     def gather(self):
         """All ranks' folds -> COMMIT_FOLD[world] (host)."""

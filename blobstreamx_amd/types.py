@@ -130,3 +130,46 @@ def _layout(B, n_bytes, n_words, n_bools):
     lay["compact_stride"] = int(lay["off_bools"]) + a16(n_bools)
     lay["n_elements"] = 8 * n_bytes + n_words + n_bools
     return lay
+
+
+# ---- round 4: commit / skip / step units (include/bsx_layout.h; builder.skip / builder.step, header_range.rs:42-48, next_header.rs:32-36)
+SECTION_MAP, SECTION_REDUCE, SECTION_COMMIT, SECTION_SKIP, SECTION_STEP = range(5)
+
+
+def pow2_ceil(v):
+    p = 1
+    while p < v:
+        p *= 2
+    return p
+
+
+def commit_layout(v_max):
+    """Python twin of bsx_commit_layout: the COMMIT unit (one commit of v_max validator slots)."""
+    V, P = v_max, pow2_ceil(v_max)
+    n_bytes = 32 + 64 * V + 32 * V + 48 * V + 32 * P + 64 * (P - 1) + 32 + 220 * V
+    return _layout(V, n_bytes, 4 * V + 6, 7 * V + 2 * P - 1 + 3)
+
+
+SKIP_PROOF_CAPS = (52, 12, 36, 36)
+STEP_PROOF_CAPS = (52, 12, 36, 76, 36, 36)
+
+
+def skip_layout(v_max):
+    """Python twin of bsx_skip_layout: the SKIP unit of CombinedSkipCircuit::define."""
+    V, P = v_max, pow2_ceil(v_max)
+    n_bytes = 96 + 48 * V + 32 * P + 64 * (P - 1) + 32 + 32 * V + sum(288 + c for c in SKIP_PROOF_CAPS)
+    return _layout(V, n_bytes, 12 + 3 * V, 2 * V + 2 * P - 1 + 9)
+
+
+def step_layout():
+    """Python twin of bsx_step_layout: the STEP unit of CombinedStepCircuit::define."""
+    return _layout(0, 96 + sum(288 + c for c in STEP_PROOF_CAPS) + 64, 10, 10)
+
+
+def header_range_witness_elements(nb_map_jobs, batch_size, v_max):
+    return (nb_map_jobs * int(map_layout(batch_size)["n_elements"]) + (nb_map_jobs - 1) * int(reduce_layout()["n_elements"])
+            + int(commit_layout(v_max)["n_elements"]) + int(skip_layout(v_max)["n_elements"]))
+
+
+def next_header_witness_elements(v_max):
+    return int(commit_layout(v_max)["n_elements"]) + int(step_layout()["n_elements"])

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BSX_VERSION 0x00010000
+#define BSX_VERSION 0x00020000
 
 /* ------------------------------------------------------------------ constants (circuits/consts.rs) */
 #define BSX_HASH_SIZE 32                 /* consts.rs:1  HASH_SIZE */
@@ -225,6 +225,30 @@ typedef struct bsx_manifest_entry {
 } bsx_manifest_entry;           /* sizeof == 136 */
 int bsx_witness_manifest(uint32_t batch_size, bsx_manifest_entry* entries, uint32_t capacity, uint32_t* out_n);
 
+/* Round 4: the witness of the WHOLE circuit.  CombinedSkipCircuit::define is builder.skip ∘ prove_data_commitment
+ * (header_range.rs:42-55): besides the map jobs and reduce nodes above, a proof request's witness holds one COMMIT unit (the
+ * per-validator loop of builder.skip against the target header: pubkeys, signatures, messages, SHA-512 digests and reduced
+ * challenges, signature / message verdicts, validator leaves and the masked validator-set tree, power sums, 2/3 rule) and one
+ * SKIP unit (public inputs / outputs, header-field inclusion proofs for chain id / height / validators_hash with their path
+ * digests, the trusted validator set's leaves and tree, the 1/3 overlap rule, every assertion bool) — include/bsx_layout.h
+ * documents every variable.  CombinedStepCircuit::define (next_header.rs:25-46) = one COMMIT unit + one STEP unit.
+ * Same three dense sections per unit (bytes -> 8 bools MSB first, u32 words, bools), so bsx_dev_expand_witness and the fused
+ * Poseidon leaf hashing take them through the layouts below.  [UPSTREAM] tendermintx v1.0.0: ordering = this layout. */
+#define BSX_SECTION_MAP 0u      /* param = BATCH_SIZE */
+#define BSX_SECTION_REDUCE 1u   /* param ignored */
+#define BSX_SECTION_COMMIT 2u   /* param = validator slots V (1..512) */
+#define BSX_SECTION_SKIP 3u     /* param = V */
+#define BSX_SECTION_STEP 4u     /* param ignored */
+int bsx_witness_manifest_section(uint32_t section, uint32_t param, bsx_manifest_entry* entries, uint32_t capacity, uint32_t* out_n);
+int bsx_commit_witness_layout(uint32_t v_max, bsx_witness_layout* out);
+int bsx_skip_witness_layout(uint32_t v_max, bsx_witness_layout* out);
+int bsx_step_witness_layout(bsx_witness_layout* out);
+/* u64 elements of the witness bsx_header_range returns: nb_map_jobs map jobs, nb_map_jobs - 1 reduce nodes (level order), then
+ * the COMMIT unit of the target commit, then the SKIP unit.  0 on invalid arguments. */
+uint64_t bsx_header_range_witness_elements(uint32_t nb_map_jobs, uint32_t batch_size, uint32_t v_max);
+/* u64 elements of the witness bsx_next_header returns: the COMMIT unit of the next header's commit, then the STEP unit. */
+uint64_t bsx_next_header_witness_elements(uint32_t v_max);
+
 /* ------------------------------------------------------------------ host tier */
 
 /* encode_data_root_tuple — circuits/builder.rs:23-27,82-103.  out = 0x00*24 ‖ height BE ‖ data_hash. */
@@ -288,9 +312,12 @@ int bsx_prove_next_header_data_commitment(bsx_ctx* ctx, uint64_t prev_block_numb
  * v1.0.0; host twin is_valid_skip at circuits/fetcher.rs:76-80).  n_commits commits of
  * v_max validator slots each.  header_hashes: n_commits×32, the hash every signed message must
  * carry (offset 16, or 25 when a round field is present).  out_sig_ok: n_commits×v_max bytes
- * (1 = signed and valid).  Does not fail on bad signatures: the result says so. */
+ * (1 = signed and valid).  Does not fail on bad signatures: the result says so.  witness: the Goldilocks witness of the loop —
+ * per validator the hint's record, the SHA-512 digest and reduced challenge, signature / message verdicts, the SimpleValidator
+ * leaf, then the masked validator-set tree, power sums and the 2/3 bool (COMMIT unit, include/bsx_layout.h). */
 int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n_commits, uint32_t v_max,
-                       const uint8_t* header_hashes, bsx_commit_result* out_results, uint8_t* out_sig_ok);
+                       const uint8_t* header_hashes, bsx_commit_result* out_results, uint8_t* out_sig_ok,
+                       uint64_t* witness /* optional: n_commits COMMIT units, bsx_commit_witness_layout(v_max).n_elements u64 each */);
 
 /* CombinedSkipCircuit::define — circuits/header_range.rs:32-59: input48 = u64 BE trusted_block ‖
  * bytes32 trusted_header_hash ‖ u64 BE target_block (header_range.rs:33-35); output64 =
@@ -301,7 +328,11 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
  * validators_hash of both sets against the headers' field 7, 2/3 of target power signed, more
  * than 1/3 of trusted power signed; the target header's chain-id leaf (field 1: 0a len bytes) equals chain_id — the
  * circuit constant C::CHAIN_ID_BYTES that builder.skip is called with (header_range.rs:42-43; config.rs:6-28),
- * chain_id_len <= 50.  A header of another chain signed by the same keys fails with BSX_ERR_ASSERT. */
+ * chain_id_len <= 50.  A header of another chain signed by the same keys fails with BSX_ERR_ASSERT.
+ * witness (optional): bsx_header_range_witness_elements(nb_map_jobs, batch_size, v_max) u64 — the WHOLE circuit's variables:
+ * nb_map_jobs map jobs, nb_map_jobs - 1 reduce nodes (level order), the COMMIT unit of the target commit, the SKIP unit.  It is
+ * filled whenever the return code is BSX_OK, BSX_ERR_ASSERT, BSX_ERR_BAD_SIGNATURE or BSX_ERR_VOTING_POWER (a failing witness
+ * shows which assertion bool is 0). */
 int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48],
                      const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
@@ -483,7 +514,8 @@ uint64_t bsx_ed25519_verify_scratch_bytes(uint64_t n);
  * The data commitment is prove_next_header_data_commitment (builder.rs:411-443).  Failure codes as bsx_header_range. */
 int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
                     uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max,
-                    const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit);
+                    const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit,
+                    uint64_t* witness /* optional: bsx_next_header_witness_elements(v_max) u64 = COMMIT unit, STEP unit */);
 
 /* ------------------------------------------------------------------ mode S: a commit on EVERY header, sharded with the headers
  * BASELINE configs #4/#5 ("N headers x V validators"): N back-to-back next_header / skip verifications (circuits/next_header.rs:
@@ -507,7 +539,10 @@ typedef struct bsx_commit_fold {
 uint64_t bsx_dev_verify_commits_scratch_bytes(uint32_t n_commits, uint32_t v_max);
 int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits, uint32_t v_max,
                            const uint8_t* d_header_hashes, uint32_t first_index, void* d_keytable, void* d_scratch, uint8_t* d_ok,
-                           bsx_commit_result* d_results, bsx_commit_fold* d_fold);
+                           bsx_commit_result* d_results, bsx_commit_fold* d_fold,
+                           uint8_t* d_commit_compact /* optional, 16-byte aligned, n_commits * bsx_commit_witness_layout(v_max).compact_stride
+                                                        bytes, ZERO before the first call on the buffer: every commit's COMMIT unit in compact
+                                                        form (config #5's witness; bsx_dev_expand_witness turns it into Goldilocks elements) */);
 
 /* ------------------------------------------------------------------ operator skip-target search
  * circuits/fetcher.rs:60-87 find_block_to_request: starting at max_end_block, return the first candidate c with
@@ -640,10 +675,12 @@ int bsx_calibrate(bsx_ctx* ctx, bsx_calibration* out);
  * several — may be driven by different threads concurrently. */
 typedef struct bsx_pipeline bsx_pipeline;
 
-#define BSX_PIPE_WITNESS 1u             /* materialise the Goldilocks witness (map jobs + reduce nodes) in HBM every step */
+#define BSX_PIPE_WITNESS 1u             /* materialise the Goldilocks witness in HBM every step: map jobs + reduce nodes, and with
+                                           BSX_PIPE_COMMIT the COMMIT + SKIP units of every owned range (the whole circuit) */
 #define BSX_PIPE_COMMIT 2u              /* verify the target commit of every owned range (builder.skip) */
-#define BSX_PIPE_CAPS 4u                /* Poseidon Merkle cap of every map-job witness, hashed straight from the compact bytes
-                                           (plonky2 PoseidonGoldilocksConfig; rows of leaf_len elements, cap_height) */
+#define BSX_PIPE_CAPS 4u                /* Poseidon Merkle cap of every map-job witness — and with BSX_PIPE_COMMIT of every COMMIT / SKIP
+                                           unit — hashed straight from the compact bytes (plonky2 PoseidonGoldilocksConfig; rows of
+                                           leaf_len elements, cap_height) */
 #define BSX_PIPE_ED_GENERIC 8u          /* per-signature Ed25519 kernel instead of the fixed-key tables (same verdicts) */
 #define BSX_PIPE_COMMIT_BESIDE_HASH 16u /* run the whole commit check beside the hashing phase instead of beside the expansion */
 #define BSX_PIPE_RECOMPUTE_PATHS 32u    /* prove_subchain re-derives both proof paths per slot (builder.rs:189-199 literally)
@@ -750,6 +787,14 @@ int bsx_pipeline_get_results(bsx_pipeline* p, bsx_pipeline_results* out);
 #define BSX_PIPE_BUF_LB_AUNTS 12u            /* last_block_id proof aunts, 128 B per header */
 #define BSX_PIPE_BUF_PATHS 13u               /* BSX_HEADER_PATH_BYTES per header (absent with BSX_PIPE_RECOMPUTE_PATHS) */
 #define BSX_PIPE_BUF_RANGES 14u              /* bsx_shared_ctx of the chunk's ranges (end_header_hash filled by the step) */
+/* BSX_PIPE_COMMIT with BSX_PIPE_WITNESS and / or BSX_PIPE_CAPS: builder.skip's variables of every owned range (round 4) */
+#define BSX_PIPE_BUF_WITNESS_COMMIT 15u      /* u64 [owned ranges][bsx_commit_witness_layout(v_max).n_elements]: the target commit's COMMIT unit */
+#define BSX_PIPE_BUF_WITNESS_SKIP 16u        /* u64 [owned ranges][bsx_skip_witness_layout(v_max).n_elements] */
+#define BSX_PIPE_BUF_COMPACT_COMMIT 17u      /* compact COMMIT units [owned ranges][compact_stride] */
+#define BSX_PIPE_BUF_COMPACT_SKIP 18u        /* compact SKIP units */
+#define BSX_PIPE_BUF_TREES_COMMIT 19u        /* BSX_PIPE_CAPS: Poseidon trees of the COMMIT units, u64 [owned ranges][digests][4] (rows of leaf_len
+                                                elements; cap height = min(cap_height, log2 leaves)); the cap is each tree's tail */
+#define BSX_PIPE_BUF_TREES_SKIP 20u          /* same for the SKIP units */
 int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** out_d_ptr, uint64_t* out_bytes);
 
 /* Kernel timing with HIP events on the launch streams: when on, every step brackets prove_subchain, the map-job witness

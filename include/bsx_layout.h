@@ -131,4 +131,134 @@ BSX_HD bsx_witness_layout bsx_reduce_layout(void) {
     return bsx_make_layout(0, BSX_RED_N_BYTES, BSX_RED_N_WORDS, BSX_RED_N_BOOLS);
 }
 
+/* ====================================================================================================================
+ * Commit / skip / step sections (round 4): the variables of builder.skip / builder.step — circuits/header_range.rs:42-48,
+ * circuits/next_header.rs:32-36; the circuit bodies are [UPSTREAM] tendermintx v1.0.0 (verify_skip / verify_step; SURVEY
+ * App. B lists the hint's outputs: validators {pubkey, signature, message, message_byte_length, voting_power,
+ * validator_byte_length, enabled, signed, present_on_trusted_header}, header inclusion proofs for chain id / height /
+ * validators_hash, the trusted validator-hash fields) — as the same three dense sections (bytes, u32 words, bools) per
+ * unit, so that k_expand_witness / the fused Poseidon leaf kernel take them unchanged.  As with the map job the target
+ * indices plonky2x would assign are unknowable here: the ORDER is this documented layout, the VALUES are what the
+ * restated rules (oracle/commit.c) compute.  P = V rounded up to a power of two (padding leaves = the all-zero validator).
+ *
+ * COMMIT unit = verification of ONE commit of V validator slots against a header hash (P6-P9): bsx_commit_layout(V)
+ *  bytes
+ *    header_hash[32]                 the hash every signed message must carry
+ *    sha512_digest[V][64]            SHA512(R ‖ A ‖ M)                                              (P6)
+ *    challenge[V][32]                digest mod L, little endian                                    (P6)
+ *    leaf[V][48]                     SimpleValidator bytes 0a 22 0a 20 pk [10 varint(power)], zero padded   (P8)
+ *    leaf_hash[P][32]  inner[P-1][32]  node[P-1][32] (select(both enabled, inner, left); levels bottom-up)
+ *    validators_hash[32]
+ *    validator[V] {pubkey[32], signature[64] (R ‖ s), message[124]}                                 (hint output)
+ *  words: slot[V]{message_byte_length, validator_byte_length, voting_power lo, hi}, total_power, signed_power,
+ *         trusted_signed_power (U64: lo, hi)
+ *  bools: slot[V]{enabled, signed, present_on_trusted_header, signature_valid (P7), message_has_round,
+ *         message_carries_header_hash, counted = enabled & signed & signature_valid & message ok}, leaf_enabled[P],
+ *         node_enabled[P-1], two_thirds_ok (P9), power_overflow, signatures_ok (no signed validator failed P7 / the message check)
+ *
+ * Header-field proof record (tendermintx *ProofVariable): aunts[4][32], path[5][32] (leaf hash, then the 4 nodes of
+ * get_root_from_merkle_proof; last = the header hash), leaf[cap] (zero padded to the field's bsx_header capacity).
+ *
+ * SKIP unit = the rest of CombinedSkipCircuit::define per range: bsx_skip_layout(V)
+ *  bytes
+ *    trusted_header_hash[32] (public input, header_range.rs:34)  target_header_hash[32] (:57)  data_commitment[32] (:58)
+ *    trusted_leaf[V][48]  trusted_leaf_hash[P][32]  trusted_inner[P-1][32]  trusted_node[P-1][32]  trusted_validators_hash[32]
+ *    trusted_pubkey[V][32]
+ *    proof[4]: target chain_id (field 1, cap 52), target height (2, cap 12), target validators_hash (7, cap 36),
+ *              trusted validators_hash (7, cap 36)
+ *  words: trusted_block, target_block (U64, :33,:35), proof leaf lengths[4], trusted slot[V]{validator_byte_length,
+ *         voting_power lo, hi}, trusted_total_power, trusted_overlap_power (U64)
+ *  bools: trusted slot[V]{enabled, signed_target (its key validly signed the target commit)}, trusted_leaf_enabled[P],
+ *         trusted_node_enabled[P-1], checks: trusted_hash_ok, height_ok, chain_id_ok, signatures_ok, target_validators_hash_ok,
+ *         trusted_validators_hash_ok, two_thirds_ok, one_third_ok, power_overflow
+ *
+ * STEP unit = the rest of CombinedStepCircuit::define (next_header.rs:25-46) incl. prove_next_header_data_commitment
+ * (builder.rs:411-443): bsx_step_layout()
+ *  bytes
+ *    prev_header_hash[32] (public input, next_header.rs:27)  next_header_hash[32] (:45)  data_commitment[32] (:46)
+ *    proof[6]: next chain_id (1), next height (2), next validators_hash (7), next last_block_id (4, cap 76),
+ *              prev next_validators_hash (8), prev data_hash (6: data_hash_proofs[0] of the MAX_LEAVES = 1 hint, builder.rs:418-433;
+ *              all zero when the hint clamps it away, input.rs:160-172,220-239)
+ *    data_root_tuple[64] (builder.rs:436-439; its leaf hash is data_commitment, :442)
+ *  words: prev_block, next_block (U64), proof leaf lengths[6]
+ *  bools: prev_hash_ok, height_ok, chain_id_ok, signatures_ok, validators_hash_ok, next_validators_hash_ok, last_block_id_ok,
+ *         two_thirds_ok, power_overflow, data_hash_root_ok (A10, builder.rs:434)
+ */
+BSX_HD uint32_t bsx_pow2_ceil(uint32_t v) { uint32_t p = 1; while (p < v) p *= 2; return p; }
+
+#define BSX_CM_VAL_BYTES 220u
+#define BSX_CM_SLOT_WORDS 4u
+#define BSX_CM_SLOT_BOOLS 7u
+#define BSX_CM_TAIL_BOOLS 3u
+BSX_HD uint32_t bsx_cm_off_header_hash(void) { return 0; }
+BSX_HD uint32_t bsx_cm_off_digest(uint32_t V) { (void)V; return 32; }
+BSX_HD uint32_t bsx_cm_off_challenge(uint32_t V) { return 32 + 64 * V; }
+BSX_HD uint32_t bsx_cm_off_leaf(uint32_t V) { return 32 + 96 * V; }
+BSX_HD uint32_t bsx_cm_off_leaf_hash(uint32_t V) { return 32 + 144 * V; }
+BSX_HD uint32_t bsx_cm_off_inner(uint32_t V) { return bsx_cm_off_leaf_hash(V) + 32 * bsx_pow2_ceil(V); }
+BSX_HD uint32_t bsx_cm_off_node(uint32_t V) { return bsx_cm_off_inner(V) + 32 * (bsx_pow2_ceil(V) - 1); }
+BSX_HD uint32_t bsx_cm_off_root(uint32_t V) { return bsx_cm_off_node(V) + 32 * (bsx_pow2_ceil(V) - 1); }
+BSX_HD uint32_t bsx_cm_off_validators(uint32_t V) { return bsx_cm_off_root(V) + 32; }
+BSX_HD uint32_t bsx_cm_n_bytes(uint32_t V) { return bsx_cm_off_validators(V) + BSX_CM_VAL_BYTES * V; }
+BSX_HD uint32_t bsx_cm_w_total(uint32_t V) { return BSX_CM_SLOT_WORDS * V; }         /* then signed (+2), trusted_signed (+4) */
+BSX_HD uint32_t bsx_cm_n_words(uint32_t V) { return BSX_CM_SLOT_WORDS * V + 6; }
+BSX_HD uint32_t bsx_cm_b_leaf_enabled(uint32_t V) { return BSX_CM_SLOT_BOOLS * V; }
+BSX_HD uint32_t bsx_cm_b_node_enabled(uint32_t V) { return BSX_CM_SLOT_BOOLS * V + bsx_pow2_ceil(V); }
+BSX_HD uint32_t bsx_cm_b_tail(uint32_t V) { return BSX_CM_SLOT_BOOLS * V + 2 * bsx_pow2_ceil(V) - 1; }
+BSX_HD uint32_t bsx_cm_n_bools(uint32_t V) { return bsx_cm_b_tail(V) + BSX_CM_TAIL_BOOLS; }
+BSX_HD bsx_witness_layout bsx_commit_layout(uint32_t V) {
+    return bsx_make_layout(V, bsx_cm_n_bytes(V), bsx_cm_n_words(V), bsx_cm_n_bools(V));   /* batch_size field = V */
+}
+
+/* header-field proof record: aunts 0, path 128, leaf 288 */
+#define BSX_PROOF_FIXED 288u
+BSX_HD uint32_t bsx_proof_bytes(uint32_t cap) { return BSX_PROOF_FIXED + cap; }
+
+#define BSX_SK_N_PROOFS 4u
+#define BSX_SK_CHECK_BOOLS 9u
+BSX_HD uint32_t bsx_sk_proof_cap(uint32_t k) { return k == 0 ? 52u : k == 1 ? 12u : 36u; }
+BSX_HD uint32_t bsx_sk_off_leaf(uint32_t V) { (void)V; return 96; }
+BSX_HD uint32_t bsx_sk_off_leaf_hash(uint32_t V) { return bsx_sk_off_leaf(V) + 48 * V; }
+BSX_HD uint32_t bsx_sk_off_inner(uint32_t V) { return bsx_sk_off_leaf_hash(V) + 32 * bsx_pow2_ceil(V); }
+BSX_HD uint32_t bsx_sk_off_node(uint32_t V) { return bsx_sk_off_inner(V) + 32 * (bsx_pow2_ceil(V) - 1); }
+BSX_HD uint32_t bsx_sk_off_root(uint32_t V) { return bsx_sk_off_node(V) + 32 * (bsx_pow2_ceil(V) - 1); }
+BSX_HD uint32_t bsx_sk_off_pubkeys(uint32_t V) { return bsx_sk_off_root(V) + 32; }
+BSX_HD uint32_t bsx_sk_off_proof(uint32_t V, uint32_t k) {
+    uint32_t o = bsx_sk_off_pubkeys(V) + 32 * V;
+    for (uint32_t i = 0; i < k; i++) o += bsx_proof_bytes(bsx_sk_proof_cap(i));
+    return o;
+}
+BSX_HD uint32_t bsx_sk_n_bytes(uint32_t V) { return bsx_sk_off_proof(V, BSX_SK_N_PROOFS); }
+#define BSX_SK_W_TRUSTED_BLOCK 0u
+#define BSX_SK_W_TARGET_BLOCK 2u
+#define BSX_SK_W_LEAF_LEN 4u   /* [4] */
+#define BSX_SK_W_SLOTS 8u      /* [V][3] */
+BSX_HD uint32_t bsx_sk_w_total(uint32_t V) { return 8 + 3 * V; }                     /* then overlap (+2) */
+BSX_HD uint32_t bsx_sk_n_words(uint32_t V) { return 12 + 3 * V; }
+BSX_HD uint32_t bsx_sk_b_leaf_enabled(uint32_t V) { return 2 * V; }
+BSX_HD uint32_t bsx_sk_b_node_enabled(uint32_t V) { return 2 * V + bsx_pow2_ceil(V); }
+BSX_HD uint32_t bsx_sk_b_checks(uint32_t V) { return 2 * V + 2 * bsx_pow2_ceil(V) - 1; }
+BSX_HD uint32_t bsx_sk_n_bools(uint32_t V) { return bsx_sk_b_checks(V) + BSX_SK_CHECK_BOOLS; }
+BSX_HD bsx_witness_layout bsx_skip_layout(uint32_t V) {
+    return bsx_make_layout(V, bsx_sk_n_bytes(V), bsx_sk_n_words(V), bsx_sk_n_bools(V));
+}
+
+#define BSX_ST_N_PROOFS 6u
+#define BSX_ST_CHECK_BOOLS 10u
+BSX_HD uint32_t bsx_st_proof_cap(uint32_t k) { return k == 0 ? 52u : k == 1 ? 12u : k == 3 ? 76u : 36u; }
+BSX_HD uint32_t bsx_st_off_proof(uint32_t k) {
+    uint32_t o = 96;
+    for (uint32_t i = 0; i < k; i++) o += bsx_proof_bytes(bsx_st_proof_cap(i));
+    return o;
+}
+BSX_HD uint32_t bsx_st_off_tuple(void) { return bsx_st_off_proof(BSX_ST_N_PROOFS); }
+BSX_HD uint32_t bsx_st_n_bytes(void) { return bsx_st_off_tuple() + 64; }
+#define BSX_ST_W_PREV_BLOCK 0u
+#define BSX_ST_W_NEXT_BLOCK 2u
+#define BSX_ST_W_LEAF_LEN 4u   /* [6] */
+#define BSX_ST_N_WORDS 10u
+BSX_HD bsx_witness_layout bsx_step_layout(void) {
+    return bsx_make_layout(0, bsx_st_n_bytes(), BSX_ST_N_WORDS, BSX_ST_CHECK_BOOLS);
+}
+
 #endif /* BSX_LAYOUT_H */

@@ -207,13 +207,26 @@ def expand_witness(layout, n_jobs, compact):
     return out
 
 
-def expand_range_witness(nb_map_jobs, batch_size, compact):
-    """compact = jobs then reduce nodes (orc_prove_data_commitment) -> expanded u64 (same order)"""
+def expand_range_witness(nb_map_jobs, batch_size, compact, v_max=None):
+    """compact = jobs then reduce nodes (orc_prove_data_commitment) [then the COMMIT and SKIP units (orc_header_range) when
+    v_max is given] -> expanded u64 (same order)"""
     ml, rl = T.map_layout(batch_size), T.reduce_layout()
     a = expand_witness(ml, nb_map_jobs, compact)
     off = nb_map_jobs * int(ml["compact_stride"])
     b = expand_witness(rl, nb_map_jobs - 1, compact[off:]) if nb_map_jobs > 1 else np.zeros(0, np.uint64)
-    return np.concatenate([a, b])
+    parts = [a, b]
+    if v_max is not None:
+        off += (nb_map_jobs - 1) * int(rl["compact_stride"])
+        cl, sl = T.commit_layout(v_max), T.skip_layout(v_max)
+        parts.append(expand_witness(cl, 1, compact[off:]))
+        parts.append(expand_witness(sl, 1, compact[off + int(cl["compact_stride"]):]))
+    return np.concatenate(parts)
+
+
+def range_compact_bytes(nb_map_jobs, batch_size, v_max):
+    """bytes of the compact witness orc_header_range writes: map jobs, reduce nodes, COMMIT unit, SKIP unit"""
+    return (nb_map_jobs * int(T.map_layout(batch_size)["compact_stride"]) + (nb_map_jobs - 1) * int(T.reduce_layout()["compact_stride"])
+            + int(T.commit_layout(v_max)["compact_stride"]) + int(T.skip_layout(v_max)["compact_stride"]))
 
 
 def sha512_challenge(validators):
@@ -226,12 +239,14 @@ def sha512_challenge(validators):
     return h, dig
 
 
-def verify_commit(validators, header_hash):
+def verify_commit(validators, header_hash, want_witness=False):
+    """-> (result, sig_ok[, compact COMMIT unit when want_witness])"""
     validators = np.ascontiguousarray(validators, T.VALIDATOR).reshape(-1)
     res = np.zeros(1, T.COMMIT_RESULT)
     ok = np.zeros(validators.size, np.uint8)
-    lib().orc_verify_commit(_p(validators), C.c_uint32(validators.size), _p(_b(header_hash, 32)), _p(res), _p(ok))
-    return res[0], ok
+    cw = np.zeros(int(T.commit_layout(validators.size)["compact_stride"]), np.uint8) if want_witness else None
+    lib().orc_verify_commit_w(_p(validators), C.c_uint32(validators.size), _p(_b(header_hash, 32)), _p(res), _p(ok), _p(cw))
+    return (res[0], ok, cw) if want_witness else (res[0], ok)
 
 
 CHAIN_ID = b"celestia"      # the synthetic workload's chain (synth.CHAIN_ID); the mocha-4 fixtures pass b"mocha-4"
@@ -243,9 +258,7 @@ def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest
     tv = np.ascontiguousarray(target_validators, T.VALIDATOR).reshape(-1)
     rv = np.ascontiguousarray(trusted_validators, T.VALIDATOR).reshape(-1)
     assert tv.size == rv.size
-    ml, rl = T.map_layout(batch_size), T.reduce_layout()
-    csz = nb_map_jobs * int(ml["compact_stride"]) + (nb_map_jobs - 1) * int(rl["compact_stride"])
-    compact = np.zeros(max(csz, 1), np.uint8) if want_witness else None
+    compact = np.zeros(range_compact_bytes(nb_map_jobs, batch_size, tv.size), np.uint8) if want_witness else None
     out = np.zeros(64, np.uint8)
     res = np.zeros(1, T.COMMIT_RESULT)
     rc = lib().orc_header_range(C.c_uint32(nb_map_jobs), C.c_uint32(batch_size), _p(_b(input48, 48)), _p(headers),
@@ -254,16 +267,25 @@ def header_range(nb_map_jobs, batch_size, input48, headers, first_height, latest
     return rc, out.tobytes(), res[0], compact
 
 
-def next_header(input40, prev_header, next_header_, latest_block, next_validators, chain_id=CHAIN_ID):
-    """CombinedStepCircuit::define (circuits/next_header.rs:25-46) -> (rc, output64, commit_result)."""
+def next_header(input40, prev_header, next_header_, latest_block, next_validators, chain_id=CHAIN_ID, want_witness=False):
+    """CombinedStepCircuit::define (circuits/next_header.rs:25-46) -> (rc, output64, commit_result[, compact COMMIT + STEP units])."""
     ph = np.ascontiguousarray(prev_header, T.HEADER).reshape(1)
     nh = np.ascontiguousarray(next_header_, T.HEADER).reshape(1)
     nv = np.ascontiguousarray(next_validators, T.VALIDATOR).reshape(-1)
     out = np.zeros(64, np.uint8)
     res = np.zeros(1, T.COMMIT_RESULT)
-    rc = lib().orc_next_header(_p(_b(input40, 40)), _p(ph), _p(nh), C.c_uint64(latest_block), _p(nv), C.c_uint32(nv.size),
-                               _p(_b(chain_id)), C.c_uint32(len(chain_id)), _p(out), _p(res))
-    return rc, out.tobytes(), res[0]
+    cw = None
+    if want_witness:
+        cw = np.zeros(int(T.commit_layout(nv.size)["compact_stride"]) + int(T.step_layout()["compact_stride"]), np.uint8)
+    rc = lib().orc_next_header_w(_p(_b(input40, 40)), _p(ph), _p(nh), C.c_uint64(latest_block), _p(nv), C.c_uint32(nv.size),
+                                 _p(_b(chain_id)), C.c_uint32(len(chain_id)), _p(out), _p(res), _p(cw))
+    return (rc, out.tobytes(), res[0], cw) if want_witness else (rc, out.tobytes(), res[0])
+
+
+def expand_step_witness(v_max, compact):
+    """compact COMMIT + STEP units (next_header) -> expanded u64"""
+    cl, tl = T.commit_layout(v_max), T.step_layout()
+    return np.concatenate([expand_witness(cl, 1, compact), expand_witness(tl, 1, compact[int(cl["compact_stride"]):])])
 
 
 SKIP_EVAL = np.dtype([("overlap_power", "<u8"), ("start_total_power", "<u8"), ("signed_power", "<u8"),

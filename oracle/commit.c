@@ -44,54 +44,95 @@ int orc_validator_leaf(const uint8_t pk[32], uint64_t power, uint8_t out[BSX_VAL
 
 static uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p *= 2; return p; }
 
-static void validators_hash(const bsx_validator* vals, uint32_t v_max, uint8_t out[32]) {
+/* where a validator-set tree goes in a compact witness unit (include/bsx_layout.h): the commit unit's own set, or the skip
+ * unit's trusted set */
+typedef struct {
+    uint8_t* cw;
+    uint32_t off_leaf, off_leaf_hash, off_inner, off_node, off_root;
+    uint32_t* leaf_len_word;      /* word of slot 0's validator_byte_length */
+    uint32_t word_stride;
+    uint8_t *leaf_enabled, *node_enabled;
+} tree_dst;
+
+static void validators_hash(const bsx_validator* vals, uint32_t v_max, uint8_t out[32], const tree_dst* w) {
     uint32_t P = next_pow2(v_max);
     uint8_t(*nodes)[32] = calloc(P, 32);
     uint8_t* en = calloc(P, 1);
     for (uint32_t i = 0; i < v_max; i++) {
-        uint8_t leaf[BSX_VALIDATOR_LEAF_MAX];
+        uint8_t leaf[BSX_VALIDATOR_LEAF_MAX] = {0};
         int n = orc_validator_leaf(vals[i].pubkey, vals[i].voting_power, leaf);
         orc_leaf_hash(leaf, (size_t)n, nodes[i]);
         en[i] = vals[i].enabled != 0;
+        if (w) {
+            memcpy(w->cw + w->off_leaf + 48 * i, leaf, 48);
+            w->leaf_len_word[(size_t)i * w->word_stride] = (uint32_t)n;
+        }
     }
     for (uint32_t i = v_max; i < P; i++) { /* padding slots: leaf of an all-zero validator, disabled */
         uint8_t leaf[BSX_VALIDATOR_LEAF_MAX], zero[32] = {0};
         int n = orc_validator_leaf(zero, 0, leaf);
         orc_leaf_hash(leaf, (size_t)n, nodes[i]);
     }
+    if (w)
+        for (uint32_t i = 0; i < P; i++) {
+            memcpy(w->cw + w->off_leaf_hash + 32 * i, nodes[i], 32);
+            w->leaf_enabled[i] = en[i];
+        }
+    uint32_t k = 0;
     for (uint32_t n = P; n > 1; n /= 2)
-        for (uint32_t i = 0; i < n; i += 2) {
-            uint8_t inner[32];
+        for (uint32_t i = 0; i < n; i += 2, k++) {
+            uint8_t inner[32], sel[32];
             orc_inner_hash(nodes[i], nodes[i + 1], inner);
-            if (en[i] && en[i + 1]) memcpy(nodes[i / 2], inner, 32);
-            else memcpy(nodes[i / 2], nodes[i], 32);
-            en[i / 2] = en[i] || en[i + 1];
+            memcpy(sel, (en[i] && en[i + 1]) ? inner : nodes[i], 32);
+            const uint8_t any = en[i] || en[i + 1];
+            if (w) {
+                memcpy(w->cw + w->off_inner + 32 * k, inner, 32);
+                memcpy(w->cw + w->off_node + 32 * k, sel, 32);
+                w->node_enabled[k] = any;
+            }
+            memcpy(nodes[i / 2], sel, 32);
+            en[i / 2] = any;
         }
     memcpy(out, nodes[0], 32);
+    if (w) memcpy(w->cw + w->off_root, nodes[0], 32);
     free(nodes);
     free(en);
 }
 
-void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t header_hash[32], bsx_commit_result* out,
-                       uint8_t* sig_ok) {
+static void put_u64(uint32_t* w, uint64_t v) { w[0] = (uint32_t)v; w[1] = (uint32_t)(v >> 32); }
+
+/* cw (optional): the COMMIT unit's compact witness, bsx_commit_layout(v_max).compact_stride bytes.  Every slot's challenge,
+ * message predicates and leaf are evaluated whether or not the slot is enabled / signed (static circuit). */
+void orc_verify_commit_w(const bsx_validator* vals, uint32_t v_max, const uint8_t header_hash[32], bsx_commit_result* out,
+                         uint8_t* sig_ok, uint8_t* cw) {
+    const uint32_t V = v_max;
+    bsx_witness_layout L = bsx_commit_layout(V);
+    uint32_t* W = cw ? (uint32_t*)(cw + L.off_words) : NULL;
+    uint8_t* Bo = cw ? cw + L.off_bools : NULL;
+    if (cw) {
+        memset(cw, 0, L.compact_stride);
+        memcpy(cw + bsx_cm_off_header_hash(), header_hash, 32);
+    }
     memset(out, 0, sizeof *out);
     out->first_bad_signature = 0xffffffffu;
     unsigned __int128 exact_total = 0;
     for (uint32_t i = 0; i < v_max; i++) {
         const bsx_validator* v = &vals[i];
         uint8_t ok = 0;
+        uint8_t h[32], dig[64];
+        orc_sha512_challenge(v, h, dig);
+        const int has_round = v->message_len > 12 && v->message[12] == 0x19;
+        const uint32_t off = has_round ? 25 : 16;
+        const int msg = v->message_len <= BSX_VALIDATOR_MSG_MAX && v->message_len >= off + 32 &&
+                        memcmp(v->message + off, header_hash, 32) == 0;
+        int sig = 0;
         if (v->enabled) {
             out->n_enabled++;
             out->total_power += v->voting_power;
             exact_total += v->voting_power;
             if (v->is_signed) {
                 out->n_signed++;
-                uint8_t h[32];
-                orc_sha512_challenge(v, h, NULL);
-                int sig = orc_ed25519_verify_h(v->pubkey, v->signature, h);
-                uint32_t off = (v->message_len > 12 && v->message[12] == 0x19) ? 25 : 16;
-                int msg = v->message_len <= BSX_VALIDATOR_MSG_MAX && v->message_len >= off + 32 &&
-                          memcmp(v->message + off, header_hash, 32) == 0;
+                sig = orc_ed25519_verify_h(v->pubkey, v->signature, h);
                 if (!sig) {
                     out->n_bad_signature++;
                     if (out->first_bad_signature == 0xffffffffu) out->first_bad_signature = i;
@@ -105,12 +146,62 @@ void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t 
             }
         }
         if (sig_ok) sig_ok[i] = ok;
+        if (cw) {
+            memcpy(cw + bsx_cm_off_digest(V) + 64 * i, dig, 64);
+            memcpy(cw + bsx_cm_off_challenge(V) + 32 * i, h, 32);
+            uint8_t* rec = cw + bsx_cm_off_validators(V) + BSX_CM_VAL_BYTES * i;
+            memcpy(rec, v->pubkey, 32);
+            memcpy(rec + 32, v->signature, 64);
+            memcpy(rec + 96, v->message, BSX_VALIDATOR_MSG_MAX);
+            uint32_t* ws = W + BSX_CM_SLOT_WORDS * i;
+            ws[0] = v->message_len;
+            put_u64(ws + 2, v->voting_power);
+            uint8_t* b = Bo + BSX_CM_SLOT_BOOLS * i;
+            b[0] = v->enabled != 0; b[1] = v->is_signed != 0; b[2] = v->present_on_trusted != 0; b[3] = ok;
+            b[4] = (uint8_t)has_round; b[5] = (uint8_t)msg; b[6] = (uint8_t)(v->enabled && v->is_signed && sig && msg);
+        }
     }
-    validators_hash(vals, v_max, out->validators_hash);
+    tree_dst td = {cw, bsx_cm_off_leaf(V), bsx_cm_off_leaf_hash(V), bsx_cm_off_inner(V), bsx_cm_off_node(V), bsx_cm_off_root(V),
+                   W ? W + 1 : NULL, BSX_CM_SLOT_WORDS, Bo ? Bo + bsx_cm_b_leaf_enabled(V) : NULL, Bo ? Bo + bsx_cm_b_node_enabled(V) : NULL};
+    validators_hash(vals, v_max, out->validators_hash, cw ? &td : NULL);
     /* Tendermint caps a set's total at MaxTotalVotingPower = MaxInt64 / 8; beyond it the u64 sums may have wrapped */
     out->power_overflow = exact_total > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER;
     /* 3*signed > 2*total, in 128-bit to avoid overflow */
     out->two_thirds_ok = !out->power_overflow && (unsigned __int128)out->signed_power * 3 > (unsigned __int128)out->total_power * 2;
+    if (cw) {
+        put_u64(W + bsx_cm_w_total(V), out->total_power);
+        put_u64(W + bsx_cm_w_total(V) + 2, out->signed_power);
+        put_u64(W + bsx_cm_w_total(V) + 4, out->trusted_signed_power);
+        uint8_t* t = Bo + bsx_cm_b_tail(V);
+        t[0] = (uint8_t)out->two_thirds_ok; t[1] = (uint8_t)out->power_overflow;
+        t[2] = (uint8_t)(!out->n_bad_signature && !out->n_bad_message);
+    }
+}
+
+void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t header_hash[32], bsx_commit_result* out,
+                       uint8_t* sig_ok) {
+    orc_verify_commit_w(vals, v_max, header_hash, out, sig_ok, NULL);
+}
+
+/* header-field inclusion proof record (include/bsx_layout.h): aunts[4][32], path[5][32], leaf[cap]; *len_word = leaf length.
+ * Tree of the 14 encoded fields: tendermint Header::hash (RFC 6962 style); index <= 11 -> depth 4. */
+static void field_proof(const bsx_header* h, uint32_t idx, uint8_t* rec, uint32_t cap, uint32_t* len_word) {
+    const uint8_t* items[14];
+    size_t lens[14];
+    items[0] = h->version; items[1] = h->chain_id; items[2] = h->height; items[3] = h->time; items[4] = h->last_block_id;
+    for (int i = 0; i < 8; i++) items[5 + i] = h->hash[i];
+    items[13] = h->proposer;
+    for (int i = 0; i < 14; i++) lens[i] = h->len[i];
+    uint8_t aunts[4][32], path[5][32], root[32], bits[4];
+    int depth = orc_merkle_proof(items, lens, 14, idx, aunts);
+    (void)depth;
+    for (int k = 0; k < 4; k++) bits[k] = (uint8_t)((idx >> k) & 1);
+    orc_root_from_proof(items[idx], lens[idx], (const uint8_t(*)[32])aunts, bits, 4, root, path);
+    memcpy(rec, aunts, 128);
+    memcpy(rec + 128, path, 160);
+    memset(rec + BSX_PROOF_FIXED, 0, cap);
+    memcpy(rec + BSX_PROOF_FIXED, items[idx], lens[idx] < cap ? lens[idx] : cap);
+    *len_word = (uint32_t)lens[idx];
 }
 
 static int varint_height_field(uint64_t h, uint8_t out[12]) {
@@ -149,11 +240,16 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
     int hn = varint_height_field(target_block, hf);
     if (th->len[BSX_BLOCK_HEIGHT_INDEX] != hn || memcmp(th->height, hf, (size_t)hn) != 0) header_assert = 1;
     /* builder.skip is called with C::CHAIN_ID_BYTES (:42-43): the target header's chain-id leaf is 0a len bytes */
-    if (chain_id_len > 50 || th->len[1] != chain_id_len + 2 || th->chain_id[0] != 0x0a || th->chain_id[1] != chain_id_len ||
-        memcmp(th->chain_id + 2, chain_id, chain_id_len) != 0) header_assert = 1;
+    const int chain_ok = !(chain_id_len > 50 || th->len[1] != chain_id_len + 2 || th->chain_id[0] != 0x0a || th->chain_id[1] != chain_id_len ||
+                           memcmp(th->chain_id + 2, chain_id, chain_id_len) != 0);
+    if (!chain_ok) header_assert = 1;
     bsx_commit_result cr, trc;
     uint8_t* ok = malloc(v_max);
-    orc_verify_commit(target_validators, v_max, target_hash, &cr, ok);
+    /* compact (optional) = J map jobs, J - 1 reduce nodes, the COMMIT unit of the target commit, the SKIP unit */
+    const bsx_witness_layout ML = bsx_map_layout(B), RL = bsx_reduce_layout(), CL = bsx_commit_layout(v_max), SL = bsx_skip_layout(v_max);
+    uint8_t* ccw = compact ? compact + (size_t)J * ML.compact_stride + (size_t)(J - 1) * RL.compact_stride : NULL;
+    uint8_t* scw = ccw ? ccw + CL.compact_stride : NULL;
+    orc_verify_commit_w(target_validators, v_max, target_hash, &cr, ok, ccw);
     if (out_commit) *out_commit = cr;
     int status = BSX_OK;
     {
@@ -165,7 +261,13 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
     if (!status && (cr.n_bad_signature || cr.n_bad_message)) status = BSX_ERR_BAD_SIGNATURE;
     /* validators_hash (field 7 = hash[2]) of both headers */
     if (!status && (th->len[7] != 34 || memcmp(th->hash[2] + 2, cr.validators_hash, 32) != 0)) status = BSX_ERR_ASSERT;
-    validators_hash(trusted_validators, v_max, trc.validators_hash);
+    uint32_t* SW = scw ? (uint32_t*)(scw + SL.off_words) : NULL;
+    uint8_t* SB = scw ? scw + SL.off_bools : NULL;
+    if (scw) memset(scw, 0, SL.compact_stride);
+    tree_dst td = {scw, bsx_sk_off_leaf(v_max), bsx_sk_off_leaf_hash(v_max), bsx_sk_off_inner(v_max), bsx_sk_off_node(v_max),
+                   bsx_sk_off_root(v_max), SW ? SW + BSX_SK_W_SLOTS : NULL, 3, SB ? SB + bsx_sk_b_leaf_enabled(v_max) : NULL,
+                   SB ? SB + bsx_sk_b_node_enabled(v_max) : NULL};
+    validators_hash(trusted_validators, v_max, trc.validators_hash, scw ? &td : NULL);
     if (!status && (tr->len[7] != 34 || memcmp(tr->hash[2] + 2, trc.validators_hash, 32) != 0)) status = BSX_ERR_ASSERT;
     if (!status && !cr.two_thirds_ok) status = BSX_ERR_VOTING_POWER;
     /* > 1/3 of the trusted power signed the target (fetcher.rs:76-80 is_valid_skip) */
@@ -177,6 +279,7 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
             if (target_validators[k].enabled && target_validators[k].is_signed && ok[k] &&
                 memcmp(target_validators[k].pubkey, trusted_validators[i].pubkey, 32) == 0) {
                 overlap += trusted_validators[i].voting_power;
+                if (SB) SB[2 * i + 1] = 1;
                 break;
             }
     }
@@ -196,6 +299,36 @@ int orc_header_range(uint32_t J, uint32_t B, const uint8_t input48[48], const bs
     if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
     memcpy(output64, target_hash, 32);      /* :57 */
     memcpy(output64 + 32, commitment, 32);  /* :58 */
+    if (scw) {
+        const uint32_t V = v_max;
+        memcpy(scw, trusted_header_hash, 32);
+        memcpy(scw + 32, target_hash, 32);
+        memcpy(scw + 64, commitment, 32);
+        for (uint32_t i = 0; i < V; i++) {
+            memcpy(scw + bsx_sk_off_pubkeys(V) + 32 * i, trusted_validators[i].pubkey, 32);
+            SW[BSX_SK_W_SLOTS + 3 * i + 1] = (uint32_t)trusted_validators[i].voting_power;
+            SW[BSX_SK_W_SLOTS + 3 * i + 2] = (uint32_t)(trusted_validators[i].voting_power >> 32);
+            SB[2 * i] = trusted_validators[i].enabled != 0;
+        }
+        field_proof(th, 1, scw + bsx_sk_off_proof(V, 0), bsx_sk_proof_cap(0), SW + BSX_SK_W_LEAF_LEN);
+        field_proof(th, BSX_BLOCK_HEIGHT_INDEX, scw + bsx_sk_off_proof(V, 1), bsx_sk_proof_cap(1), SW + BSX_SK_W_LEAF_LEN + 1);
+        field_proof(th, 7, scw + bsx_sk_off_proof(V, 2), bsx_sk_proof_cap(2), SW + BSX_SK_W_LEAF_LEN + 2);
+        field_proof(tr, 7, scw + bsx_sk_off_proof(V, 3), bsx_sk_proof_cap(3), SW + BSX_SK_W_LEAF_LEN + 3);
+        put_u64(SW + BSX_SK_W_TRUSTED_BLOCK, trusted_block);
+        put_u64(SW + BSX_SK_W_TARGET_BLOCK, target_block);
+        put_u64(SW + bsx_sk_w_total(V), (uint64_t)trusted_total);
+        put_u64(SW + bsx_sk_w_total(V) + 2, (uint64_t)overlap);
+        uint8_t* c = SB + bsx_sk_b_checks(V);
+        c[0] = memcmp(trusted_hash, trusted_header_hash, 32) == 0;
+        c[1] = th->len[BSX_BLOCK_HEIGHT_INDEX] == hn && memcmp(th->height, hf, (size_t)hn) == 0;
+        c[2] = chain_ok;
+        c[3] = !cr.n_bad_signature && !cr.n_bad_message;
+        c[4] = th->len[7] == 34 && memcmp(th->hash[2] + 2, cr.validators_hash, 32) == 0;
+        c[5] = tr->len[7] == 34 && memcmp(tr->hash[2] + 2, trc.validators_hash, 32) == 0;
+        c[6] = (uint8_t)cr.two_thirds_ok;
+        c[7] = (unsigned __int128)(uint64_t)overlap * 3 > (unsigned __int128)(uint64_t)trusted_total;   /* on the u64 sums, like the words above */
+        c[8] = cr.power_overflow || trusted_total > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER;
+    }
     if (status) return status;
     return rc;
 }
@@ -218,11 +351,13 @@ typedef struct {
 
 static void* worker(void* arg) {
     job_t* jb = arg;
-    bsx_witness_layout L = bsx_map_layout(jb->B), R = bsx_reduce_layout();
-    size_t csz = (size_t)jb->J * L.compact_stride + (size_t)(jb->J - 1) * R.compact_stride;
+    bsx_witness_layout L = bsx_map_layout(jb->B), R = bsx_reduce_layout(), CL = bsx_commit_layout(jb->v_max), SL = bsx_skip_layout(jb->v_max);
+    size_t csz = (size_t)jb->J * L.compact_stride + (size_t)(jb->J - 1) * R.compact_stride + CL.compact_stride + SL.compact_stride;
     uint8_t* compact = jb->with_witness ? malloc(csz) : NULL;
     /* one map job's worth of expanded elements at a time (3.6 MB at B = 64): same work, bounded memory per thread */
     size_t wel = L.n_elements > (size_t)(jb->J - 1) * R.n_elements ? L.n_elements : (size_t)(jb->J - 1) * R.n_elements;
+    if (CL.n_elements > wel) wel = CL.n_elements;
+    if (SL.n_elements > wel) wel = SL.n_elements;
     uint64_t* wit = jb->with_witness ? malloc(wel * 8) : NULL;
     uint64_t cs = 0;
     uint8_t o64[64];
@@ -248,6 +383,11 @@ static void* worker(void* arg) {
                 orc_expand_witness(&R, jb->J - 1, compact + (size_t)jb->J * L.compact_stride, wit);
                 for (size_t i = 0; i < (size_t)(jb->J - 1) * R.n_elements; i += 61) cs += wit[i] * (i + 1);
             }
+            const uint8_t* ccw = compact + (size_t)jb->J * L.compact_stride + (size_t)(jb->J - 1) * R.compact_stride;
+            orc_expand_witness(&CL, 1, ccw, wit);                      /* the COMMIT unit, then the SKIP unit */
+            for (size_t i = 0; i < CL.n_elements; i += 4099) cs += wit[i] * (i + 1);
+            orc_expand_witness(&SL, 1, ccw + CL.compact_stride, wit);
+            for (size_t i = 0; i < SL.n_elements; i += 61) cs += wit[i] * (i + 1);
         }
         for (int i = 0; i < 64; i++) cs += o64[i];
     }
@@ -388,9 +528,10 @@ int orc_find_block_to_request(uint64_t start_block, uint64_t max_end_block, cons
 
 
 /* ---------------------------------------------------------------- next_header (circuits/next_header.rs:25-46) */
-int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
-                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
-                    uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit) {
+/* compact (optional): the COMMIT unit of the next header's commit, then the STEP unit (include/bsx_layout.h) */
+int orc_next_header_w(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                      uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
+                      uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact) {
     uint64_t prev_block = 0;                                       /* :26 */
     for (int i = 0; i < 8; i++) prev_block = prev_block << 8 | input40[i];
     const uint8_t* prev_hash = input40 + 8;                        /* :27 */
@@ -401,32 +542,79 @@ int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, co
     orc_header_hash(next_header, hn_, NULL, NULL);
     /* builder.step :32-36 [UPSTREAM] */
     bsx_commit_result cr;
+    const bsx_witness_layout CL = bsx_commit_layout(v_max ? v_max : 1), TL = bsx_step_layout();
+    uint8_t* scw = compact ? compact + CL.compact_stride : NULL;
     uint8_t* ok = (uint8_t*)malloc(v_max ? v_max : 1);
-    orc_verify_commit(next_validators, v_max, hn_, &cr, ok);
+    orc_verify_commit_w(next_validators, v_max, hn_, &cr, ok, compact);
     free(ok);
     if (out_commit) *out_commit = cr;
     int st = BSX_OK;
     if (cr.power_overflow) return BSX_ERR_BAD_ARG;
-    if (memcmp(hp, prev_hash, 32) != 0) st = BSX_ERR_ASSERT;
+    const int c_prev = memcmp(hp, prev_hash, 32) == 0;
+    if (!c_prev) st = BSX_ERR_ASSERT;
     uint8_t hf[12];
     int hl = 0;
     hf[hl++] = 0x08;
     for (uint64_t hv = next_block;; hv >>= 7) { if (hv >= 0x80) hf[hl++] = (uint8_t)(hv | 0x80); else { hf[hl++] = (uint8_t)hv; break; } }
-    if (!st && (next_header->len[BSX_BLOCK_HEIGHT_INDEX] != hl || memcmp(next_header->height, hf, (size_t)hl) != 0)) st = BSX_ERR_ASSERT;
-    if (!st && (chain_id_len > 50 || next_header->len[1] != chain_id_len + 2 || next_header->chain_id[0] != 0x0a ||
-                next_header->chain_id[1] != chain_id_len || memcmp(next_header->chain_id + 2, chain_id, chain_id_len) != 0))
-        st = BSX_ERR_ASSERT;   /* builder.step is called with C::CHAIN_ID_BYTES (next_header.rs:32-33) */
-    if (!st && (cr.n_bad_signature || cr.n_bad_message)) st = BSX_ERR_BAD_SIGNATURE;
-    if (!st && (next_header->len[7] != 34 || memcmp(next_header->hash[2] + 2, cr.validators_hash, 32) != 0)) st = BSX_ERR_ASSERT;
-    if (!st && (prev_header->len[8] != 34 || memcmp(prev_header->hash[3] + 2, cr.validators_hash, 32) != 0)) st = BSX_ERR_ASSERT;
-    if (!st && (next_header->len[BSX_LAST_BLOCK_ID_INDEX] < 34 || memcmp(next_header->last_block_id + 2, hp, 32) != 0)) st = BSX_ERR_ASSERT;
+    const int c_height = next_header->len[BSX_BLOCK_HEIGHT_INDEX] == hl && memcmp(next_header->height, hf, (size_t)hl) == 0;
+    if (!st && !c_height) st = BSX_ERR_ASSERT;
+    const int c_chain = !(chain_id_len > 50 || next_header->len[1] != chain_id_len + 2 || next_header->chain_id[0] != 0x0a ||
+                          next_header->chain_id[1] != chain_id_len || memcmp(next_header->chain_id + 2, chain_id, chain_id_len) != 0);
+    if (!st && !c_chain) st = BSX_ERR_ASSERT;   /* builder.step is called with C::CHAIN_ID_BYTES (next_header.rs:32-33) */
+    const int c_sigs = !cr.n_bad_signature && !cr.n_bad_message;
+    if (!st && !c_sigs) st = BSX_ERR_BAD_SIGNATURE;
+    const int c_vh = next_header->len[7] == 34 && memcmp(next_header->hash[2] + 2, cr.validators_hash, 32) == 0;
+    if (!st && !c_vh) st = BSX_ERR_ASSERT;
+    const int c_nvh = prev_header->len[8] == 34 && memcmp(prev_header->hash[3] + 2, cr.validators_hash, 32) == 0;
+    if (!st && !c_nvh) st = BSX_ERR_ASSERT;
+    const int c_lb = next_header->len[BSX_LAST_BLOCK_ID_INDEX] >= 34 && memcmp(next_header->last_block_id + 2, hp, 32) == 0;
+    if (!st && !c_lb) st = BSX_ERR_ASSERT;
     if (!st && !cr.two_thirds_ok) st = BSX_ERR_VOTING_POWER;
     uint8_t dc[32];
     const int rc = orc_prove_next_header_data_commitment(prev_block, prev_hash, next_block, prev_header, latest_block, dc);   /* :38-42 */
     if (rc != BSX_OK && rc != BSX_ERR_ASSERT) return rc;
     memcpy(output64, hn_, 32);                                     /* :44 */
     memcpy(output64 + 32, dc, 32);                                 /* :45 */
+    if (scw) {
+        memset(scw, 0, TL.compact_stride);
+        uint32_t* W = (uint32_t*)(scw + TL.off_words);
+        uint8_t* Bo = scw + TL.off_bools;
+        memcpy(scw, prev_hash, 32);
+        memcpy(scw + 32, hn_, 32);
+        memcpy(scw + 64, dc, 32);
+        field_proof(next_header, 1, scw + bsx_st_off_proof(0), bsx_st_proof_cap(0), W + BSX_ST_W_LEAF_LEN);
+        field_proof(next_header, BSX_BLOCK_HEIGHT_INDEX, scw + bsx_st_off_proof(1), bsx_st_proof_cap(1), W + BSX_ST_W_LEAF_LEN + 1);
+        field_proof(next_header, 7, scw + bsx_st_off_proof(2), bsx_st_proof_cap(2), W + BSX_ST_W_LEAF_LEN + 2);
+        field_proof(next_header, BSX_LAST_BLOCK_ID_INDEX, scw + bsx_st_off_proof(3), bsx_st_proof_cap(3), W + BSX_ST_W_LEAF_LEN + 3);
+        field_proof(prev_header, 8, scw + bsx_st_off_proof(4), bsx_st_proof_cap(4), W + BSX_ST_W_LEAF_LEN + 4);
+        /* data_hash_proofs[0] of the MAX_LEAVES = 1 hint (builder.rs:418-423): real iff prev < min(next, latest - 2)
+         * (input.rs:160-172), otherwise the all-zero proof (:220-239) — its path is then the zero proof's */
+        const uint64_t req_end = next_block < latest_block - 2 ? next_block : latest_block - 2;
+        uint8_t* pr = scw + bsx_st_off_proof(5);
+        if (prev_block < req_end) {
+            field_proof(prev_header, BSX_DATA_HASH_INDEX, pr, bsx_st_proof_cap(5), W + BSX_ST_W_LEAF_LEN + 5);
+        } else {
+            static const uint8_t DH_PATH[4] = {0, 1, 1, 0};
+            uint8_t zl[BSX_PROTOBUF_HASH_SIZE] = {0}, za[4][32] = {{0}}, root[32], path[5][32];
+            orc_root_from_proof(zl, BSX_PROTOBUF_HASH_SIZE, (const uint8_t(*)[32])za, DH_PATH, 4, root, path);
+            memcpy(pr + 128, path, 160);
+            W[BSX_ST_W_LEAF_LEN + 5] = BSX_PROTOBUF_HASH_SIZE;
+        }
+        orc_encode_data_root_tuple(pr + BSX_PROOF_FIXED + 2, prev_block, scw + bsx_st_off_tuple());   /* builder.rs:436-439 */
+        put_u64(W + BSX_ST_W_PREV_BLOCK, prev_block);
+        put_u64(W + BSX_ST_W_NEXT_BLOCK, next_block);
+        Bo[0] = (uint8_t)c_prev; Bo[1] = (uint8_t)c_height; Bo[2] = (uint8_t)c_chain; Bo[3] = (uint8_t)c_sigs; Bo[4] = (uint8_t)c_vh;
+        Bo[5] = (uint8_t)c_nvh; Bo[6] = (uint8_t)c_lb; Bo[7] = (uint8_t)cr.two_thirds_ok; Bo[8] = (uint8_t)cr.power_overflow;
+        Bo[9] = memcmp(pr + 128 + 128, prev_hash, 32) == 0;        /* builder.rs:434 (A10): data_hash proof root == prev_header_hash */
+    }
     return st ? st : rc;
+}
+
+int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                    uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
+                    uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit) {
+    return orc_next_header_w(input40, prev_header, next_header, latest_block, next_validators, v_max, chain_id, chain_id_len,
+                             output64, out_commit, NULL);
 }
 
 /* ---------------------------------------------------------------- mode-S fold (checker of bsx_dev_verify_commits' d_fold)

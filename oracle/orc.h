@@ -88,19 +88,28 @@ void orc_sha512_challenge(const bsx_validator* v, uint8_t h[32], uint8_t digest[
 int orc_validator_leaf(const uint8_t pk[32], uint64_t power, uint8_t out[BSX_VALIDATOR_LEAF_MAX]);
 void orc_verify_commit(const bsx_validator* vals, uint32_t v_max, const uint8_t header_hash[32],
                        bsx_commit_result* out, uint8_t* sig_ok);
+/* same, also emitting the COMMIT unit's compact witness (bsx_commit_layout(v_max).compact_stride bytes; optional) */
+void orc_verify_commit_w(const bsx_validator* vals, uint32_t v_max, const uint8_t header_hash[32],
+                         bsx_commit_result* out, uint8_t* sig_ok, uint8_t* compact);
 /* mode-S fold of a slice of commit results (checker of bsx_dev_verify_commits' d_fold; include/bsx.h bsx_commit_fold) */
 void orc_commit_fold(const bsx_commit_result* res, uint32_t n, uint32_t first_index, bsx_commit_fold* out);
 int orc_header_range(uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const bsx_header* headers,
                      uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
                      const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
                      const uint8_t* chain_id, uint32_t chain_id_len,
-                     uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact);
+                     uint8_t output64[64], bsx_commit_result* out_commit,
+                     uint8_t* compact /* optional: J map jobs, J - 1 reduce nodes, the COMMIT unit, the SKIP unit */);
 
 /* CombinedStepCircuit::define (circuits/next_header.rs:25-46); builder.step is [UPSTREAM] (checks restated from
  * SURVEY App. B, same list as include/bsx.h bsx_next_header) */
 int orc_next_header(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
                     uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
                     uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit);
+
+/* same, also emitting the compact witness: the COMMIT unit then the STEP unit (optional) */
+int orc_next_header_w(const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                      uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id,
+                      uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit, uint8_t* compact);
 
 /* ---- operator skip-target search (circuits/fetcher.rs:60-87 find_block_to_request).  The loop is
  * the reference's; the predicate is_valid_skip is [UPSTREAM] tendermintx v1.0.0 (not under /root/reference): restated

@@ -470,7 +470,9 @@ def test_header_range_vs_oracle(J, B, v, n_blocks):
     assert rc == T.OK
     assert out == ref_out and out[:32] == w.hashes[0, n_blocks].tobytes()
     assert res_bytes(res) == res_bytes(ref_res)
-    assert (wit == oracle.expand_range_witness(J, B, cw)).all()
+    # the WHOLE circuit's witness: map jobs, reduce nodes, the COMMIT unit of the target commit, the SKIP unit (round 4)
+    assert wit.size == T.header_range_witness_elements(J, B, v)
+    assert (wit == oracle.expand_range_witness(J, B, cw, v_max=v)).all()
 
 
 def test_chain_id_is_checked_on_gpu_like_the_oracle():
