@@ -87,7 +87,52 @@ def parse():
     ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only: none of the secondary objects")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dry-run", action="store_true", help="launcher check only: spawn / join the ranks, one all-gather over the process group, "
+                    "ONE JSON line with the world that really ran — no GPU work (CPU-only boxes: BSX_DIST_BACKEND=gloo)")
+    ap.add_argument("--collective", choices=["rccl-c", "torch"], default="rccl-c", help="N > 1: the all-gather of the data path is ncclAllGather "
+                    "called by the library (bsx_pipeline_set_rccl; default) or torch.distributed through a callback")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): re-run this very command under
+    torch.distributed.run with N ranks on this node, one per GPU, and hand its exit code on — so that the multi-GPU bench cannot
+    silently run as N = 1 (VERDICT r3 #2).  Returns only when nothing had to be launched."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    if not args.dry_run and os.environ.get("BSX_BENCH_DEVICE") is None:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: no launcher in the environment — starting {args.gpus} ranks: {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=dict(os.environ, BSX_BENCH_SELF_LAUNCHED="1")).returncode)
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the launcher contract without a GPU — every rank joins the process group, one all-gather of (rank, pid), rank 0
+    prints what really ran."""
+    import torch.distributed as dist
+    ranks = [(rank, os.getpid())]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("BSX_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+        got = [None] * world
+        dist.all_gather_object(got, (rank, os.getpid()))
+        ranks = got
+    assert world == args.gpus, f"--gpus {args.gpus} but {world} rank(s) are running"
+    assert sorted(r for r, _ in ranks) == list(range(world)) and len({p for _, p in ranks}) == world
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": [r for r, _ in ranks], "processes": len({p for _, p in ranks}),
+                          "launched_by": "bench.py itself" if os.environ.get("BSX_BENCH_SELF_LAUNCHED") else "the caller / an external launcher"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def host_threads():
@@ -556,17 +601,25 @@ def sharded_self_check(eng, w, J, B, V, R, rank, dev, res):
 # ---------------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    self_launch(args)                                   # --gpus N without a launcher: spawns the N ranks and exits with their code
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    # the line's n_gpus is the world that RUNS: a launcher's WORLD_SIZE wins over a stale --gpus, and N ranks need N GPUs
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
         args.gpus = world
+    if os.environ.get("BSX_BENCH_DEVICE") is None:
+        assert torch.cuda.device_count() >= world, f"{world} ranks on this node need {world} GPUs, {torch.cuda.device_count()} visible"
     # test hooks (tests/test_gpu_engine.py runs the N > 1 code path with two ranks on ONE GPU): device override and a
     # gloo process group; the driver's multi-GPU runs use neither (one rank per GPU over RCCL)
     if os.environ.get("BSX_BENCH_DEVICE") is not None:
         local = int(os.environ["BSX_BENCH_DEVICE"])
     from blobstreamx_amd import _lib
-    _lib.lib()                     # loads libbsx.so before the first HIP call (its constructor raises GPU_MAX_HW_QUEUES)
+    _lib.lib()                     # loads libbsx.so and calls bsx_prepare_process() before the first HIP call (16 hardware queues)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     backend = None
@@ -610,6 +663,22 @@ def main():
     eng = E.AlternatingPipelines(args.alternate, J, B, V, R, **kw) if args.alternate > 1 else E.PipelinedEngines(J, B, V, R, **kw)
     eng.upload_workload(w)
     p0 = eng
+    collective = None
+    if world > 1:
+        # The one collective of the path.  Default: ncclAllGather called by the LIBRARY on its exchange stream, on a communicator made
+        # through the C ABI (rank 0's unique id goes over the torch.distributed group: control plane only) — no Python between the
+        # local fold and the top fold.  Every rank must take the same branch: the availability probe is agreed on first, and
+        # bsx_pipeline_check_allgather proves the collective end to end before the first step.
+        import torch.distributed as dist
+        collective = "torch.distributed all_gather_into_tensor through the bsx_pipeline_set_allgather callback"
+        if args.collective == "rccl-c" and backend == "nccl":
+            probe = np.zeros(128, np.uint8)
+            ok = torch.tensor([1 if _lib.lib().bsx_rccl_get_unique_id(_lib.p(probe)) == 0 else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                comm = E.c_rccl_comm(eng.ctx, rank, world)
+                eng.set_rccl(comm)
+                collective = "ncclAllGather called by libbsx (bsx_pipeline_set_rccl), communicator from bsx_rccl_comm_init_rank"
 
     # correctness gate before timing: statuses clean, public output = (target header hash, commitment) for every owned range
     eng.step()
@@ -673,7 +742,7 @@ def main():
                        "parallelism": (f"{world} x ({J // world} of {J} map jobs = {J * B // world} headers of every range), 1 all-gather of 128-B "
                                        f"records per chunk; {'strong: ' + str(R * world) + ' ranges in total' if strong else 'weak: ' + str(R) + ' ranges per GPU'}")
                        if world > 1 else "1 GPU",
-                       "nccl_ranks": torch.distributed.get_world_size() if world > 1 else 1, "dist_backend": backend,
+                       "nccl_ranks": torch.distributed.get_world_size() if world > 1 else 1, "dist_backend": backend, "collective": collective,
                        "sharded_vs_unsharded_self_check_per_rank": self_check,
                        "witness_checked_ranges": n_checked,
                        "witness_bytes_per_step_per_gpu": int(Ech * n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
@@ -694,8 +763,17 @@ def main():
                 torch.cuda.synchronize(dev)
                 t_iso += iso[0].elapsed_time(iso[1]) / 5
             traffic, traffic_src = pmc_traffic(n_jobs, B)
+            # SURVEY §8(d)'s LITERAL per-slot figure (362 B read + (362 + 384) x 64 B written = 48,106 B per header slot) beside the
+            # layout's own count (every variable bsx_witness_manifest lists: 57,124 B per slot at B = 64) — VERDICT r3 weak #8
+            survey_bytes = slots * 48106
             out["roofline"] = {"kernel": "k_expand_witness (map-job section)", "bound": "hbm", "achieved": exp_bytes / t_exp / 1e6,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exp_bytes / t_exp / 1e6 / HBM_PEAK_GBS,
+                               "byte_accounting": {"layout_bytes_per_slot": exp_bytes / slots, "frac_layout_bytes": exp_bytes / t_exp / 1e6 / HBM_PEAK_GBS,
+                                                   "survey_8d_bytes_per_slot": 48106, "achieved_survey_8d": survey_bytes / t_exp / 1e6,
+                                                   "frac_survey_8d": survey_bytes / t_exp / 1e6 / HBM_PEAK_GBS,
+                                                   "note": "`frac` prices the bytes the kernel really moves (the layout's variables, = PMC traffic 1.00x); "
+                                                           "SURVEY §8(d)'s literal figure counts 12 digests per slot where the layout holds the 10 path digests, "
+                                                           "curr_header, the tuple, leaf hash, two tree nodes, words and bools"},
                                "traffic": traffic, "traffic_source": traffic_src,
                                "avg_launch_ms": t_exp, "algorithmic_bytes_per_launch": exp_bytes, "launches_timed": tm["launches"],
                                "measured_store_ceiling_GBps": cal["hbm_store_bytes_per_s"] / 1e9,

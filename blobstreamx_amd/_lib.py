@@ -38,7 +38,8 @@ SYMBOLS = [
     "bsx_pipeline_timing", "bsx_pipeline_autotune", "bsx_calibrate", "bsx_dev_verify_commits", "bsx_dev_verify_commits_scratch_bytes",
     "bsx_ed25519_decoded_r_bytes", "bsx_dev_ed25519_decode_r", "bsx_dev_ed25519_verify_keyed_r",
     "bsx_witness_manifest_section", "bsx_commit_witness_layout", "bsx_skip_witness_layout", "bsx_step_witness_layout",
-    "bsx_header_range_witness_elements", "bsx_next_header_witness_elements",
+    "bsx_header_range_witness_elements", "bsx_next_header_witness_elements", "bsx_prepare_process",
+    "bsx_pipeline_set_rccl", "bsx_rccl_get_unique_id", "bsx_rccl_comm_init_rank", "bsx_rccl_comm_destroy", "bsx_pipeline_check_allgather",
 ]
 
 
@@ -72,6 +73,11 @@ def lib():
                 except Exception:  # torch is plumbing, not a requirement of the C ABI
                     pass
             L = C.CDLL(_SO)
+            # the pipeline's 16 streams need their own hardware queues: asked for BEFORE the HIP runtime initialises (it usually has
+            # not: importing torch does not initialise HIP).  An explicit, documented call — the library itself never touches the
+            # environment (bsx.h bsx_prepare_process); BSX_KEEP_ENV=1 skips it
+            if os.environ.get("BSX_KEEP_ENV") != "1":
+                L.bsx_prepare_process()
             L.bsx_version.restype = C.c_uint32
             L.bsx_ed25519_keytable_bytes.restype = C.c_uint64
             L.bsx_ed25519_verify_scratch_bytes.restype = C.c_uint64

@@ -64,9 +64,13 @@ hipStream_t S(bsx_ctx*, void* s) { return static_cast<hipStream_t>(s); }
 // HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.  A pipeline
 // drives 2 main + 2 commit-check streams beside the context's own two, copy and exchange streams: with 4 queues the second
 // chunk's stream lands on the first chunk's side-stream queue (measured: 3.2 -> 4.8 ms per step).  The variable is read when
-// the HIP runtime initialises, i.e. at the first HIP call of the process — normally after this library has been loaded, so
-// the default is raised here; a value the caller has set is left alone.
-__attribute__((constructor)) static void bsx_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// the HIP runtime initialises, i.e. at the first HIP call of the process.  The library does NOT touch the process environment
+// (round 3's load-time constructor did): a host that wants the 16 queues calls bsx_prepare_process() before its first HIP call
+// (or exports the variable itself), and bsx_pipeline_autotune reports how many queues the pool really got.
+int bsx_prepare_process(void) {
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;            // the caller's choice stands
+    return setenv("GPU_MAX_HW_QUEUES", "16", 0) == 0 ? 1 : -1;
+}
 
 extern "C" {
 
@@ -383,7 +387,7 @@ int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
     if ((uintptr_t)d_table & 127) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
     if ((uintptr_t)d_scratch & 15) return fail(BSX_ERR_BAD_ARG, "scratch must be 16-byte aligned");
-    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch, nullptr));
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch, nullptr, -1));
     return BSX_OK;
 }
 
@@ -404,7 +408,7 @@ int bsx_dev_ed25519_verify_keyed_r(bsx_ctx* ctx, void* stream, const bsx_validat
     if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
     if ((uintptr_t)d_table & 127) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
-    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, nullptr, d_decoded_r));
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, nullptr, d_decoded_r, -1));
     return BSX_OK;
 }
 
@@ -448,7 +452,7 @@ uint64_t bsx_dev_verify_commits_scratch_bytes(uint32_t n_commits, uint32_t v_max
 
 int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_commits, uint32_t v_max,
                            const uint8_t* d_header_hashes, uint32_t first_index, void* d_keytable, void* d_scratch, uint8_t* d_ok,
-                           bsx_commit_result* d_results, bsx_commit_fold* d_fold, uint8_t* d_commit_compact) {
+                           bsx_commit_result* d_results, bsx_commit_fold* d_fold, uint8_t* d_commit_compact, uint32_t flags) {
     DEV_ENTER();
     if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
     if (!n_commits || n_commits > BSX_COMMIT_FOLD_MAX) return fail(BSX_ERR_UNSUPPORTED, "n_commits %u not in 1..%u", n_commits, BSX_COMMIT_FOLD_MAX);
@@ -463,11 +467,24 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     const bsx_witness_layout CL = bsx_commit_layout(v_max);
     const bsxk_unit_dst cw = bsxk_unit(d_commit_compact, CL);
     HIPCHK(bsxk_sha512_challenge(st, d_validators, n, d_h, nullptr, v_max, d_commit_compact ? &cw : nullptr));
-    HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable)));
-    HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed, nullptr));
+    if (flags & ~(BSX_COMMITS_KEYTABLE_READY | BSX_COMMITS_KEYS_UNIFORM)) return fail(BSX_ERR_BAD_ARG, "bsx_dev_verify_commits: unknown flags 0x%x", flags);
+    if (!(flags & BSX_COMMITS_KEYTABLE_READY)) HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable)));
+    HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed, nullptr,
+                                     (flags & BSX_COMMITS_KEYS_UNIFORM) ? 0 : -1));
     HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results, d_commit_compact ? &cw : nullptr));
     HIPCHK(bsxk_commit_fold(st, d_results, n_commits, first_index, d_fs, d_fold));
     return BSX_OK;
+}
+
+// host-side bookkeeping for the fixed-key signature check (no arithmetic: 32-byte compares)
+uint64_t bsxh_key_mismatches(const bsx_validator* v, uint64_t n_commits, uint32_t v_max) {
+    uint64_t n = 0;
+    for (uint64_t c = 1; c < n_commits; c++)
+        for (uint32_t i = 0; i < v_max; i++) {
+            const bsx_validator& x = v[c * v_max + i];
+            if (x.enabled && x.is_signed && memcmp(x.pubkey, v[i].pubkey, 32) != 0) n++;
+        }
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------ host tier
@@ -497,7 +514,7 @@ static int ctx_keytable(bsx_ctx* ctx, uint32_t v_max, uint8_t** out, hipStream_t
 // signature check of n = n_commits * v_max slots: keyed (table of the first commit's keys, kept in the context) or, when the
 // table could not be allocated, generic
 static int ctx_verify(bsx_ctx* ctx, hipStream_t st, const bsx_validator* dv, const uint8_t* dh, uint64_t n, uint32_t v_max, uint8_t* dok,
-                      void* dscratch, void* drdec) {
+                      void* dscratch, void* drdec, int64_t n_deferred) {
     uint8_t* tab = nullptr;
     RET(ctx_keytable(ctx, v_max, &tab, st));
     if (!tab) {
@@ -507,7 +524,7 @@ static int ctx_verify(bsx_ctx* ctx, hipStream_t st, const bsx_validator* dv, con
     HIPCHK(bsxk_ed25519_keytable(st, dv, v_max, tab));
     // small batches (a proof request): R decoded ahead, 16 lanes per signature, projective comparison — no inversion on the chain
     if (drdec && !dscratch) HIPCHK(bsxk_ed25519_decode_r(st, dv, n, drdec));
-    HIPCHK(bsxk_ed25519_verify_keyed(st, dv, dh, n, v_max, tab, v_max, ctx->btab, dok, dscratch, dscratch ? nullptr : drdec));
+    HIPCHK(bsxk_ed25519_verify_keyed(st, dv, dh, n, v_max, tab, v_max, ctx->btab, dok, dscratch, dscratch ? nullptr : drdec, n_deferred));
     return BSX_OK;
 }
 
@@ -1014,7 +1031,8 @@ int bsx_verify_commits(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n
         DBuf dscr, drd;                             // batch inversion pays from tens of thousands of signatures on; below: the latency form
         if (n >= 65536) RET(dscr.alloc(bsxk_ed25519_scratch_bytes(n)));
         else RET(drd.alloc(bsxk_ed25519_rdec_bytes(n)));
-        RET(ctx_verify(ctx, st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dok.as<uint8_t>(), dscr.p, drd.p));
+        RET(ctx_verify(ctx, st, dv.as<bsx_validator>(), dh.as<uint8_t>(), n, v_max, dok.as<uint8_t>(), dscr.p, drd.p,
+                       (int64_t)bsxh_key_mismatches(validators, n_commits, v_max)));
     }
     HIPCHK(bsxk_commit_tally(st, dv.as<bsx_validator>(), n_commits, v_max, dhh.as<uint8_t>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(), cwp));
     if (witness) {
@@ -1049,6 +1067,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     if (!(target_block > trusted_block) || target_block - trusted_block > (uint64_t)nb_map_jobs * batch_size)
         return fail(BSX_ERR_RANGE_TOO_LONG, "skip: need trusted < target <= trusted + %llu", (unsigned long long)nb_map_jobs * batch_size);
     if (trusted_block < first_height || target_block - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "trusted/target header not supplied");
+    if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");   // also on the graph-replay path, which skips upload_range's checks
     hipStream_t st = ctx->stream;
     // Three streams: the hashing chain (header hashes, hint, prove_subchain, reduce, finalize) on `st`; the commit check
     // (challenges, key table, signatures, tallies, skip conditions — latency bound at <= 100 signatures) beside it on `sb`; and
@@ -1166,7 +1185,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     if (tab) {
         HIPCHK(bsxk_ed25519_keytable(sb, dv.as<bsx_validator>(), v_max, tab));
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_d, 0));
-        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), nullptr, drd.p));
+        HIPCHK(bsxk_ed25519_verify_keyed(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), nullptr, drd.p, 0));   // one commit: the table rows ARE its keys, nothing is deferred
     } else {
         HIPCHK(bsxk_ed25519_verify(sb, dv.as<bsx_validator>(), dh.as<uint8_t>(), v_max, dok.as<uint8_t>()));
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_d, 0));
@@ -1195,7 +1214,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         D2H(witness + nmr + CL.n_elements, dws.p, SL.n_elements * 8);
     }
     HIPCHK(hipMemcpyAsync(io.h + io.out_off, io.dout(0), SmallIO::OUT_BYTES, hipMemcpyDeviceToHost, st));
-    static const bool trace_host = getenv("BSX_TRACE_HOST") != nullptr;       // experiments: host enqueue time vs wait for the GPU
+    static const bool trace_host = bsx_knob("BSX_TRACE_HOST", 0) != 0;       // experiments build: host enqueue time vs wait for the GPU
     const auto t_enq = std::chrono::steady_clock::now();
     if (capture) {
         hipGraph_t g = nullptr;
@@ -1289,7 +1308,7 @@ int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* p
     HIPCHK(bsxk_header_merkle(st, d_hdr, 2, dhash.as<uint8_t>(), nullptr, nullptr, nullptr, d_st, 0, 0));
     // builder.step (:32-36) [UPSTREAM tendermintx v1.0.0]: the commit of the next header
     HIPCHK(bsxk_sha512_challenge(st, d_val, v_max, dh.as<uint8_t>(), nullptr, v_max, &cwd));
-    RET(ctx_verify(ctx, st, d_val, dh.as<uint8_t>(), v_max, v_max, dok.as<uint8_t>(), nullptr, drd.p));
+    RET(ctx_verify(ctx, st, d_val, dh.as<uint8_t>(), v_max, v_max, dok.as<uint8_t>(), nullptr, drd.p, 0));   // one commit: the table IS its keys
     HIPCHK(bsxk_commit_tally(st, d_val, 1, v_max, dhash.as<uint8_t>() + 32, dok.as<uint8_t>(), dres.as<bsx_commit_result>(), &cwd));
     {
         bsxk_field_proofs_args fa{};

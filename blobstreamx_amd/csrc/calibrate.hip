@@ -6,6 +6,7 @@
 // of — the library's own device functions — alone, at 8 waves per SIMD, with no memory traffic.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstring>
 
 #include "api_internal.h"
@@ -86,7 +87,46 @@ __global__ void k_cal_store(ulonglong2* out, size_t n16, unsigned long long v) {
     }
 }
 
+// one wave that keeps its queue busy for `ticks` of the 100 MHz wall clock (bsxk_queue_groups)
+__global__ void k_spin(unsigned long long ticks, uint32_t* out) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+    if (out && threadIdx.x == 0) out[0] = 1;
+}
+
 }  // namespace bsx
+
+// How many distinct HARDWARE queues a set of HIP streams sits on: HIP binds streams to GPU_MAX_HW_QUEUES queues (default 4), and
+// kernels of streams that share one run one after the other whatever the stream flags say.  Measured, not read from the
+// environment: stream s is put in the group of the first representative it serialises with — two single-wave kernels that each
+// spin 0.3 ms take 0.3 ms together on different queues and 0.6 ms on one.  groups[i] (optional) receives stream i's group.
+extern "C" int bsxk_queue_groups(hipStream_t* streams, uint32_t n, uint32_t* groups) {
+    constexpr unsigned long long TICKS = 30000;          // 0.3 ms at 100 MHz
+    uint32_t reps[64], n_groups = 0;
+    auto pair_ms = [&](hipStream_t a, hipStream_t b, double* ms) -> int {
+        HIPCHK(hipStreamSynchronize(a));
+        HIPCHK(hipStreamSynchronize(b));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(bsx::k_spin, dim3(1), dim3(64), 0, a, TICKS, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(bsx::k_spin, dim3(1), dim3(64), 0, b, TICKS, (uint32_t*)nullptr);
+        HIPCHK(hipStreamSynchronize(a));
+        HIPCHK(hipStreamSynchronize(b));
+        *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return BSX_OK;
+    };
+    if (n > 64) n = 64;
+    for (uint32_t s = 0; s < n; s++) {
+        uint32_t g = n_groups;
+        for (uint32_t k = 0; k < n_groups && g == n_groups; k++) {
+            double ms = 0;
+            RET(pair_ms(streams[reps[k]], streams[s], &ms));
+            if (ms > 0.48) g = k;                        // serialised: same hardware queue
+        }
+        if (g == n_groups) reps[n_groups++] = s;
+        if (groups) groups[s] = g;
+    }
+    return (int)n_groups;
+}
 
 namespace {
 template <typename F>

@@ -3,7 +3,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/bsx.h"
+
+// Experiment knobs of the launchers (tools/*.sh sweeps).  A release build reads NO environment variable: the value is the default,
+// resolved at compile time; `make EXPERIMENTS=1` (-DBSX_EXPERIMENTS) builds the variant the sweep scripts drive.
+#ifdef BSX_EXPERIMENTS
+static inline long bsx_knob(const char* name, long dflt) {
+    const char* v = getenv(name);
+    return v ? atol(v) : dflt;
+}
+#else
+#define bsx_knob(name, dflt) (static_cast<long>(dflt))
+#endif
 
 // Where a kernel of the commit chain leaves the witness variables it holds (include/bsx_layout.h): unit c at base + c * stride
 // (COMMIT units: c = commit; SKIP / STEP units: c = range); base == nullptr: no witness.  mode (k_commit_tally): 0 = the COMMIT
@@ -31,7 +44,10 @@ hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, ui
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
 uint64_t bsxk_keytable_bytes(uint32_t);
 hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
-hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*, const void*);
+hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*, const void*, int64_t);
+// active (enabled and signed) slots of commits 1.. whose public key differs from the first commit's slot of the same index: what a
+// fixed-key table built from the first commit's keys cannot serve (host-side compare; api.hip)
+uint64_t bsxh_key_mismatches(const bsx_validator* validators, uint64_t n_commits, uint32_t v_max);
 // sentinel for bsxk_ed25519_verify_keyed's last argument: no decoded R, and (with a scratch) prefer the form with the least total work
 #ifndef BSXK_ED_THROUGHPUT
 #define BSXK_ED_THROUGHPUT (reinterpret_cast<const void*>(static_cast<uintptr_t>(1)))
@@ -89,6 +105,9 @@ hipError_t bsxk_skip_eval(hipStream_t, const bsx_validator*, const bsx_validator
 uint64_t bsxk_commit_fold_scratch_bytes(uint32_t);
 hipError_t bsxk_commit_fold(hipStream_t, const bsx_commit_result*, uint32_t, uint32_t, void*, bsx_commit_fold*);
 }
+
+// number of distinct hardware queues the given streams sit on (measured; calibrate.hip); < 0: a bsx_status error code negated
+extern "C" int bsxk_queue_groups(hipStream_t* streams, uint32_t n, uint32_t* groups);
 
 extern "C" {
 hipError_t bsxk_poseidon_permute(hipStream_t, const uint64_t*, uint64_t, uint64_t*);

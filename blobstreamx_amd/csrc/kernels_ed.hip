@@ -773,7 +773,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
                 total_hi += power >> 32; total_lo += power & 0xffffffffull;
                 if (is_signed) {
                     nsig++;
-                    sig = ok_in ? (ok_in[(uint64_t)c * v_max + v] != 0) : false;
+                    sig = ok_in ? (ok_in[(uint64_t)c * v_max + v] == 1) : false;     // a deferred / pending marker never counts as valid
                     if (!sig) { nbad++; atomicMin(&s_firstbad, v); }
                     if (!msg) nbadmsg++;
                     if (sig && msg) { signedp += power; if (present) trusted += power; }
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void k_skip_check(SkipArgs a) {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(tv[k].pubkey);
 #pragma unroll
         for (int q = 0; q < 8; q++) tpk[k * 8 + q] = p[q];
-        tsig[k] = (tv[k].enabled && tv[k].is_signed && a.target_ok[(uint64_t)r * V + k]) ? 1 : 0;
+        tsig[k] = (tv[k].enabled && tv[k].is_signed && a.target_ok[(uint64_t)r * V + k] == 1) ? 1 : 0;
     }
     __syncthreads();
     uint8_t* const scw = a.wit.base ? a.wit.base + (uint64_t)r * a.wit.stride : nullptr;
@@ -1108,8 +1108,8 @@ hipError_t bsxk_ed25519_verify(hipStream_t s, const bsx_validator* vals, const u
 uint64_t bsxk_keytable_bytes(uint32_t n_keys) { return kt_bytes(n_keys); }
 hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint32_t n_keys, uint8_t* table) {
     if (n_keys == 0) return hipSuccess;
-    // BSX_KEYTABLE_REUSE=0 forces a full rebuild on every call (cold-build measurements)
-    static const uint32_t force = getenv("BSX_KEYTABLE_REUSE") && atol(getenv("BSX_KEYTABLE_REUSE")) == 0 ? 1u : 0u;
+    // experiments build only: BSX_KEYTABLE_REUSE=0 forces a full rebuild on every call (cold-build measurements)
+    static const uint32_t force = bsx_knob("BSX_KEYTABLE_REUSE", 1) == 0 ? 1u : 0u;
     hipLaunchKernelGGL(k_keytable_check, dim3(1), dim3(KC_THREADS), 0, s, vals, n_keys, table, force);
     TableBuildArgs a{reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)), reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)), table,
                      reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)), n_keys * (uint32_t)KT_PARTS, (uint32_t)KT_PARTS, (uint32_t)KT_HALF_ENTRIES, (uint32_t)KT_W};
@@ -1130,10 +1130,20 @@ hipError_t bsxk_ed25519_btable(hipStream_t s, uint8_t* table) {
     return hipGetLastError();
 }
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t n) { return n * ED_SLOT_I32 * 4; }
-static inline uint32_t deferred_grid(uint64_t n) {
+// The pass behind a fixed-key kernel for the slots it deferred (key != table row).  n_deferred = how many the CALLER knows there
+// are (it compared the keys on the host when the validators were uploaded): 0 -> no launch at all; a few -> a 64-workgroup scan
+// (one round of waves that read a marker byte per slot); many -> one wave per 64 slots, or every deferred slot's 256 doublings
+// would queue up on 4096 lanes; < 0 = unknown -> the scan.
+static inline uint32_t deferred_grid(uint64_t n, int64_t n_deferred) {
     const uint64_t wgs = (n + ED_THREADS - 1) / ED_THREADS;
+    if (n_deferred > 4096) return (uint32_t)wgs;
     return (uint32_t)(wgs < 64 ? wgs : 64);
 }
+#define BSX_LAUNCH_DEFERRED()                                                                                                                   \
+    do {                                                                                                                                        \
+        if (n_deferred != 0)                                                                                                                    \
+            hipLaunchKernelGGL(k_ed25519_verify<true>, dim3(deferred_grid(n, n_deferred)), dim3(ED_THREADS), 0, s, vals, h, n, ok);              \
+    } while (0)
 uint64_t bsxk_ed25519_rdec_bytes(uint64_t n) { return n * ED_RDEC_I32 * 4; }
 hipError_t bsxk_ed25519_decode_r(hipStream_t s, const bsx_validator* vals, uint64_t n, void* rdec) {
     if (!n) return hipSuccess;
@@ -1143,26 +1153,27 @@ hipError_t bsxk_ed25519_decode_r(hipStream_t s, const bsx_validator* vals, uint6
 // rdec (optional, from bsxk_ed25519_decode_r over the same records): batches below ED_SPLIT_BELOW signatures without a
 // batch-inversion scratch take the latency form (k_ed25519_verify_keyed_proj)
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
-                                     const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch, const void* rdec) {
+                                     const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch, const void* rdec,
+                                     int64_t n_deferred) {
     if (n == 0) return hipSuccess;
     const int32_t* b_tab = reinterpret_cast<const int32_t*>(btable + bt_entries_off());
     if (rdec && rdec != BSXK_ED_THROUGHPUT && !scratch && n < ED_SPLIT_BELOW) {
         // BSX_ED_PROJ_SPLIT (experiments): 8 / 16 lanes per signature; default 16 while the launch is a single wave round anyway
-        static const long env_ps = getenv("BSX_ED_PROJ_SPLIT") ? atol(getenv("BSX_ED_PROJ_SPLIT")) : 0;
+        static const long env_ps = bsx_knob("BSX_ED_PROJ_SPLIT", 0);
         const bool s16 = env_ps ? env_ps == 16 : n <= 8192;
         const int32_t* rd = static_cast<const int32_t*>(rdec);
         if (s16) hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<16>, dim3((uint32_t)((n + 3) / 4)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
         else hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<8>, dim3((uint32_t)((n + 7) / 8)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
-        hipLaunchKernelGGL(k_ed25519_verify<true>, dim3(deferred_grid(n)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
+        BSX_LAUNCH_DEFERRED();
         return hipGetLastError();
     }
     int32_t* scr = static_cast<int32_t*>(scratch);
     const uint64_t n_commits = (n + v_max - 1) / v_max;
     // BSX_ED_BY_KEY (experiments): 0 / 1 forces the lane order; default: by key from 32 commits on (waves at least half full)
-    static const long env_by_key = getenv("BSX_ED_BY_KEY") ? atol(getenv("BSX_ED_BY_KEY")) : -1;
+    static const long env_by_key = bsx_knob("BSX_ED_BY_KEY", -1);
     // BSX_ED_SPLIT (experiments): 1 / 4 lanes per signature; default: 4 while the batch cannot fill the GPU's wave slots
     // anyway (latency is what counts) or fills them so barely that finer units balance better, 1 above (20 % less work)
-    static const long env_split = getenv("BSX_ED_SPLIT") ? atol(getenv("BSX_ED_SPLIT")) : -1;
+    static const long env_split = bsx_knob("BSX_ED_SPLIT", -1);
     // rdec == BSXK_ED_THROUGHPUT (with a scratch): the caller has a whole step of slack and an ALU-bound GPU (the compact
     // pipeline) — one lane per signature + batch inversion is the form with the least total work (280 multiplications per
     // signature against 421 on four lanes and 761 in the latency form), whatever the batch size
@@ -1180,7 +1191,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
 #define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_) \
     hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr)
     // BSX_ED_SMALL=0 (experiments): no decode-R form for small batches
-    static const bool small_form = !(getenv("BSX_ED_SMALL") && atol(getenv("BSX_ED_SMALL")) == 0);
+    static const bool small_form = bsx_knob("BSX_ED_SMALL", 1) != 0;
     if (split4 && !scr && !by_key && small_form) {
         hipLaunchKernelGGL(k_ed25519_verify_keyed_small, dim3((uint32_t)((n + EL_SIGS - 1) / EL_SIGS)), dim3(128), 0, s, vals, h, n, v_max, table,
                            n_keys, b_tab, ok);
@@ -1193,12 +1204,12 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     }
 #undef BSX_LAUNCH_KEYED
     if (scr) {
-        static const long env_k = getenv("BSX_ED_FIN_K") ? atol(getenv("BSX_ED_FIN_K")) : 0;     // experiments
+        static const long env_k = bsx_knob("BSX_ED_FIN_K", 0);
         const uint32_t K = env_k > 0 ? (uint32_t)env_k : ed_fin_k(n);
         const uint64_t lanes = (n + K - 1) / K;
         hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
     }
-    hipLaunchKernelGGL(k_ed25519_verify<true>, dim3(deferred_grid(n)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
+    BSX_LAUNCH_DEFERRED();
     return hipGetLastError();
 }
 hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,

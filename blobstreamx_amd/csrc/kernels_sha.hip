@@ -22,6 +22,7 @@
 
 #include "../../include/bsx.h"
 #include "../../include/bsx_layout.h"
+#include "kernels.h"
 #include "sha256.h"
 
 namespace bsx {
@@ -946,12 +947,12 @@ hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, 
                               uint32_t* status, uint32_t max_wgs, uint32_t low_prio) {
     if (!n) return hipSuccess;
     uint32_t grid = (uint32_t)((n + HM_GROUP - 1) / HM_GROUP);
-    // cap on the grid (the workgroups then stride over the header groups): the context's BSX_TUNE_MERKLE_WORKGROUPS, or the
-    // BSX_MERKLE_WGS environment variable (experiments); 0 = one workgroup per 64 headers
-    static const long env_cap = getenv("BSX_MERKLE_WGS") ? atol(getenv("BSX_MERKLE_WGS")) : -1;
+    // cap on the grid (the workgroups then stride over the header groups): the context's BSX_TUNE_MERKLE_WORKGROUPS (an experiments
+    // build also reads BSX_MERKLE_WGS); 0 = one workgroup per 64 headers
+    static const long env_cap = bsx_knob("BSX_MERKLE_WGS", -1);
     const long cap = env_cap >= 0 ? env_cap : (long)max_wgs;
     if (cap > 0 && grid > (uint32_t)cap) grid = (uint32_t)cap;
-    static const long env_lp = getenv("BSX_MERKLE_LOW_PRIO") ? atol(getenv("BSX_MERKLE_LOW_PRIO")) : -1;       // experiments
+    static const long env_lp = bsx_knob("BSX_MERKLE_LOW_PRIO", -1);
     hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status, env_lp >= 0 ? (uint32_t)env_lp : low_prio);
     return hipGetLastError();
 }
@@ -986,7 +987,7 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
     const uint64_t slots = (uint64_t)n_jobs * B;
     // BSX_SUBCHAIN_FUSED=0 / 1 (experiments) overrides BSX_SUBCHAIN_SEPARATE_LAUNCHES
-    static const long env_fuse = getenv("BSX_SUBCHAIN_FUSED") ? atol(getenv("BSX_SUBCHAIN_FUSED")) : -1;
+    static const long env_fuse = bsx_knob("BSX_SUBCHAIN_FUSED", -1);
     const bool fuse = env_fuse >= 0 ? env_fuse != 0 : !(flags & BSX_SUBCHAIN_SEPARATE_LAUNCHES);
     if ((flags & BSX_SUBCHAIN_PATHS_FROM_HINT) && fuse) {
         a.level = 1; a.width = B / 2; a.level_off = 0;        // every level inside the one launch
@@ -1032,13 +1033,13 @@ hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uin
     // 2.1-2.6 ms (14.97 GB: 5.8-7.1 TB/s) depending on the box; plain stores 2.6-2.8 ms.  In the pipelined step, beside the
     // other chunk's hashing: 256 B uncapped 89.0-89.4 / 93.2-93.8 M headers/s on two boxes, 512 B 85.0-85.3 / 92.9-94.0, 256 B
     // capped at 262,144 workgroups (the round-1 choice) 79.9-85.1, plain stores 74-81.
-    static const long chunk = getenv("BSX_EXPAND_CHUNK") ? atol(getenv("BSX_EXPAND_CHUNK")) : 256;
-    static const long nt = getenv("BSX_EXPAND_NT") ? atol(getenv("BSX_EXPAND_NT")) : 1;
+    static const long chunk = bsx_knob("BSX_EXPAND_CHUNK", 256);
+    static const long nt = bsx_knob("BSX_EXPAND_NT", 1);
     const uint32_t ppb = (uint32_t)chunk * 4;
     const uint32_t gx = (uint32_t)((npairs + ppb - 1) / ppb);
     ExpandArgs a{*lay, n_jobs, gx, compact, out};
     // BSX_EXPAND_BLOCKS > 0 caps the grid (workgroups then stride over the items); default: one workgroup per item
-    static const long cap = getenv("BSX_EXPAND_BLOCKS") ? atol(getenv("BSX_EXPAND_BLOCKS")) : 0;
+    static const long cap = bsx_knob("BSX_EXPAND_BLOCKS", 0);
     uint64_t grid = (uint64_t)gx * n_jobs;
     if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
 #define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)

@@ -9,6 +9,8 @@
 //
 // Host code only: buffer ownership, stream/event choreography, argument validation.  All arithmetic is in kernels_*.hip.
 // No environment variables, no Python, no torch: a Rust caller binds exactly this.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -60,6 +62,7 @@ struct Chunk {
     uint8_t *commit_compact = nullptr, *skip_compact = nullptr;
     uint64_t *witness_commit = nullptr, *witness_skip = nullptr, *trees_commit = nullptr, *trees_skip = nullptr;
     bool fin_recorded = false, wit_pending = false, units_done_valid = false;
+    uint64_t n_key_mismatch = 0;             // active slots whose key differs from the chunk's first range's (bsx_pipeline_upload)
     hipEvent_t ev_finalized = nullptr, ev_units_done = nullptr;
     size_t compact_bytes = 0, records_bytes = 0, headers_bytes = 0;
     // state
@@ -103,6 +106,7 @@ struct bsx_pipeline {
     Chunk* pending_verify = nullptr;
     bsx_allgather_fn allgather = nullptr;
     void* allgather_user = nullptr;
+    void* rccl_comm = nullptr;               // bsx_pipeline_set_rccl: the all-gather is ncclAllGather on this communicator
     bool timing_on = false, streaming = false, uploaded = false, compact_tokens = false;
 };
 
@@ -242,7 +246,11 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
     return BSX_OK;
 }
 
+// at most PIPE_TIMING_SLOTS un-read chunk-steps per chunk (6 events each): a caller that leaves timing on and never calls
+// bsx_pipeline_timing stops recording there instead of growing without bound
+constexpr size_t PIPE_TIMING_SLOTS = 4096;
 TimingSlot* timing_slot(Chunk& c) {
+    if (c.timing_used >= PIPE_TIMING_SLOTS) return nullptr;
     if (c.timing_used == c.timing.size()) {
         TimingSlot t{};
         for (auto& e : t.ev)
@@ -284,17 +292,17 @@ int commit_part(bsx_pipeline* p, Chunk& c, hipStream_t st, bool prep, bool verif
         // everything that needs nothing from this step's hashing: challenges, R decoded for the projective comparison, the
         // key-table check, the trusted set's hash and power sum — off the critical chain (verify -> tally -> skip conditions)
         HIPCHK(bsxk_sha512_challenge(st, vals, n, c.h, nullptr, V, cwp));
-        if (p->keyed) {
-            if (c.rdec) HIPCHK(bsxk_ed25519_decode_r(st, vals, n, c.rdec));
-            HIPCHK(bsxk_ed25519_keytable(st, vals, V, c.keytable));
-        }
+        // the fixed-key tables were validated against the uploaded validator sets (and rebuilt where a key changed) by
+        // bsx_pipeline_upload: validator sets only change there, so a step launches neither the key compare nor the build
+        if (p->keyed && c.rdec) HIPCHK(bsxk_ed25519_decode_r(st, vals, n, c.rdec));
         HIPCHK(bsxk_commit_tally(st, trs, R, V, nullptr, nullptr, tres, swtp));
         // resident inputs: the header pairs do not change under the prep phase; streamed inputs: see below
         if (p->units && !p->streaming) RET(field_proofs(p, c, st, c.headers_all + c.nh_main * sizeof(bsx_header)));
     }
     if (!verify) return BSX_OK;
     if (p->keyed)   // latency form beside an expansion (ALU to spare, one step to finish in); least-work form in the compact pipeline
-        HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, V, p->ctx->btab, c.ok, c.ed_scratch, c.rdec ? c.rdec : BSXK_ED_THROUGHPUT));
+        HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, V, p->ctx->btab, c.ok, c.ed_scratch, c.rdec ? c.rdec : BSXK_ED_THROUGHPUT,
+                                         (int64_t)c.n_key_mismatch));
     else
         HIPCHK(bsxk_ed25519_verify(st, vals, c.h, n, c.ok));
     HIPCHK(bsxk_commit_tally(st, vals, R, V, c.target_hashes_pp[c.parity], c.ok, cres, cwp));
@@ -499,9 +507,125 @@ int join_impl(bsx_pipeline* p) {
     return BSX_OK;
 }
 
+// ---- RCCL, bound at run time (no link-time dependency: a single-GPU host never loads it).  If the process already holds an RCCL
+// (a Rust host linking librccl, PyTorch) its symbols are used, so that a communicator the HOST created can be handed in; otherwise
+// librccl.so is opened.  Only the five entry points the one collective of the path needs (rccl.h, ROCm 7.2).
+struct RcclApi {
+    struct UniqueId { char b[128]; };                                                 // ncclUniqueId: passed BY VALUE to ncclCommInitRank
+    int (*get_unique_id)(void* id128) = nullptr;                                      // ncclGetUniqueId(ncclUniqueId*)
+    int (*comm_init_rank)(void** comm, int n, UniqueId id, int rank) = nullptr;
+    int (*comm_destroy)(void* comm) = nullptr;
+    int (*all_gather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t st) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void* h = nullptr;
+        if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+            // a copy the process already mapped (PyTorch loads its own with local visibility), then the system's
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+                if (h) break;
+            }
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+                if (h) break;
+                h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            }
+            if (!h) { a.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return a; }
+        }
+        auto sym = [&](const char* n) -> void* { void* q = h ? dlsym(h, n) : nullptr; return q ? q : dlsym(RTLD_DEFAULT, n); };
+        a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(sym("ncclGetUniqueId"));
+        a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(sym("ncclCommInitRank"));
+        a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(sym("ncclCommDestroy"));
+        a.all_gather = reinterpret_cast<decltype(a.all_gather)>(sym("ncclAllGather"));
+        a.error_string = reinterpret_cast<decltype(a.error_string)>(sym("ncclGetErrorString"));
+        a.ok = a.get_unique_id && a.comm_init_rank && a.comm_destroy && a.all_gather;
+        if (!a.ok) a.why = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+        return a;
+    }();
+    return api;
+}
+const char* rccl_err(int rc) { return rccl().error_string ? rccl().error_string(rc) : "RCCL error"; }
+constexpr int NCCL_UINT8 = 1;                 // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
+
+int rccl_allgather_cb(void* user, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream) {
+    bsx_pipeline* p = static_cast<bsx_pipeline*>(user);
+    const int rc = rccl().all_gather(d_send, d_recv, (size_t)bytes_per_rank, NCCL_UINT8, p->rccl_comm, static_cast<hipStream_t>(stream));
+    if (rc != 0) { fail(BSX_ERR_HIP, "ncclAllGather: %s", rccl_err(rc)); return 1; }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int bsx_rccl_get_unique_id(uint8_t out_id[128]) {
+    if (!out_id) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (!rccl().ok) return fail(BSX_ERR_UNSUPPORTED, "RCCL unavailable: %s", rccl().why.c_str());
+    const int rc = rccl().get_unique_id(out_id);
+    if (rc != 0) return fail(BSX_ERR_HIP, "ncclGetUniqueId: %s", rccl_err(rc));
+    return BSX_OK;
+}
+int bsx_rccl_comm_init_rank(bsx_ctx* ctx, uint32_t world, const uint8_t id[128], uint32_t rank, void** out_comm) {
+    RET(use(ctx));                                                                    // the communicator binds to the context's device
+    if (!id || !out_comm || !world || rank >= world) return fail(BSX_ERR_BAD_ARG, "bsx_rccl_comm_init_rank: bad arguments");
+    if (!rccl().ok) return fail(BSX_ERR_UNSUPPORTED, "RCCL unavailable: %s", rccl().why.c_str());
+    RcclApi::UniqueId u;
+    memcpy(u.b, id, 128);
+    void* comm = nullptr;
+    const int rc = rccl().comm_init_rank(&comm, (int)world, u, (int)rank);
+    if (rc != 0) return fail(BSX_ERR_HIP, "ncclCommInitRank: %s", rccl_err(rc));
+    *out_comm = comm;
+    return BSX_OK;
+}
+int bsx_rccl_comm_destroy(void* comm) {
+    if (!comm) return BSX_OK;
+    if (!rccl().ok) return fail(BSX_ERR_UNSUPPORTED, "RCCL unavailable: %s", rccl().why.c_str());
+    const int rc = rccl().comm_destroy(comm);
+    if (rc != 0) return fail(BSX_ERR_HIP, "ncclCommDestroy: %s", rccl_err(rc));
+    return BSX_OK;
+}
+
+int bsx_pipeline_set_rccl(bsx_pipeline* p, void* nccl_comm) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    if (!nccl_comm) { p->rccl_comm = nullptr; p->allgather = nullptr; p->allgather_user = nullptr; return BSX_OK; }
+    if (!rccl().ok) return fail(BSX_ERR_UNSUPPORTED, "RCCL unavailable: %s", rccl().why.c_str());
+    p->rccl_comm = nccl_comm;
+    p->allgather = rccl_allgather_cb;
+    p->allgather_user = p;
+    return BSX_OK;
+}
+
+// The configured all-gather, once, on a scratch payload: rank g sends 128 bytes of (g, i) and must find every rank's block in
+// place.  Collective (every rank calls it); world 1 exercises the same call (a one-rank all-gather).  BSX_ERR_HIP on any mismatch.
+int bsx_pipeline_check_allgather(bsx_pipeline* p) {
+    if (!p) return fail(BSX_ERR_BAD_ARG, "null pipeline");
+    RET(use(p->ctx));
+    if (!p->allgather) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_check_allgather: no all-gather set (bsx_pipeline_set_allgather / _set_rccl)");
+    RET(join_impl(p));
+    const uint32_t world = p->world;
+    uint8_t* d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), 128 * ((size_t)world + 1)));
+    struct Free { void* q; hipStream_t s; bool own; ~Free() { (void)hipFree(q); if (own) (void)hipStreamDestroy(s); } } guard{d, nullptr, false};
+    hipStream_t st = p->chunks[0].xchg;
+    if (!st) { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); guard.s = st; guard.own = true; }
+    uint8_t mine[128];
+    for (int i = 0; i < 128; i++) mine[i] = (uint8_t)(p->rank * 37 + i);
+    HIPCHK(hipMemcpyAsync(d, mine, 128, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d + 128, 0xee, 128 * (size_t)world, st));
+    if (p->allgather(p->allgather_user, d, d + 128, 128, st) != 0) return fail(BSX_ERR_HIP, "bsx_pipeline_check_allgather: the all-gather failed: %s", bsxapi::g_err.c_str());
+    std::vector<uint8_t> got(128 * (size_t)world);
+    HIPCHK(hipMemcpyAsync(got.data(), d + 128, got.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint32_t g = 0; g < world; g++)
+        for (int i = 0; i < 128; i++)
+            if (got[128 * (size_t)g + i] != (uint8_t)(g * 37 + i))
+                return fail(BSX_ERR_HIP, "bsx_pipeline_check_allgather: rank %u's block is wrong at byte %d (world %u)", g, i, world);
+    return BSX_OK;
+}
 
 int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeline** out) {
     RET(use(ctx));
@@ -654,6 +778,21 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
                                            (unsigned long long)(p->hfr + p->hpr));
     RET(join_impl(p));                         // steps in flight read the buffers about to be overwritten
     const uint32_t R = p->R, Rc = p->Rc, V = p->V;
+    // every owned range is validated BEFORE the first copy is enqueued: an error return leaves the device buffers and the caller's
+    // memory untouched (nothing in flight), and the previous upload — if any — stays valid
+    if (p->with_commit)
+        for (uint32_t k = 0; k < R; k++) {
+            const bsx_shared_ctx& rg = in->ranges[(size_t)p->rank * R + k];
+            const uint64_t ti = rg.end_block - rg.start_block;
+            if (rg.end_block <= rg.start_block || ti >= HPR)
+                return fail(BSX_ERR_BAD_ARG, "range %zu: target header (end - start = %llu) is not among the %llu supplied headers", (size_t)p->rank * R + k,
+                            (unsigned long long)ti, (unsigned long long)HPR);
+        }
+    p->uploaded = false;                       // until every copy below has landed
+    struct DrainOnError {                      // a failing HIP call mid-way: nothing may still read the caller's buffers on return
+        bsx_pipeline* p; bool armed = true;
+        ~DrainOnError() { if (armed) for (Chunk& c : p->chunks) (void)hipStreamSynchronize(c.main); }
+    } drain{p};
     std::vector<bsx_header> sk((size_t)Rc * 2);
     for (uint32_t ce = 0; ce < p->E * p->K; ce++) {
         const uint32_t e = ce % p->E;                                  // every buffer set holds the same inputs
@@ -672,10 +811,7 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
             const size_t r0 = (size_t)p->rank * R + (size_t)e * Rc;    // owned block
             for (uint32_t k = 0; k < Rc; k++) {
                 const bsx_shared_ctx& rg = in->ranges[r0 + k];
-                const uint64_t ti = rg.end_block - rg.start_block;
-                if (rg.end_block <= rg.start_block || ti >= HPR)
-                    return fail(BSX_ERR_BAD_ARG, "range %zu: target header (end - start = %llu) is not among the %llu supplied headers", r0 + k,
-                                (unsigned long long)ti, (unsigned long long)HPR);
+                const uint64_t ti = rg.end_block - rg.start_block;     // validated above
                 sk[2 * k] = in->headers[(r0 + k) * HPR];               // trusted header: height S
                 sk[2 * k + 1] = in->headers[(r0 + k) * HPR + ti];      // target header: height E
             }
@@ -684,6 +820,14 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
             HIPCHK(hipMemcpyAsync(c.skip_ranges_side, in->ranges + r0, (size_t)Rc * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(c.validators, in->target_validators + r0 * V, (size_t)Rc * V * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(c.trusted, in->trusted_validators + r0 * V, (size_t)Rc * V * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+            if (p->keyed) {
+                // Fixed-key Ed25519 tables: validator sets change HERE and nowhere else, so this is where the rows are compared with
+                // the new keys and rebuilt where they differ (k_keytable_check + k_table_entries; rows persist) — not once per step.
+                // Slots of the chunk's other ranges whose key is not the first range's are counted on the host: the step's
+                // signature check sizes (or skips) its generic-kernel pass from this count.
+                c.n_key_mismatch = bsxh_key_mismatches(in->target_validators + r0 * V, Rc, V);
+                HIPCHK(bsxk_ed25519_keytable(st, reinterpret_cast<const bsx_validator*>(c.validators), V, c.keytable));
+            }
         }
         HIPCHK(hipStreamSynchronize(st));      // `sk` and the caller's buffers are free again
         if (c.host_image) {                    // keep the streamed image in step with the resident block
@@ -691,6 +835,7 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
             HIPCHK(hipStreamSynchronize(st));
         }
     }
+    drain.armed = false;
     p->uploaded = true;
     return BSX_OK;
 }
@@ -850,6 +995,8 @@ int bsx_pipeline_autotune(bsx_pipeline* p, uint32_t steps_per_trial, bsx_pipelin
     for (Chunk& c : p->chunks) c.timing_used = 0;
     if (out) {
         memset(out, 0, sizeof *out);
+        const int q = bsxk_queue_groups(p->pool.data(), (uint32_t)p->pool.size(), nullptr);
+        out->hw_queues = q > 0 ? (uint32_t)q : 0;
         out->n_trials = (uint32_t)cand.size();
         out->best_trial = (uint32_t)best;
         out->steps_per_trial = steps_per_trial;

@@ -59,7 +59,7 @@ class _Timing(C.Structure):
 
 
 class _Autotune(C.Structure):
-    _fields_ = [("n_trials", C.c_uint32), ("best_trial", C.c_uint32), ("steps_per_trial", C.c_uint32), ("_pad", C.c_uint32),
+    _fields_ = [("n_trials", C.c_uint32), ("best_trial", C.c_uint32), ("steps_per_trial", C.c_uint32), ("hw_queues", C.c_uint32),
                 ("initial_ms", C.c_double), ("best_ms", C.c_double), ("worst_ms", C.c_double), ("assignment", C.c_uint32 * 16)]
 
 
@@ -146,6 +146,24 @@ def torch_allgather(dev, world):
     return fn
 
 
+def c_rccl_comm(ctx, rank, world):
+    """An RCCL communicator made through the C ABI (bsx_rccl_get_unique_id / bsx_rccl_comm_init_rank, include/bsx.h): rank 0's
+    128-byte unique id travels over the already initialised torch.distributed group — control plane only; the collective of the
+    data path is then ncclAllGather called by the library itself (bsx_pipeline_set_rccl), no Python in the loop.  Collective."""
+    L = _lib.lib()
+    idb = np.zeros(128, np.uint8)
+    if rank == 0:
+        _lib.check(L.bsx_rccl_get_unique_id(_lib.p(idb)))
+    if world > 1:
+        import torch.distributed as dist
+        obj = [idb.tobytes()]
+        dist.broadcast_object_list(obj, src=0)
+        idb = np.frombuffer(obj[0], np.uint8).copy()
+    comm = C.c_void_p()
+    _lib.check(L.bsx_rccl_comm_init_rank(ctx, C.c_uint32(world), _lib.p(idb), C.c_uint32(rank), C.byref(comm)))
+    return comm
+
+
 class Pipeline:
     """bsx_pipeline: `n_ranges_local` header_range instances per step on this rank, cut into `n_chunks` chunks."""
 
@@ -217,6 +235,16 @@ class Pipeline:
         self._cb = ALLGATHER_FN(cb)      # keep the trampoline alive
         _lib.check(self.L.bsx_pipeline_set_allgather(self._h, self._cb, None))
 
+    def set_rccl(self, comm):
+        """bsx_pipeline_set_rccl: the library calls ncclAllGather on `comm` (an ncclComm_t as c_void_p) itself; then
+        bsx_pipeline_check_allgather proves the collective end to end (collective call)."""
+        _lib.check(self.L.bsx_pipeline_set_rccl(self._h, comm))
+        self._cb = None
+        _lib.check(self.L.bsx_pipeline_check_allgather(self._h))
+
+    def check_allgather(self):
+        _lib.check(self.L.bsx_pipeline_check_allgather(self._h))
+
     # ------------------------------------------------------------------ data
     def upload(self, headers, ranges, latest, validators=None, trusted=None):
         """headers [world*R, hpr_full] HEADER (height S_r + k), ranges [world*R] SHARED_CTX, latest [world*R] u64,
@@ -253,7 +281,7 @@ class Pipeline:
         r = _Autotune()
         _lib.check(self.L.bsx_pipeline_autotune(self._h, C.c_uint32(steps_per_trial), C.byref(r)))
         return {"n_trials": r.n_trials, "best_trial": r.best_trial, "steps_per_trial": r.steps_per_trial, "initial_ms": r.initial_ms,
-                "best_ms": r.best_ms, "worst_ms": r.worst_ms, "assignment": list(r.assignment)[:2 * self.E * getattr(self, "K", 1)]}
+                "best_ms": r.best_ms, "worst_ms": r.worst_ms, "hw_queues": r.hw_queues, "assignment": list(r.assignment)[:2 * self.E * getattr(self, "K", 1)]}
 
     def set_timing(self, on=True):
         _lib.check(self.L.bsx_pipeline_set_timing(self._h, C.c_int(1 if on else 0)))

@@ -83,6 +83,15 @@ class CommitShard:
         self.vals[:v.nbytes].copy_(torch.from_numpy(np.ascontiguousarray(v).view(np.uint8).reshape(-1)))
         self.hh[:h.nbytes].copy_(torch.from_numpy(np.ascontiguousarray(h).reshape(-1)))
         torch.cuda.synchronize(self.dev)
+        # validator sets change here and nowhere else: the fixed-key table is checked / rebuilt now (bsx_dev_ed25519_keytable), and
+        # the keys are compared on the host, so that a step launches neither the key compare nor — when every active slot carries
+        # the first commit's key of its index — the generic-kernel pass (bsx.h BSX_COMMITS_*)
+        st = torch.cuda.current_stream(self.dev)
+        _lib.check(self.L.bsx_dev_ed25519_keytable(self.ctx, C.c_void_p(st.cuda_stream), _lib.dp(self.vals), C.c_uint32(self.V), _lib.dp(self.keytable)))
+        torch.cuda.synchronize(self.dev)
+        active = (v["enabled"] != 0) & (v["is_signed"] != 0)
+        uniform = bool((~active | (v["pubkey"] == v["pubkey"][0][None]).all(axis=2)).all())
+        self.flags = 1 | (2 if uniform else 0)
 
     def step(self, stream=None):
         import torch
@@ -90,7 +99,7 @@ class CommitShard:
         dp = _lib.dp
         _lib.check(self.L.bsx_dev_verify_commits(self.ctx, C.c_void_p(st.cuda_stream), dp(self.vals), C.c_uint32(self.n), C.c_uint32(self.V),
                                                  dp(self.hh), C.c_uint32(self.first), dp(self.keytable), dp(self.scratch), dp(self.ok),
-                                                 dp(self.res), dp(self.fold), dp(self.compact)))
+                                                 dp(self.res), dp(self.fold), dp(self.compact), C.c_uint32(getattr(self, "flags", 0))))
         if self.witness is not None:
             lay = np.ascontiguousarray(self.lay).reshape(1)
             _lib.check(self.L.bsx_dev_expand_witness(self.ctx, C.c_void_p(st.cuda_stream), _lib.p(lay), C.c_uint32(self.n), dp(self.compact),

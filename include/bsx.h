@@ -178,6 +178,12 @@ typedef struct bsx_ctx bsx_ctx;
 
 /* ------------------------------------------------------------------ lifecycle */
 uint32_t bsx_version(void);
+/* OPTIONAL, once per process, BEFORE its first HIP call (the HIP runtime reads the variable when it initialises): ask for 16
+ * hardware queues (GPU_MAX_HW_QUEUES=16) unless the caller's environment already sets the variable.  The pipeline tier drives up
+ * to 16 streams whose kernels must overlap; on HIP's default of 4 queues they share queues (measured 3.2 -> 4.8 ms per step).
+ * The library never changes the environment on its own — results do not depend on this, only the pipeline's speed.  Returns 1
+ * (set), 0 (left alone: already set) or -1. */
+int bsx_prepare_process(void);
 /* device = HIP ordinal.  Fails with BSX_ERR_NO_DEVICE when no GPU is visible (no CPU fallback). */
 int bsx_init(int device, bsx_ctx** out);
 void bsx_shutdown(bsx_ctx* ctx);
@@ -542,7 +548,16 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
                            bsx_commit_result* d_results, bsx_commit_fold* d_fold,
                            uint8_t* d_commit_compact /* optional, 16-byte aligned, n_commits * bsx_commit_witness_layout(v_max).compact_stride
                                                         bytes, ZERO before the first call on the buffer: every commit's COMMIT unit in compact
-                                                        form (config #5's witness; bsx_dev_expand_witness turns it into Goldilocks elements) */);
+                                                        form (config #5's witness; bsx_dev_expand_witness turns it into Goldilocks elements) */,
+                           uint32_t flags /* BSX_COMMITS_*: promises of a caller whose validators are resident across calls */);
+/* The caller has run bsx_dev_ed25519_keytable(d_validators, v_max, d_keytable) since the validators' keys last changed: the call
+ * skips the per-call key compare of the table rows (one launch + a no-op build launch per call otherwise). */
+#define BSX_COMMITS_KEYTABLE_READY 1u
+/* Every enabled and signed slot i of every commit carries the public key of the FIRST commit's slot i (the caller compared them
+ * when it uploaded the validators): no slot can be deferred to the generic per-signature kernel, whose scan launch is skipped.  A
+ * false promise never turns into an accepted signature: a slot the fixed-key kernel had to defer then counts as a BAD signature. */
+#define BSX_COMMITS_KEYS_UNIFORM 2u
+/* flags 0 = the call is self-contained (as in round 3). */
 
 /* ------------------------------------------------------------------ operator skip-target search
  * circuits/fetcher.rs:60-87 find_block_to_request: starting at max_end_block, return the first candidate c with
@@ -740,7 +755,11 @@ int bsx_pipeline_enable_input_streaming(bsx_pipeline* p, int on);
  * ranks run the same number of steps (with steps_per_trial 0 they agree on one through the all-gather callback) and each keeps
  * its own best assignment. */
 typedef struct bsx_pipeline_autotune_result {
-    uint32_t n_trials, best_trial, steps_per_trial, _pad;
+    uint32_t n_trials, best_trial, steps_per_trial;
+    uint32_t hw_queues;                        /* distinct hardware queues the pool's 16 streams sit on, MEASURED (two spinning waves on
+                                                  two streams take twice as long when they share a queue).  HIP's default is 4
+                                                  (GPU_MAX_HW_QUEUES): chunks' streams then share queues and their phases cannot
+                                                  overlap — call bsx_prepare_process() before the process's first HIP call */
     double initial_ms, best_ms, worst_ms;      /* per step: the assignment the pipeline had, the one it keeps (re-timed twice as long
                                                   with the two runners-up), the slowest tried */
     uint32_t assignment[16];                   /* pool index of chunk i's main (2 i) and side (2 i + 1) stream */
@@ -758,6 +777,21 @@ int bsx_pipeline_join(bsx_pipeline* p);
  * chunk order, on every rank.  Return 0 on success. */
 typedef int (*bsx_allgather_fn)(void* user, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream);
 int bsx_pipeline_set_allgather(bsx_pipeline* p, bsx_allgather_fn fn, void* user);
+/* The same collective as RCCL's ncclAllGather, called by the library itself on its exchange stream (round 4: no host-language
+ * callback on the data path).  nccl_comm = an ncclComm_t of `world` ranks whose rank order is the pipeline's: one the host created
+ * with its own RCCL binding, or bsx_rccl_comm_init_rank below.  RCCL is bound at run time (the process's own copy if it has one,
+ * else librccl.so): BSX_ERR_UNSUPPORTED when there is none.  NULL clears it.  Replaces the map->reduce hand-off of
+ * circuits/builder.rs:337-395 across GPUs. */
+int bsx_pipeline_set_rccl(bsx_pipeline* p, void* nccl_comm);
+/* Communicator plumbing for hosts without an RCCL binding of their own: rank 0 calls bsx_rccl_get_unique_id and hands the 128
+ * bytes to the other ranks by any means (the reference's hosts already talk HTTP); every rank then calls
+ * bsx_rccl_comm_init_rank (collective; binds to ctx's device). */
+int bsx_rccl_get_unique_id(uint8_t out_id[128]);
+int bsx_rccl_comm_init_rank(bsx_ctx* ctx, uint32_t world, const uint8_t id[128], uint32_t rank, void** out_comm);
+int bsx_rccl_comm_destroy(void* comm);
+/* Runs the configured all-gather once on a 128-byte test pattern and checks every rank's block (collective; also valid at world 1):
+ * a wrong communicator / rank order fails here instead of in the first step's assertions. */
+int bsx_pipeline_check_allgather(bsx_pipeline* p);
 
 /* Results of the most recent step (joins first).  Every pointer is optional.  Owned ranges are indexed k < n_ranges. */
 typedef struct bsx_pipeline_results {

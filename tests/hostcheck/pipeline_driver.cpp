@@ -1,7 +1,10 @@
 // tests/hostcheck/pipeline_driver.cpp — drives the batched pipeline through the C ABI ALONE: no Python, no torch, no HIP
 // headers — exactly what a Rust / C host binding include/bsx.h would do.  Test harness only.
 //
-//   pipeline_driver <case file>
+//   pipeline_driver <case file> [--rccl]
+// --rccl: the all-gather of the multi-GPU path is RCCL called from the library (bsx_pipeline_set_rccl): the driver makes a
+// one-rank communicator with bsx_rccl_get_unique_id / bsx_rccl_comm_init_rank, checks the collective end to end
+// (bsx_pipeline_check_allgather) and runs the case with it set — what a Rust host does at world N, without any Python.
 // The case file (written by tests/test_gpu_engine.py from a synthetic workload and the oracle's verdicts) holds the inputs of R
 // header_range instances and the expected public outputs / statuses.  The driver creates a pipeline of E chunks, uploads,
 // enqueues `steps` steps back to back WITHOUT joining, fetches the results and compares.  Exit code 0 = every byte equal.
@@ -21,7 +24,9 @@ struct CaseHeader {
 static bool read_exact(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <case file>\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <case file> [--rccl]\n", argv[0]); return 2; }
+    const bool with_rccl = argc > 2 && strcmp(argv[2], "--rccl") == 0;
+    if (bsx_prepare_process() < 0) { fprintf(stderr, "bsx_prepare_process failed\n"); return 3; }   // before the first HIP call
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror("open"); return 2; }
     CaseHeader h;
@@ -52,6 +57,13 @@ int main(int argc, char** argv) {
     memcpy(cfg.chain_id, h.chain_id, h.chain_id_len);
     bsx_pipeline* p = nullptr;
     if (bsx_pipeline_create(ctx, &cfg, &p) != BSX_OK) { fprintf(stderr, "bsx_pipeline_create: %s\n", bsx_last_error()); return 3; }
+    void* comm = nullptr;
+    if (with_rccl) {
+        uint8_t id[128];
+        if (bsx_rccl_get_unique_id(id) != BSX_OK || bsx_rccl_comm_init_rank(ctx, 1, id, 0, &comm) != BSX_OK) { fprintf(stderr, "rccl: %s\n", bsx_last_error()); return 4; }
+        if (bsx_pipeline_set_rccl(p, comm) != BSX_OK || bsx_pipeline_check_allgather(p) != BSX_OK) { fprintf(stderr, "rccl: %s\n", bsx_last_error()); return 4; }
+        fprintf(stderr, "rccl: ncclAllGather from the C tier verified on a one-rank communicator\n");
+    }
     bsx_pipeline_inputs in;
     memset(&in, 0, sizeof in);
     in.headers = headers.data(); in.headers_per_range = HPR; in.ranges = ranges.data(); in.latest = latest.data();
@@ -59,7 +71,7 @@ int main(int argc, char** argv) {
     if (bsx_pipeline_upload(p, &in) != BSX_OK) { fprintf(stderr, "bsx_pipeline_upload: %s\n", bsx_last_error()); return 3; }
     bsx_pipeline_autotune_result tune;
     if (bsx_pipeline_autotune(p, 2, &tune) != BSX_OK) { fprintf(stderr, "bsx_pipeline_autotune: %s\n", bsx_last_error()); return 3; }
-    fprintf(stderr, "autotune: %u placements tried, %.3f -> %.3f ms per step\n", tune.n_trials, tune.initial_ms, tune.best_ms);
+    fprintf(stderr, "autotune: %u placements tried, %.3f -> %.3f ms per step, %u hardware queues\n", tune.n_trials, tune.initial_ms, tune.best_ms, tune.hw_queues);
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t s = 0; s < h.steps; s++)
         if (bsx_pipeline_step(p) != BSX_OK) { fprintf(stderr, "bsx_pipeline_step: %s\n", bsx_last_error()); return 3; }
@@ -83,9 +95,11 @@ int main(int argc, char** argv) {
     void* wptr = nullptr;
     uint64_t wbytes = 0;
     (void)bsx_pipeline_buffer(p, 0, BSX_PIPE_BUF_WITNESS_MAP, &wptr, &wbytes);
+    if (with_rccl && bsx_pipeline_check_allgather(p) != BSX_OK) { fprintf(stderr, "rccl after the steps: %s\n", bsx_last_error()); bad++; }
     bsx_pipeline_destroy(p);
+    if (comm && bsx_rccl_comm_destroy(comm) != BSX_OK) { fprintf(stderr, "rccl: %s\n", bsx_last_error()); bad++; }
     bsx_shutdown(ctx);
-    printf("%s ranges=%zu steps=%u chunks=%u ms=%.3f witness_bytes_chunk0=%llu\n", bad ? "PIPELINE_DRIVER_MISMATCH" : "PIPELINE_DRIVER_OK", R, h.steps, h.E, ms,
-           (unsigned long long)wbytes);
+    printf("%s ranges=%zu steps=%u chunks=%u ms=%.3f witness_bytes_chunk0=%llu hw_queues=%u%s\n", bad ? "PIPELINE_DRIVER_MISMATCH" : "PIPELINE_DRIVER_OK", R, h.steps,
+           h.E, ms, (unsigned long long)wbytes, tune.hw_queues, with_rccl ? " rccl=ok" : "");
     return bad ? 1 : 0;
 }

@@ -52,7 +52,7 @@ def _worker(rank, world, port, J, B, R, n_blocks, q):
             _, partial[r], _ = oracle.reduce(np.array(recs, T.SUBCHAIN))
         flat = torch.from_numpy(partial.view(np.uint8).reshape(-1).copy())
         top = gather_partials(flat, rank, world, R)
-        # the branch the GPU engine takes at N > 1 (engine.step_exchange_begin / _end): the collective issued with
+        # the branch bench.py's gloo path takes at N > 1 (engine.torch_allgather inside the bsx_pipeline_set_allgather callback): the collective issued with
         # async_op=True into a preallocated buffer, finished by work.wait() — must deliver the same [rank][range] image
         g_sync = all_gather_records(flat, world, RT)
         g_async, work = all_gather_records(flat, world, RT, out_gathered=torch.full((world * RT * 128,), 0xEE, dtype=torch.uint8), async_op=True)
@@ -184,3 +184,28 @@ def test_commit_fold_is_sensitive_to_every_field_and_index():
     assert len(seen) == 15
     r2 = res.copy(); r2[5]["_pad"] = 7
     assert bytes(oracle.commit_fold(r2, 0)["root"]) == bytes(base["root"])    # padding bytes are not part of the record
+
+
+def _run_bench(argv, extra_env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BSX_DIST_BACKEND="gloo", **(extra_env or {}))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in the environment must not run as N = 1 — it re-executes itself
+    under torch.distributed.run with 2 ranks (the CPU-only dry path: process group + one all-gather, no GPU work) and reports the
+    world that really ran; modes F and S share the launcher."""
+    for argv in (["--gpus", "2", "--dry-run"], ["--gpus", "2", "--mode", "S", "--dry-run"]):
+        out, lines = _run_bench(argv)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks"] == [0, 1] and lines[0]["processes"] == 2, lines
+        assert lines[0]["launched_by"] == "bench.py itself"
+    out, lines = _run_bench(["--gpus", "1", "--dry-run"])
+    assert out.returncode == 0 and lines[0]["n_gpus"] == 1 and lines[0]["launched_by"] == "the caller / an external launcher"

@@ -317,6 +317,13 @@ def test_pipeline_driven_from_cpp_without_python(tmp_path):
     out = subprocess.run([os.path.join(root, "tests", "hostcheck", "pipeline_driver"), str(case)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "PIPELINE_DRIVER_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
     assert f"ranges={R} steps={steps} chunks={E}" in out.stdout
+    # bsx_prepare_process (called by the driver before its first HIP call) asked for 16 hardware queues and the pool got them:
+    # measured by the library, reported by bsx_pipeline_autotune
+    assert "hw_queues=16" in out.stdout or "hw_queues=8" in out.stdout, out.stdout
+    # RCCL called from the C tier — a one-rank communicator made through bsx_rccl_*, ncclAllGather checked end to end
+    # by bsx_pipeline_check_allgather before and after the steps; no Python, no torch in that process
+    out = subprocess.run([os.path.join(root, "tests", "hostcheck", "pipeline_driver"), str(case), "--rccl"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "PIPELINE_DRIVER_OK" in out.stdout and "rccl=ok" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
 
 
 @pytest.mark.parametrize("J,B,V,R,leaf_len,cap_h", [(8, 32, 20, 4, 135, 4), (32, 64, 100, 2, 135, 4), (4, 16, 6, 6, 80, 2)])
@@ -393,6 +400,44 @@ def test_rccl_all_gather_on_an_external_stream_world_1():
         "dist.destroy_process_group()\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_WORLD1_OK nccl" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_rccl_from_the_c_tier_beside_torchs_own_process_group():
+    """bench.py's N > 1 branch, at a world of ONE (one GPU cannot host two RCCL ranks): a torch.distributed process group over "nccl"
+    is alive, a SECOND communicator is made through the C ABI (engine.c_rccl_comm -> bsx_rccl_get_unique_id / _comm_init_rank), the
+    pipeline is told to call ncclAllGather itself (bsx_pipeline_set_rccl + bsx_pipeline_check_allgather), and steps still equal the
+    oracle — RCCL bound at run time next to PyTorch's own copy."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from blobstreamx_amd import _lib, types as T\n"
+        "from blobstreamx_amd import engine as E\n"
+        "import synth, oracle\n"
+        "_lib.lib(); torch.cuda.set_device(0); dev = torch.device('cuda:0')\n"
+        "os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ.setdefault('MASTER_PORT', '29519')\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "t = torch.ones(4, device=dev); dist.all_reduce(t)              # torch's own communicator is live\n"
+        "J, B, V, R = 4, 8, 10, 4\n"
+        "w = synth.Workload(3, R, J, B, v=V)\n"
+        "pe = E.PipelinedEngines(J, B, V, R, n_engines=2)\n"
+        "comm = E.c_rccl_comm(pe.ctx, 0, 1)\n"
+        "pe.set_rccl(comm)                                               # includes bsx_pipeline_check_allgather\n"
+        "pe.upload_workload(w); pe.step(); pe.step(); pe.check_allgather()\n"
+        "res = pe.download()\n"
+        "for r in range(R):\n"
+        "    rc, out, _, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])\n"
+        "    assert rc == 0 and res['output64'][r].tobytes() == out and res['skip_status'][r] == 0\n"
+        "pe.close()\n"
+        "assert _lib.lib().bsx_rccl_comm_destroy(comm) == 0\n"
+        "dist.all_reduce(t); assert float(t[0]) == 1.0\n"
+        "print('C_RCCL_WORLD1_OK')\n"
+        "dist.destroy_process_group()\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "C_RCCL_WORLD1_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
 
 
 def test_pipeline_does_not_trust_the_callers_end_header_hash():

@@ -930,7 +930,7 @@ def test_trim_releases_host_tier_state_and_the_next_call_rebuilds_it():
         out, _, wit = circ.prove(w.input48(r), InputDataFetcher(w.headers[r], S, int(w.latest[r])), w.validators[r], w.trusted[r], want_witness=want_witness)
         assert out == want_out
         if want_witness:
-            full = oracle.expand_range_witness(J, B, cw)
+            full = oracle.expand_range_witness(J, B, cw, v_max=V)
             assert np.asarray(wit).shape == full.shape and (np.asarray(wit) == full).all()
 
     one(0, want_witness=True)

@@ -25,7 +25,8 @@ def _clean(r):
     return r.tobytes()
 
 
-@pytest.mark.parametrize("world,J,B,V,tamper", [(1, 2, 16, 12, False), (2, 4, 16, 33, True), (4, 8, 8, 7, True), (8, 32, 64, 100, False), (1, 32, 64, 100, True)])
+@pytest.mark.parametrize("world,J,B,V,tamper", [(1, 2, 16, 12, False), (2, 4, 16, 33, True), (4, 8, 8, 7, True), (8, 32, 64, 100, False), (1, 32, 64, 100, True),
+                                                 (8, 32, 64, 512, True)])      # the last one: BASELINE config #5 literally
 def test_commit_shards_vs_oracle(world, J, B, V, tamper):
     """Every rank's CommitShard of an N-GPU mode-S run on ONE GPU: its slice's ok bits, commit results and fold equal the
     oracle's; the concatenation of the folds (= the all-gather's result) gives the range verdict, incl. the global index of a
@@ -40,7 +41,12 @@ def test_commit_shards_vs_oracle(world, J, B, V, tamper):
         bad = nh // 2 + 3
         k = int(np.nonzero(vals[bad]["is_signed"])[0][0])
         vals[bad, k]["signature"][9] ^= 8
-    ref = [oracle.verify_commit(vals[c], w.commit_hashes[c].tobytes()) for c in range(nh)]
+    if nh * V > 100_000:      # a million signatures: the oracle on every host thread (same function, orc_verify_commit per commit)
+        import os
+        rres_all, rok_all = oracle.bench_verify_commits(vals, w.commit_hashes, len(os.sched_getaffinity(0)))
+        ref = [(rres_all[c], rok_all[c]) for c in range(nh)]
+    else:
+        ref = [oracle.verify_commit(vals[c], w.commit_hashes[c].tobytes()) for c in range(nh)]
     folds = []
     for g in range(world):
         sh = CommitShard(nh, V, rank=g, world=world)
