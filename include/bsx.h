@@ -756,10 +756,11 @@ int bsx_pipeline_enable_input_streaming(bsx_pipeline* p, int on);
  * its own best assignment. */
 typedef struct bsx_pipeline_autotune_result {
     uint32_t n_trials, best_trial, steps_per_trial;
-    uint32_t hw_queues;                        /* distinct hardware queues the pool's 16 streams sit on, MEASURED (two spinning waves on
-                                                  two streams take twice as long when they share a queue).  HIP's default is 4
-                                                  (GPU_MAX_HW_QUEUES): chunks' streams then share queues and their phases cannot
-                                                  overlap — call bsx_prepare_process() before the process's first HIP call */
+    uint32_t hw_queues;                        /* how many of the pool's 16 streams can run kernels CONCURRENTLY, MEASURED (two spinning waves
+                                                  on two streams take twice as long when they share a hardware queue or a dispatch pipe;
+                                                  streams are grouped greedily).  <= 4 means HIP's default GPU_MAX_HW_QUEUES: the chunks'
+                                                  streams share queues and their phases cannot overlap — call bsx_prepare_process()
+                                                  before the process's first HIP call.  11-16 on MI355X with 16 queues */
     double initial_ms, best_ms, worst_ms;      /* per step: the assignment the pipeline had, the one it keeps (re-timed twice as long
                                                   with the two runners-up), the slowest tried */
     uint32_t assignment[16];                   /* pool index of chunk i's main (2 i) and side (2 i + 1) stream */

@@ -317,9 +317,13 @@ def test_pipeline_driven_from_cpp_without_python(tmp_path):
     out = subprocess.run([os.path.join(root, "tests", "hostcheck", "pipeline_driver"), str(case)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "PIPELINE_DRIVER_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
     assert f"ranges={R} steps={steps} chunks={E}" in out.stdout
-    # bsx_prepare_process (called by the driver before its first HIP call) asked for 16 hardware queues and the pool got them:
-    # measured by the library, reported by bsx_pipeline_autotune
-    assert "hw_queues=16" in out.stdout or "hw_queues=8" in out.stdout, out.stdout
+    # bsx_prepare_process (called by the driver before its first HIP call) asked for 16 hardware queues; what the pool's streams
+    # really got is MEASURED by the library (groups of streams whose kernels run one after the other) and reported by
+    # bsx_pipeline_autotune: more than HIP's default of 4 (queues that share a dispatch pipe still serialise, so it
+    # need not be 16)
+    import re
+    hq = int(re.search(r"hw_queues=(\d+)", out.stdout).group(1))
+    assert 4 < hq <= 16, out.stdout
     # RCCL called from the C tier — a one-rank communicator made through bsx_rccl_*, ncclAllGather checked end to end
     # by bsx_pipeline_check_allgather before and after the steps; no Python, no torch in that process
     out = subprocess.run([os.path.join(root, "tests", "hostcheck", "pipeline_driver"), str(case), "--rccl"], capture_output=True, text=True, timeout=600, env=env)
