@@ -166,9 +166,19 @@ def test_cli_prove_input_json(tmp_path, golden):
     assert cj["map_jobs"][1] == ["0x" + "".join(f"{int(x):016x}" for x in d) for d in cap]
     got = json.load(open(out))["data"]["output"]
     assert got == "0x" + golden["blocks"]["10004"]["header_hash"] + golden["data_commitments"]["10000-10004"]
-    ml, rl = T.map_layout(2), T.reduce_layout()
-    assert wit.stat().st_size == 8 * (2 * int(ml["n_elements"]) + int(rl["n_elements"]))
+    # the whole circuit's witness: 2 map jobs, 1 reduce node, the COMMIT unit of block 10004's commit, the SKIP unit (4 slots)
+    assert wit.stat().st_size == 8 * T.header_range_witness_elements(2, 2, 4)
+    assert set(cj["cap_height"]) == {"map_jobs", "reduce_nodes", "commit", "skip"} and len(cj["commit"]) == 1 and len(cj["skip"]) == 1
+    cl = T.commit_layout(4)
+    off = 2 * nel + int(T.reduce_layout()["n_elements"])
+    unit = wv[off:off + int(cl["n_elements"])]
+    nl = 1
+    while nl * 135 < unit.size:
+        nl *= 2
+    _, cap = oracle.poseidon_merkle_tree(unit, 135, nl, cj["cap_height"]["commit"])
+    assert cj["commit"][0] == ["0x" + "".join(f"{int(x):016x}" for x in d) for d in cap]
     inp.write_text(json.dumps({"type": "req_bytes", "data": {"input": "0x" + (10000).to_bytes(8, "big").hex() + h0}}))
-    assert cli.main(["next_header_mocha", "prove", str(inp), "--fixtures", FIX, "--validators", "4", "--output", str(out)]) == 0
+    assert cli.main(["next_header_mocha", "prove", str(inp), "--fixtures", FIX, "--validators", "4", "--output", str(out), "--witness", str(wit)]) == 0
+    assert wit.stat().st_size == 8 * T.next_header_witness_elements(4)
     got = json.load(open(out))["data"]["output"]
     assert got == "0x" + golden["blocks"]["10001"]["header_hash"] + golden["data_commitments"]["10000-10001"]
