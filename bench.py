@@ -361,8 +361,54 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
                                             "algorithmic_GBps": n * 237 / t_sha / 1e6}}
     if not check:
         return out
-    # CPU leg = checker: the oracle's verify_commit of this rank's commits on all host threads, repeated to fill ~cpu_seconds
     import oracle
+    # The WITNESS of the per-validator loop (BASELINE config #5: "bit-exact witness diff vs CPU"): the same call also leaves every
+    # commit's COMPACT COMMIT unit (digests, challenges, verdicts, leaves, the masked validator-set tree, sums: include/bsx_layout.h),
+    # expanded into Goldilocks elements by k_expand_witness on the same stream — HBM-write bound, its own roofline next to the VALU one.
+    del sh
+    torch.cuda.empty_cache()
+    shw = CommitShard(nh, V, rank=rank, world=world, device=dev, expand=True)
+    shw.upload(w.validators.reshape(nh, V), w.commit_hashes)
+    lay = shw.lay
+    exp_bytes = shw.n * (int(lay["n_bytes"]) + 4 * int(lay["n_words"]) + int(lay["n_bools"]) + 8 * int(lay["n_elements"]))
+    evw = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    layp = np.ascontiguousarray(lay).reshape(1)
+    shw.step(); shw.step()
+    t_x = 0.0
+    for _ in range(3):
+        evw[0].record()
+        _lib.check(L.bsx_dev_expand_witness(ctx, st, _lib.p(layp), C.c_uint32(shw.n), dp(shw.compact), dp(shw.witness)))
+        evw[1].record()
+        torch.cuda.synchronize(dev)
+        t_x += evw[0].elapsed_time(evw[1]) / 3
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        shw.step()
+        shw.gather()
+    barrier()
+    dtw = (time.perf_counter() - t0) / K
+    pick = sorted({0, 1, shw.n // 3, shw.n // 2, shw.n - 1})
+    got = shw.witness_of(pick)
+    vv_all = w.validators.reshape(nh, V)
+    for i, c in enumerate(pick):
+        gc = shw.first + c
+        _, _, cwc = oracle.verify_commit(vv_all[gc], w.commit_hashes[gc].tobytes(), want_witness=True)
+        want = oracle.expand_witness(lay, 1, cwc)
+        assert got[i].shape == want.shape and (got[i] == want).all(), f"mode S: the COMMIT unit of commit {gc} differs from the oracle's"
+    gpu_ok_w, gpu_res_w, gpu_fold_w = shw.download()
+    out["witness"] = {"headers_per_s": nh / dtw, "ms": dtw * 1e3, "elements_per_commit": int(lay["n_elements"]),
+                      "bytes_per_step_this_rank": int(shw.n * 8 * int(lay["n_elements"])),
+                      "checked_against_oracle_commits": len(pick),
+                      "roofline": {"kernel": "k_expand_witness (COMMIT units)", "bound": "hbm", "achieved": exp_bytes / t_x / 1e6, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": exp_bytes / t_x / 1e6 / HBM_PEAK_GBS, "avg_launch_ms": t_x,
+                                   "algorithmic_bytes_per_launch": exp_bytes, "traffic": None,
+                                   "frac_of_measured_store_ceiling": min(1.0, exp_bytes / t_x * 1e3 / cal["hbm_store_bytes_per_s"])},
+                      "note": "the whole mode-S step WITH the witness: verification + compact units + their 64x expansion into HBM; sampled commits' "
+                              "units diffed element by element against the oracle"}
+    assert (gpu_ok_w == gpu_ok).all() and gpu_fold_w.tobytes() == gpu_fold.tobytes(), "mode S: emitting the witness changed the verdicts"
+    sh = shw
+    # CPU leg = checker: the oracle's verify_commit of this rank's commits on all host threads, repeated to fill ~cpu_seconds
     cores, cores_desc = host_threads()
     vv = w.validators.reshape(nh, V)[sh.first:sh.first + sh.n]
     hh = w.commit_hashes[sh.first:sh.first + sh.n]
