@@ -27,8 +27,8 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        if not os.environ.get("ORACLE_SO_OVERRIDE"):
+            build()            # mtime check: a library older than its sources is rebuilt (a stale one once overran a buffer sized by newer code)
         _lib = C.CDLL(_SO)
         _lib.orc_sha256_has_shani.restype = C.c_int
     return _lib
