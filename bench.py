@@ -462,6 +462,105 @@ def latency_leg(dev, J, B, V):
     return out
 
 
+def concurrent_leg(dev, J, B, V, ks=(1, 2, 4, 8, 16), seconds=0.4):
+    """The reference's shape of use: ONE range per `prove` call, several calls in flight under a multi-thread runtime
+    (circuits/header_range.rs:180-181, bin/header_range_2048.rs:6-17).  K host threads, each with ITS OWN bsx context (contexts
+    serialise their host-tier calls; distinct contexts run concurrently), call bsx_header_range back to back on their own range for
+    `seconds`: headers/s and per-call p50 / p99 by K.  ctypes releases the GIL for the duration of the C call."""
+    import threading
+    import synth
+    from blobstreamx_amd import _lib
+    from blobstreamx_amd import types as T
+    L = _lib.lib()
+    kmax = max(ks)
+    w = synth.Workload(4, kmax, J, B, v=V)
+    ctxs = []
+    for _ in range(kmax):
+        h = C.c_void_p()
+        _lib.check(L.bsx_init(C.c_int(dev.index or 0), C.byref(h)))
+        ctxs.append(h)
+    cid = np.frombuffer(b"celestia", np.uint8).copy()
+
+    def call(k, out, res):
+        hdr = w.headers[k]
+        return L.bsx_header_range(ctxs[k], C.c_uint32(J), C.c_uint32(B), _lib.p(inp[k]), _lib.p(hdr), C.c_uint64(int(w.first_height[k])),
+                                  C.c_uint64(hdr.size), C.c_uint64(int(w.latest[k])), _lib.p(tv[k]), _lib.p(rv[k]), C.c_uint32(V), _lib.p(cid),
+                                  C.c_uint32(8), _lib.p(out), _lib.p(res), None)
+    inp = [np.frombuffer(w.input48(k), np.uint8).copy() for k in range(kmax)]
+    tv = [np.ascontiguousarray(w.validators[k]) for k in range(kmax)]
+    rv = [np.ascontiguousarray(w.trusted[k]) for k in range(kmax)]
+    for k in range(kmax):                                       # warm every context (key tables, arenas) and check the outputs
+        out, res = np.zeros(64, np.uint8), np.zeros(1, T.COMMIT_RESULT)
+        for _ in range(3):
+            assert call(k, out, res) == 0
+        assert out[:32].tobytes() == w.hashes[k, w.n_blocks].tobytes()
+    rows = []
+    for K in ks:
+        lat = [[] for _ in range(K)]
+        stop = [False]
+        go = threading.Barrier(K + 1)
+
+        def worker(k):
+            out, res = np.zeros(64, np.uint8), np.zeros(1, T.COMMIT_RESULT)
+            go.wait()
+            while not stop[0]:
+                t0 = time.perf_counter()
+                rc = call(k, out, res)
+                lat[k].append((time.perf_counter() - t0) * 1e3)
+                assert rc == 0
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
+        for t in th:
+            t.start()
+        go.wait()
+        t0 = time.perf_counter()
+        time.sleep(seconds)
+        stop[0] = True
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        allv = sorted(x for l in lat for x in l)
+        rows.append({"threads": K, "calls": len(allv), "headers_per_s": len(allv) * J * B / dt, "p50_ms": allv[len(allv) // 2],
+                     "p99_ms": allv[min(len(allv) - 1, int(len(allv) * 0.99))]})
+    for h in ctxs:
+        L.bsx_shutdown(h)
+    return {"workload": f"K threads x own bsx context x bsx_header_range (one header_range_{J * B}, {V} validators per call, host pointers in, 64 B out)",
+            "by_threads": rows,
+            "note": "the reference proves ONE range per call under a multi-thread runtime (header_range.rs:180-181): this is that shape; the "
+                    "batched pipeline (headline) is the form for a prover farm that keeps a GPU busy"}
+
+
+def range_sweep_leg(dev, J, B, V, rs=(1, 4, 16, 64, 256), witness=False):
+    """The pipeline's throughput by the number of ranges resident per step (R): how many concurrent proof requests it takes to fill
+    the GPU.  Compact form (no expansion) unless `witness`; R = 1 .. 256, one chunk below 16 ranges, autotuned stream placement."""
+    import synth
+    from blobstreamx_amd import engine as E
+    w = synth.Workload(4, max(rs), J, B, v=V)
+    rows = []
+    for R in rs:
+        nch = 2 if (witness and R >= 16) else 1
+        pe = E.PipelinedEngines(J, B, V, R, n_engines=nch, device=dev, with_witness=witness) if witness else \
+            E.AlternatingPipelines(2, J, B, V, R, n_engines=1, device=dev, with_witness=False)
+        pe.upload_workload(w, sel=np.arange(R))
+        pe.step()
+        res = pe.download()
+        assert not res["range_status"].any() and not res["skip_status"].any()
+        steps = max(20, min(400, int(2000 // max(R, 1))))
+        for _ in range(3):
+            pe.step()
+        pe.join()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pe.step()
+        pe.join()
+        dt = (time.perf_counter() - t0) / steps
+        rows.append({"ranges": R, "headers_per_s": R * J * B / dt, "ms_per_step": dt * 1e3, "steps": steps})
+        pe.close()
+        del pe
+        torch.cuda.empty_cache()
+    return {"workload": f"bsx_pipeline_step over R resident header_range_{J * B} instances, {V} validators, "
+                        + ("witness materialised" if witness else "compact form (no expansion), two buffer sets"), "by_ranges": rows}
+
+
 def upload_leg(eng, args, steps, tune_streams=True):
     """The headline step with the header block (headers + skip headers, 512 B each) streamed from pinned host memory EVERY
     step on a copy stream inside the library (bsx_pipeline_enable_input_streaming), overlapped with the previous step's
@@ -551,13 +650,32 @@ def commitment_leg(dev, J, B, V, cal, R=32, leaf_len=135, cap_height=4):
     perms = n_jobs * wc.perms_per_job
     perm_per_s = perms / t_fused * 1e3
     peak = cal["goldilocks_mul_per_s"] / GL_MUL_PER_PERMUTATION
+    # CPU leg = checker: the oracle's Poseidon over the SAME compact witnesses on all host threads (expand one job,
+    # hash its rows, tree down to the cap), a bounded sample of the jobs, every cap compared with the GPU's
+    cores, cores_desc = host_threads()
+    compact_host = compact.cpu().numpy()
+    n_cpu = min(n_jobs, 2 * cores)
+    t0 = time.perf_counter()
+    cpu_caps = oracle.bench_witness_caps(eng.ml, compact_host, n_cpu, leaf_len, wc.n_leaves, wc.cap_height, cores)
+    dt_cpu = time.perf_counter() - t0
+    creps = int(max(1, min(16, round(8.0 / max(dt_cpu, 1e-3)))))
+    if creps > 1:
+        t0 = time.perf_counter()
+        cpu_caps = oracle.bench_witness_caps(eng.ml, compact_host, n_cpu, leaf_len, wc.n_leaves, wc.cap_height, cores, reps=creps)
+        dt_cpu = time.perf_counter() - t0
+    assert (cpu_caps == caps_fused[:n_cpu]).all(), "witness commitment: the CPU leg's caps differ from the GPU's"
+    cpu_leg = {"value": n_cpu * creps * B / dt_cpu, "unit": "headers/s", "permutations_per_s": n_cpu * creps * wc.perms_per_job / dt_cpu,
+               "cores": cores, "kind": "port",
+               "sample": f"oracle Poseidon (128-bit accumulation form, oracle/poseidon.c) over the compact witnesses of {n_cpu} map jobs x {creps} "
+                         f"repetitions: expand, hash {wc.n_leaves} rows of {leaf_len}, tree to the cap; {dt_cpu:.1f} s wall on {cores_desc}; "
+                         f"all {n_cpu} caps equal the GPU's"}
     return {"workload": f"{R} x header_range_{J * B}: {n_jobs} map-job witnesses of {wc.nel} elements, rows of {leaf_len}, "
                         f"{wc.n_leaves} leaves, cap height {wc.cap_height}",
             "pipeline_caps_mode": {"headers_per_s": R * J * B / dt_pipe, "ms_per_step": dt_pipe * 1e3, "steps": steps, "caps_launch_ms": tm["caps_ms"],
                                    "note": "bsx_pipeline with BSX_PIPE_CAPS (no expansion): the whole step incl. commit check + Poseidon caps of every "
                                            "map-job witness from the compact bytes; steps not joined"},
             "fused_ms": t_fused, "materialised_ms": t_mat, "headers_per_s_fused": R * J * B / t_fused * 1e3,
-            "permutations": perms, "checked_against_oracle_jobs": 2,
+            "permutations": perms, "checked_against_oracle_jobs": 2 + n_cpu, "cpu_baseline": cpu_leg,
             "roofline": {"kernel": "k_leaf_hashes<fused> + k_merkle_level", "bound": "valu", "unit": "G Poseidon permutations/s",
                          "achieved": perm_per_s / 1e9, "peak": peak / 1e9, "frac": min(1.0, perm_per_s / peak), "traffic": None,
                          "valu_issue": valu_issue(cal, "k_leaf_hashes<true>", n_jobs * wc.n_rows * (-(-leaf_len // 8)), t_fused * 1e-3),
@@ -863,6 +981,8 @@ def main():
         torch.cuda.empty_cache()
         if legs:
             out["latency"] = latency_leg(dev, J, B, V)
+            out["latency"]["concurrent"] = concurrent_leg(dev, J, B, V)
+            out["range_sweep"] = {"compact": range_sweep_leg(dev, J, B, V), "witness": range_sweep_leg(dev, J, B, V, rs=(1, 4, 16, 64), witness=True)}
             out["fused_commitment"] = commitment_leg(dev, J, B, V, cal)
             if not args.no_stress:
                 out["stress"] = {"v100": stress(args, dev, 100, 6.0, cal), "v512": stress(args, dev, 512, 6.0, cal)}

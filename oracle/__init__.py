@@ -332,6 +332,25 @@ def poseidon_permute(state):
     return s
 
 
+def poseidon_permute_fast(state):
+    """the cpu_baseline form of the permutation (oracle/poseidon.c): must equal poseidon_permute"""
+    s = np.ascontiguousarray(state, np.uint64).reshape(12).copy()
+    lib().orc_poseidon_permute_fast(_p(s))
+    return s
+
+
+def bench_witness_caps(layout, compact, n_jobs, leaf_len, n_leaves, cap_height, n_threads, reps=1):
+    """cpu_baseline of the witness commitment: caps [n_jobs, 2^cap_height, 4] of n_jobs compact witnesses on n_threads threads"""
+    lay = np.ascontiguousarray(layout, T.WITNESS_LAYOUT).reshape(1)
+    c = np.ascontiguousarray(compact, np.uint8).reshape(-1)
+    assert c.size >= n_jobs * int(lay["compact_stride"][0])
+    caps = np.zeros((n_jobs, 1 << cap_height, 4), np.uint64)
+    rc = lib().orc_bench_witness_caps(_p(lay), C.c_uint32(n_jobs), C.c_uint32(reps), _p(c), C.c_uint32(leaf_len), C.c_uint32(n_leaves),
+                                      C.c_uint32(cap_height), C.c_int(n_threads), _p(caps))
+    assert rc == 0, rc
+    return caps
+
+
 def poseidon_hash_no_pad(elems):
     e = np.ascontiguousarray(elems, np.uint64).reshape(-1)
     out = np.zeros(4, np.uint64)

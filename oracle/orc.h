@@ -135,6 +135,13 @@ void orc_poseidon_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t 
 int orc_poseidon_merkle_tree(const uint64_t* elements, uint64_t n_elements, uint32_t leaf_len, uint32_t n_leaves,
                              uint32_t cap_height, uint64_t* tree /* (2*n_leaves - 2^cap_height) * 4 */);
 
+/* the same permutation in the form a CPU implementation takes (128-bit accumulation, 2^64 = 2^32 - 1 folds; no `%`): only for the
+ * bench's Poseidon cpu_baseline; held equal to orc_poseidon_permute by tests/test_oracle_poseidon.py */
+void orc_poseidon_permute_fast(uint64_t state[12]);
+/* cpu_baseline of the witness commitment: Merkle caps of n_jobs compact witnesses on n_threads threads (expand, hash rows, tree) */
+int orc_bench_witness_caps(const bsx_witness_layout* L, uint32_t n_jobs, uint32_t reps, const uint8_t* compact, uint32_t leaf_len,
+                           uint32_t n_leaves, uint32_t cap_height, int n_threads, uint64_t* out_caps);
+
 /* ---- batch drivers for the cpu_baseline leg (pthread pool, n_threads >= 1) */
 int orc_bench_header_range(uint32_t n_ranges, uint32_t reps, uint32_t nb_map_jobs, uint32_t batch_size,
                            const bsx_shared_ctx* ranges, const bsx_header* headers, uint64_t headers_per_range,

@@ -146,3 +146,120 @@ int orc_poseidon_merkle_tree(const uint64_t* elements, uint64_t n_elements, uint
     }
     return BSX_OK;
 }
+
+
+/* ------------------------------------------------------------------ cpu_baseline form of the permutation
+ * Same function as orc_poseidon_permute, written the way a CPU implementation of plonky2's Poseidon is (no `%`): products and MDS
+ * rows accumulate in 128 bits and are folded with 2^64 = 2^32 - 1, 2^96 = -1 (mod p) — one fold per output.  The definition-level
+ * version above stays the reference of every parity test; tests/test_oracle_poseidon.py holds the two equal.  Used only by the
+ * bench's `fused_commitment.cpu_baseline` leg, so that the CPU figure is not an artefact of 5,000 __umodti3 calls per permutation. */
+#define GL_EPS 0xFFFFFFFFull
+static inline uint64_t gl_reduce128(u128 x) {
+    const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    const uint64_t hh = hi >> 32, hl = hi & GL_EPS;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= GL_EPS;              /* borrow: add p = 2^64 - EPS, i.e. subtract EPS mod 2^64 */
+    const uint64_t t1 = hl * GL_EPS;
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;                /* carry: 2^64 = EPS */
+    return r;
+}
+static inline uint64_t gl_mul_f(uint64_t a, uint64_t b) { return gl_reduce128((u128)a * b); }
+static inline uint64_t gl_pow7_f(uint64_t x) {
+    const uint64_t x2 = gl_mul_f(x, x), x3 = gl_mul_f(x2, x), x4 = gl_mul_f(x2, x2);
+    return gl_mul_f(x4, x3);
+}
+void orc_poseidon_permute_fast(uint64_t s[12]) {
+    static const uint64_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint64_t* rc = orc_poseidon_round_constants();
+    for (int r = 0; r < 30; r++) {
+        for (int i = 0; i < 12; i++) s[i] = gl_reduce128((u128)s[i] + rc[12 * r + i]);
+        if (r < 4 || r >= 26) {
+            for (int i = 0; i < 12; i++) s[i] = gl_pow7_f(s[i]);
+        } else {
+            s[0] = gl_pow7_f(s[0]);
+        }
+        uint64_t t[12];
+        for (int k = 0; k < 12; k++) {
+            u128 acc = (u128)s[k] * (k == 0 ? 8u : 0u);
+            for (int i = 0; i < 12; i++) acc += (u128)s[(i + k) % 12] * C[i];     /* < 2^64 * 264: no overflow */
+            t[k] = gl_reduce128(acc);
+        }
+        memcpy(s, t, sizeof t);
+    }
+    for (int i = 0; i < 12; i++) if (s[i] >= GL_P) s[i] -= GL_P;
+}
+
+/* Merkle caps of n_jobs compact witnesses (layout L) the way bsx_dev_witness_leaf_hashes + bsx_dev_poseidon_merkle_caps produce
+ * them: expand one job at a time, rows of leaf_len elements -> hash_or_noop, tree down to 2^cap_height; jobs dealt to n_threads
+ * threads, `reps` passes (task t works on job t % n_jobs).  out_caps: n_jobs x 2^cap_height x 4. */
+typedef struct {
+    const bsx_witness_layout* L;
+    uint32_t n_jobs, leaf_len, n_leaves, cap_height, reps;
+    const uint8_t* compact;
+    uint64_t* out_caps;
+    int n_threads, tid;
+} cjob_t;
+static void fast_hash_or_noop(const uint64_t* in, uint32_t n, uint64_t out[4]) {
+    if (n <= 4) { for (uint32_t i = 0; i < 4; i++) out[i] = i < n ? in[i] % GL_P : 0; return; }
+    uint64_t s[12] = {0};
+    for (uint32_t k = 0; k < n; k += 8) {
+        for (uint32_t i = 0; i < 8 && k + i < n; i++) s[i] = in[k + i];
+        orc_poseidon_permute_fast(s);
+    }
+    memcpy(out, s, 32);
+}
+#include <pthread.h>
+static void* cworker(void* arg) {
+    cjob_t* jb = arg;
+    const bsx_witness_layout* L = jb->L;
+    const uint32_t ncap = 1u << jb->cap_height;
+    const size_t nd = 2 * (size_t)jb->n_leaves - ncap;
+    uint64_t* wit = malloc((size_t)L->n_elements * 8);
+    uint64_t* tree = malloc(nd * 32);
+    uint64_t* row = malloc((size_t)jb->leaf_len * 8);
+    const uint32_t n_tasks = jb->n_jobs * jb->reps;
+    for (uint32_t t = (uint32_t)jb->tid; t < n_tasks; t += (uint32_t)jb->n_threads) {
+        const uint32_t j = t % jb->n_jobs;
+        orc_expand_witness(L, 1, jb->compact + (size_t)j * L->compact_stride, wit);
+        for (uint32_t r = 0; r < jb->n_leaves; r++) {
+            for (uint32_t k = 0; k < jb->leaf_len; k++) {
+                const uint64_t e = (uint64_t)r * jb->leaf_len + k;
+                row[k] = e < L->n_elements ? wit[e] : 0;
+            }
+            fast_hash_or_noop(row, jb->leaf_len, tree + 4 * (size_t)r);
+        }
+        uint64_t* level = tree;
+        for (uint32_t w = jb->n_leaves; w > ncap; w /= 2) {
+            uint64_t* up = level + 4 * (size_t)w;
+            for (uint32_t q = 0; q < w / 2; q++) {
+                uint64_t s[12] = {0};
+                memcpy(s, level + 8 * (size_t)q, 64);
+                orc_poseidon_permute_fast(s);
+                memcpy(up + 4 * (size_t)q, s, 32);
+            }
+            level = up;
+        }
+        if (t < jb->n_jobs) memcpy(jb->out_caps + (size_t)j * ncap * 4, tree + (nd - ncap) * 4, (size_t)ncap * 32);
+    }
+    free(wit); free(tree); free(row);
+    return NULL;
+}
+int orc_bench_witness_caps(const bsx_witness_layout* L, uint32_t n_jobs, uint32_t reps, const uint8_t* compact, uint32_t leaf_len,
+                           uint32_t n_leaves, uint32_t cap_height, int n_threads, uint64_t* out_caps) {
+    if (!leaf_len || !n_leaves || (n_leaves & (n_leaves - 1)) || (1u << cap_height) > n_leaves) return BSX_ERR_BAD_ARG;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    if (reps < 1) reps = 1;
+    cjob_t* jobs = calloc((size_t)n_threads, sizeof *jobs);
+    pthread_t* th = calloc((size_t)n_threads, sizeof *th);
+    for (int t = 0; t < n_threads; t++) {
+        cjob_t j = {L, n_jobs, leaf_len, n_leaves, cap_height, reps, compact, out_caps, n_threads, t};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, cworker, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    free(jobs);
+    free(th);
+    return BSX_OK;
+}

@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 
 import oracle
+from blobstreamx_amd import types as T
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
@@ -153,3 +154,27 @@ def test_oracle_merkle_tree_shape_and_cap():
     while len(lvl) > 1:
         lvl = np.array([oracle.poseidon_two_to_one(lvl[2 * i], lvl[2 * i + 1]) for i in range(len(lvl) // 2)])
     assert (cap[0] == lvl[0]).all()
+
+
+def test_cpu_baseline_permutation_equals_the_definition():
+    """oracle/poseidon.c holds a second, CPU-shaped permutation (128-bit accumulation, no `%`) that only bench.py's
+    fused_commitment.cpu_baseline uses: equal to the definition-level one on the public KAT inputs, edge words and random states,
+    and its threaded caps driver equals orc_poseidon_merkle_tree over the expanded witness."""
+    rng = np.random.default_rng(11)
+    P = 0xFFFFFFFF00000001
+    states = [np.zeros(12, np.uint64), np.arange(12, dtype=np.uint64), np.full(12, P - 1, np.uint64), np.full(12, 2 ** 64 - 1, np.uint64)]
+    states += [rng.integers(0, 2 ** 64, 12, dtype=np.uint64) for _ in range(200)]
+    for s in states:
+        assert (oracle.poseidon_permute_fast(s) == oracle.poseidon_permute(s)).all()
+    lay = T.map_layout(2)
+    compact = rng.integers(0, 256, 3 * int(lay["compact_stride"]), dtype=np.uint8)
+    bo = int(lay["off_bools"])
+    for j in range(3):                       # bools are 0/1, words any u32
+        c = compact[j * int(lay["compact_stride"]):(j + 1) * int(lay["compact_stride"])]
+        c[bo:] &= 1
+    caps = oracle.bench_witness_caps(lay, compact, 3, 135, 128, 2, n_threads=2, reps=2)
+    wit = oracle.expand_witness(lay, 3, compact)
+    nel = int(lay["n_elements"])
+    for j in range(3):
+        _, cap = oracle.poseidon_merkle_tree(wit[j * nel:(j + 1) * nel], 135, 128, 2)
+        assert (caps[j] == cap).all(), j
