@@ -579,8 +579,7 @@ constexpr uint32_t BF_TOP_WIDTH = 8;
 // start / end headers for a batch the hint serves no header for (input.rs:246-262) — since k_assemble_inputs does not run.
 template <int MODE>
 __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) {
-    // MODE 3 = MODE 1's hashing (tuples + tree here) with MODE 2's self-made witness head: behind k_map_groups run WITHOUT its tuple / tree stage
-    constexpr bool FUSED = MODE == 1 || MODE == 3, PRED_ONLY = MODE == 2, SELF = MODE == 2 || MODE == 3;
+    constexpr bool FUSED = MODE == 1, PRED_ONLY = MODE == 2;
     BSX_CHAIN_PRIO();
     __shared__ uint32_t job_fail[BF_THREADS];
     __shared__ uint32_t job_first_bad[BF_THREADS];
@@ -604,7 +603,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const bsx_shared_ctx* rg = a.ranges + q / a.job_count;
     const uint64_t E = rg->end_block;
     uint64_t batch_start, batch_end, temp_end, end_block_num;
-    if (SELF) {
+    if (PRED_ONLY) {
         // batch bounds from the job index (builder.rs:315-322): nobody has written the words yet
         const uint64_t S = rg->start_block;
         batch_start = S + (uint64_t)(a.job_first + q % a.job_count) * B;
@@ -667,7 +666,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const uint8_t* slots = cw + bsx_off_slots(B);
     // curr_header entering slot i = start_header (i == 0 or m == 0) else lb_root of slot min(i, m) - 1
     Digest start_header = load_digest_global(cw + bsx_off_start_header());
-    if (SELF) {                                      // a batch without headers: zero, whatever an earlier step left there (lane 0 stores it)
+    if (PRED_ONLY) {                                 // a batch without headers: zero, whatever an earlier step left there (lane 0 stores it)
         const uint64_t latest = a.latest[q / a.job_count], safe = latest - 2;
         const uint64_t req_end = batch_end < safe ? batch_end : safe;
         if (!(batch_start < req_end)) start_header = Digest{};
@@ -764,7 +763,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
         const bool curr_enabled_end = batch_enabled && !(jstar < (uint64_t)B);   // enabled after the last slot
         const Digest curr_final = (m > 0) ? load_digest_global(slots + BSX_SLOT_BYTES * (m - 1) + 160 + 128) : start_header;
         Digest end_header = load_digest_global(cw + bsx_off_end_header());
-        if (SELF) {
+        if (PRED_ONLY) {
             const uint64_t latest = a.latest[q / a.job_count], safe = latest - 2;
             const uint64_t req_end = batch_end < safe ? batch_end : safe;
             if (!(batch_start < req_end)) end_header = Digest{};
@@ -836,7 +835,6 @@ struct MapGroupArgs {
     uint32_t compact_stride, off_words, off_bools;
     uint32_t* status;                            // [0]: bit 0 = bad header; [1]: bit 1 = inclusion-proof leaf not 34 / 72 bytes, bit 2 = latest < 2
     const uint8_t* zero_paths;                   // path digests of the all-zero proofs: dh[5] then lb[5]
-    uint32_t do_tree;                            // 1: tuples, leaf hashes and the commitment trees here; 0: left to k_batch_finish<3>
 };
 
 // where header k of a range lands: slot of its data_hash proof (d) and of its last_block_id proof (l)
@@ -966,7 +964,7 @@ __global__ __launch_bounds__(MG_THREADS, 4) void k_map_groups(MapGroupArgs a) {
                         *reinterpret_cast<uint16_t*>(lf + 32) = rd ? (uint16_t)d[8] : (uint16_t)0;
                     }
                     // data_hash = leaf[2..34] (builder.rs:250) as LE dwords, for the tuple stage
-                    if (!tail && a.do_tree) {
+                    if (!tail) {
 #pragma unroll
                         for (int q = 0; q < 8; q++) leafbuf[(gq * 64 + lane) * 8 + q] = rd ? funnel_r(d[q + 1], d[q], 16) : 0u;
                     }
@@ -1027,7 +1025,7 @@ __global__ __launch_bounds__(MG_THREADS, 4) void k_map_groups(MapGroupArgs a) {
                 if (ml) atomicOr(a.status + 1, 2u);
             }
         }
-        if (tail || !a.do_tree) continue;                                // block-uniform
+        if (tail) continue;                                              // block-uniform
         __syncthreads();
         // ---- the quad's 256 data-root tuples and their leaf hashes (builder.rs:82-103,134-137,144-147): one per lane, all four waves
         const uint64_t S = a.ranges[r_item].start_block, E = a.ranges[r_item].end_block, latest = a.latest[r_item];
@@ -1345,7 +1343,7 @@ bool bsxk_map_groups_fits(uint32_t B, uint32_t job_count, uint64_t hpr) {
 }
 hipError_t bsxk_map_groups(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_t job_first, uint32_t job_count, const bsx_shared_ctx* ranges,
                            const uint64_t* latest, const bsx_header* headers, uint64_t hpr, uint8_t* hashes, uint8_t* compact, uint32_t* status,
-                           const uint8_t* zero_paths, uint32_t max_wgs, uint32_t do_tree) {
+                           const uint8_t* zero_paths, uint32_t max_wgs) {
     if (!n_ranges || !job_count) return hipSuccess;
     if (!bsxk_map_groups_fits(B, job_count, hpr)) return hipErrorNotSupported;
     const bsx_witness_layout L = bsx_map_layout(B);
@@ -1357,7 +1355,6 @@ hipError_t bsxk_map_groups(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_
     a.items_tail = (n_ranges + 63) / 64;
     a.ranges = ranges; a.latest = latest; a.headers = headers; a.hpr = hpr; a.hashes = hashes; a.compact = compact;
     a.compact_stride = L.compact_stride; a.off_words = L.off_words; a.off_bools = L.off_bools; a.status = status; a.zero_paths = zero_paths;
-    a.do_tree = do_tree;
     uint32_t grid = a.items_main + a.items_tail;
     if (max_wgs && grid > max_wgs) grid = max_wgs;
     hipLaunchKernelGGL(k_map_groups, dim3(grid), dim3(MG_THREADS), 0, s, a);
@@ -1365,14 +1362,13 @@ hipError_t bsxk_map_groups(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_
 }
 // predicates + job tail + records behind bsxk_map_groups (k_batch_finish<2>)
 hipError_t bsxk_prove_subchain_tail(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_t job_first, uint32_t job_count, const bsx_shared_ctx* ranges,
-                                    const uint64_t* latest, uint8_t* compact, bsx_subchain* records, uint32_t with_tree) {
+                                    const uint64_t* latest, uint8_t* compact, bsx_subchain* records) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     const uint32_t n_jobs = n_ranges * job_count;
-    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 1, B / 2, 0, job_first, latest};
+    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0, job_first, latest};
     const uint64_t slots = (uint64_t)n_jobs * B;
-    if (with_tree) hipLaunchKernelGGL(k_batch_finish<3>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_batch_finish<2>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_batch_finish<2>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, uint64_t stride_range,

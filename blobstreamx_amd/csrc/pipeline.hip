@@ -85,8 +85,7 @@ struct bsx_pipeline {
     uint32_t last_set = 0;
     uint64_t hpr = 0, hfr = 0;
     bool with_witness = false, with_commit = false, with_caps = false, keyed = false, commit_beside_hash = false, fused_hint = true;
-    bool map_groups = false;                 // hashing + hint (+ tuples + tree: map_tree) in ONE launch (k_map_groups), predicates behind it
-    bool map_tree = false;
+    bool map_groups = false;                 // hashing + hint + tuples + tree in ONE launch (k_map_groups), predicates behind it
     uint32_t subchain_flags = 0, merkle_wgs = 0;
     uint32_t leaf_len = 0, cap_height = 0, n_leaves = 0;
     uint64_t tree_digests = 0;
@@ -405,7 +404,7 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
     }
     if (p->map_groups) {
         HIPCHK(bsxk_map_groups(st, RT, B, p->jf, jc, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), reinterpret_cast<const uint64_t*>(c.latest), hdrs,
-                               p->hpr, c.hashes_all, c.compact, c.status, p->ctx->zero_paths, p->merkle_wgs, p->map_tree ? 1u : 0u));
+                               p->hpr, c.hashes_all, c.compact, c.status, p->ctx->zero_paths, p->merkle_wgs));
         HIPCHK(hipEventRecord(c.ev_merkle, st));
         if (p->compact_tokens) p->merkle_token = c.ev_merkle;
         HIPCHK(hipEventRecord(c.ev_inputs_consumed, st));       // headers_all may be overwritten from here on (input streaming)
@@ -414,7 +413,7 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
         HIPCHK(bsxk_fill_end_hash(st, RT, reinterpret_cast<bsx_shared_ctx*>(c.ranges), c.hashes_all, p->hpr, nullptr, nullptr, nullptr, p->hfr));
         if (ts) { HIPCHK(hipEventRecord(ts->ev[0], st)); }
         HIPCHK(bsxk_prove_subchain_tail(st, RT, B, p->jf, jc, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), reinterpret_cast<const uint64_t*>(c.latest),
-                                        c.compact, reinterpret_cast<bsx_subchain*>(c.records), p->map_tree ? 0u : 1u));
+                                        c.compact, reinterpret_cast<bsx_subchain*>(c.records)));
         if (ts) { HIPCHK(hipEventRecord(ts->ev[1], st)); ts->sub = true; }
     } else {
     // ctx.end_header_hash of every range := the hash of its target header (what builder.skip hands to prove_data_commitment,
@@ -666,7 +665,7 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     if (cfg->rank >= world || J % world) return fail(BSX_ERR_BAD_ARG, "world %u must divide NB_MAP_JOBS %u and rank %u be below it", world, J, cfg->rank);
     if (!pow2(J / world)) return fail(BSX_ERR_BAD_ARG, "each rank needs a power-of-two slice of the map jobs (the local fold is a subtree of the reference's reduce tree)");
     if (cfg->chain_id_len > 50) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
-    if (cfg->tune_subchain > 4) return fail(BSX_ERR_BAD_ARG, "tune_subchain must be 0 .. 4");
+    if (cfg->tune_subchain > 3) return fail(BSX_ERR_BAD_ARG, "tune_subchain must be 0 .. 3");
     if (cfg->n_sets > 8) return fail(BSX_ERR_BAD_ARG, "n_sets must be in 0..8");
     bsx_pipeline* p = new bsx_pipeline();
     p->ctx = ctx;
@@ -697,8 +696,7 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     if (beside_expansion && p->fused_hint) p->subchain_flags |= BSX_SUBCHAIN_SEPARATE_LAUNCHES;
     // the whole map stage as k_map_groups + k_batch_finish<2> whenever the shape fits (B | 64, 64 | jobs x B): the production shapes
     // do; tune_subchain 1 / 2 / 3 force the round-3 forms (header_merkle, assemble_inputs, prove_subchain as one / several launches)
-    p->map_groups = p->fused_hint && (cfg->tune_subchain == 0 || cfg->tune_subchain == 4) && bsxk_map_groups_fits(B, p->jc, p->hpr);
-    p->map_tree = cfg->tune_subchain == 4;
+    p->map_groups = p->fused_hint && cfg->tune_subchain == 0 && bsxk_map_groups_fits(B, p->jc, p->hpr);
     if (cfg->tune_subchain == 1) p->subchain_flags &= ~BSX_SUBCHAIN_SEPARATE_LAUNCHES;
     if (cfg->tune_subchain == 2 && p->fused_hint) p->subchain_flags |= BSX_SUBCHAIN_SEPARATE_LAUNCHES;
     if (cfg->tune_merkle_workgroups) {
