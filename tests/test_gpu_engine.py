@@ -549,72 +549,3 @@ def test_pipeline_argument_errors():
     with pytest.raises(_lib.BsxError) as e:
         p2.step()
     assert "bsx_pipeline_set_allgather" in str(e.value)
-
-
-@pytest.mark.parametrize("J,B,R,n_blocks,world", [(32, 64, 3, 2048, 1), (32, 64, 2, 1000, 1), (32, 32, 3, 1024, 1), (8, 32, 4, 201, 1), (64, 2, 3, 100, 1),
-                                                  (128, 1, 2, 128, 1), (16, 16, 2, 256, 1), (4, 64, 3, 130, 1), (32, 64, 2, 2048, 4), (8, 32, 2, 77, 2)])
-def test_map_groups_kernel_equals_the_three_kernel_form_and_the_oracle(J, B, R, n_blocks, world):
-    """Round 4: k_map_groups (header hashing + hint + tuples + tree in ONE launch) + k_batch_finish<2> against the round-3 form
-    (k_header_merkle / k_assemble_inputs / prove_subchain, forced with tune_subchain = 3) byte for byte on the COMPACT witnesses, the
-    header hashes and the records — and both against the oracle — with every edge of the hint in play: chain heads that clamp a
-    batch in the middle / at its first slot / away entirely (zero-padded proofs, dummy start / end headers), a chain head below 2
-    (status bit), ranges that end inside a batch (disabled slots keep real headers), a tampered link, and job slices of a sharded
-    world (header_first_rel)."""
-    import torch
-    from blobstreamx_amd import engine as E
-    w = synth.Workload(300 + J + B, R * world, J, B, v=4, n_blocks=n_blocks)
-    S0 = int(w.first_height[0])
-    w.latest[0] = S0 + J * B + 2                      # nothing clamped
-    if R * world > 1:
-        w.latest[1] = S0 + 10_000 + (J * B * 5) // 8 + 1  # clamps in the middle of a batch (range 1 starts 10,000 above range 0)
-    if R * world > 2:
-        w.latest[2] = int(w.first_height[2]) + 2      # latest - 2 = S: every batch zero padded
-    w.headers[0, min(n_blocks, 40)]["hash"][1][3] ^= 1    # data_hash of one header: A4 fails in range 0
-    ml = T.map_layout(B)
-    cs = int(ml["compact_stride"])
-    for g in range(world):
-        got = {}
-        for form in (0, 3):
-            pe = E.Pipeline(J, B, 4, R, n_chunks=1, rank=g, world=world, with_witness=False, with_commit=False, subchain_form=form)
-            pe.set_allgather(lambda send, recv, stream: None) if world > 1 else None
-            pe.upload_workload(w)
-            pe.step(); pe.step(); pe.join()
-            res = pe.download() if world == 1 else None
-            got[form] = (pe.buffer(0, E.BUF_COMPACT).cpu().numpy().copy(), pe.buffer(0, E.BUF_HASHES).cpu().numpy().copy(),
-                         pe.buffer(0, E.BUF_RECORDS).cpu().numpy().copy(), res)
-            pe.close()
-        jc = J // world
-        a, b = got[0], got[3]
-        assert (a[1] == b[1]).all(), "header hashes differ"
-        if not (a[0] == b[0]).all():
-            d = np.nonzero(a[0] != b[0])[0]
-            job, off = int(d[0]) // cs, int(d[0]) % cs
-            raise AssertionError(f"compact witnesses differ at {d.size} bytes; first: job {job} byte {off} (rank {g})")
-        assert (a[2] == b[2]).all(), "records differ"
-        if world == 1:
-            assert a[3]["output64"].tobytes() == b[3]["output64"].tobytes() and (a[3]["range_status"] == b[3]["range_status"]).all()
-            assert a[3]["assemble_status"] == b[3]["assemble_status"] and a[3]["header_status"] == b[3]["header_status"] == 0
-            # and the oracle: compact witness of every job of every range
-            for r in range(R):
-                ctx = w.ranges[r:r + 1].copy()
-                rc, ref = oracle.prove_data_commitment(J, B, ctx, w.headers[r], int(w.first_height[r]), int(w.latest[r]), want_witness=True)
-                mine = a[0][r * J * cs:(r + 1) * J * cs]
-                want = ref["compact"][:J * cs]
-                if not (mine == want).all():
-                    d = np.nonzero(mine != want)[0]
-                    raise AssertionError(f"range {r}: compact witness differs from the oracle at {d.size} bytes; first: job {int(d[0]) // cs} byte {int(d[0]) % cs}")
-                assert bool(a[3]["range_status"][r]) == (rc != T.OK), (r, rc, a[3]["range_status"][r])
-    torch.cuda.empty_cache()
-
-
-def test_map_groups_reports_a_chain_head_below_two():
-    from blobstreamx_amd import engine as E
-    J, B, R = 2, 32, 2
-    w = synth.Workload(77, R, J, B, v=4)
-    w.latest[1] = 1
-    for form in (0, 3):
-        pe = E.Pipeline(J, B, 4, R, n_chunks=1, with_witness=False, with_commit=False, subchain_form=form)
-        pe.upload_workload(w)
-        pe.step()
-        assert pe.download()["assemble_status"] & 4, form
-        pe.close()
