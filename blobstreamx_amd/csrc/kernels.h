@@ -36,10 +36,6 @@ hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint3
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
                                 uint8_t*, uint32_t*, const uint8_t*, const uint8_t*);
 hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*, uint32_t);
-bool bsxk_map_groups_fits(uint32_t B, uint32_t job_count, uint64_t hpr);
-hipError_t bsxk_map_groups(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const uint64_t*, const bsx_header*, uint64_t,
-                           uint8_t*, uint8_t*, uint32_t*, const uint8_t*, uint32_t);
-hipError_t bsxk_prove_subchain_tail(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const uint64_t*, uint8_t*, bsx_subchain*);
 hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
 hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_subchain*, const uint8_t*,
                          uint8_t*, uint32_t*, uint8_t*, uint32_t);

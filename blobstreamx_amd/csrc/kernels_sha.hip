@@ -405,8 +405,6 @@ struct SubchainArgs {
     uint32_t compact_stride, off_words, off_bools;
     bsx_subchain* records;
     uint32_t level, width, level_off;        // k_tree_level: nodes per job at this level, offset of the level in inner[]/node[]
-    uint32_t job_first;                      // k_batch_finish<2>: global index of a range's first job in this call
-    const uint64_t* latest;                  // k_batch_finish<2>: chain heads (the hint's clamp, input.rs:160-162)
 };
 
 // dword k of a byte region starting at global byte address p (2-byte aligned): funnel of two aligned dwords
@@ -574,12 +572,8 @@ constexpr uint32_t BF_TOP_WIDTH = 8;
 // the slot's data-root tuple and its leaf hash (what k_slot_hashes<false> does), then EVERY level of the commitment tree
 // through LDS, then the predicates.  The separate launches (k_slot_hashes, one k_tree_level per wide level) each held a few
 // compressions per lane and cost 25-45 us of launch gap and memory round trips: 0.23 -> 0.1 ms per 262,144 slots.
-// MODE 2 (behind k_map_groups, which has hashed the tuples and the whole tree): predicates, words, bools, the job tail and the record
-// only; it also writes what the hint leaves at the head of the witness — ctx hashes and block numbers, batch bounds, and zero
-// start / end headers for a batch the hint serves no header for (input.rs:246-262) — since k_assemble_inputs does not run.
-template <int MODE>
+template <bool FUSED>
 __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) {
-    constexpr bool FUSED = MODE == 1, PRED_ONLY = MODE == 2;
     BSX_CHAIN_PRIO();
     __shared__ uint32_t job_fail[BF_THREADS];
     __shared__ uint32_t job_first_bad[BF_THREADS];
@@ -603,34 +597,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const bsx_shared_ctx* rg = a.ranges + q / a.job_count;
     const uint64_t E = rg->end_block;
     uint64_t batch_start, batch_end, temp_end, end_block_num;
-    if (PRED_ONLY) {
-        // batch bounds from the job index (builder.rs:315-322): nobody has written the words yet
-        const uint64_t S = rg->start_block;
-        batch_start = S + (uint64_t)(a.job_first + q % a.job_count) * B;
-        batch_end = batch_start + B;
-        temp_end = (batch_end < E) ? batch_end : E;
-        end_block_num = (temp_end < batch_start) ? batch_start : temp_end;
-        if (live && i == 0) {
-            const uint64_t latest = a.latest[q / a.job_count], safe = latest - 2;
-            const uint64_t req_end = batch_end < safe ? batch_end : safe;
-            uint32_t* c32 = reinterpret_cast<uint32_t*>(cw);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                c32[k] = reinterpret_cast<const uint32_t*>(rg->start_header_hash)[k];
-                c32[8 + k] = reinterpret_cast<const uint32_t*>(rg->end_header_hash)[k];
-            }
-            if (!(batch_start < req_end)) {                     // input.rs:249: dummy (zero) start / end headers
-#pragma unroll
-                for (int k = 0; k < 16; k++) c32[16 + k] = 0u;
-            }
-            W[BSX_W_CTX_START] = (uint32_t)S; W[BSX_W_CTX_START + 1] = (uint32_t)(S >> 32);
-            W[BSX_W_CTX_END] = (uint32_t)E; W[BSX_W_CTX_END + 1] = (uint32_t)(E >> 32);
-            W[BSX_W_BATCH_START] = (uint32_t)batch_start; W[BSX_W_BATCH_START + 1] = (uint32_t)(batch_start >> 32);
-            W[BSX_W_BATCH_END] = (uint32_t)batch_end; W[BSX_W_BATCH_END + 1] = (uint32_t)(batch_end >> 32);
-        }
-    } else {
-        batch_bounds(W, E, batch_start, batch_end, temp_end, end_block_num);
-    }
+    batch_bounds(W, E, batch_start, batch_end, temp_end, end_block_num);
     const uint64_t curr_idx = batch_start + i;                       // builder.rs:182 / :134
     Digest tleaf = Digest{};
     if (FUSED && live) {
@@ -665,12 +632,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const bool is_last = (last_to_process == curr_idx);              // :185
     const uint8_t* slots = cw + bsx_off_slots(B);
     // curr_header entering slot i = start_header (i == 0 or m == 0) else lb_root of slot min(i, m) - 1
-    Digest start_header = load_digest_global(cw + bsx_off_start_header());
-    if (PRED_ONLY) {                                 // a batch without headers: zero, whatever an earlier step left there (lane 0 stores it)
-        const uint64_t latest = a.latest[q / a.job_count], safe = latest - 2;
-        const uint64_t req_end = batch_end < safe ? batch_end : safe;
-        if (!(batch_start < req_end)) start_header = Digest{};
-    }
+    const Digest start_header = load_digest_global(cw + bsx_off_start_header());
     Digest curr_before = start_header, curr_after = start_header;
     if (i > 0 && m > 0) curr_before = load_digest_global(slots + BSX_SLOT_BYTES * (min(i, m) - 1) + 160 + 128);
     if (m > 0) curr_after = load_digest_global(slots + BSX_SLOT_BYTES * (min(i + 1, m) - 1) + 160 + 128);
@@ -719,10 +681,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     if (live && i == 0) job_nb[jl] = nb_enabled;
     __syncthreads();
     Digest root = start_header;
-    if (PRED_ONLY) {
-        // the tree is k_map_groups': the root is its last selected node (B = 1: the slot's leaf hash)
-        if (live && i == 0) root = load_digest_global(B > 1 ? cw + bsx_off_nodes(B) + 32 * (B - 2) : cw + bsx_off_leaf_hashes(B));
-    } else if (B > 1) {
+    if (B > 1) {
         const uint32_t q0 = (uint32_t)(gs0 / B), jobs_here = BF_THREADS / B;
         uint32_t level = a.level, level_off = a.level_off, cur = 0;
         for (uint32_t width = a.width; width >= 1; width /= 2, level++) {
@@ -759,15 +718,10 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     }
     // batch tail + record (builder.rs:229-270): one lane per job
     if (live && i == 0) {
-        if (B == 1 && !PRED_ONLY) root = FUSED ? tleaf : load_digest_global(cw + bsx_off_leaf_hashes(B));
+        if (B == 1) root = FUSED ? tleaf : load_digest_global(cw + bsx_off_leaf_hashes(B));
         const bool curr_enabled_end = batch_enabled && !(jstar < (uint64_t)B);   // enabled after the last slot
         const Digest curr_final = (m > 0) ? load_digest_global(slots + BSX_SLOT_BYTES * (m - 1) + 160 + 128) : start_header;
-        Digest end_header = load_digest_global(cw + bsx_off_end_header());
-        if (PRED_ONLY) {
-            const uint64_t latest = a.latest[q / a.job_count], safe = latest - 2;
-            const uint64_t req_end = batch_end < safe ? batch_end : safe;
-            if (!(batch_start < req_end)) end_header = Digest{};
-        }
+        const Digest end_header = load_digest_global(cw + bsx_off_end_header());
         const bool last_disabled = !curr_enabled_end;                     // :229
         const bool last_matches = digest_eq(curr_final, end_header);      // :230
         const bool end_header_check = last_disabled || last_matches;      // :231
@@ -802,285 +756,6 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
         out->assert_fail = fail;
         out->first_bad_slot = first_bad;
         out->_pad = 0;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------ k_map_groups (round 4)
-// The compact path's ALU work in ONE kernel: tendermint Header::hash of every header (k_header_merkle's four sub-tree roles), the hint
-// (input.rs:149-271: each header's tree nodes ARE the inclusion proofs and path digests of the slots it serves, written straight
-// into the map jobs' compact witnesses with the hint's clamp / zero-padding rules), the data-root tuples + leaf hashes and the whole
-// commitment tree of every job (builder.rs:134-147).  Round 3 ran these as k_header_merkle -> k_assemble_inputs -> k_batch_finish:
-// the two followers hash little (4 of the 45 compressions per header) but their waves — parked on barriers and memory round trips at
-// 128 registers each — displaced the hashing kernel's waves of the OTHER buffer set (k_header_merkle 0.84 ms alone, 1.29 ms beside
-// them: profiles/r3_compact_kernel_avg_steady_state.txt), and the per-header digest arrays made a 0.5 GB round trip through HBM per
-// step.  Here a workgroup takes a QUAD of 4 consecutive 64-header groups of one range: four passes of the four roles (rotating, so
-// every wave does each role once: 41 compressions per lane), then the quad's 256 tuple leaf hashes on all four waves, then the tree
-// levels dealt densely over the lanes (128 / 64 / 32 ... nodes) — 46.5 wave-compressions per 64 headers against 45 of pure work.
-// What needs another workgroup's header (a job's last slot takes its last_block_id proof from the NEXT group's first header: that
-// lane writes it, nobody here reads it) or the target header's hash (H_E) is left to the predicate kernel k_batch_finish<2> behind.
-// Header k (relative to this rank's slice) of range r serves: the data_hash proof + path of slot k % B of job k / B, and the
-// last_block_id proof + path of slot (k - 1) % B of job (k - 1) / B; the range's extra header (k = jc * B) is taken by tail items
-// (one lane per range).  Requires B | 64 and 64 | jc * B (the launcher falls back to the three-kernel form otherwise).
-struct MapGroupArgs {
-    uint32_t n_ranges, batch, job_first, job_count;
-    uint32_t groups_per_range, quad;             // 64-header groups per range; groups per work item (<= 4)
-    uint32_t items_main, items_tail;
-    const bsx_shared_ctx* ranges;
-    const uint64_t* latest;
-    const bsx_header* headers;
-    uint64_t hpr;                                // headers per range held: job_count * batch + 1
-    uint8_t* hashes;                             // [n_ranges * hpr][32]
-    uint8_t* compact;
-    uint32_t compact_stride, off_words, off_bools;
-    uint32_t* status;                            // [0]: bit 0 = bad header; [1]: bit 1 = inclusion-proof leaf not 34 / 72 bytes, bit 2 = latest < 2
-    const uint8_t* zero_paths;                   // path digests of the all-zero proofs: dh[5] then lb[5]
-};
-
-// where header k of a range lands: slot of its data_hash proof (d) and of its last_block_id proof (l)
-struct MgDest {
-    uint8_t *cw_d, *cw_l;       // compact witness of the job, or nullptr when header k serves no such slot
-    uint32_t i_d, i_l;          // slot index inside the job
-    bool real_d, real_l;        // false: the hint zero-pads the slot (input.rs:220-239) — zeros / the zero proof's path digests
-};
-__device__ __forceinline__ uint64_t mg_n_real(uint64_t S, uint32_t j, uint32_t B, uint64_t latest) {
-    const uint64_t bs = S + (uint64_t)j * B, be = bs + B, safe = latest - 2;     // builder.rs:315-322, input.rs:160-161
-    const uint64_t req_end = be < safe ? be : safe;                              // input.rs:162
-    return bs <= req_end ? req_end - bs : 0;                                     // input.rs:167-198
-}
-__device__ __forceinline__ MgDest mg_dest(const MapGroupArgs& a, uint32_t r, uint64_t k, uint64_t S, uint64_t latest) {
-    MgDest d;
-    const uint32_t B = a.batch, jc = a.job_count;
-    d.cw_d = d.cw_l = nullptr;
-    d.i_d = d.i_l = 0;
-    d.real_d = d.real_l = false;
-    if (k < (uint64_t)jc * B) {
-        const uint32_t jl = (uint32_t)(k / B);
-        d.i_d = (uint32_t)(k % B);
-        d.cw_d = a.compact + ((uint64_t)r * jc + jl) * a.compact_stride;
-        d.real_d = d.i_d < mg_n_real(S, a.job_first + jl, B, latest);
-    }
-    if (k >= 1) {
-        const uint32_t jl = (uint32_t)((k - 1) / B);
-        d.i_l = (uint32_t)((k - 1) % B);
-        d.cw_l = a.compact + ((uint64_t)r * jc + jl) * a.compact_stride;
-        d.real_l = d.i_l < mg_n_real(S, a.job_first + jl, B, latest);
-    }
-    return d;
-}
-// a digest, or the zero proof's digest at `zp` when the slot is padding
-__device__ __forceinline__ void mg_store(uint8_t* dst, const Digest& d, bool real, const uint8_t* zp) {
-    if (real) store_digest_u(dst, d);
-    else { stu4(dst, ldu4(zp)); stu4(dst + 16, ldu4(zp + 16)); }
-}
-__device__ __forceinline__ void mg_store_aunt(uint8_t* dst, const Digest& d, bool real) {      // the zero proof's aunts are zero
-    if (real) store_digest_u(dst, d);
-    else { const uint4 z = make_uint4(0, 0, 0, 0); stu4(dst, z); stu4(dst + 16, z); }
-}
-
-constexpr int MG_THREADS = 256;
-__global__ __launch_bounds__(MG_THREADS, 4) void k_map_groups(MapGroupArgs a) {
-    __shared__ uint32_t sub2[2][3][HM_GROUP * HM_LDS_STRIDE];
-    __shared__ uint32_t leafbuf[256 * 8];          // data hashes (LE dwords) of the quad's 256 headers, then their tuple leaf hashes
-    __shared__ uint32_t nodebuf[2][128 * 8];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-    const uint32_t B = a.batch, jc = a.job_count;
-    uint32_t pass = 0;
-    const uint32_t quads_per_range = a.groups_per_range / a.quad;
-    for (uint32_t item = blockIdx.x; item < a.items_main + a.items_tail; item += gridDim.x) {
-        const bool tail = item >= a.items_main;
-        const uint32_t n_pass = tail ? 1u : a.quad;
-        uint32_t r_item = 0, g0 = 0;
-        if (!tail) { r_item = item / quads_per_range; g0 = (item % quads_per_range) * a.quad; }
-        for (uint32_t gq = 0; gq < n_pass; gq++, pass ^= 1) {
-            uint32_t (*sub)[HM_GROUP * HM_LDS_STRIDE] = sub2[pass];
-            const uint32_t role = (wave + gq) & 3;                       // wave-uniform; every wave takes each role once per quad
-            // which header this lane hashes
-            uint32_t r;
-            uint64_t k;
-            bool live;
-            if (tail) { r = (item - a.items_main) * 64 + lane; k = (uint64_t)jc * B; live = r < a.n_ranges; }
-            else { r = r_item; k = (uint64_t)(g0 + gq) * 64 + lane; live = true; }
-            const uint32_t rr = live ? r : 0;
-            const uint64_t hidx = (uint64_t)rr * a.hpr + k;
-            const uint8_t* my = reinterpret_cast<const uint8_t*>(a.headers + hidx);
-            const uint32_t* rec = reinterpret_cast<const uint32_t*>(my);
-            const uint64_t S = a.ranges[rr].start_block, latest = a.latest[rr];
-            const MgDest dst = mg_dest(a, rr, k, S, latest);
-            uint8_t* const dh_rec = dst.cw_d ? dst.cw_d + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * dst.i_d : nullptr;    // aunts 0, leaf 128
-            uint8_t* const lb_rec = dst.cw_l ? dst.cw_l + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * dst.i_l : nullptr;
-            uint8_t* const dh_path = dst.cw_d ? dst.cw_d + bsx_off_slots(B) + BSX_SLOT_BYTES * dst.i_d : nullptr;         // 5 digests
-            uint8_t* const lb_path = dst.cw_l ? dst.cw_l + bsx_off_slots(B) + BSX_SLOT_BYTES * dst.i_l + 160 : nullptr;
-            const bool wd = live && dh_rec != nullptr, wl = live && lb_rec != nullptr;
-            const bool rd = dst.real_d, rl = dst.real_l;
-            const uint8_t* zp = a.zero_paths;
-            bool bad = false, bad_leaf = false;
-            Digest top;
-            const uint32_t lens = rec[role];
-            if (role == 0) {
-                const Digest L0 = leaf_from_global<6>(rec + 4, hm_len(lens, 0, 24, bad));
-                const Digest L1 = leaf_from_global<13>(rec + 10, hm_len(lens, 1, 52, bad));
-                const Digest n01 = inner_hash(L0, L1);
-                const Digest L2 = leaf_from_global<3>(rec + 23, hm_len(lens, 2, 12, bad));
-                const Digest L3 = leaf_from_global<5>(rec + 26, hm_len(lens, 3, 20, bad));
-                top = inner_hash(n01, inner_hash(L2, L3));               // n0123: aunt 2 of both proofs
-                if (wd) mg_store_aunt(dh_rec + 64, top, rd);
-                if (wl) mg_store_aunt(lb_rec + 64, top, rl);
-            } else if (role == 1) {
-                Digest L4;
-                {
-                    uint32_t d[19];
-#pragma unroll
-                    for (int j = 0; j < 19; j++) d[j] = rec[31 + j];
-                    const int l4 = hm_len(lens, 4, 76, bad);
-                    L4 = (l4 <= 54) ? leaf_hash_1block(d, l4) : leaf_hash_2block(d, l4);
-                    if (wl) {                                            // last_block_id proof leaf of slot k - 1 (72 bytes; input.rs:187-197)
-                        if (rl && l4 != (int)BSX_PROTOBUF_BLOCK_ID_SIZE) bad_leaf = true;
-                        uint8_t* lf = lb_rec + 128;
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            stu4(lf + 16 * q, rl ? make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]) : make_uint4(0, 0, 0, 0));
-                        *reinterpret_cast<uint2*>(lf + 64) = rl ? make_uint2(d[16], d[17]) : make_uint2(0, 0);
-                    }
-                }
-                if (wl) mg_store(lb_path, L4, rl, zp + 160);
-                const Digest L5 = leaf_from_global<9>(rec + 50, hm_len(lens, 5, 36, bad));
-                if (wl) mg_store_aunt(lb_rec, L5, rl);                   // index 4: [L5, n67, n0123, right]
-                const Digest n45 = inner_hash(L4, L5);
-                if (wl) mg_store(lb_path + 32, n45, rl, zp + 160 + 32);
-                if (wd) mg_store_aunt(dh_rec + 32, n45, rd);             // index 6: [L7, n45, n0123, right]
-                Digest L6;
-                {
-                    uint32_t d[14];
-#pragma unroll
-                    for (int j = 0; j < 14; j++) d[j] = (j < 9) ? rec[59 + j] : 0u;
-                    const int l6 = hm_len(lens, 6, 36, bad);
-                    L6 = leaf_hash_1block(d, l6);                        // data_hash
-                    if (wd) {                                            // data_hash proof leaf of slot k (34 bytes; input.rs:172-181)
-                        if (rd && l6 != (int)BSX_PROTOBUF_HASH_SIZE) bad_leaf = true;
-                        uint8_t* lf = dh_rec + 128;
-                        stu4(lf, rd ? make_uint4(d[0], d[1], d[2], d[3]) : make_uint4(0, 0, 0, 0));
-                        stu4(lf + 16, rd ? make_uint4(d[4], d[5], d[6], d[7]) : make_uint4(0, 0, 0, 0));
-                        *reinterpret_cast<uint16_t*>(lf + 32) = rd ? (uint16_t)d[8] : (uint16_t)0;
-                    }
-                    // data_hash = leaf[2..34] (builder.rs:250) as LE dwords, for the tuple stage
-                    if (!tail) {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) leafbuf[(gq * 64 + lane) * 8 + q] = rd ? funnel_r(d[q + 1], d[q], 16) : 0u;
-                    }
-                }
-                if (wd) mg_store(dh_path, L6, rd, zp);
-                const Digest L7 = leaf_from_global<9>(rec + 68, hm_len(lens, 7, 36, bad));
-                if (wd) mg_store_aunt(dh_rec, L7, rd);
-                const Digest n67 = inner_hash(L6, L7);
-                if (wd) mg_store(dh_path + 32, n67, rd, zp + 32);
-                if (wl) mg_store_aunt(lb_rec + 32, n67, rl);
-                top = inner_hash(n45, n67);                              // n4567
-                if (wd) mg_store(dh_path + 64, top, rd, zp + 64);
-                if (wl) mg_store(lb_path + 64, top, rl, zp + 160 + 64);
-            } else if (role == 2) {
-                const Digest L8 = leaf_from_global<9>(rec + 77, hm_len(lens, 8, 36, bad));
-                const Digest L9 = leaf_from_global<9>(rec + 86, hm_len(lens, 9, 36, bad));
-                const Digest n89 = inner_hash(L8, L9);
-                const Digest L10 = leaf_from_global<9>(rec + 95, hm_len(lens, 10, 36, bad));
-                const Digest L11 = leaf_from_global<9>(rec + 104, hm_len(lens, 11, 36, bad));
-                top = inner_hash(n89, inner_hash(L10, L11));             // n8_11
-            } else {
-                const Digest L12 = leaf_from_global<9>(rec + 113, hm_len(lens, 12, 36, bad));
-                const Digest L13 = leaf_from_global<6>(rec + 122, hm_len(lens, 13, 24, bad));
-                top = inner_hash(L12, L13);                              // n12_13
-            }
-            if (role != 3) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) sub[role][lane * HM_LDS_STRIDE + q] = top.w[q];
-            }
-            __syncthreads();
-            if (role == 3) {
-                Digest x, y;
-#pragma unroll
-                for (int q = 0; q < 8; q++) { x.w[q] = sub[0][lane * HM_LDS_STRIDE + q]; y.w[q] = sub[1][lane * HM_LDS_STRIDE + q]; }
-                const Digest left = inner_hash(x, y);
-#pragma unroll
-                for (int q = 0; q < 8; q++) x.w[q] = sub[2][lane * HM_LDS_STRIDE + q];
-                const Digest right = inner_hash(x, top);
-                const Digest root = inner_hash(left, right);
-                if (live) store_digest_u(a.hashes + hidx * 32, root);
-                if (wd) { mg_store_aunt(dh_rec + 96, right, rd); mg_store(dh_path + 96, left, rd, zp + 96); mg_store(dh_path + 128, root, rd, zp + 128); }
-                if (wl) { mg_store_aunt(lb_rec + 96, right, rl); mg_store(lb_path + 96, left, rl, zp + 160 + 96); mg_store(lb_path + 128, root, rl, zp + 160 + 128); }
-                if (live) {
-                    // the hint's start_header / end_header (input.rs:246-262) = hashes of the headers at batch_start and at req_end
-                    if (dst.cw_d && dst.i_d == 0 && mg_n_real(S, a.job_first + (uint32_t)(k / B), B, latest) > 0)
-                        store_digest_global(dst.cw_d + bsx_off_start_header(), root);
-                    if (dst.cw_d) {                                      // req_end inside this header's own job (a clamped batch)
-                        const uint64_t nr = mg_n_real(S, a.job_first + (uint32_t)(k / B), B, latest);
-                        if (nr > 0 && nr < B && dst.i_d == nr) store_digest_global(dst.cw_d + bsx_off_end_header(), root);
-                    }
-                    if (dst.cw_l && dst.i_l == B - 1 && mg_n_real(S, a.job_first + (uint32_t)((k - 1) / B), B, latest) == B)
-                        store_digest_global(dst.cw_l + bsx_off_end_header(), root);      // a full batch ends at the next job's first header
-                }
-            }
-            const unsigned long long mb = __ballot(live && bad), ml = __ballot(live && bad_leaf);
-            if (lane == 0 && a.status) {
-                if (mb) atomicOr(a.status, 1u);
-                if (ml) atomicOr(a.status + 1, 2u);
-            }
-        }
-        if (tail) continue;                                              // block-uniform
-        __syncthreads();
-        // ---- the quad's 256 data-root tuples and their leaf hashes (builder.rs:82-103,134-137,144-147): one per lane, all four waves
-        const uint64_t S = a.ranges[r_item].start_block, E = a.ranges[r_item].end_block, latest = a.latest[r_item];
-        const uint32_t n_hdr = a.quad * 64;                              // headers (= slots) of this item
-        const uint64_t k0 = (uint64_t)g0 * 64;
-        if (tid == 0 && latest < 2 && a.status) atomicOr(a.status + 1, 4u);
-        if (tid < n_hdr) {
-            const uint64_t k = k0 + tid;
-            const uint32_t jl = (uint32_t)(k / B), i = (uint32_t)(k % B);
-            uint8_t* cw = a.compact + ((uint64_t)r_item * jc + jl) * a.compact_stride;
-            const uint64_t height = S + (uint64_t)(a.job_first + jl) * B + i;        // builder.rs:134 curr_idx
-            uint32_t t[16];
-#pragma unroll
-            for (int q = 0; q < 6; q++) t[q] = 0;
-            t[6] = (uint32_t)(height >> 32);
-            t[7] = (uint32_t)height;
-#pragma unroll
-            for (int q = 0; q < 8; q++) t[8 + q] = bswap32(leafbuf[tid * 8 + q]);
-            const Digest tleaf = leaf_hash_tuple(t);
-            uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                stu4(tp + 16 * q, make_uint4(bswap32(t[4 * q]), bswap32(t[4 * q + 1]), bswap32(t[4 * q + 2]), bswap32(t[4 * q + 3])));
-            store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
-#pragma unroll
-            for (int q = 0; q < 8; q++) leafbuf[tid * 8 + q] = tleaf.w[q];       // in place: this lane's own slot
-        }
-        __syncthreads();
-        // ---- compute_root_from_leaves [UPSTREAM plonky2x; SURVEY App. B], every level of every job of the quad, nodes dealt densely
-        if (B > 1) {
-            const uint32_t jobs_here = n_hdr / B;
-            uint32_t level = 1, level_off = 0, cur = 0;
-            for (uint32_t width = B / 2; width >= 1; width /= 2, level++) {
-                const uint32_t jn = tid / width, tt = tid % width;
-                if (jn < jobs_here) {
-                    const uint32_t jl = (uint32_t)(k0 / B) + jn;
-                    uint8_t* cwn = a.compact + ((uint64_t)r_item * jc + jl) * a.compact_stride;
-                    // nb_enabled_leaves of the job (builder.rs:119-128): end_block_num - batch_start, low limb
-                    const uint64_t bs = S + (uint64_t)(a.job_first + jl) * B, be = bs + B;
-                    const uint64_t temp_end = be < E ? be : E, ebn = temp_end < bs ? bs : temp_end;
-                    const uint32_t nb = (uint32_t)(ebn - bs);
-                    Digest l, rr2;
-                    const uint32_t* src = (level == 1) ? &leafbuf[(jn * B + 2 * tt) * 8] : &nodebuf[cur][(jn * 2 * width + 2 * tt) * 8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) { l.w[q] = src[q]; rr2.w[q] = src[8 + q]; }
-                    const Digest node = tree_node(cwn, a.off_bools, B, level, level_off, tt, nb, l, rr2);
-                    uint32_t* d = &nodebuf[cur ^ 1][(jn * width + tt) * 8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) d[q] = node.w[q];
-                }
-                __syncthreads();
-                cur ^= 1;
-                level_off += width;
-            }
-        }
     }
 }
 
@@ -1309,14 +984,14 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     const uint32_t n_jobs = n_ranges * job_count;
-    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0, 0, nullptr};
+    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
     const uint64_t slots = (uint64_t)n_jobs * B;
     // BSX_SUBCHAIN_FUSED=0 / 1 (experiments) overrides BSX_SUBCHAIN_SEPARATE_LAUNCHES
     static const long env_fuse = bsx_knob("BSX_SUBCHAIN_FUSED", -1);
     const bool fuse = env_fuse >= 0 ? env_fuse != 0 : !(flags & BSX_SUBCHAIN_SEPARATE_LAUNCHES);
     if ((flags & BSX_SUBCHAIN_PATHS_FROM_HINT) && fuse) {
         a.level = 1; a.width = B / 2; a.level_off = 0;        // every level inside the one launch
-        hipLaunchKernelGGL(k_batch_finish<1>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_batch_finish<true>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
         return hipGetLastError();
     }
     if (flags & BSX_SUBCHAIN_PATHS_FROM_HINT)
@@ -1332,43 +1007,7 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     }
     // the remaining levels (width <= BF_TOP_WIDTH) run inside k_batch_finish
     a.level = level; a.width = B / 2 < BF_TOP_WIDTH ? B / 2 : BF_TOP_WIDTH; a.level_off = level_off;
-    hipLaunchKernelGGL(k_batch_finish<0>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
-    return hipGetLastError();
-}
-// The compact path in two launches: k_map_groups (hashing + hint + tuples + tree) and k_batch_finish<2> (predicates, tail, records).
-// Returns hipErrorNotSupported when the shape does not fit (B must divide 64, 64 must divide job_count * B, headers_per_range must
-// be exactly job_count * B + 1): the caller then runs header_merkle / assemble_inputs / prove_subchain.
-bool bsxk_map_groups_fits(uint32_t B, uint32_t job_count, uint64_t hpr) {
-    return B >= 1 && B <= 64 && (64 % B) == 0 && (((uint64_t)job_count * B) % 64) == 0 && hpr == (uint64_t)job_count * B + 1;
-}
-hipError_t bsxk_map_groups(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_t job_first, uint32_t job_count, const bsx_shared_ctx* ranges,
-                           const uint64_t* latest, const bsx_header* headers, uint64_t hpr, uint8_t* hashes, uint8_t* compact, uint32_t* status,
-                           const uint8_t* zero_paths, uint32_t max_wgs) {
-    if (!n_ranges || !job_count) return hipSuccess;
-    if (!bsxk_map_groups_fits(B, job_count, hpr)) return hipErrorNotSupported;
-    const bsx_witness_layout L = bsx_map_layout(B);
-    MapGroupArgs a{};
-    a.n_ranges = n_ranges; a.batch = B; a.job_first = job_first; a.job_count = job_count;
-    a.groups_per_range = (uint32_t)((uint64_t)job_count * B / 64);
-    a.quad = a.groups_per_range % 4 == 0 ? 4 : a.groups_per_range % 2 == 0 ? 2 : 1;
-    a.items_main = n_ranges * (a.groups_per_range / a.quad);
-    a.items_tail = (n_ranges + 63) / 64;
-    a.ranges = ranges; a.latest = latest; a.headers = headers; a.hpr = hpr; a.hashes = hashes; a.compact = compact;
-    a.compact_stride = L.compact_stride; a.off_words = L.off_words; a.off_bools = L.off_bools; a.status = status; a.zero_paths = zero_paths;
-    uint32_t grid = a.items_main + a.items_tail;
-    if (max_wgs && grid > max_wgs) grid = max_wgs;
-    hipLaunchKernelGGL(k_map_groups, dim3(grid), dim3(MG_THREADS), 0, s, a);
-    return hipGetLastError();
-}
-// predicates + job tail + records behind bsxk_map_groups (k_batch_finish<2>)
-hipError_t bsxk_prove_subchain_tail(hipStream_t s, uint32_t n_ranges, uint32_t B, uint32_t job_first, uint32_t job_count, const bsx_shared_ctx* ranges,
-                                    const uint64_t* latest, uint8_t* compact, bsx_subchain* records) {
-    if (!n_ranges || !job_count) return hipSuccess;
-    const bsx_witness_layout L = bsx_map_layout(B);
-    const uint32_t n_jobs = n_ranges * job_count;
-    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0, job_first, latest};
-    const uint64_t slots = (uint64_t)n_jobs * B;
-    hipLaunchKernelGGL(k_batch_finish<2>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_batch_finish<false>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, uint64_t stride_range,

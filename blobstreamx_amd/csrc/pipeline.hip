@@ -85,7 +85,6 @@ struct bsx_pipeline {
     uint32_t last_set = 0;
     uint64_t hpr = 0, hfr = 0;
     bool with_witness = false, with_commit = false, with_caps = false, keyed = false, commit_beside_hash = false, fused_hint = true;
-    bool map_groups = false;                 // hashing + hint + tuples + tree in ONE launch (k_map_groups), predicates behind it
     uint32_t subchain_flags = 0, merkle_wgs = 0;
     uint32_t leaf_len = 0, cap_height = 0, n_leaves = 0;
     uint64_t tree_digests = 0;
@@ -375,18 +374,10 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
     // (two header hashings sharing the GPU, then two chains leaving it idle); the token lets exactly ONE header hashing run
     // at a time, back to back across chunks, sets and steps, with the other chunks' chains filling in beside it.
     if (p->compact_tokens && p->merkle_token) HIPCHK(hipStreamWaitEvent(st, p->merkle_token, 0));
-    auto* hdrs = reinterpret_cast<const bsx_header*>(c.headers_all);
-    if (p->map_groups) {
-        // the (trusted, target) header pairs of the commit check first (2 R headers: a handful of workgroups), so that the side
-        // stream's inputs do not wait for the big launch; then every map job's hashing + hint + tuples + tree in ONE kernel
-        if (commit)
-            HIPCHK(bsxk_header_merkle(st, hdrs + c.nh_main, c.nh_skip, c.hashes_all + c.nh_main * 32, nullptr, nullptr, nullptr, c.status, 0, 0));
-    } else {
-        HIPCHK(bsxk_header_merkle(st, hdrs, commit ? c.nh_all : c.nh_main, c.hashes_all, c.dh_aunts,
-                                  c.lb_aunts, c.paths, c.status, p->merkle_wgs, p->compact_tokens ? 1u : 0u));
-        HIPCHK(hipEventRecord(c.ev_merkle, st));
-        if (p->compact_tokens) p->merkle_token = c.ev_merkle;
-    }
+    HIPCHK(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(c.headers_all), commit ? c.nh_all : c.nh_main, c.hashes_all, c.dh_aunts,
+                              c.lb_aunts, c.paths, c.status, p->merkle_wgs, p->compact_tokens ? 1u : 0u));
+    HIPCHK(hipEventRecord(c.ev_merkle, st));
+    if (p->compact_tokens) p->merkle_token = c.ev_merkle;
     if (commit) {
         c.parity ^= 1;
         if (c.commit_done_valid[c.parity]) HIPCHK(hipStreamWaitEvent(st, c.ev_commit_done[c.parity], 0));   // the check two steps ago read these
@@ -402,20 +393,6 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
             RET(commit_part(p, c, c.side, true, true));
         }
     }
-    if (p->map_groups) {
-        HIPCHK(bsxk_map_groups(st, RT, B, p->jf, jc, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), reinterpret_cast<const uint64_t*>(c.latest), hdrs,
-                               p->hpr, c.hashes_all, c.compact, c.status, p->ctx->zero_paths, p->merkle_wgs));
-        HIPCHK(hipEventRecord(c.ev_merkle, st));
-        if (p->compact_tokens) p->merkle_token = c.ev_merkle;
-        HIPCHK(hipEventRecord(c.ev_inputs_consumed, st));       // headers_all may be overwritten from here on (input streaming)
-        c.inputs_consumed_valid = true;
-        // ctx.end_header_hash of every range := the hash of its target header wherever it lies in this rank's slice
-        HIPCHK(bsxk_fill_end_hash(st, RT, reinterpret_cast<bsx_shared_ctx*>(c.ranges), c.hashes_all, p->hpr, nullptr, nullptr, nullptr, p->hfr));
-        if (ts) { HIPCHK(hipEventRecord(ts->ev[0], st)); }
-        HIPCHK(bsxk_prove_subchain_tail(st, RT, B, p->jf, jc, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), reinterpret_cast<const uint64_t*>(c.latest),
-                                        c.compact, reinterpret_cast<bsx_subchain*>(c.records)));
-        if (ts) { HIPCHK(hipEventRecord(ts->ev[1], st)); ts->sub = true; }
-    } else {
     // ctx.end_header_hash of every range := the hash of its target header (what builder.skip hands to prove_data_commitment,
     // header_range.rs:42-55) wherever that header lies in this rank's slice: the caller's value is not trusted
     HIPCHK(bsxk_fill_end_hash(st, RT, reinterpret_cast<bsx_shared_ctx*>(c.ranges), c.hashes_all, p->hpr, nullptr, nullptr, nullptr, p->hfr));
@@ -428,7 +405,6 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
     HIPCHK(bsxk_prove_subchain(st, RT, B, jc, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), c.compact, reinterpret_cast<bsx_subchain*>(c.records),
                                p->subchain_flags));
     if (ts) { HIPCHK(hipEventRecord(ts->ev[1], st)); ts->sub = true; }
-    }
     HIPCHK(bsxk_reduce(st, RT, jc, reinterpret_cast<const bsx_subchain*>(c.records), jc, 1, reinterpret_cast<bsx_subchain*>(c.partial),
                        jc > 1 ? c.red_compact_local : nullptr));
     return BSX_OK;
@@ -665,7 +641,7 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     if (cfg->rank >= world || J % world) return fail(BSX_ERR_BAD_ARG, "world %u must divide NB_MAP_JOBS %u and rank %u be below it", world, J, cfg->rank);
     if (!pow2(J / world)) return fail(BSX_ERR_BAD_ARG, "each rank needs a power-of-two slice of the map jobs (the local fold is a subtree of the reference's reduce tree)");
     if (cfg->chain_id_len > 50) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
-    if (cfg->tune_subchain > 3) return fail(BSX_ERR_BAD_ARG, "tune_subchain must be 0 .. 3");
+    if (cfg->tune_subchain > 2) return fail(BSX_ERR_BAD_ARG, "tune_subchain must be 0, 1 or 2");
     if (cfg->n_sets > 8) return fail(BSX_ERR_BAD_ARG, "n_sets must be in 0..8");
     bsx_pipeline* p = new bsx_pipeline();
     p->ctx = ctx;
@@ -694,9 +670,6 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     p->subchain_flags = p->fused_hint ? BSX_SUBCHAIN_PATHS_FROM_HINT : 0;
     const bool beside_expansion = p->with_witness && p->E > 1;
     if (beside_expansion && p->fused_hint) p->subchain_flags |= BSX_SUBCHAIN_SEPARATE_LAUNCHES;
-    // the whole map stage as k_map_groups + k_batch_finish<2> whenever the shape fits (B | 64, 64 | jobs x B): the production shapes
-    // do; tune_subchain 1 / 2 / 3 force the round-3 forms (header_merkle, assemble_inputs, prove_subchain as one / several launches)
-    p->map_groups = p->fused_hint && cfg->tune_subchain == 0 && bsxk_map_groups_fits(B, p->jc, p->hpr);
     if (cfg->tune_subchain == 1) p->subchain_flags &= ~BSX_SUBCHAIN_SEPARATE_LAUNCHES;
     if (cfg->tune_subchain == 2 && p->fused_hint) p->subchain_flags |= BSX_SUBCHAIN_SEPARATE_LAUNCHES;
     if (cfg->tune_merkle_workgroups) {

@@ -711,11 +711,7 @@ typedef struct bsx_pipeline_config {
     uint8_t chain_id[52];
     /* launch forms; results never depend on them.  0 = automatic (the measured choice for the configuration) */
     uint32_t tune_merkle_workgroups;    /* resident workgroups of the header-hashing kernel; 0xffffffff = one per 64 headers */
-    uint32_t tune_subchain;             /* 0 = automatic: the map stage as TWO launches (k_map_groups: header hashing + hint + tuples + tree;
-                                           then predicates and records) whenever BATCH_SIZE divides 64 and 64 divides this rank's
-                                           jobs x BATCH_SIZE — the production shapes; otherwise / 1, 2, 3: header hashing, hint and
-                                           prove_subchain as separate kernels, prove_subchain as one launch (1), its stages in
-                                           separate launches (2), or the form round 3 chose for the configuration (3) */
+    uint32_t tune_subchain;             /* 1 = prove_subchain as one launch, 2 = its stages in separate launches */
     /* Buffer sets (0 / 1 = one): with K sets step i runs on set i mod K, so step i + 1 starts on its own buffers while step i's
      * chain of short kernels drains — software pipelining ACROSS steps, the form for the compact path (no BSX_PIPE_WITNESS),
      * whose step has nothing HBM-bound to hide behind.  Every set holds the same uploaded inputs; results / buffers are those
