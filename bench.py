@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--caps", action="store_true", help="Poseidon Merkle caps of the map-job witnesses from the compact bytes (with --no-witness: instead of the expansion)")
     ap.add_argument("--alternate", type=int, default=1, help="K buffer sets inside the pipeline, step i on set i mod K (pipelining across steps; the compact-only leg uses 2)")
     ap.add_argument("--merkle-wgs", type=int, default=0, help="bsx_pipeline_config.tune_merkle_workgroups (experiments; 0 = automatic)")
-    ap.add_argument("--subchain-form", type=int, default=0, help="bsx_pipeline_config.tune_subchain (experiments; 0 = automatic: k_map_groups; 3 = round 3's kernels)")
+    ap.add_argument("--subchain-form", type=int, default=0, help="bsx_pipeline_config.tune_subchain (experiments; 0 = automatic)")
     ap.add_argument("--no-commit", action="store_true", help="experiments: no target-commit verification (not a valid headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true")

@@ -169,11 +169,19 @@ def test_pipeline_unit_witness_vs_oracle(J, B, V, R, E, streaming):
         p.step()
     res = p.download()
     Rc = R // E
+    nm = J * int(T.map_layout(B)["n_elements"])
     for e in range(E):
         cu, su = p.unit_witness_numpy(e)
+        wm, wr, _ = p.witness_numpy(e)
         for k in range(Rc):
             r = e * Rc + k
             rc, out, wc, ws = _oracle_units(w, r, J, B, V)
+            if k in (0, Rc - 1):          # the streamed-input path had no correctness test — map-job witness too
+                _, _, _, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r],
+                                                  w.trusted[r], want_witness=True)
+                full = oracle.expand_range_witness(J, B, cw)
+                assert first_diff(wm[k * nm:(k + 1) * nm], full[:nm]) is None, (r, "map jobs")
+                assert first_diff(wr[k * (full.size - nm):(k + 1) * (full.size - nm)], full[nm:]) is None, (r, "reduce nodes")
             assert res["output64"][r].tobytes() == out
             want_skip = rc if rc in (T.ERR_BAD_SIGNATURE, T.ERR_VOTING_POWER, T.ERR_ASSERT) else T.OK
             assert int(res["skip_status"][r]) == want_skip or int(res["range_status"][r]) != 0, (r, rc, res["skip_status"][r])
