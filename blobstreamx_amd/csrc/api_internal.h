@@ -52,6 +52,8 @@ struct bsx_ctx {
     uint8_t* zero_paths = nullptr;       // 320 B: path digests of the hint's zero-padded proofs (k_zero_paths)
     uint8_t* keytab = nullptr;           // host tier's persistent fixed-key Ed25519 table (rows survive between calls)
     uint32_t keytab_rows = 0;
+    std::vector<uint8_t> keytab_mirror;  // host copy of the public keys the table's rows were last built for (bsx_header_range)
+    bool keytab_mirror_valid = false;
     uint8_t* btab = nullptr;             // fixed-key Ed25519 table of the base point B (built by bsx_init)
     uint8_t* hstage = nullptr;           // page-locked host staging of the host tier's small inputs / results (SmallIO)
     size_t hstage_cap = 0;

@@ -37,6 +37,8 @@ hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint3
                                 uint8_t*, uint32_t*, const uint8_t*, const uint8_t*);
 hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*, uint32_t);
 hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
+hipError_t bsxk_reduce_finalize(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, bsx_subchain*, uint8_t*, uint32_t, uint32_t, const bsx_shared_ctx*,
+                                const uint8_t*, uint8_t*, uint32_t*);
 hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_subchain*, const uint8_t*,
                          uint8_t*, uint32_t*, uint8_t*, uint32_t);
 hipError_t bsxk_expand_witness(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, uint64_t*);
@@ -58,6 +60,8 @@ hipError_t bsxk_ed25519_btable(hipStream_t, uint8_t*);
 uint64_t bsxk_ed25519_btable_bytes();
 uint64_t bsxk_ed25519_scratch_bytes(uint64_t);
 hipError_t bsxk_commit_tally(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*, const bsxk_unit_dst*);
+// the signature-dependent half of the tally behind an EARLY bsxk_commit_tally(ok = nullptr): verdict bools, signed sums, 2/3 rule
+hipError_t bsxk_commit_sums(hipStream_t, const bsx_validator*, uint32_t, uint32_t, const uint8_t*, const uint8_t*, bsx_commit_result*, const bsxk_unit_dst*);
 hipError_t bsxk_skip_check(hipStream_t, uint32_t, uint32_t, const bsx_shared_ctx*, const bsx_header*, uint64_t, const uint8_t*,
                            const bsx_validator*, const bsx_validator*, const uint8_t*, bsx_commit_result*, const bsx_commit_result*,
                            uint32_t*, uint8_t*, const uint32_t*, const uint8_t*, uint32_t, const bsxk_unit_dst*);

@@ -884,6 +884,91 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
 #undef en
 }
 
+// ------------------------------------------------------------------------------------------------ k_commit_sums
+// The signature-dependent half of k_commit_tally on its own: per-slot verdicts (signature valid, message carries the header hash),
+// the signed / trusted-signed power sums, the counters and the 2/3 rule — no hashing.  The host tier runs k_commit_tally EARLY with
+// ok_in = nullptr (validator leaves, the masked tree, total power: nothing there depends on the signatures) beside the R decoding,
+// and this kernel behind the signature check: the commit chain of a proof request loses the tree's ~50 us (round 4; the chain was
+// verify -> tally -> skip conditions).  Completes the bsx_commit_result k_commit_tally began (validators_hash, total_power,
+// n_enabled, power_overflow stay) and, with `wit`, the COMMIT unit's slot bools / sums / verdict bools.  One workgroup per commit.
+__global__ __launch_bounds__(TL_THREADS) void k_commit_sums(const bsx_validator* __restrict__ vals, uint32_t v_max,
+                                                            const uint8_t* __restrict__ header_hashes, const uint8_t* __restrict__ ok_in,
+                                                            bsx_commit_result* __restrict__ results, bsxk_unit_dst wit) {
+    __shared__ unsigned long long s_signed, s_trusted;
+    __shared__ uint32_t s_nsig, s_nbad, s_firstbad, s_nbadmsg;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    const bsx_validator* cv = vals + (uint64_t)c * v_max;
+    if (tid == 0) { s_signed = 0; s_trusted = 0; s_nsig = 0; s_nbad = 0; s_firstbad = 0xffffffffu; s_nbadmsg = 0; }
+    __syncthreads();
+    uint32_t hh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) hh[k] = reinterpret_cast<const uint32_t*>(header_hashes + 32 * (uint64_t)c)[k];
+    const bool w_on = wit.base != nullptr;
+    uint8_t* const cw = w_on ? wit.base + (uint64_t)c * wit.stride : nullptr;
+    uint32_t* const WW = w_on ? reinterpret_cast<uint32_t*>(cw + wit.off_words) : nullptr;
+    uint8_t* const WB = w_on ? cw + wit.off_bools : nullptr;
+    if (w_on && tid < 8) reinterpret_cast<uint32_t*>(cw + bsx_cm_off_header_hash())[tid] = hh[tid];
+    uint64_t signedp = 0, trusted = 0;
+    uint32_t nsig = 0, nbad = 0, nbadmsg = 0;
+    for (uint32_t v = tid; v < v_max; v += nthreads) {
+        const uint4 fl = reinterpret_cast<const uint4*>(cv + v)[14];
+        const uint64_t power = (uint64_t)fl.x | ((uint64_t)fl.y << 32);
+        const bool enabled = (fl.z & 0xffu) != 0, is_signed = ((fl.z >> 8) & 0xffu) != 0, present = ((fl.z >> 16) & 0xffu) != 0;
+        bool sig = false, msg = false, has_round = false;
+        uint32_t mlen = 0;
+        if ((enabled && is_signed) || w_on) {
+            const uint32_t* mw = reinterpret_cast<const uint32_t*>(cv[v].message);
+            mlen = cv[v].message_len;
+            has_round = mlen > 12 && (mw[3] & 0xffu) == 0x19u;
+            const uint32_t off = has_round ? 25u : 16u;
+            msg = mlen <= BSX_VALIDATOR_MSG_MAX && mlen >= off + 32;
+            uint32_t diff = 0;
+            if (has_round) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) diff |= funnel_r(mw[7 + k], mw[6 + k], 8) ^ hh[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) diff |= mw[4 + k] ^ hh[k];
+            }
+            msg = msg && diff == 0;
+        }
+        if (enabled && is_signed) {
+            nsig++;
+            sig = ok_in[(uint64_t)c * v_max + v] == 1;
+            if (!sig) { nbad++; atomicMin(&s_firstbad, v); }
+            if (!msg) nbadmsg++;
+            if (sig && msg) { signedp += power; if (present) trusted += power; }
+        }
+        if (w_on) {
+            WW[BSX_CM_SLOT_WORDS * v] = mlen;
+            uint8_t* b = WB + BSX_CM_SLOT_BOOLS * v;
+            b[3] = sig; b[4] = has_round; b[5] = msg; b[6] = enabled && is_signed && sig && msg;
+        }
+    }
+    signedp = wave_sum_u64(signedp); trusted = wave_sum_u64(trusted);
+    nsig = wave_sum_u32(nsig); nbad = wave_sum_u32(nbad); nbadmsg = wave_sum_u32(nbadmsg);
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_signed, (unsigned long long)signedp); atomicAdd(&s_trusted, (unsigned long long)trusted);
+        atomicAdd(&s_nsig, nsig); atomicAdd(&s_nbad, nbad); atomicAdd(&s_nbadmsg, nbadmsg);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bsx_commit_result* o = results + c;
+        o->signed_power = s_signed; o->trusted_signed_power = s_trusted;
+        o->n_signed = s_nsig; o->n_bad_signature = s_nbad; o->first_bad_signature = s_firstbad; o->n_bad_message = s_nbadmsg;
+        const bool overflow = o->power_overflow != 0;
+        const bool two_thirds = !overflow && (unsigned __int128)s_signed * 3 > (unsigned __int128)o->total_power * 2;
+        o->two_thirds_ok = two_thirds ? 1u : 0u;
+        if (w_on) {
+            uint32_t* wt = WW + bsx_cm_w_total(v_max);
+            wt[2] = (uint32_t)s_signed; wt[3] = (uint32_t)(s_signed >> 32);
+            wt[4] = (uint32_t)s_trusted; wt[5] = (uint32_t)(s_trusted >> 32);
+            uint8_t* t = WB + bsx_cm_b_tail(v_max);
+            t[0] = two_thirds; t[2] = (s_nbad == 0 && s_nbadmsg == 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ k_skip_check
 // One workgroup per range.  skip_status[r] = bsx_status of the skip part (BSX_OK when every condition holds).
 struct SkipArgs {
@@ -1234,6 +1319,13 @@ hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, con
                chain_id_len, {0}, wit ? *wit : bsxk_unit_dst{nullptr, 0, 0, 0, 0}};
     for (uint32_t i = 0; i < chain_id_len && i < 50; i++) a.chain_id[i] = chain_id[i];
     hipLaunchKernelGGL(k_skip_check, dim3(n_ranges), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t bsxk_commit_sums(hipStream_t s, const bsx_validator* vals, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes, const uint8_t* ok,
+                            bsx_commit_result* results, const bsxk_unit_dst* wit) {
+    if (!n_commits) return hipSuccess;
+    const bsxk_unit_dst w = wit ? *wit : bsxk_unit_dst{nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_commit_sums, dim3(n_commits), dim3(v_max <= 128 ? 128 : TL_THREADS), 0, s, vals, v_max, header_hashes, ok, results, w);
     return hipGetLastError();
 }
 int bsxk_tally_vmax(void) { return TL_VMAX; }

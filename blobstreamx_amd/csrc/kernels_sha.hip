@@ -768,6 +768,13 @@ struct ReduceArgs {
     bsx_subchain* out;
     uint8_t* reduce_compact;       // optional: (n-1) node witnesses per range
     uint32_t compact_stride, off_words, off_bools;
+    // optional: the final assertions + public output of k_finalize for the range, by the lane that holds the root record (the host
+    // tier's single proof request: one launch and one kernel boundary less on its critical chain)
+    uint32_t fin_jobs, fin_batch;
+    const bsx_shared_ctx* fin_ranges;
+    const uint8_t* fin_target_hashes;
+    uint8_t* fin_output64;
+    uint32_t* fin_status;
 };
 __global__ __launch_bounds__(128) void k_reduce(ReduceArgs a) {
     __shared__ bsx_subchain rec[256];
@@ -827,6 +834,18 @@ __global__ __launch_bounds__(128) void k_reduce(ReduceArgs a) {
         k0 += mcount / 2;
     }
     if (tid < 8) reinterpret_cast<uint4*>(a.out + r)[tid] = reinterpret_cast<uint4*>(rec)[tid];
+    if (a.fin_output64 && tid == 0) {                                     // builder.rs:292-297,400-406; header_range.rs:57-58 (= k_finalize)
+        const bsx_shared_ctx& rg = a.fin_ranges[r];
+        const bsx_subchain& res = rec[0];
+        uint32_t st = res.assert_fail;
+        if (!(rg.end_block <= rg.start_block + (uint64_t)a.fin_jobs * a.fin_batch)) st |= BSX_A7_RANGE;
+        bool ok = res.start_block == rg.start_block && res.end_block == rg.end_block;
+        for (int q = 0; q < 32; q++) ok = ok && res.start_header[q] == rg.start_header_hash[q] && res.end_header[q] == rg.end_header_hash[q];
+        if (!ok) st |= BSX_A9_FINAL;
+        const uint8_t* th = a.fin_target_hashes ? a.fin_target_hashes + 32 * (uint64_t)r : rg.end_header_hash;
+        for (int q = 0; q < 32; q++) { a.fin_output64[64 * (uint64_t)r + q] = th[q]; a.fin_output64[64 * (uint64_t)r + 32 + q] = res.data_merkle_root[q]; }
+        if (a.fin_status) a.fin_status[r] = st;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_finalize
@@ -1014,7 +1033,16 @@ hipError_t bsxk_reduce(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_s
                        uint64_t stride_record, bsx_subchain* out, uint8_t* reduce_compact) {
     if (!n_ranges) return hipSuccess;
     const bsx_witness_layout L = bsx_reduce_layout();
-    ReduceArgs a{n_ranges, n, stride_range, stride_record, records, out, reduce_compact, L.compact_stride, L.off_words, L.off_bools};
+    ReduceArgs a{n_ranges, n, stride_range, stride_record, records, out, reduce_compact, L.compact_stride, L.off_words, L.off_bools, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_reduce, dim3(n_ranges), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+// reduce + the final assertions / public output in ONE launch (n records per range, consecutive)
+hipError_t bsxk_reduce_finalize(hipStream_t s, uint32_t n_ranges, uint32_t n, const bsx_subchain* records, bsx_subchain* out, uint8_t* reduce_compact,
+                                uint32_t J, uint32_t B, const bsx_shared_ctx* ranges, const uint8_t* target_hashes, uint8_t* output64, uint32_t* status) {
+    if (!n_ranges) return hipSuccess;
+    const bsx_witness_layout L = bsx_reduce_layout();
+    ReduceArgs a{n_ranges, n, n, 1, records, out, reduce_compact, L.compact_stride, L.off_words, L.off_bools, J, B, ranges, target_hashes, output64, status};
     hipLaunchKernelGGL(k_reduce, dim3(n_ranges), dim3(128), 0, s, a);
     return hipGetLastError();
 }
