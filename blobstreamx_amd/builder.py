@@ -276,11 +276,15 @@ class CombinedSkipCircuit:
         wit = None
         if want_witness:
             wit = self._witness_buffer(T.header_range_witness_elements(self.J, self.B, self.V))
-        self.last_rc = _lib.check(_lib.lib().bsx_header_range(
-            _lib.context(self.device), C.c_uint32(self.J), C.c_uint32(self.B), _lib.p(_b(input48, 48)), _lib.p(fetcher.headers),
+        if getattr(self, "_cid", None) is None:         # per-object constants of the call, marshalled once
+            self._cid = np.frombuffer(self.chain_id, np.uint8).copy() if self.chain_id else None
+            self._fixed = (_lib.lib().bsx_header_range, _lib.context(self.device), C.c_uint32(self.J), C.c_uint32(self.B), C.c_uint32(self.V),
+                           _lib.p(self._cid), C.c_uint32(len(self.chain_id)))
+        fn, ctx, cJ, cB, cV, cid, cidn = self._fixed
+        self.last_rc = _lib.check(fn(
+            ctx, cJ, cB, _lib.p(_b(input48, 48)), _lib.p(fetcher.headers),
             C.c_uint64(fetcher.first_height), C.c_uint64(fetcher.headers.size), C.c_uint64(fetcher.latest_block), _lib.p(tv),
-            _lib.p(rv), C.c_uint32(self.V), _lib.p(np.frombuffer(self.chain_id, np.uint8).copy()) if self.chain_id else None,
-            C.c_uint32(len(self.chain_id)), _lib.p(out), _lib.p(res), _lib.p(wit)), allow=allow)
+            _lib.p(rv), cV, cid, cidn, _lib.p(out), _lib.p(res), _lib.p(wit)), allow=allow)
         return out.tobytes(), res[0], wit
 
 

@@ -861,7 +861,10 @@ static int run_data_commitment(bsx_ctx* ctx, hipStream_t st, uint32_t J, uint32_
         RET(o64.alloc(64));
         RET(stw.alloc(4));
     }
-    HIPCHK(hipMemsetAsync(cw.p, 0, (size_t)J * L.compact_stride, st));
+    // every byte of the three sections is written by the hint and prove_subchain below (padding slots included); only the alignment
+    // gaps between the sections are not, and nothing reads those — cleared when the image is expanded for a caller, skipped on the
+    // latency path (one launch less in front of the hint)
+    if (witness) HIPCHK(hipMemsetAsync(cw.p, 0, (size_t)J * L.compact_stride, st));
     HIPCHK(bsxk_assemble_inputs(st, 1, J, B, 0, J, B, rd.ranges.as<bsx_shared_ctx>(), rd.latest.as<uint64_t>(), rd.headers.as<bsx_header>(), rd.hpr, 0,
                                 rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(), cw.as<uint8_t>(), rd.astatus.as<uint32_t>(),
                                 rd.paths.as<uint8_t>(), ctx->zero_paths));

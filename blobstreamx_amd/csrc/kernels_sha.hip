@@ -805,9 +805,17 @@ __global__ __launch_bounds__(128) void k_reduce(ReduceArgs a) {
             const Digest root = right_disabled ? l_root : computed;               // :367-371
             o.start_block = l.start_block;                                        // :389
             o.end_block = right_disabled ? l.end_block : rt.end_block;            // :374-378
-            for (int q = 0; q < 32; q++) {
-                o.start_header[q] = l.start_header[q];                            // :390
-                o.end_header[q] = right_disabled ? l.end_header[q] : rt.end_header[q];   // :379-383
+            {   // 32-byte fields as dwords (the records are 8-byte aligned in LDS)
+                const uint32_t* ls = reinterpret_cast<const uint32_t*>(l.start_header);
+                const uint32_t* le = reinterpret_cast<const uint32_t*>(l.end_header);
+                const uint32_t* re = reinterpret_cast<const uint32_t*>(rt.end_header);
+                uint32_t* os = reinterpret_cast<uint32_t*>(o.start_header);
+                uint32_t* oe = reinterpret_cast<uint32_t*>(o.end_header);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    os[q] = ls[q];                                                // :390
+                    oe[q] = right_disabled ? le[q] : re[q];                       // :379-383
+                }
             }
             store_digest_global(o.data_merkle_root, root);
             o.is_enabled = l.is_enabled;                                          // :388
@@ -820,7 +828,14 @@ __global__ __launch_bounds__(128) void k_reduce(ReduceArgs a) {
             if (a.reduce_compact) {
                 uint8_t* cw = a.reduce_compact + ((uint64_t)r * (n - 1) + k) * a.compact_stride;
                 store_digest_global(cw, computed);
-                for (int q = 0; q < 32; q++) { cw[32 + q] = o.start_header[q]; cw[64 + q] = o.end_header[q]; cw[96 + q] = o.data_merkle_root[q]; }
+                {
+                    uint32_t* c32 = reinterpret_cast<uint32_t*>(cw);
+                    const uint32_t* os = reinterpret_cast<const uint32_t*>(o.start_header);
+                    const uint32_t* oe = reinterpret_cast<const uint32_t*>(o.end_header);
+                    const uint32_t* om = reinterpret_cast<const uint32_t*>(o.data_merkle_root);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { c32[8 + q] = os[q]; c32[16 + q] = oe[q]; c32[24 + q] = om[q]; }
+                }
                 uint32_t* W = reinterpret_cast<uint32_t*>(cw + a.off_words);
                 W[0] = (uint32_t)o.start_block; W[1] = (uint32_t)(o.start_block >> 32);
                 W[2] = (uint32_t)o.end_block; W[3] = (uint32_t)(o.end_block >> 32);
