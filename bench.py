@@ -700,7 +700,7 @@ def subprocess_leg(args, extra, timeout=900):
 def pmc_traffic(n_jobs, B):
     """HBM bytes of one k_expand_witness launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.csv +
     .meta.json written by the profiling command), scaled per map job.  None when no profile of this shape is committed."""
-    for tag in ("r3", "r2", "r1"):
+    for tag in ("r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.csv")
         meta = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.meta.json")
         if not os.path.exists(path):
