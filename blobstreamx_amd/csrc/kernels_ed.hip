@@ -1264,7 +1264,9 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     // signature against 421 on four lanes and 761 in the latency form), whatever the batch size
     const bool throughput = rdec == BSXK_ED_THROUGHPUT && scratch;
     const bool split4 = env_split >= 0 ? env_split == 4 : (n < ED_SPLIT_BELOW && !throughput);
-    const uint32_t sigs = split4 ? ED_THREADS / 4 : ED_THREADS;               // signatures per workgroup
+    // two lanes per signature (with the batch-inversion scratch, lanes by key): the middle form, experiments build only for now
+    const bool split2 = env_split == 2 && scratch != nullptr;
+    const uint32_t sigs = split4 ? ED_THREADS / 4 : split2 ? ED_THREADS / 2 : ED_THREADS;               // signatures per workgroup
     const bool by_key = env_by_key >= 0 ? env_by_key != 0 : n_commits >= sigs / 2;
     dim3 grid;
     if (by_key) {
@@ -1280,6 +1282,8 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
     if (split4 && !scr && !by_key && small_form) {
         hipLaunchKernelGGL(k_ed25519_verify_keyed_small, dim3((uint32_t)((n + EL_SIGS - 1) / EL_SIGS)), dim3(128), 0, s, vals, h, n, v_max, table,
                            n_keys, b_tab, ok);
+    } else if (split2) {
+        if (by_key) BSX_LAUNCH_KEYED(true, true, 2); else BSX_LAUNCH_KEYED(true, false, 2);
     } else if (split4) {
         if (scr) { if (by_key) BSX_LAUNCH_KEYED(true, true, 4); else BSX_LAUNCH_KEYED(true, false, 4); }
         else     { if (by_key) BSX_LAUNCH_KEYED(false, true, 4); else BSX_LAUNCH_KEYED(false, false, 4); }
