@@ -136,6 +136,11 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def log(msg):
+    """progress on stderr (stdout carries the ONE JSON line)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def host_threads():
     """Threads for the CPU legs and what the box really grants: the GPU boxes show 256 logical CPUs but run the container
     under a cgroup CPU quota (cpu.max 1600000/100000 = 16 CPUs): 256 threads then thrash the quota (152 k Ed25519 verifies/s
@@ -973,20 +978,30 @@ def main():
                                    "measured_sha256_ceiling_per_s": cal["sha256_compress_per_s"]}
         # rank 0 keeps the CPU baseline at every N (north_star: GPU throughput next to the CPU path, core count stated);
         # the other legs are N = 1 only
+        log("headline timed; cpu_baseline")
         if not args.no_legs and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, J, B, V, args.cpu_seconds, gpu_out64, min(R, 256), first=rank * R)
         legs = world == 1 and not args.no_legs
         if legs and not args.no_witness:
+            log("leg: with_input_upload")
             out["with_input_upload"] = upload_leg(p0, args, max(5, args.steps // 2))
         del eng, p0
         torch.cuda.empty_cache()
         if legs:
+            log("leg: latency")
             out["latency"] = latency_leg(dev, J, B, V)
+            log("leg: latency.concurrent")
             out["latency"]["concurrent"] = concurrent_leg(dev, J, B, V)
+            log("leg: range_sweep")
             out["range_sweep"] = {"compact": range_sweep_leg(dev, J, B, V), "witness": range_sweep_leg(dev, J, B, V, rs=(1, 4, 16, 64), witness=True)}
+            log("leg: fused_commitment")
             out["fused_commitment"] = commitment_leg(dev, J, B, V, cal)
             if not args.no_stress:
-                out["stress"] = {"v100": stress(args, dev, 100, 6.0, cal), "v512": stress(args, dev, 512, 6.0, cal)}
+                log("leg: stress v100")
+                sv100 = stress(args, dev, 100, 6.0, cal)
+                log("leg: stress v512")
+                out["stress"] = {"v100": sv100, "v512": stress(args, dev, 512, 6.0, cal)}
+            log("leg: compact_only (subprocess)")
             # one chunk per step: without an expansion to run beside there is nothing to pipeline against, and a chunk of 256
             # ranges quantises better (8196 header groups on 4096 wave slots) than two of 128
             # ... and two pipelines stepped in turn: step i + 1 starts while step i's chain of small kernels drains
