@@ -543,6 +543,7 @@ def range_sweep_leg(dev, J, B, V, rs=(1, 4, 16, 64, 256), witness=False):
     w = synth.Workload(4, max(rs), J, B, v=V)
     rows = []
     for R in rs:
+        log(f"  range_sweep R={R} witness={witness}")
         nch = 2 if (witness and R >= 16) else 1
         pe = E.PipelinedEngines(J, B, V, R, n_engines=nch, device=dev, with_witness=witness) if witness else \
             E.AlternatingPipelines(2, J, B, V, R, n_engines=1, device=dev, with_witness=False)

@@ -139,6 +139,7 @@ void bsx_shutdown(bsx_ctx* ctx) {
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     if (ctx->ev_c) (void)hipEventDestroy(ctx->ev_c);
     for (auto& b : ctx->vmm) { (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size); }
+    for (auto& b : ctx->vmm_free) { (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size); }
     delete ctx;
 }
 
@@ -204,6 +205,24 @@ int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr) {
     HIPCHK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (gran < (2u << 20)) gran = 2u << 20;
     const size_t size = (bytes + gran - 1) / gran * gran;
+    // a block this context released earlier (bsx_dev_free keeps them mapped): the smallest one that fits.  Repeated
+    // reserve / map / unmap / free cycles of multi-GB ranges ended in GPU memory-access faults on ROCm 7.2 (round 4: the
+    // fourth witness pipeline of one process, bench.py's range sweep; never with hipMalloc-backed buffers), so a virtual range
+    // is mapped ONCE and recycled; bsx_trim / bsx_shutdown give the memory back.
+    {
+        size_t best = ctx->vmm_free.size();
+        for (size_t i = 0; i < ctx->vmm_free.size(); i++)
+            if (ctx->vmm_free[i].size >= size && (best == ctx->vmm_free.size() || ctx->vmm_free[i].size < ctx->vmm_free[best].size)) best = i;
+        if (best != ctx->vmm_free.size()) {
+            const bsx_vmm_block b = ctx->vmm_free[best];
+            HIPCHK(hipMemsetAsync(b.va, 0, size, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            ctx->vmm_free.erase(ctx->vmm_free.begin() + (long)best);
+            ctx->vmm.push_back(b);
+            *out_ptr = b.va;
+            return BSX_OK;
+        }
+    }
     bsx_vmm_block b{nullptr, size, {}};
     HIPCHK(hipMemCreate(&b.handle, size, &prop, 0));
     hipError_t e = hipMemAddressReserve(&b.va, size, 1ull << 30, nullptr, 0);
@@ -233,11 +252,9 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
         if (ctx->vmm[i].va == ptr) {
             // the block stays registered until its teardown has succeeded: a failure here leaves it to bsx_shutdown
             const bsx_vmm_block b = ctx->vmm[i];
-            HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipMemUnmap(b.va, b.size));
+            HIPCHK(hipDeviceSynchronize());                 // nothing in flight may still use it when the next owner clears it
             ctx->vmm.erase(ctx->vmm.begin() + (long)i);
-            HIPCHK(hipMemRelease(b.handle));
-            HIPCHK(hipMemAddressFree(b.va, b.size));
+            ctx->vmm_free.push_back(b);                     // stays mapped: recycled by bsx_dev_alloc, released by bsx_trim / bsx_shutdown
             return BSX_OK;
         }
     return fail(BSX_ERR_BAD_ARG, "bsx_dev_free: pointer was not returned by bsx_dev_alloc on this context");
@@ -254,6 +271,11 @@ int bsx_trim(bsx_ctx* ctx, uint64_t* freed_bytes) {
     ctx->hr_seen = false;
     if (ctx->arena.base) { freed += ctx->arena.cap; (void)hipFree(ctx->arena.base); ctx->arena.base = nullptr; ctx->arena.cap = 0; }
     if (ctx->keytab) { freed += bsxk_keytable_bytes(ctx->keytab_rows); (void)hipFree(ctx->keytab); ctx->keytab = nullptr; ctx->keytab_rows = 0; }
+    for (auto& b : ctx->vmm_free) {                         // recycled bsx_dev_alloc blocks nobody holds
+        freed += b.size;
+        (void)hipMemUnmap(b.va, b.size); (void)hipMemRelease(b.handle); (void)hipMemAddressFree(b.va, b.size);
+    }
+    ctx->vmm_free.clear();
     if (freed_bytes) *freed_bytes = freed;
     return BSX_OK;
 }

@@ -49,6 +49,7 @@ struct bsx_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bsx_arena arena;
     std::vector<bsx_vmm_block> vmm;      // bsx_dev_alloc blocks still alive
+    std::vector<bsx_vmm_block> vmm_free; // released by bsx_dev_free, still mapped: recycled by the next bsx_dev_alloc that fits
     uint8_t* zero_paths = nullptr;       // 320 B: path digests of the hint's zero-padded proofs (k_zero_paths)
     uint8_t* keytab = nullptr;           // host tier's persistent fixed-key Ed25519 table (rows survive between calls)
     uint32_t keytab_rows = 0;

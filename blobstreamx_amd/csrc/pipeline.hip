@@ -216,7 +216,8 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
         // the map-job image (14.7 GB per chunk at the bench shape) comes from the HIP virtual-memory API: one physical handle,
         // deterministic placement (bsx_dev_alloc)
         const uint64_t bytes = (c.n_map_el + 2) * 8;
-        if (bytes >= (64ull << 20)) {
+        static const uint64_t vmm_min = (uint64_t)bsx_knob("BSX_VMM_MIN_MB", 64) << 20;      // experiments build: where VMM backing starts
+        if (bytes >= vmm_min) {
             void* q = nullptr;
             RET(bsx_dev_alloc(p->ctx, bytes, &q));
             c.witness_map = static_cast<uint64_t*>(q);

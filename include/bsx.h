@@ -371,7 +371,9 @@ int bsx_ingest_data_commitment_json(const char* json, size_t len, uint8_t out[32
  * bandwidth of a multi-GB buffer depends on where its physical pages lie — hipMalloc'ed buffers of one process ran the
  * same store sweep at 5.5 .. 6.6 TB/s, slices of one big hipMalloc arena at 5.4 .. 6.2 TB/s by offset, VMM-backed buffers
  * at 6.0 .. 6.25 TB/s every time (tools/exp_vmm.hip) — so this replaces the round-1 "allocate candidates and
- * time them" probe with one deterministic allocation.  Zero-filled.  Free with bsx_dev_free (or bsx_shutdown). */
+ * time them" probe with one deterministic allocation.  Zero-filled.  Free with bsx_dev_free (or bsx_shutdown).  A freed block
+ * stays mapped inside the context and is recycled by the next bsx_dev_alloc it fits (mapping and unmapping multi-GB ranges over and
+ * over ended in GPU memory faults on ROCm 7.2); bsx_trim returns the recycled blocks' memory to the device. */
 int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr);
 int bsx_dev_free(bsx_ctx* ctx, void* ptr);
 
