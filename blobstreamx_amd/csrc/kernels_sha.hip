@@ -405,6 +405,8 @@ struct SubchainArgs {
     uint32_t compact_stride, off_words, off_bools;
     bsx_subchain* records;
     uint32_t level, width, level_off;        // k_tree_level: nodes per job at this level, offset of the level in inner[]/node[]
+    uint32_t top_inputs;                     // k_batch_finish: 0 = every remaining level + the batch tail; else it stops below the level
+                                             // of width top_inputs / 2 and k_batch_top finishes (level / width / level_off = its first)
 };
 
 // dword k of a byte region starting at global byte address p (2-byte aligned): funnel of two aligned dwords
@@ -564,6 +566,59 @@ __global__ __launch_bounds__(TR_THREADS) void k_tree_level(SubchainArgs a) {
     tree_node(cw, a.off_bools, B, a.level, a.level_off, t, nb, l, r);
 }
 
+// batch tail + MapReduceSubchainVariable record of job qj (builder.rs:229-270) given the root of its commitment tree and the
+// assertion bits of its slots
+__device__ __forceinline__ void batch_tail(const SubchainArgs& a, uint32_t qj, const Digest& root, uint32_t fail, uint32_t first_bad) {
+    const uint32_t B = a.batch;
+    uint8_t* cwj = a.compact + (uint64_t)qj * a.compact_stride;
+    uint32_t* Wj = reinterpret_cast<uint32_t*>(cwj + a.off_words);
+    uint8_t* Bj = cwj + a.off_bools;
+    const uint64_t Ej = a.ranges[qj / a.job_count].end_block;
+    uint64_t bs, be, te, ebn;
+    batch_bounds(Wj, Ej, bs, be, te, ebn);
+    const bool enabled = bs < Ej;                                      // :174
+    const uint64_t jst = Ej - 1 - bs;                                  // slot index of the last block (wrapping)
+    const uint32_t mj = enabled ? (uint32_t)((jst < (uint64_t)B) ? jst + 1 : B) : 0u;
+    const uint8_t* sl = cwj + bsx_off_slots(B);
+    const Digest first = load_digest_global(cwj + bsx_off_start_header());
+    const bool curr_enabled_end = enabled && !(jst < (uint64_t)B);     // enabled after the last slot
+    const Digest curr_final = (mj > 0) ? load_digest_global(sl + BSX_SLOT_BYTES * (mj - 1) + 160 + 128) : first;
+    const Digest end_header = load_digest_global(cwj + bsx_off_end_header());
+    const bool last_disabled = !curr_enabled_end;                     // :229
+    const bool last_matches = digest_eq(curr_final, end_header);      // :230
+    const bool end_header_check = last_disabled || last_matches;      // :231
+    const bool gte = ebn >= bs;                                       // :113 (A1)
+    const uint64_t nb_blocks = ebn - bs;                              // :119
+    const uint64_t last = Ej - 1;                                     // :177
+    if (!end_header_check) { fail |= BSX_A6_BATCH_END; if (first_bad == 0xffffffffu) first_bad = B; }
+    if (!gte) { fail |= BSX_A1_END_GTE_START; if (first_bad == 0xffffffffu) first_bad = B; }
+    if ((nb_blocks >> 32) != 0) { fail |= BSX_A2_NB_BLOCKS_U32; if (first_bad == 0xffffffffu) first_bad = B; }
+    uint8_t* t = Bj + bsx_b_tail(B);
+    t[0] = last_disabled; t[1] = last_matches; t[2] = end_header_check; t[3] = be < Ej; t[4] = te < bs; t[5] = gte;
+    Bj[BSX_B_BATCH_ENABLED] = enabled;
+    Bj[bsx_b_rec_enabled(B)] = enabled;
+    Wj[BSX_W_LAST_TO_PROCESS] = (uint32_t)last; Wj[BSX_W_LAST_TO_PROCESS + 1] = (uint32_t)(last >> 32);
+    Wj[bsx_w_temp_end(B)] = (uint32_t)te; Wj[bsx_w_temp_end(B) + 1] = (uint32_t)(te >> 32);
+    Wj[bsx_w_end_block_num(B)] = (uint32_t)ebn; Wj[bsx_w_end_block_num(B) + 1] = (uint32_t)(ebn >> 32);
+    Wj[bsx_w_nb_blocks(B)] = (uint32_t)nb_blocks; Wj[bsx_w_nb_blocks(B) + 1] = (uint32_t)(nb_blocks >> 32);
+    Wj[bsx_w_rec_start(B)] = (uint32_t)bs; Wj[bsx_w_rec_start(B) + 1] = (uint32_t)(bs >> 32);
+    Wj[bsx_w_rec_end(B)] = (uint32_t)ebn; Wj[bsx_w_rec_end(B) + 1] = (uint32_t)(ebn >> 32);
+    uint8_t* rec_b = cwj + bsx_off_record(B);
+    store_digest_global(rec_b, first);
+    store_digest_global(rec_b + 32, curr_final);
+    store_digest_global(rec_b + 64, root);
+    bsx_subchain* out = a.records + qj;
+    out->start_block = bs;
+    out->end_block = ebn;
+    store_digest_global(out->start_header, first);
+    store_digest_global(out->end_header, curr_final);
+    store_digest_global(out->data_merkle_root, root);
+    out->is_enabled = enabled ? 1u : 0u;
+    out->assert_fail = fail;
+    out->first_bad_slot = first_bad;
+    out->_pad = 0;
+}
+
 // ---- stage 3: predicates + batch tail (builder.rs:174-270), no hashing.  256 consecutive slots per workgroup;
 // per-slot assertion bits are reduced with a wave ballot and at most one LDS atomic per failing lane.
 constexpr int BF_THREADS = 256;
@@ -687,8 +742,14 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const uint32_t q0 = (uint32_t)(gs0 / B), jobs_here = BF_THREADS / B;
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u);
     uint32_t cur = 0;
+    const bool top = a.top_inputs != 0;                                 // k_batch_top takes over below width stop_w: hand it the slots' bits
+    const uint32_t stop_w = top ? a.top_inputs / 2 : 0;
+    if (top && tid < jobs_here && q0 + tid < a.n_jobs) {
+        a.records[q0 + tid].assert_fail = job_fail[tid];
+        a.records[q0 + tid].first_bad_slot = job_first_bad[tid];
+    }
     if (B > 1) {
-        if (wave_base >= jobs_here * a.width) return;
+        if (a.width <= stop_w || wave_base >= jobs_here * a.width) return;
         uint32_t level = a.level, level_off = a.level_off;
         for (uint32_t width = a.width; width >= 1; width /= 2, level++) {
             const uint32_t jn = tid / width, t = tid % width;          // job (inside the block) and node of this lane
@@ -716,69 +777,52 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
             __syncthreads();
             cur ^= 1;
             level_off += width;
-            const uint32_t later = jobs_here * (width / 2 > 1 ? width / 2 : 1);   // lanes of the next level / of the tail
+            // lanes of the next level / of the tail; none once k_batch_top has the rest
+            const uint32_t later = (top && width / 2 <= stop_w) ? 0u : jobs_here * (width / 2 > 1 ? width / 2 : 1);
             if (wave_base >= later) return;
         }
     }
+    if (top) return;
     // batch tail + record (builder.rs:229-270): lane jn of the workgroup for its job jn
     if (tid < jobs_here && q0 + tid < a.n_jobs) {
-        const uint32_t qj = q0 + tid;
-        uint8_t* cwj = a.compact + (uint64_t)qj * a.compact_stride;
-        uint32_t* Wj = reinterpret_cast<uint32_t*>(cwj + a.off_words);
-        uint8_t* Bj = cwj + a.off_bools;
-        const uint64_t Ej = a.ranges[qj / a.job_count].end_block;
-        uint64_t bs, be, te, ebn;
-        batch_bounds(Wj, Ej, bs, be, te, ebn);
-        const bool enabled = bs < Ej;                                      // :174
-        const uint64_t jst = Ej - 1 - bs;                                  // slot index of the last block (wrapping)
-        const uint32_t mj = enabled ? (uint32_t)((jst < (uint64_t)B) ? jst + 1 : B) : 0u;
-        const uint8_t* sl = cwj + bsx_off_slots(B);
-        const Digest first = load_digest_global(cwj + bsx_off_start_header());
         Digest root;
-        if (B == 1) root = FUSED ? tleaf : load_digest_global(cwj + bsx_off_leaf_hashes(B));   // jobs_here = BF_THREADS: own slot
+        if (B == 1) root = FUSED ? tleaf : load_digest_global(a.compact + (uint64_t)(q0 + tid) * a.compact_stride + bsx_off_leaf_hashes(B));   // own slot
         else {
 #pragma unroll
             for (int k = 0; k < 8; k++) root.w[k] = top_nodes[cur][(tid * a.width) * 8 + k];   // node 0 of the last level written
         }
-        const bool curr_enabled_end = enabled && !(jst < (uint64_t)B);     // enabled after the last slot
-        const Digest curr_final = (mj > 0) ? load_digest_global(sl + BSX_SLOT_BYTES * (mj - 1) + 160 + 128) : first;
-        const Digest end_header = load_digest_global(cwj + bsx_off_end_header());
-        const bool last_disabled = !curr_enabled_end;                     // :229
-        const bool last_matches = digest_eq(curr_final, end_header);      // :230
-        const bool end_header_check = last_disabled || last_matches;      // :231
-        const bool gte = ebn >= bs;                                       // :113 (A1)
-        const uint64_t nb_blocks = ebn - bs;                              // :119
-        const uint64_t last = Ej - 1;                                     // :177
-        uint32_t fail = job_fail[tid];
-        uint32_t first_bad = job_first_bad[tid];
-        if (!end_header_check) { fail |= BSX_A6_BATCH_END; if (first_bad == 0xffffffffu) first_bad = B; }
-        if (!gte) { fail |= BSX_A1_END_GTE_START; if (first_bad == 0xffffffffu) first_bad = B; }
-        if ((nb_blocks >> 32) != 0) { fail |= BSX_A2_NB_BLOCKS_U32; if (first_bad == 0xffffffffu) first_bad = B; }
-        uint8_t* t = Bj + bsx_b_tail(B);
-        t[0] = last_disabled; t[1] = last_matches; t[2] = end_header_check; t[3] = be < Ej; t[4] = te < bs; t[5] = gte;
-        Bj[BSX_B_BATCH_ENABLED] = enabled;
-        Bj[bsx_b_rec_enabled(B)] = enabled;
-        Wj[BSX_W_LAST_TO_PROCESS] = (uint32_t)last; Wj[BSX_W_LAST_TO_PROCESS + 1] = (uint32_t)(last >> 32);
-        Wj[bsx_w_temp_end(B)] = (uint32_t)te; Wj[bsx_w_temp_end(B) + 1] = (uint32_t)(te >> 32);
-        Wj[bsx_w_end_block_num(B)] = (uint32_t)ebn; Wj[bsx_w_end_block_num(B) + 1] = (uint32_t)(ebn >> 32);
-        Wj[bsx_w_nb_blocks(B)] = (uint32_t)nb_blocks; Wj[bsx_w_nb_blocks(B) + 1] = (uint32_t)(nb_blocks >> 32);
-        Wj[bsx_w_rec_start(B)] = (uint32_t)bs; Wj[bsx_w_rec_start(B) + 1] = (uint32_t)(bs >> 32);
-        Wj[bsx_w_rec_end(B)] = (uint32_t)ebn; Wj[bsx_w_rec_end(B) + 1] = (uint32_t)(ebn >> 32);
-        uint8_t* rec_b = cwj + bsx_off_record(B);
-        store_digest_global(rec_b, first);
-        store_digest_global(rec_b + 32, curr_final);
-        store_digest_global(rec_b + 64, root);
-        bsx_subchain* out = a.records + qj;
-        out->start_block = bs;
-        out->end_block = ebn;
-        store_digest_global(out->start_header, first);
-        store_digest_global(out->end_header, curr_final);
-        store_digest_global(out->data_merkle_root, root);
-        out->is_enabled = enabled ? 1u : 0u;
-        out->assert_fail = fail;
-        out->first_bad_slot = first_bad;
-        out->_pad = 0;
+        batch_tail(a, q0 + tid, root, job_fail[tid], job_first_bad[tid]);
     }
+}
+
+// The top of every job's commitment tree, one lane per job: N sub-tree roots (the level k_batch_finish stopped at, or the leaf hashes)
+// -> N - 1 nodes depth first (log2 N digests live), then the batch tail.  A workgroup of k_batch_finish holds too few nodes of
+// these levels to fill a wave (B = 64: 16, 8, 4 of 64 lanes, each level 2 dependent compressions behind a barrier) — a third of the
+// kernel's wave time at a quarter of the lanes; here the same nodes are 1 / 8 of the lanes' time at full width.
+template <int N>
+__device__ __forceinline__ Digest top_subtree(const SubchainArgs& a, uint8_t* cw, uint32_t nb, uint32_t first) {
+    if constexpr (N == 1) {
+        const uint8_t* in = (a.level == 1) ? cw + bsx_off_leaf_hashes(a.batch) : cw + bsx_off_nodes(a.batch) + 32 * (a.level_off - 2 * a.width);
+        return load_digest_global(in + 32 * first);
+    } else {
+        const Digest l = top_subtree<N / 2>(a, cw, nb, first);
+        const Digest r = top_subtree<N / 2>(a, cw, nb, first + N / 2);
+        uint32_t level = a.level, off = a.level_off, w = a.width;
+#pragma unroll
+        for (int n = 2; n < N; n *= 2) { level++; off += w; w /= 2; }
+        return tree_node(cw, a.off_bools, a.batch, level, off, first / N, nb, l, r);
+    }
+}
+template <int N>
+__global__ __launch_bounds__(64) void k_batch_top(SubchainArgs a) {
+    BSX_CHAIN_PRIO();
+    const uint32_t q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= a.n_jobs) return;
+    uint8_t* cw = a.compact + (uint64_t)q * a.compact_stride;
+    uint64_t bs, be, te, ebn;
+    batch_bounds(reinterpret_cast<const uint32_t*>(cw + a.off_words), a.ranges[q / a.job_count].end_block, bs, be, te, ebn);
+    const Digest root = top_subtree<N>(a, cw, (uint32_t)(ebn - bs), 0);
+    batch_tail(a, q, root, a.records[q].assert_fail, a.records[q].first_bad_slot);
 }
 
 // ------------------------------------------------------------------------------------------------ k_reduce
@@ -1046,8 +1090,29 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     static const long env_fuse = bsx_knob("BSX_SUBCHAIN_FUSED", -1);
     const bool fuse = env_fuse >= 0 ? env_fuse != 0 : !(flags & BSX_SUBCHAIN_SEPARATE_LAUNCHES);
     if ((flags & BSX_SUBCHAIN_PATHS_FROM_HINT) && fuse) {
-        a.level = 1; a.width = B / 2; a.level_off = 0;        // every level inside the one launch
+        a.level = 1; a.width = B / 2; a.level_off = 0;        // every level inside the one launch ...
+        // ... of a small batch (a proof request: one kernel boundary less on its chain); a big one hands the levels that no longer
+        // fill half a wave of a workgroup to k_batch_top
+        static const long env_top = bsx_knob("BSX_SUBCHAIN_TOP", 1);
+        SubchainArgs t = a;
+        if (env_top && n_jobs >= 1024 && B > 1) {
+            const uint32_t jobs_here = BF_THREADS / B;
+            for (uint32_t w = a.width; w >= 1; t.level_off += w, w /= 2, t.level++)
+                if (jobs_here * w < 32) { a.top_inputs = 2 * w; t.width = w; break; }
+            if (a.top_inputs > 32) a.top_inputs = 0;           // (B = 256 asks for 64: not instantiated)
+        }
         hipLaunchKernelGGL(k_batch_finish<true>, dim3((uint32_t)((slots + BF_THREADS - 1) / BF_THREADS)), dim3(BF_THREADS), 0, s, a);
+        if (a.top_inputs) {
+            t.top_inputs = a.top_inputs;
+            const dim3 g((n_jobs + 63) / 64), b(64);
+            switch (a.top_inputs) {
+                case 2: hipLaunchKernelGGL(k_batch_top<2>, g, b, 0, s, t); break;
+                case 4: hipLaunchKernelGGL(k_batch_top<4>, g, b, 0, s, t); break;
+                case 8: hipLaunchKernelGGL(k_batch_top<8>, g, b, 0, s, t); break;
+                case 16: hipLaunchKernelGGL(k_batch_top<16>, g, b, 0, s, t); break;
+                default: hipLaunchKernelGGL(k_batch_top<32>, g, b, 0, s, t); break;
+            }
+        }
         return hipGetLastError();
     }
     if (flags & BSX_SUBCHAIN_PATHS_FROM_HINT)

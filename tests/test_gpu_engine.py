@@ -105,6 +105,44 @@ def test_pipelined_engines_multi_step_vs_oracle(J, B, V, R, n_blocks):
     assert not res["range_status"].any() and not res["skip_status"].any()
 
 
+@pytest.mark.parametrize("J,B,R,n_blocks,top", [(32, 64, 32, 2048 - 37, 8), (32, 32, 32, 1024, 4), (64, 16, 16, 1024 - 5, 2)])
+def test_commitment_tree_tops_in_their_own_launch_vs_oracle(J, B, R, n_blocks, top):
+    """A chunk of >= 1024 map jobs: k_batch_finish stops at the level that no longer fills half a wave of a workgroup and
+    k_batch_top<top> (one lane per job) hashes the rest and writes the batch tail.  Outputs, statuses and records of every range,
+    the complete map + reduce witness of five of them (a tampered one, a range ending inside a batch: masked tree nodes) vs the
+    oracle."""
+    from blobstreamx_amd.engine import PipelinedEngines, BUF_WITNESS_MAP, BUF_WITNESS_REDUCE_LOCAL
+    assert R * J >= 1024
+    V = 6
+    w = synth.Workload(11, R, J, B, v=V, n_blocks=n_blocks)
+    w.headers[3, n_blocks // 2]["hash"][6][3] ^= 1          # data_hash of one header of range 3
+    pe = PipelinedEngines(J, B, V, R, n_engines=1)
+    pe.upload_workload(w)
+    pe.step()
+    pe.step()
+    res = pe.download()
+    assert res["header_status"] == 0 and res["assemble_status"] == 0
+    ml, rl = T.map_layout(B), T.reduce_layout()
+    nm, nr = J * int(ml["n_elements"]), (J - 1) * int(rl["n_elements"])
+    wm, wr = pe.buffer(0, BUF_WITNESS_MAP, i64=True), pe.buffer(0, BUF_WITNESS_REDUCE_LOCAL, i64=True)
+    for r in range(R):
+        full = r in (0, 3, 7, R // 2, R - 1)
+        rc, out, cres, cw = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]),
+                                                w.validators[r], w.trusted[r], want_witness=full)
+        mine = res["skip_status"][r] if res["skip_status"][r] else (T.ERR_ASSERT if res["range_status"][r] else T.OK)
+        assert mine == rc, (r, mine, rc)
+        assert res["output64"][r].tobytes() == out, r
+        ctx = w.ranges[r:r + 1].copy()
+        ctx["end_header_hash"][0] = np.frombuffer(out[:32], np.uint8)
+        _, ref = oracle.prove_data_commitment(J, B, ctx, w.headers[r], int(w.first_height[r]), int(w.latest[r]))
+        assert [_rec(x) for x in res["records"][r]] == [_rec(x) for x in ref["records"]], r
+        if full:
+            want = oracle.expand_range_witness(J, B, cw)
+            assert (wm[r * nm:(r + 1) * nm].cpu().numpy().view(np.uint64) == want[:nm]).all(), r
+            assert (wr[r * nr:(r + 1) * nr].cpu().numpy().view(np.uint64) == want[nm:]).all(), r
+    assert res["range_status"][3] != 0 and not np.delete(res["range_status"], 3).any()
+
+
 @pytest.mark.parametrize("n_engines", [1, 2])
 def test_alternating_pipelines_compact_only_vs_oracle(n_engines):
     """The compact-only leg's object: ONE bsx_pipeline with two buffer sets (bsx_pipeline_config.n_sets = 2; step i on set i mod 2)
