@@ -4,6 +4,7 @@
 // their ceilings differ by up to 15 % between boxes of the same model, so a roofline fraction has to be priced against
 // ceilings measured in the same process on the same device.  Each body below is the arithmetic a kernel is made
 // of — the library's own device functions — alone, at 8 waves per SIMD, with no memory traffic.
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -100,6 +101,18 @@ __global__ void k_spin(unsigned long long ticks, uint32_t* out) {
 // kernels of streams that share one run one after the other whatever the stream flags say.  Measured, not read from the
 // environment: stream s is put in the group of the first representative it serialises with — two single-wave kernels that each
 // spin 0.3 ms take 0.3 ms together on different queues and 0.6 ms on one.  groups[i] (optional) receives stream i's group.
+extern "C" uint32_t bsxk_compute_units() {
+    static std::atomic<uint32_t> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    uint32_t v = cached[dev].load(std::memory_order_relaxed);
+    if (!v) {
+        int n = 0;
+        v = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? (uint32_t)n : 256u;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 extern "C" int bsxk_queue_groups(hipStream_t* streams, uint32_t n, uint32_t* groups) {
     constexpr unsigned long long TICKS = 30000;          // 0.3 ms at 100 MHz
     uint32_t reps[64], n_groups = 0;

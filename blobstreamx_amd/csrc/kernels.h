@@ -112,6 +112,8 @@ hipError_t bsxk_commit_fold(hipStream_t, const bsx_commit_result*, uint32_t, uin
 
 // number of distinct hardware queues the given streams sit on (measured; calibrate.hip); < 0: a bsx_status error code negated
 extern "C" int bsxk_queue_groups(hipStream_t* streams, uint32_t n, uint32_t* groups);
+// compute units of the CURRENT device (hipDeviceAttributeMultiprocessorCount, cached per device; 256 if the query fails)
+extern "C" uint32_t bsxk_compute_units();
 
 extern "C" {
 hipError_t bsxk_poseidon_permute(hipStream_t, const uint64_t*, uint64_t, uint64_t*);

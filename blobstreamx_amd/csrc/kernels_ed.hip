@@ -331,19 +331,19 @@ constexpr uint64_t ED_SPLIT_BELOW = 300000;
 // a contiguous run of keys.  With few commits (a single proof: 1 x 100 signatures) lanes take consecutive signatures.
 // SPLIT lanes per signature (1 or 4): each sums its share of the 48 table entries, the shares are joined by a butterfly of
 // full additions through wave shuffles (ed25519.h ed25519_keyed_partial).  SPLIT = 4 is the small-batch form.
+// (block, n_blocks): the workgroup's index and the size of the grid it belongs to — the launch's own, or a part of it
+// (k_ed25519_verify_keyed_mixed)
 template <bool DEFER, bool BY_KEY, int SPLIT>
-__global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
-                                                                     const uint8_t* __restrict__ hs, uint64_t n,
-                                                                     uint32_t v_max, const uint8_t* __restrict__ table,
-                                                                     uint32_t n_keys, const int32_t* __restrict__ b_tab,
-                                                                     uint8_t* __restrict__ ok_out,
-                                                                     int32_t* __restrict__ scratch) {
+__device__ __forceinline__ void verify_keyed_body(uint32_t block, uint32_t n_blocks, const bsx_validator* __restrict__ vals,
+                                                  const uint8_t* __restrict__ hs, uint64_t n, uint32_t v_max,
+                                                  const uint8_t* __restrict__ table, uint32_t n_keys, const int32_t* __restrict__ b_tab,
+                                                  uint8_t* __restrict__ ok_out, int32_t* __restrict__ scratch) {
     constexpr uint32_t SIGS = ED_THREADS / SPLIT;                              // signatures per workgroup
     const uint32_t sub = threadIdx.x / SPLIT, part0 = threadIdx.x % SPLIT;
     uint64_t me;
     if (BY_KEY) {
-        const uint32_t per_xcd = gridDim.x >> 3;                               // the launcher pads the grid to a multiple of 8
-        const uint32_t blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // logical block: XCD x owns [x, x + 1) * per_xcd
+        const uint32_t per_xcd = n_blocks >> 3;                                // the launcher pads the grid to a multiple of 8
+        const uint32_t blk = (block & 7) * per_xcd + (block >> 3);             // logical block: XCD x owns [x, x + 1) * per_xcd
         const uint64_t n_commits = (n + v_max - 1) / v_max;
         const uint32_t wpk = (uint32_t)((n_commits + SIGS - 1) / SIGS);        // workgroups per key
         const uint32_t slot_ = blk / wpk;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
         if (slot_ >= v_max || commit >= n_commits) return;
         me = commit * v_max + slot_;
     } else {
-        me = (uint64_t)blockIdx.x * SIGS + sub;
+        me = (uint64_t)block * SIGS + sub;
     }
     if (me >= n) return;                        // whole groups of SPLIT lanes leave together (every test below is per signature)
     const uint4* rec = reinterpret_cast<const uint4*>(vals + me);
@@ -427,6 +427,32 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
         }
     }
     if (part0 == 0) ok_out[me] = ok ? 1 : 0;
+}
+template <bool DEFER, bool BY_KEY, int SPLIT>
+__global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bsx_validator* __restrict__ vals,
+                                                                     const uint8_t* __restrict__ hs, uint64_t n,
+                                                                     uint32_t v_max, const uint8_t* __restrict__ table,
+                                                                     uint32_t n_keys, const int32_t* __restrict__ b_tab,
+                                                                     uint8_t* __restrict__ ok_out,
+                                                                     int32_t* __restrict__ scratch) {
+    verify_keyed_body<DEFER, BY_KEY, SPLIT>(blockIdx.x, gridDim.x, vals, hs, n, v_max, table, n_keys, b_tab, ok_out, scratch);
+}
+// A batch whose one-lane-per-signature waves come to a little MORE than a whole number per SIMD (2048 commits x 100 slots: 3200
+// waves on 1024 SIMDs) takes as long as the SIMDs with the extra wave: 4 chains where the average is 3.125.  Here the first
+// blocks_a workgroups take commits [0, commits_a) one lane per signature — a whole number of waves per SIMD — and the others the
+// remaining commits on FOUR lanes each (quarter-length chains, 1.5x the work, spread over four times as many SIMDs).  Four waves per
+// SIMD (128 registers, 16 dwords spilled) so that both kinds are resident from the start.  Same scratch records: one k_ed25519_finish.
+__global__ __launch_bounds__(ED_THREADS, 4) void k_ed25519_verify_keyed_mixed(const bsx_validator* __restrict__ vals,
+                                                                           const uint8_t* __restrict__ hs, uint64_t n, uint32_t v_max,
+                                                                           const uint8_t* __restrict__ table, uint32_t n_keys,
+                                                                           const int32_t* __restrict__ b_tab, uint8_t* __restrict__ ok_out,
+                                                                           int32_t* __restrict__ scratch, uint32_t blocks_a, uint64_t commits_a) {
+    const uint64_t na = commits_a * v_max;
+    if (blockIdx.x < blocks_a)
+        verify_keyed_body<true, true, 1>(blockIdx.x, blocks_a, vals, hs, na, v_max, table, n_keys, b_tab, ok_out, scratch);
+    else
+        verify_keyed_body<true, true, 4>(blockIdx.x - blocks_a, gridDim.x - blocks_a, vals + na, hs + na * 32, n - na, v_max, table, n_keys, b_tab,
+                                         ok_out + na, scratch + na * ED_SLOT_I32);
 }
 
 // The small-batch form (a single proof: 100 signatures): latency is everything, and a third of a signature's dependent
@@ -1274,6 +1300,30 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
         grid = dim3((uint32_t)((wpk * v_max + 7) / 8 * 8));                   // k_ed25519_verify_keyed: the XCD remap needs a multiple of 8
     } else {
         grid = dim3((uint32_t)((n + sigs - 1) / sigs));
+    }
+    // one lane per signature, lanes by key, with the batch-inversion scratch (mode S): peel the waves beyond a whole number per SIMD
+    // off into the four-lane form (k_ed25519_verify_keyed_mixed).  BSX_ED_MIXED=0 (experiments): never
+    static const bool mixed_on = bsx_knob("BSX_ED_MIXED", 1) != 0;
+    if (mixed_on && env_split < 0 && env_by_key < 0 && n_commits >= ED_THREADS / 2 && scr && !throughput) {
+        const uint64_t simds = (uint64_t)bsxk_compute_units() * 4;
+        const uint64_t waves = (n_commits + ED_THREADS - 1) / ED_THREADS * v_max, per = waves / simds, extra = waves % simds;
+        // worth it while the batch is a few rounds deep and the extra waves would leave most SIMDs waiting for a few
+        if (per >= 1 && per <= 6 && extra && extra * 2 <= simds) {
+            const uint64_t wpk_a = per * simds / v_max;                                   // one-lane workgroups per key
+            const uint64_t commits_a = wpk_a * ED_THREADS;
+            if (wpk_a && commits_a < n_commits) {
+                const uint32_t blocks_a = (uint32_t)((wpk_a * v_max + 7) / 8 * 8);
+                const uint64_t wpk_b = (n_commits - commits_a + ED_THREADS / 4 - 1) / (ED_THREADS / 4);
+                const uint32_t blocks_b = (uint32_t)((wpk_b * v_max + 7) / 8 * 8);
+                hipLaunchKernelGGL(k_ed25519_verify_keyed_mixed, dim3(blocks_a + blocks_b), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys,
+                                   b_tab, ok, scr, blocks_a, commits_a);
+                const uint32_t K = ed_fin_k(n);
+                const uint64_t lanes = (n + K - 1) / K;
+                hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
+                BSX_LAUNCH_DEFERRED();
+                return hipGetLastError();
+            }
+        }
     }
 #define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_) \
     hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr)

@@ -41,6 +41,10 @@ def test_commit_shards_vs_oracle(world, J, B, V, tamper):
         bad = nh // 2 + 3
         k = int(np.nonzero(vals[bad]["is_signed"])[0][0])
         vals[bad, k]["signature"][9] ^= 8
+        if nh >= 2000:        # 2048 x 100 at world 1 is verified in two forms in one launch (k_ed25519_verify_keyed_mixed: commits
+            bad2 = nh - 40    # [0, 1920) one lane per signature, the rest on four): one bad signature in the second part too
+            k2 = int(np.nonzero(vals[bad2]["is_signed"])[0][-1])
+            vals[bad2, k2]["signature"][40] ^= 1
     if nh * V > 100_000:      # a million signatures: the oracle on every host thread (same function, orc_verify_commit per commit)
         import os
         rres_all, rok_all = oracle.bench_verify_commits(vals, w.commit_hashes, len(os.sched_getaffinity(0)))
