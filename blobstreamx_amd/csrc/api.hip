@@ -102,6 +102,9 @@ int bsx_init(int device, bsx_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_d, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_e, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_f, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_g, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming);
@@ -130,6 +133,9 @@ void bsx_shutdown(bsx_ctx* ctx) {
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_d) (void)hipEventDestroy(ctx->ev_d);
     if (ctx->ev_e) (void)hipEventDestroy(ctx->ev_e);
+    if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
+    if (ctx->ev_f) (void)hipEventDestroy(ctx->ev_f);
+    if (ctx->ev_g) (void)hipEventDestroy(ctx->ev_g);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
@@ -586,6 +592,19 @@ struct StagedD2H {
 #define H2D(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, st))
 #define D2H(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyDeviceToHost, st))
 #define SYNC() HIPCHK(hipStreamSynchronize(st))
+// A proof request's last wait: poll the stream for up to 2 ms before blocking on it — waking a blocked thread costs 10 - 20 us of a
+// 0.25 ms call (the blocking wait sleeps on an interrupt); longer waits (a witness download) block as usual
+static hipError_t sync_polling(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(st);
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
 
 static int header_status_to_rc(uint32_t hs, uint32_t as) {
     if (hs & 1u) return fail(BSX_ERR_BAD_HEADER, "a packed header violates the field-size rules of bsx_header");
@@ -703,7 +722,7 @@ struct RangeDev {
 };
 static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
                         uint64_t S_, const bsx_shared_ctx& range, uint64_t latest_block, RangeDev& rd, const SmallIO* io = nullptr,
-                        bool skip_header_copy = false) {
+                        bool skip_header_copy = false, const bsxk_merkle_tap* tap = nullptr, bool hash_later = false) {
     if (!headers || !n_headers) return fail(BSX_ERR_BAD_ARG, "no headers supplied");
     if (S_ < first_height || S_ - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "header for start block %llu not supplied (first_height %llu, n %llu)", (unsigned long long)S_, (unsigned long long)first_height, (unsigned long long)n_headers);
     if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
@@ -731,9 +750,15 @@ static int upload_range(bsx_ctx* ctx, hipStream_t st, const bsx_header* headers,
         HIPCHK(hipMemsetAsync(rd.hstatus.p, 0, 4, st));
         HIPCHK(hipMemsetAsync(rd.astatus.p, 0, 4, st));
     }
+    if (hash_later) return BSX_OK;          // the caller launches hash_range_headers() itself (more enqueues while the copy is in flight)
     HIPCHK(bsxk_header_merkle(st, rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
-                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>(), 0, 0));
+                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>(), 0, 0, tap));
     (void)ctx;
+    return BSX_OK;
+}
+static int hash_range_headers(hipStream_t st, RangeDev& rd, const bsxk_merkle_tap* tap) {
+    HIPCHK(bsxk_header_merkle(st, rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(), rd.dh.as<uint8_t>(), rd.lb.as<uint8_t>(),
+                              rd.paths.as<uint8_t>(), rd.hstatus.as<uint32_t>(), 0, 0, tap));
     return BSX_OK;
 }
 
@@ -1101,7 +1126,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     // (challenges, key table, signatures, tallies, skip conditions — latency bound at <= 100 signatures) beside it on `sb`; and
     // what the commit check needs but does not have to wait for in line (R decoded for the projective comparison, the trusted
     // set's hash and power sum) on `s3`.  All are drained before the arena is rewound, also on the error paths (Drain).
-    hipStream_t sb = ctx->stream2, s3 = ctx->stream3;
+    hipStream_t sb = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
     struct Drain {
         hipStream_t a, b, c;
         ~Drain() { (void)hipStreamSynchronize(c); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(a); }
@@ -1178,28 +1203,34 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     }
     HIPCHK(hipMemcpyAsync(io.d, io.h, io.out_off + SmallIO::OUT_BYTES, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(ctx->ev_c, st));
-    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_c, 0));                       // the commit check's inputs
-    HIPCHK(hipStreamWaitEvent(s3, ctx->ev_c, 0));
     dbuf_alias(dv, io.d + 256);
     dbuf_alias(dtv, io.d + 256 + vbytes);
     dbuf_alias(dskip, io.dout(204));
     dbuf_alias(dres, io.dout(256));
     RET(dth.alloc(32));
-    RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd, &io, capture));
-    // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash (and the first output half)
-    HIPCHK(bsxk_fill_end_hash(st, 1, rd.ranges.as<bsx_shared_ctx>(), rd.hashes.as<uint8_t>(), rd.hpr, nullptr, dth.as<uint8_t>(), nullptr, 0));
+    // the headers: a pageable megabyte is staged by the runtime (25 us on this thread) and then copied (25 us of DMA) — the head of
+    // the hashing chain, the longer one.  Enqueued FIRST; everything else that has to be enqueued before the header hashing can start
+    // (the side streams' waits, the R decoding) is enqueued while the DMA runs
+    const bsxk_merkle_tap tap{target_block - trusted_block, io.d + offsetof(bsx_shared_ctx, end_header_hash), dth.as<uint8_t>()};
+    RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd, &io, capture, &tap, /*hash_later=*/true));
+    HIPCHK(hipStreamWaitEvent(s3, ctx->ev_c, 0));                       // the commit check's inputs
+    RET(drd.alloc(bsxk_ed25519_rdec_bytes(v_max)));
+    // s3: R decoded (a square-root chain as long as a field inversion — the longest kernel of the commit check, and it needs only the
+    // validator records)
+    uint8_t* tab = nullptr;
+    RET(ctx_keytable(ctx, v_max, &tab, sb));
+    if (tab) HIPCHK(bsxk_ed25519_decode_r(s3, dv.as<bsx_validator>(), v_max, drd.p));
+    HIPCHK(hipEventRecord(ctx->ev_d, s3));                              // the signature check waits for this
+    // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash (and the first output half) — stored by
+    // the header hashing itself (the lane that joins the target header's tree), not by a k_fill_end_hash launch behind it
+    RET(hash_range_headers(st, rd, &tap));
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_c, 0));
+    HIPCHK(hipStreamWaitEvent(s4, ctx->ev_c, 0));
     RET(dh.alloc((size_t)v_max * 32));
     RET(dok.alloc(v_max));
     RET(dtres.alloc(sizeof(bsx_commit_result)));
     RET(dth2.alloc(32));
-    RET(drd.alloc(bsxk_ed25519_rdec_bytes(v_max)));
     HIPCHK(hipEventRecord(ctx->ev_a, st));                              // header hashes
-    // s3: R decoded (a square-root chain as long as a field inversion, independent of the challenges) and the trusted tally
-    uint8_t* tab = nullptr;
-    RET(ctx_keytable(ctx, v_max, &tab, sb));
-    if (tab) HIPCHK(bsxk_ed25519_decode_r(s3, dv.as<bsx_validator>(), v_max, drd.p));
-    HIPCHK(hipEventRecord(ctx->ev_d, s3));                              // the signature check waits for this ...
-    HIPCHK(bsxk_commit_tally(s3, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>(), swtp));
     if (witness) {
         // header-field inclusion proofs of the target (chain id, height, validators_hash) and the trusted header (validators_hash)
         bsxk_field_proofs_args fa{};
@@ -1211,11 +1242,17 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         HIPCHK(hipStreamWaitEvent(s3, ctx->ev_a, 0));                   // the range's headers are uploaded on `st`
         HIPCHK(bsxk_field_proofs(s3, &fa));
     }
-    HIPCHK(hipEventRecord(ctx->ev_e, s3));                              // ... only the skip conditions for this
+    HIPCHK(hipEventRecord(ctx->ev_e, s3));                              // the skip conditions wait for this (field proofs)
     const uint8_t* d_target_hash = rd.hashes.as<uint8_t>() + (target_block - trusted_block) * 32;
     HIPCHK(bsxk_sha512_challenge(sb, dv.as<bsx_validator>(), v_max, dh.as<uint8_t>(), nullptr, v_max, cwp));
-    // validator-set hash + total power of the target set: nothing here depends on the signatures — ahead of the verification
-    HIPCHK(bsxk_commit_tally(sb, dv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dres.as<bsx_commit_result>(), cwp));
+    // validator-set hash + total power of the target set: nothing here depends on the signatures — on its own stream beside the
+    // challenges and the R decoding (on `sb` its 16 dependent compressions sat between the challenges and the verification: 50 us of
+    // the commit chain, which had become the longer one)
+    HIPCHK(bsxk_commit_tally(s4, dv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dres.as<bsx_commit_result>(), cwp));
+    HIPCHK(hipEventRecord(ctx->ev_f, s4));
+    // ... and the trusted set's behind it (only the skip conditions need it)
+    HIPCHK(bsxk_commit_tally(s4, dtv.as<bsx_validator>(), 1, v_max, nullptr, nullptr, dtres.as<bsx_commit_result>(), swtp));
+    HIPCHK(hipEventRecord(ctx->ev_g, s4));
     if (tab) {
         // the table rows are compared with the request's keys on the HOST (a mirror of the keys the rows were built for): an unchanged
         // validator set — every request of a prover's working day — launches neither the key compare nor the (no-op) build
@@ -1232,9 +1269,11 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         HIPCHK(hipStreamWaitEvent(sb, ctx->ev_d, 0));
     }
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // header hashes (target hash, field-7 checks) from `st`
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_f, 0));                       // the target set's tally
     // the signature-dependent half of the tally (the validator leaves, the tree and the total ran EARLY, beside the R decoding)
     HIPCHK(bsxk_commit_sums(sb, dv.as<bsx_validator>(), 1, v_max, d_target_hash, dok.as<uint8_t>(), dres.as<bsx_commit_result>(), cwp));
     HIPCHK(hipStreamWaitEvent(sb, ctx->ev_e, 0));
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_g, 0));
     HIPCHK(bsxk_skip_check(sb, 1, v_max, rd.ranges.as<bsx_shared_ctx>(), rd.headers.as<bsx_header>(), rd.hpr, rd.hashes.as<uint8_t>(),
                            dv.as<bsx_validator>(), dtv.as<bsx_validator>(), dok.as<uint8_t>(), dres.as<bsx_commit_result>(),
                            dtres.as<bsx_commit_result>(), dskip.as<uint32_t>(), dth2.as<uint8_t>(), nullptr, chain_id, chain_id_len, swp));
@@ -1271,7 +1310,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         HIPCHK(hipMemcpyAsync(ctx->hr_d_headers, h0, key.hpr * sizeof(bsx_header), hipMemcpyHostToDevice, st));
         HIPCHK(hipGraphLaunch(ctx->hr_exec, st));
     }
-    SYNC();
+    if (witness) SYNC(); else HIPCHK(sync_polling(st));
     if (trace_host)
         fprintf(stderr, "bsx_header_range: enqueue %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(t_enq - t_entry).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count());

@@ -40,6 +40,8 @@ struct bsx_ctx {
     hipStream_t stream;
     hipStream_t stream3 = nullptr;       // host tier: work the commit check needs but need not wait for in line
     hipEvent_t ev_d = nullptr, ev_e = nullptr;
+    hipStream_t stream4 = nullptr;       // host tier: the target set's leaves + tree + total, beside the challenges (round 4)
+    hipEvent_t ev_f = nullptr, ev_g = nullptr;
     bool graphs_enabled = false;         // BSX_TUNE_HOST_GRAPHS (off: ROCm 7.2 runs a graph's parallel branches one after the other)
     bool hr_seen = false;                // the previous bsx_header_range request was graphable, with key hr_seen_key
     HrGraphKey hr_seen_key{}, hr_key{};

@@ -30,7 +30,11 @@ inline bsxk_unit_dst bsxk_unit(uint8_t* base, const bsx_witness_layout& L, uint3
 }
 
 extern "C" {
-hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t, uint32_t);
+// tap (optional): the root of header `idx` of the launch is ALSO stored at dst_a / dst_b (32 bytes each, either may be null) — the
+// host tier's ctx.end_header_hash and dense target hash, which k_fill_end_hash would copy one kernel boundary later
+struct bsxk_merkle_tap { uint64_t idx; uint8_t* dst_a; uint8_t* dst_b; };
+hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t, uint32_t,
+                              const bsxk_merkle_tap* tap = nullptr);
 hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
 hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,

@@ -856,7 +856,11 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     __syncthreads();
     int cur = 0;
     uint32_t level_off = 0;
+    // a wave beyond the level's width has no node left on this or any later level: it ends (a barrier counts the surviving waves),
+    // and its slot goes to the next commit's workgroup instead of idling through the narrow levels
+    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u);
     for (uint32_t width = P / 2; width >= 1; width /= 2) {
+        if (wave_base && wave_base >= width) return;
         for (uint32_t t = tid; t < width; t += nthreads) {
             Digest l, r;
 #pragma unroll

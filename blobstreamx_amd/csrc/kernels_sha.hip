@@ -147,7 +147,7 @@ constexpr uint32_t HM_PATH_BYTES = 7 * 32;
 __global__ __launch_bounds__(HM_THREADS, 4) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
                                                               uint8_t* __restrict__ lb_aunts, uint8_t* __restrict__ paths,
-                                                              uint32_t* __restrict__ status, uint32_t low_prio) {
+                                                              uint32_t* __restrict__ status, uint32_t low_prio, bsxk_merkle_tap tap) {
     // beside an expansion: above the commit check's waves (BSX_CHAIN_PRIO).  In the compact pipeline this kernel is the bulk
     // ALU work that the OTHER buffer set's short chain kernels (hint, prove_subchain, reduce, ...) must get through: it yields
     if (!low_prio) BSX_CHAIN_PRIO();
@@ -240,6 +240,10 @@ __global__ __launch_bounds__(HM_THREADS, 4) void k_header_merkle(const bsx_heade
                 }
                 if (lb_aunts) store_digest_u(lb_aunts + me * 128 + 96, right);
                 if (dh_aunts) store_digest_u(dh_aunts + me * 128 + 96, right);
+                if (me == tap.idx) {
+                    if (tap.dst_a) store_digest_u(tap.dst_a, root);
+                    if (tap.dst_b) store_digest_u(tap.dst_b, root);
+                }
             }
         }
         // wave-ballot reduction of the "bad header" predicate: one atomic per wave
@@ -1044,7 +1048,7 @@ extern "C" {
 using namespace bsx;
 
 hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint8_t* paths,
-                              uint32_t* status, uint32_t max_wgs, uint32_t low_prio) {
+                              uint32_t* status, uint32_t max_wgs, uint32_t low_prio, const bsxk_merkle_tap* tap) {
     if (!n) return hipSuccess;
     uint32_t grid = (uint32_t)((n + HM_GROUP - 1) / HM_GROUP);
     // cap on the grid (the workgroups then stride over the header groups): the context's BSX_TUNE_MERKLE_WORKGROUPS (an experiments
@@ -1053,7 +1057,8 @@ hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, 
     const long cap = env_cap >= 0 ? env_cap : (long)max_wgs;
     if (cap > 0 && grid > (uint32_t)cap) grid = (uint32_t)cap;
     static const long env_lp = bsx_knob("BSX_MERKLE_LOW_PRIO", -1);
-    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status, env_lp >= 0 ? (uint32_t)env_lp : low_prio);
+    hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status, env_lp >= 0 ? (uint32_t)env_lp : low_prio,
+                       tap ? *tap : bsxk_merkle_tap{~0ull, nullptr, nullptr});
     return hipGetLastError();
 }
 hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {
