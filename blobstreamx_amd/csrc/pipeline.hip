@@ -34,6 +34,7 @@ struct TimingSlot {
     bool sub, exp, caps;
 };
 
+constexpr uint64_t PIPE_LATENCY_FORM_BELOW = 16384;     // signatures per chunk: at or below, the commit check's latency form
 struct Chunk {
     uint32_t R = 0, RT = 0;                  // owned ranges / ranges whose job slice this rank computes, in this chunk
     uint64_t nh_main = 0, nh_skip = 0, nh_all = 0;
@@ -206,7 +207,10 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
     }
     if (p->with_commit && p->keyed) {
         RET(dalloc_t(p, bsxk_keytable_bytes(V), &c.keytable));   // zeroed: no row to reuse yet
-        if (p->with_witness) RET(dalloc_t(p, bsxk_ed25519_rdec_bytes((uint64_t)R * V), &c.rdec));
+        // beside an expansion (ALU to spare, one step to finish in) and for a FEW ranges (nothing to fill the GPU with anyway: the
+        // commit chain's latency is the step) the latency form — R decoded beside the challenges, 8 / 16 lanes per signature, projective
+        // compare: ~0.1 ms where the least-work form (one lane per signature, batch inversion) is a 0.7 ms chain whatever the batch
+        if (p->with_witness || (uint64_t)R * V <= PIPE_LATENCY_FORM_BELOW) RET(dalloc_t(p, bsxk_ed25519_rdec_bytes((uint64_t)R * V), &c.rdec));
         else RET(dalloc_t(p, bsxk_ed25519_scratch_bytes((uint64_t)R * V), &c.ed_scratch));
     }
     c.n_map_el = (uint64_t)RT * jc * p->ml.n_elements;
@@ -658,8 +662,10 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     p->with_caps = cfg->flags & BSX_PIPE_CAPS;
     p->commit_beside_hash = cfg->flags & BSX_PIPE_COMMIT_BESIDE_HASH;
     p->fused_hint = !(cfg->flags & BSX_PIPE_RECOMPUTE_PATHS);
-    // fixed-key tables pay from a handful of commits per chunk on (below, the generic kernel's 256 doublings are hidden anyway)
-    p->keyed = !(cfg->flags & BSX_PIPE_ED_GENERIC) && p->Rc >= 8;
+    // fixed-key tables at any chunk size: they are built where validator sets change (bsx_pipeline_upload), not per step, and the
+    // generic kernel is a 1.4 ms chain of 256 doublings that a chunk of a few ranges has nothing to hide behind (rounds 2-3 kept it
+    // below 8 ranges per chunk, when a step still paid for the tables: a 1-range step took 1.6 ms, a 16-range step 0.47)
+    p->keyed = !(cfg->flags & BSX_PIPE_ED_GENERIC);
     p->ml = bsx_map_layout(B);
     p->rl = bsx_reduce_layout();
     p->cl = bsx_commit_layout(p->V);
