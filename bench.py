@@ -291,7 +291,9 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     from blobstreamx_amd.stress import CommitShard, range_verdict
     nh = args.jobs * args.batch
     w = synth.Workload(5 if V > 100 else 4, 1, args.jobs, args.batch, v=V, mode="S")
-    sh = CommitShard(nh, V, rank=rank, world=world, device=dev)
+    # two buffer sets on two streams: step i + 1 starts while step i's stages drain (stress.py CommitShard); the fold all-gather of
+    # step i is taken while step i + 1 runs
+    sh = CommitShard(nh, V, rank=rank, world=world, device=dev, n_sets=2)
     sh.upload(w.validators.reshape(nh, V), w.commit_hashes)
     n = sh.n * V
     L, ctx, dp = sh.L, sh.ctx, _lib.dp
@@ -323,26 +325,38 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     t = np.mean([staged() for _ in range(5)], axis=0)
     t_sha, t_tab, t_ed, t_tally = (float(x) for x in t)
     # the timed object: K steps of the ONE composite call + the fold all-gather, barrier on both sides, max over ranks
-    sh.step()
-    folds = sh.gather()
-    K = 5
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        sh.step()
-        folds = sh.gather()
-    barrier()
-    dt = (time.perf_counter() - t0) / K
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed(shard, K, in_flight):
+        """K steps; in_flight = 1: a step's folds are gathered (host sync) before the next step is enqueued; 2: one step later"""
+        shard.gather(shard.step())
+        barrier()
+        t0 = time.perf_counter()
+        prev, folds = None, None
+        for _ in range(K):
+            k = shard.step()
+            if in_flight == 1:
+                folds = shard.gather(k)
+            else:
+                if prev is not None:
+                    folds = shard.gather(prev)
+                prev = k
+        if prev is not None:
+            folds = shard.gather(prev)
+        barrier()
+        dt = (time.perf_counter() - t0) / K
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, folds
+    dt1, _ = timed(sh, 5, 1)
+    dt, folds = timed(sh, 20, 2)
     tot = dt * 1e3
     gpu_ok, gpu_res, gpu_fold = sh.download()
     verdict = range_verdict(folds)
     out = {"workload": f"mode S: {nh} headers x {V} validators = {nh * V} signatures (one header_range_{nh}, a commit per header)"
                        + (f", sharded {world} x {sh.n} commits, one all-gather of 128-byte folds" if world > 1 else ""),
-           "headers_per_s": nh / dt, "verifies_per_s_all_stages": nh * V / dt, "ms": tot,
+           "headers_per_s": nh / dt, "verifies_per_s_all_stages": nh * V / dt, "ms": tot, "steps_in_flight": 2,
+           "one_step_in_flight": {"headers_per_s": nh / dt1, "ms": dt1 * 1e3},
            "verifies_per_s_incl_table": n / (t_ed + t_tab) * 1e3, "signatures": nh * V, "signatures_this_rank": n,
            "range_verdict": verdict,
            "stage_ms": {"sha512_challenge": t_sha, "keytable": t_tab, "ed25519_verify_keyed": t_ed, "tally_validator_hash": t_tally,
@@ -357,7 +371,8 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
                        "avg_launch_ms": t_ed, "traffic": None,
                        "field_ops_per_verification": {"mul": FE_MUL_PER_VERIFY, "sq": FE_SQ_PER_VERIFY},
                        "achieved_G_field_ops_per_s": ver_per_s * (FE_MUL_PER_VERIFY + FE_SQ_PER_VERIFY) / 1e9,
-                       "valu_issue": valu_issue(cal, "k_ed25519_verify_keyed<true, true, 4>" if n < 300000 else "k_ed25519_verify_keyed<true, true, 1>", n, t_ed * 1e-3),
+                       # 2048 x 100 runs k_ed25519_verify_keyed_mixed (kernels_ed.hip: whole waves per SIMD one lane per signature, the rest on four)
+                       "valu_issue": valu_issue(cal, "k_ed25519_verify_keyed_mixed" if n < 300000 else "k_ed25519_verify_keyed<true, true, 1>", n, t_ed * 1e-3),
                        "note": "peak = the time the kernel's GF(2^255-19) multiplications and squarings would take at the fe_mul / fe_sq "
                                f"rates measured in this run ({cal['fe25519_mul_per_s'] / 1e9:.0f} / {cal['fe25519_sq_per_s'] / 1e9:.0f} G/s); additions, "
                                "table selection, recoding and the launch's partial last wave round are what is left; ALU bound, bytes are "
@@ -373,13 +388,14 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     # expanded into Goldilocks elements by k_expand_witness on the same stream — HBM-write bound, its own roofline next to the VALU one.
     del sh
     torch.cuda.empty_cache()
-    shw = CommitShard(nh, V, rank=rank, world=world, device=dev, expand=True)
+    shw = CommitShard(nh, V, rank=rank, world=world, device=dev, expand=True, n_sets=2)
     shw.upload(w.validators.reshape(nh, V), w.commit_hashes)
     lay = shw.lay
     exp_bytes = shw.n * (int(lay["n_bytes"]) + 4 * int(lay["n_words"]) + int(lay["n_bools"]) + 8 * int(lay["n_elements"]))
     evw = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     layp = np.ascontiguousarray(lay).reshape(1)
     shw.step(); shw.step()
+    torch.cuda.synchronize(dev)                     # the steps ran on the sets' own streams
     t_x = 0.0
     for _ in range(3):
         evw[0].record()
@@ -387,13 +403,8 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
         evw[1].record()
         torch.cuda.synchronize(dev)
         t_x += evw[0].elapsed_time(evw[1]) / 3
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        shw.step()
-        shw.gather()
-    barrier()
-    dtw = (time.perf_counter() - t0) / K
+    dtw1, _ = timed(shw, 3, 1)
+    dtw, _ = timed(shw, 8, 2)
     pick = sorted({0, 1, shw.n // 3, shw.n // 2, shw.n - 1})
     got = shw.witness_of(pick)
     vv_all = w.validators.reshape(nh, V)
@@ -403,7 +414,8 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
         want = oracle.expand_witness(lay, 1, cwc)
         assert got[i].shape == want.shape and (got[i] == want).all(), f"mode S: the COMMIT unit of commit {gc} differs from the oracle's"
     gpu_ok_w, gpu_res_w, gpu_fold_w = shw.download()
-    out["witness"] = {"headers_per_s": nh / dtw, "ms": dtw * 1e3, "elements_per_commit": int(lay["n_elements"]),
+    out["witness"] = {"headers_per_s": nh / dtw, "ms": dtw * 1e3, "steps_in_flight": 2,
+                      "one_step_in_flight": {"headers_per_s": nh / dtw1, "ms": dtw1 * 1e3}, "elements_per_commit": int(lay["n_elements"]),
                       "bytes_per_step_this_rank": int(shw.n * 8 * int(lay["n_elements"])),
                       "checked_against_oracle_commits": len(pick),
                       "roofline": {"kernel": "k_expand_witness (COMMIT units)", "bound": "hbm", "achieved": exp_bytes / t_x / 1e6, "peak": HBM_PEAK_GBS,

@@ -49,10 +49,14 @@ def range_verdict(folds):
 
 
 class CommitShard:
-    def __init__(self, n_commits_total, v_max, rank=0, world=1, device=None, with_witness=False, expand=False):
+    def __init__(self, n_commits_total, v_max, rank=0, world=1, device=None, with_witness=False, expand=False, n_sets=1):
         """with_witness: every step also leaves the commits' COMMIT units (include/bsx_layout.h: the Goldilocks witness of the
         per-validator loop, BASELINE config #5) in compact form in `self.compact`; expand: and expands them into `self.witness`
-        (u64 [n][commit_layout(V).n_elements]: 15 MB per commit at V = 512) on the same stream."""
+        (u64 [n][commit_layout(V).n_elements]: 15 MB per commit at V = 512) on the same stream.
+        n_sets = K > 1: K sets of output buffers (verdicts, results, fold, scratch, units) and K streams; step i runs on set i mod K,
+        so that step i + 1 starts while step i's stages drain (a stage is a few resident rounds of long waves: alone, its ramp-up,
+        its last partial round and the SIMDs with one wave less than their neighbours idle).  The inputs and the key tables are shared,
+        read only.  `ok` / `res` / `fold` / `compact` / `witness` name the set of the LAST step."""
         import torch
         self.N, self.V, self.rank, self.world = n_commits_total, v_max, rank, world
         self.first, self.n = commit_slice(n_commits_total, rank, world)
@@ -61,19 +65,29 @@ class CommitShard:
         self.L = _lib.lib()
         n, V, d = self.n, v_max, self.dev
         z = lambda nbytes: torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=d)
+        self.K = int(n_sets)
+        assert self.K >= 1
         self.vals = z(n * V * 256)
         self.hh = z(n * 32)
-        self.ok = z(n * V)
-        self.res = z(n * 96)
-        self.fold = z(128)
         self.keytable = z(int(self.L.bsx_ed25519_keytable_bytes(C.c_uint32(V))))
-        self.scratch = z(int(self.L.bsx_dev_verify_commits_scratch_bytes(C.c_uint32(n), C.c_uint32(V))))
         self.lay = T.commit_layout(V)
-        self.compact = z(n * int(self.lay["compact_stride"])) if (with_witness or expand) else None
-        self.witness = None
-        if expand:
-            self._wbuf = _lib.DeviceBuffer(n * int(self.lay["n_elements"]) + 2, self.dev.index if self.dev.index is not None else 0)
-            self.witness = self._wbuf.tensor()
+        self._sets = []
+        for _ in range(self.K):
+            st = {"ok": z(n * V), "res": z(n * 96), "fold": z(128),
+                  "scratch": z(int(self.L.bsx_dev_verify_commits_scratch_bytes(C.c_uint32(n), C.c_uint32(V)))),
+                  "compact": z(n * int(self.lay["compact_stride"])) if (with_witness or expand) else None, "witness": None, "wbuf": None,
+                  "stream": torch.cuda.Stream(d) if self.K > 1 else None}
+            if expand:
+                st["wbuf"] = _lib.DeviceBuffer(n * int(self.lay["n_elements"]) + 2, self.dev.index if self.dev.index is not None else 0)
+                st["witness"] = st["wbuf"].tensor()
+            self._sets.append(st)
+        self.steps = 0
+        self._use(0)
+
+    def _use(self, k):
+        s = self._sets[k]
+        self.cur = k
+        self.ok, self.res, self.fold, self.scratch, self.compact, self.witness = s["ok"], s["res"], s["fold"], s["scratch"], s["compact"], s["witness"]
 
     def upload(self, validators, header_hashes):
         """validators [N, V] VALIDATOR and header_hashes [N, 32] of the WHOLE range; this rank keeps its slice."""
@@ -94,8 +108,13 @@ class CommitShard:
         self.flags = 1 | (2 if uniform else 0)
 
     def step(self, stream=None):
+        """One bsx_dev_verify_commits over this rank's slice [+ the units' expansion], on `stream` (default: the current stream; with
+        n_sets > 1 the set's own stream).  Returns the index of the buffer set it runs on."""
         import torch
-        st = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        k = self.steps % self.K
+        self.steps += 1
+        self._use(k)
+        st = stream if stream is not None else (self._sets[k]["stream"] or torch.cuda.current_stream(self.dev))
         dp = _lib.dp
         _lib.check(self.L.bsx_dev_verify_commits(self.ctx, C.c_void_p(st.cuda_stream), dp(self.vals), C.c_uint32(self.n), C.c_uint32(self.V),
                                                  dp(self.hh), C.c_uint32(self.first), dp(self.keytable), dp(self.scratch), dp(self.ok),
@@ -104,6 +123,7 @@ class CommitShard:
             lay = np.ascontiguousarray(self.lay).reshape(1)
             _lib.check(self.L.bsx_dev_expand_witness(self.ctx, C.c_void_p(st.cuda_stream), _lib.p(lay), C.c_uint32(self.n), dp(self.compact),
                                                      dp(self.witness)))
+        return k
 
     def witness_of(self, commits):
         """Expanded COMMIT units of the given local commit indices -> u64 [len(commits), n_elements] (host)."""
@@ -118,9 +138,19 @@ class CommitShard:
         cs = int(self.lay["compact_stride"])
         return np.stack([self.compact[c * cs:(c + 1) * cs].cpu().numpy() for c in commits])
 
-    def gather(self):
-        """All ranks' folds -> COMMIT_FOLD[world] (host)."""
-        return all_gather_folds(self.fold, self.world).cpu().numpy().reshape(-1).view(T.COMMIT_FOLD).copy()
+    def gather(self, k=None):
+        """All ranks' folds -> COMMIT_FOLD[world] (host).  k: the buffer set whose step to gather (default: the last step's); with
+        n_sets > 1 the collective and the copy are ordered on that set's stream, the other sets' steps keep running."""
+        import torch
+        s = self._sets[self.cur if k is None else k]
+        if s["stream"] is None:
+            return all_gather_folds(s["fold"], self.world).cpu().numpy().reshape(-1).view(T.COMMIT_FOLD).copy()
+        with torch.cuda.stream(s["stream"]):
+            g = all_gather_folds(s["fold"], self.world)
+            h = torch.empty(g.shape, dtype=g.dtype, pin_memory=True)
+            h.copy_(g, non_blocking=True)
+        s["stream"].synchronize()
+        return h.numpy().reshape(-1).view(T.COMMIT_FOLD).copy()
 
     def download(self):
         import torch

@@ -80,6 +80,39 @@ def test_commit_shards_vs_oracle(world, J, B, V, tamper):
         assert v["all_ok"] and v["signatures_ok"] == nh * V
 
 
+def test_two_steps_in_flight_give_the_same_answers():
+    """CommitShard(n_sets=2): step i on buffer set i mod 2 and its own stream, un-joined (bench.py's mode-S loop).  After an odd and
+    after an even number of steps the verdicts, results, fold and COMMIT units of the last step equal the one-set shard's, and the
+    fold gathered one step late is the fold of THAT step's set."""
+    from blobstreamx_amd.stress import CommitShard
+    J, B, V = 4, 16, 33
+    nh = J * B
+    w = synth.Workload(7, 1, J, B, v=V, mode="S", nil_permille=80, absent_permille=40)
+    vals = w.validators.reshape(nh, V).copy()
+    k = int(np.nonzero(vals[11]["is_signed"])[0][0])
+    vals[11, k]["signature"][3] ^= 2
+    one = CommitShard(nh, V, with_witness=True)
+    one.upload(vals, w.commit_hashes)
+    one.step()
+    ok1, res1, fold1 = one.download()
+    cw1 = one.compact_of(range(nh))
+    two = CommitShard(nh, V, with_witness=True, n_sets=2)
+    two.upload(vals, w.commit_hashes)
+    prev = None
+    for i in range(5):
+        k_set = two.step()
+        assert k_set == i % 2
+        if prev is not None:
+            assert two.gather(prev).tobytes() == np.array([fold1]).tobytes()
+        prev = k_set
+        if i in (2, 3, 4):
+            ok2, res2, fold2 = two.download()
+            assert (ok2 == ok1).all() and _clean(res2) == _clean(res1) and fold2.tobytes() == fold1.tobytes(), i
+            assert (two.compact_of(range(nh)) == cw1).all(), i
+    rres, rok = oracle.verify_commit(vals[11], w.commit_hashes[11].tobytes())
+    assert (ok1[11] == rok).all() and rres["n_bad_signature"] == 1
+
+
 def test_bench_mode_s_two_ranks_share_one_gpu():
     """bench.py --mode S --gpus 2 end to end over gloo with both ranks on the one GPU: commit slices, one all-gather of folds per
     step, barriers, max-over-ranks timing, oracle checks on every rank's slice, ONE JSON line from rank 0."""

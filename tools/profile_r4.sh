@@ -47,7 +47,7 @@ python tools/commit_chain_time.py > $O/r4_commit_chain_stages.txt 2>&1
 #    keyed verification of 1,048,576 signatures (mode S 512)
 python tools/valu_insts.py $O/valu_insts.json "poseidon_leaf=$O/r4_poseidon_pmc_sq.csv:k_leaf_hashes<true>:14500881:Poseidon permutation" \
    "ed25519_keyed_1lane=$O/r4_modeS_512_pmc_sq.csv:k_ed25519_verify_keyed<true, true, 1>:1048576:signature" \
-   "ed25519_keyed_4lanes=$O/r4_modeS_100_pmc_sq.csv:k_ed25519_verify_keyed<true, true, 4>:204800:signature" > $O/valu_insts.log 2>&1
+   "ed25519_keyed_mixed=$O/r4_modeS_100_pmc_sq.csv:k_ed25519_verify_keyed_mixed:204800:signature" > $O/valu_insts.log 2>&1
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmcSQ $O/ktS $O/pmcS $O/pmcS1 $O/ktP $O/pmcP $O/ktC $O/ktL
 # 10. the bench line itself (all legs) — after valu_insts.json exists so that valu_issue_frac is filled in
 cp $O/valu_insts.json profiles/valu_insts.json
