@@ -715,6 +715,38 @@ def subprocess_leg(args, extra, timeout=900):
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]), None
 
 
+def subprocess_legs(args):
+    """The legs that run in processes of their own — BEFORE this process creates its first HIP queue: a parent that still holds its
+    pipelines', contexts' and torch's streams (a hundred queues after the concurrency leg) makes the firmware time-slice the
+    processes' queue sets, and the compact step measured beside it came out 12 % slow (372 M headers/s against 425-433 M alone)."""
+    out = {}
+    J, B = args.jobs, args.batch
+    log("leg: compact_only (subprocess)")
+    # one chunk per step: without an expansion to run beside there is nothing to pipeline against, and a chunk of 256
+    # ranges quantises better (8196 header groups on 4096 wave slots) than two of 128
+    # ... and two pipelines stepped in turn: step i + 1 starts while step i's chain of small kernels drains
+    # 200 steps (0.26 s): a step's chain of dependent kernels spans two to three steps of the pipelined loop, so a 20-step
+    # loop would spend a tenth of its time filling and draining (405 M headers/s at 20 steps, 423 M at 200 .. 6000)
+    d, err = subprocess_leg(args, ["--no-witness", "--engines", "1", "--alternate", "2", "--steps", str(max(args.steps, 200))])
+    out["compact_only"] = {"error": err} if d is None else {
+        "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+        "prove_subchain_ms": d["kernels"][0]["avg_launch_ms"], "sha256_compressions_per_s_prove_subchain": d["kernels"][0]["sha256_compressions_per_s"],
+        "frac_of_measured_alu_peak_prove_subchain": d["kernels"][0]["frac_of_measured_alu_peak"],
+        **d["compact_step"],
+        "reference_equivalent_compressions_per_s_whole_step": d["value"] * (41 + 23),
+        "note": "no Goldilocks expansion, one chunk per step, two buffer sets stepped in turn inside the pipeline (one header hashing at a time): header hashing (41 compressions/header) + prove_subchain + commit check "
+                "(Ed25519, SHA-512) on the side stream; fractions are of the SHA-256 ceiling measured in that process"}
+    if (J, B) == (32, 64):
+        log("leg: header_range_1024 (subprocess)")
+        a1024 = argparse.Namespace(**vars(args))
+        a1024.batch = 32
+        d, err = subprocess_leg(a1024, [])
+        out["header_range_1024"] = {"error": err} if d is None else {
+            "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+            "steps": d["steps"], "roofline_frac": d["roofline"]["frac"], "witness_checked_ranges": d["config"]["witness_checked_ranges"]}
+    return out
+
+
 def pmc_traffic(n_jobs, B):
     """HBM bytes of one k_expand_witness launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.csv +
     .meta.json written by the profiling command), scaled per map job.  None when no profile of this shape is committed."""
@@ -801,6 +833,7 @@ def main():
     # gloo process group; the driver's multi-GPU runs use neither (one rank per GPU over RCCL)
     if os.environ.get("BSX_BENCH_DEVICE") is not None:
         local = int(os.environ["BSX_BENCH_DEVICE"])
+    pre_legs = subprocess_legs(args) if (world == 1 and args.mode == "F" and not args.no_legs) else {}
     from blobstreamx_amd import _lib
     _lib.lib()                     # loads libbsx.so and calls bsx_prepare_process() before the first HIP call (16 hardware queues)
     torch.cuda.set_device(local)
@@ -1014,28 +1047,7 @@ def main():
                 sv100 = stress(args, dev, 100, 6.0, cal)
                 log("leg: stress v512")
                 out["stress"] = {"v100": sv100, "v512": stress(args, dev, 512, 6.0, cal)}
-            log("leg: compact_only (subprocess)")
-            # one chunk per step: without an expansion to run beside there is nothing to pipeline against, and a chunk of 256
-            # ranges quantises better (8196 header groups on 4096 wave slots) than two of 128
-            # ... and two pipelines stepped in turn: step i + 1 starts while step i's chain of small kernels drains
-            # 200 steps (0.26 s): a step's chain of dependent kernels spans two to three steps of the pipelined loop, so a 20-step
-            # loop would spend a tenth of its time filling and draining (405 M headers/s at 20 steps, 423 M at 200 .. 6000)
-            d, err = subprocess_leg(args, ["--no-witness", "--engines", "1", "--alternate", "2", "--steps", str(max(args.steps, 200))])
-            out["compact_only"] = {"error": err} if d is None else {
-                "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-                "prove_subchain_ms": d["kernels"][0]["avg_launch_ms"], "sha256_compressions_per_s_prove_subchain": d["kernels"][0]["sha256_compressions_per_s"],
-                "frac_of_measured_alu_peak_prove_subchain": d["kernels"][0]["frac_of_measured_alu_peak"],
-                **d["compact_step"],
-                "reference_equivalent_compressions_per_s_whole_step": d["value"] * (41 + 23),
-                "note": "no Goldilocks expansion, one chunk per step, two buffer sets stepped in turn inside the pipeline (one header hashing at a time): header hashing (41 compressions/header) + prove_subchain + commit check "
-                        "(Ed25519, SHA-512) on the side stream; fractions are of the SHA-256 ceiling measured in that process"}
-            if (J, B) == (32, 64):
-                a1024 = argparse.Namespace(**vars(args))
-                a1024.batch = 32
-                d, err = subprocess_leg(a1024, [])
-                out["header_range_1024"] = {"error": err} if d is None else {
-                    "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                    "steps": d["steps"], "roofline_frac": d["roofline"]["frac"], "witness_checked_ranges": d["config"]["witness_checked_ranges"]}
+            out.update(pre_legs)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -592,19 +592,6 @@ struct StagedD2H {
 #define H2D(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, st))
 #define D2H(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyDeviceToHost, st))
 #define SYNC() HIPCHK(hipStreamSynchronize(st))
-// A proof request's last wait: poll the stream for up to 2 ms before blocking on it — waking a blocked thread costs 10 - 20 us of a
-// 0.25 ms call (the blocking wait sleeps on an interrupt); longer waits (a witness download) block as usual
-static hipError_t sync_polling(hipStream_t st) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0;; spins++) {
-        const hipError_t e = hipStreamQuery(st);
-        if (e != hipErrorNotReady) return e;
-        if ((spins & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(st);
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-    }
-}
 
 static int header_status_to_rc(uint32_t hs, uint32_t as) {
     if (hs & 1u) return fail(BSX_ERR_BAD_HEADER, "a packed header violates the field-size rules of bsx_header");
@@ -1310,7 +1297,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         HIPCHK(hipMemcpyAsync(ctx->hr_d_headers, h0, key.hpr * sizeof(bsx_header), hipMemcpyHostToDevice, st));
         HIPCHK(hipGraphLaunch(ctx->hr_exec, st));
     }
-    if (witness) SYNC(); else HIPCHK(sync_polling(st));
+    SYNC();
     if (trace_host)
         fprintf(stderr, "bsx_header_range: enqueue %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(t_enq - t_entry).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count());
