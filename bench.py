@@ -291,9 +291,9 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     from blobstreamx_amd.stress import CommitShard, range_verdict
     nh = args.jobs * args.batch
     w = synth.Workload(5 if V > 100 else 4, 1, args.jobs, args.batch, v=V, mode="S")
-    # two buffer sets on two streams: step i + 1 starts while step i's stages drain (stress.py CommitShard); the fold all-gather of
-    # step i is taken while step i + 1 runs
-    sh = CommitShard(nh, V, rank=rank, world=world, device=dev, n_sets=2)
+    # three buffer sets on three streams: steps i + 1, i + 2 start while step i's stages drain (stress.py CommitShard; 2048 x 100:
+    # 1.03 / 0.68 / 0.61 ms per step with 1 / 2 / 3 in flight); the fold all-gather of step i is taken while they run
+    sh = CommitShard(nh, V, rank=rank, world=world, device=dev, n_sets=3)
     sh.upload(w.validators.reshape(nh, V), w.commit_hashes)
     n = sh.n * V
     L, ctx, dp = sh.L, sh.ctx, _lib.dp
@@ -326,21 +326,19 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     t_sha, t_tab, t_ed, t_tally = (float(x) for x in t)
     # the timed object: K steps of the ONE composite call + the fold all-gather, barrier on both sides, max over ranks
     def timed(shard, K, in_flight):
-        """K steps; in_flight = 1: a step's folds are gathered (host sync) before the next step is enqueued; 2: one step later"""
-        shard.gather(shard.step())
+        """K steps with `in_flight` of them enqueued at any time: the folds of step i are gathered (the collective + a host sync on
+        that step's stream) once step i + in_flight - 1 has been enqueued; in_flight = 1 is the joined loop"""
+        for _ in range(shard.K):                      # every buffer set once (first touch of its pages, its stream's first launch)
+            shard.gather(shard.step())
         barrier()
         t0 = time.perf_counter()
-        prev, folds = None, None
+        pending, folds = [], None
         for _ in range(K):
-            k = shard.step()
-            if in_flight == 1:
-                folds = shard.gather(k)
-            else:
-                if prev is not None:
-                    folds = shard.gather(prev)
-                prev = k
-        if prev is not None:
-            folds = shard.gather(prev)
+            pending.append(shard.step())
+            if len(pending) >= in_flight:
+                folds = shard.gather(pending.pop(0))
+        while pending:
+            folds = shard.gather(pending.pop(0))
         barrier()
         dt = (time.perf_counter() - t0) / K
         if world > 1:
@@ -349,13 +347,13 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
             dt = float(tmax.item())
         return dt, folds
     dt1, _ = timed(sh, 5, 1)
-    dt, folds = timed(sh, 20, 2)
+    dt, folds = timed(sh, 30, sh.K)
     tot = dt * 1e3
     gpu_ok, gpu_res, gpu_fold = sh.download()
     verdict = range_verdict(folds)
     out = {"workload": f"mode S: {nh} headers x {V} validators = {nh * V} signatures (one header_range_{nh}, a commit per header)"
                        + (f", sharded {world} x {sh.n} commits, one all-gather of 128-byte folds" if world > 1 else ""),
-           "headers_per_s": nh / dt, "verifies_per_s_all_stages": nh * V / dt, "ms": tot, "steps_in_flight": 2,
+           "headers_per_s": nh / dt, "verifies_per_s_all_stages": nh * V / dt, "ms": tot, "steps_in_flight": sh.K,
            "one_step_in_flight": {"headers_per_s": nh / dt1, "ms": dt1 * 1e3},
            "verifies_per_s_incl_table": n / (t_ed + t_tab) * 1e3, "signatures": nh * V, "signatures_this_rank": n,
            "range_verdict": verdict,
@@ -404,7 +402,7 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
         torch.cuda.synchronize(dev)
         t_x += evw[0].elapsed_time(evw[1]) / 3
     dtw1, _ = timed(shw, 3, 1)
-    dtw, _ = timed(shw, 8, 2)
+    dtw, _ = timed(shw, 8, shw.K)
     pick = sorted({0, 1, shw.n // 3, shw.n // 2, shw.n - 1})
     got = shw.witness_of(pick)
     vv_all = w.validators.reshape(nh, V)
@@ -414,7 +412,7 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
         want = oracle.expand_witness(lay, 1, cwc)
         assert got[i].shape == want.shape and (got[i] == want).all(), f"mode S: the COMMIT unit of commit {gc} differs from the oracle's"
     gpu_ok_w, gpu_res_w, gpu_fold_w = shw.download()
-    out["witness"] = {"headers_per_s": nh / dtw, "ms": dtw * 1e3, "steps_in_flight": 2,
+    out["witness"] = {"headers_per_s": nh / dtw, "ms": dtw * 1e3, "steps_in_flight": shw.K,
                       "one_step_in_flight": {"headers_per_s": nh / dtw1, "ms": dtw1 * 1e3}, "elements_per_commit": int(lay["n_elements"]),
                       "bytes_per_step_this_rank": int(shw.n * 8 * int(lay["n_elements"])),
                       "checked_against_oracle_commits": len(pick),

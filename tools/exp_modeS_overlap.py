@@ -8,11 +8,11 @@ from blobstreamx_amd.stress import CommitShard
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 w = synth.Workload(5, 1, 32, 64, v=V, mode="S")
 vals = w.validators.reshape(2048, V)
-shards = [CommitShard(2048, V) for _ in range(2)]
+shards = [CommitShard(2048, V) for _ in range(3)]
 for s in shards:
     s.upload(vals, w.commit_hashes)
-streams = [torch.cuda.Stream() for _ in range(2)]
-for k in (1, 2):
+streams = [torch.cuda.Stream() for _ in range(3)]
+for k in (1, 2, 3):
     for i in range(4): shards[i % k].step(streams[i % k])
     torch.cuda.synchronize()
     steps = 40
