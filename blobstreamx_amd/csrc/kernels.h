@@ -38,7 +38,7 @@ hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*
 hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
 hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
-                                uint8_t*, uint32_t*, const uint8_t*, const uint8_t*);
+                                uint8_t*, uint32_t*, const uint8_t*, const uint8_t*, uint32_t lds_pad = 0);
 hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*, uint32_t);
 hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
 hipError_t bsxk_reduce_finalize(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, bsx_subchain*, uint8_t*, uint32_t, uint32_t, const bsx_shared_ctx*,

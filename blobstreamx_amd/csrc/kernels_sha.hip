@@ -1068,13 +1068,20 @@ hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {
 hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
                                 const bsx_shared_ctx* ranges, const uint64_t* latest, const bsx_header* headers, uint64_t hpr, uint64_t hfr,
                                 const uint8_t* hashes, const uint8_t* dh, const uint8_t* lb, uint8_t* compact, uint32_t* status,
-                                const uint8_t* paths, const uint8_t* zero_paths) {
+                                const uint8_t* paths, const uint8_t* zero_paths, uint32_t lds_pad) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hfr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status,
                    paths, zero_paths};
     const uint32_t it = (24u * B + 255u) / 256u;
-#define BSX_AS_LAUNCH(N) hipLaunchKernelGGL(k_assemble_inputs<N>, dim3(n_ranges * job_count), dim3(256), 0, s, a)
+    // lds_pad: bytes of (unused) dynamic LDS per workgroup = a cap on the hint's workgroups resident per CU.  The hint is 0.7 GB of
+    // 16-byte copies: at full occupancy it saturates HBM for 0.17 ms, and the header hashing it runs beside in the compact pipeline
+    // WAITS for its own loads (a round trip per leaf) — with two hint workgroups per CU (64 KB each) the copies spread over 0.3 ms
+    // and the step is 0.07 ms shorter.  Beside an expansion the opposite holds (loads in flight are what the hint needs): 0 there.
+    // BSX_HINT_LDS (experiments) overrides.
+    static const long env_lds = bsx_knob("BSX_HINT_LDS", -1);
+    const size_t hint_lds = env_lds >= 0 ? (size_t)env_lds : (size_t)lds_pad;
+#define BSX_AS_LAUNCH(N) hipLaunchKernelGGL(k_assemble_inputs<N>, dim3(n_ranges * job_count), dim3(256), hint_lds, s, a)
     if (it <= 1) BSX_AS_LAUNCH(1);
     else if (it <= 2) BSX_AS_LAUNCH(2);
     else if (it <= 3) BSX_AS_LAUNCH(3);

@@ -34,6 +34,9 @@ struct TimingSlot {
     bool sub, exp, caps;
 };
 
+constexpr uint32_t PIPE_HINT_LDS_PAD_COMPACT = 65536;   // compact pipeline: two hint workgroups per CU (bsxk_assemble_inputs) ...
+constexpr uint64_t PIPE_HINT_THROTTLE_FROM_JOBS = 6144; // ... for chunks whose header hashing is long enough to hide the stretched hint
+                                                        // (256 ranges: 1.22 -> 1.16 ms per step; 64 / 128 ranges lose 3 % with it)
 constexpr uint64_t PIPE_LATENCY_FORM_BELOW = 16384;     // signatures per chunk: at or below, the commit check's latency form
 struct Chunk {
     uint32_t R = 0, RT = 0;                  // owned ranges / ranges whose job slice this rank computes, in this chunk
@@ -401,12 +404,15 @@ int step_local(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
     // ctx.end_header_hash of every range := the hash of its target header (what builder.skip hands to prove_data_commitment,
     // header_range.rs:42-55) wherever that header lies in this rank's slice: the caller's value is not trusted
     HIPCHK(bsxk_fill_end_hash(st, RT, reinterpret_cast<bsx_shared_ctx*>(c.ranges), c.hashes_all, p->hpr, nullptr, nullptr, nullptr, p->hfr));
+    static const long abl = bsx_knob("BSX_ABLATE", 0);      // experiments build, timing only: 1 = no hint, 2 = no prove_subchain, 3 = neither
+    if (!(abl & 1))
     HIPCHK(bsxk_assemble_inputs(st, RT, p->J, B, p->jf, jc, B, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), reinterpret_cast<const uint64_t*>(c.latest),
                                 reinterpret_cast<const bsx_header*>(c.headers_all), p->hpr, p->hfr, c.hashes_all, c.dh_aunts, c.lb_aunts, c.compact,
-                                c.status + 1, c.paths, p->ctx->zero_paths));
+                                c.status + 1, c.paths, p->ctx->zero_paths, (p->compact_tokens && (uint64_t)RT * jc >= PIPE_HINT_THROTTLE_FROM_JOBS) ? PIPE_HINT_LDS_PAD_COMPACT : 0u));
     HIPCHK(hipEventRecord(c.ev_inputs_consumed, st));       // headers_all may be overwritten from here on (input streaming)
     c.inputs_consumed_valid = true;
     if (ts) { HIPCHK(hipEventRecord(ts->ev[0], st)); }
+    if (!(abl & 2))
     HIPCHK(bsxk_prove_subchain(st, RT, B, jc, reinterpret_cast<const bsx_shared_ctx*>(c.ranges), c.compact, reinterpret_cast<bsx_subchain*>(c.records),
                                p->subchain_flags));
     if (ts) { HIPCHK(hipEventRecord(ts->ev[1], st)); ts->sub = true; }
