@@ -105,7 +105,8 @@ def test_pipelined_engines_multi_step_vs_oracle(J, B, V, R, n_blocks):
     assert not res["range_status"].any() and not res["skip_status"].any()
 
 
-@pytest.mark.parametrize("J,B,R,n_blocks,top", [(32, 64, 32, 2048 - 37, 8), (32, 32, 32, 1024, 4), (64, 16, 16, 1024 - 5, 2)])
+@pytest.mark.parametrize("J,B,R,n_blocks,top", [(32, 64, 32, 2048 - 37, 8), (32, 32, 32, 1024, 4), (64, 16, 16, 1024 - 5, 2), (8, 128, 128, 1024 - 77, 16),
+                                                  (4, 256, 256, 1024 - 300, 32)])
 def test_commitment_tree_tops_in_their_own_launch_vs_oracle(J, B, R, n_blocks, top):
     """A chunk of >= 1024 map jobs: k_batch_finish stops at the level that no longer fills half a wave of a workgroup and
     k_batch_top<top> (one lane per job) hashes the rest and writes the batch tail.  Outputs, statuses and records of every range,
