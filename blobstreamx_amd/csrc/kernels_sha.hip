@@ -699,10 +699,10 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const Digest lb_root = load_digest_global(slots + BSX_SLOT_BYTES * i + 160 + 128);
     Digest claimed;                                                  // last_block_id_proofs[i].leaf[2..34] (:204)
     {
+        // 2-byte aligned in the packed image: two misaligned 16-byte loads (gfx950 serves them) instead of nine dwords + funnels
         const uint8_t* lf = cw + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * i + 128 + 2;
-        uint32_t c[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = gdword_at(lf, k);
+        const uint4 c0 = ldu4(lf), c1 = ldu4(lf + 16);
+        const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         claimed = digest_from_le(c);
     }
     const Digest H_E = load_digest_global(rg->end_header_hash);
@@ -716,11 +716,15 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const uint32_t nb_enabled = (uint32_t)(end_block_num - batch_start);   // :119,124
     if (live) {
         store_digest_global(cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i + 320, curr_after);   // :223
-        W[BSX_W_CURR_IDX + 2 * i] = (uint32_t)curr_idx; W[BSX_W_CURR_IDX + 2 * i + 1] = (uint32_t)(curr_idx >> 32);
-        W[bsx_w_block_height(B) + 2 * i] = (uint32_t)curr_idx; W[bsx_w_block_height(B) + 2 * i + 1] = (uint32_t)(curr_idx >> 32);
+        const uint2 idx2 = make_uint2((uint32_t)curr_idx, (uint32_t)(curr_idx >> 32));
+        *reinterpret_cast<uint2*>(W + BSX_W_CURR_IDX + 2 * i) = idx2;
+        *reinterpret_cast<uint2*>(W + bsx_w_block_height(B) + 2 * i) = idx2;
+        // the slot's nine bools (9-byte stride): one misaligned 8-byte store + one byte instead of nine byte stores
         uint8_t* b = Bo + BSX_B_SLOTS + BSX_SLOT_BOOLS * i;
-        b[0] = !en_before; b[1] = is_last; b[2] = valid_prev; b[3] = prev_check; b[4] = dh_valid; b[5] = dh_check;
-        b[6] = root_matches_end; b[7] = end_check; b[8] = en_after;
+        const uint32_t blo = (uint32_t)!en_before | ((uint32_t)is_last << 8) | ((uint32_t)valid_prev << 16) | ((uint32_t)prev_check << 24);
+        const uint32_t bhi = (uint32_t)dh_valid | ((uint32_t)dh_check << 8) | ((uint32_t)root_matches_end << 16) | ((uint32_t)end_check << 24);
+        *reinterpret_cast<uint2*>(b) = make_uint2(blo, bhi);
+        b[8] = en_after;
         Bo[bsx_b_leaf_enabled(B) + i] = i < nb_enabled;
     }
     {
