@@ -890,9 +890,28 @@ def main():
             ok = torch.tensor([1 if _lib.lib().bsx_rccl_get_unique_id(_lib.p(probe)) == 0 else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
-                comm = E.c_rccl_comm(eng.ctx, rank, world)
-                eng.set_rccl(comm)
-                collective = "ncclAllGather called by libbsx (bsx_pipeline_set_rccl), communicator from bsx_rccl_comm_init_rank"
+                # every step of the set-up is agreed on by all ranks before the next (a rank that fails alone would leave the others in a
+                # collective): communicator, then the library's own all-gather proven end to end; any failure anywhere -> the callback
+                def agreed(flag):
+                    t = torch.tensor([1 if flag else 0], device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    return int(t.item()) == 1
+                comm, err = None, None
+                try:
+                    comm = E.c_rccl_comm(eng.ctx, rank, world)
+                except Exception as e:                                   # noqa: BLE001 (reported below, then the fallback)
+                    err = e
+                if agreed(comm is not None):
+                    try:
+                        eng.set_rccl(comm)
+                    except Exception as e:                               # noqa: BLE001
+                        err = e
+                    if agreed(err is None):
+                        collective = "ncclAllGather called by libbsx (bsx_pipeline_set_rccl), communicator from bsx_rccl_comm_init_rank"
+                if not collective.startswith("ncclAllGather"):
+                    if rank == 0:
+                        print(f"bench.py: RCCL from the C tier not usable here ({err}); using the torch.distributed callback", file=sys.stderr)
+                    eng.set_allgather(E.torch_allgather(eng.dev, world))
 
     # correctness gate before timing: statuses clean, public output = (target header hash, commitment) for every owned range
     eng.step()
