@@ -473,6 +473,22 @@ def latency_leg(dev, J, B, V):
         assert o[:32] == w.hashes[0, w.n_blocks].tobytes()
         ts = sorted(ts[3:])
         out[key] = {"median": ts[len(ts) // 2], "min": ts[0], "p90": ts[int(len(ts) * 0.9)], "calls": n}
+    # the other entry point of the reference (bin/next_header.rs: CombinedStepCircuit, one header + its V-validator commit): one
+    # bsx_next_header call, 40 B in, 64 B out; its output is checked against the oracle in tests/test_gpu_units.py
+    from blobstreamx_amd.builder import CombinedStepCircuit
+    ws = synth.Workload(4, 1, 1, 2, v=V, mode="S")
+    step = CombinedStepCircuit(V, device=dev.index or 0)
+    inp40 = int(ws.first_height[0]).to_bytes(8, "big") + ws.hashes[0, 0].tobytes()
+    vals1 = ws.validators[0][1] if ws.validators[0].ndim == 2 else ws.validators[0]
+    ts = []
+    for i in range(43):
+        t0 = time.perf_counter()
+        o40, _ = step.prove(inp40, ws.headers[0][0], ws.headers[0][1], int(ws.latest[0]), vals1)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    assert o40[:32] == ws.hashes[0, 1].tobytes()
+    ts = sorted(ts[3:])
+    out["next_header_ms"] = {"median": ts[len(ts) // 2], "min": ts[0], "p90": ts[int(len(ts) * 0.9)], "calls": 40,
+                             "workload": f"one bsx_next_header (CombinedStepCircuit): 2 headers + a {V}-validator commit, host pointers in, 64 B out"}
     out["workload"] = f"one header_range_{J * B}, {V} validators, through bsx_header_range (H2D of {J * B + 1} headers + validators, all kernels, D2H)"
     out["headers_per_s_single_stream"] = J * B / out["output_only_ms"]["median"] * 1e3
     return out

@@ -1373,11 +1373,25 @@ int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* p
     const bsx_validator* d_val = reinterpret_cast<const bsx_validator*>(d_in40 + 128);
     uint32_t* d_st = dst_.as<uint32_t>();                                       // [0] header status, [1] step status, [2] A10
     const bsxk_unit_dst cwd = bsxk_unit(dccw.as<uint8_t>(), CL), swd = bsxk_unit(dscw.as<uint8_t>(), TL);
+    // Four streams, as in bsx_header_range: R decoding (the longest kernel, needs only the validator records), the challenges, the
+    // validator-set tally + the header-field proofs, and the two header hashes run side by side; the verification waits for the first
+    // two, the sums for the tally and the header hash, the step conditions for everything (one stream: 0.36 ms per call; now 0.2x)
+    hipStream_t sb = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
+    HIPCHK(hipEventRecord(ctx->ev_c, st));                              // inputs uploaded, units cleared
+    HIPCHK(hipStreamWaitEvent(s3, ctx->ev_c, 0));
+    uint8_t* tab = nullptr;
+    RET(ctx_keytable(ctx, v_max, &tab, sb));
+    if (tab) HIPCHK(bsxk_ed25519_decode_r(s3, d_val, v_max, drd.p));
+    HIPCHK(hipEventRecord(ctx->ev_d, s3));
     HIPCHK(bsxk_header_merkle(st, d_hdr, 2, dhash.as<uint8_t>(), nullptr, nullptr, nullptr, d_st, 0, 0));
+    HIPCHK(hipEventRecord(ctx->ev_a, st));                              // header hashes
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_c, 0));
+    HIPCHK(hipStreamWaitEvent(s4, ctx->ev_c, 0));
     // builder.step (:32-36) [UPSTREAM tendermintx v1.0.0]: the commit of the next header
-    HIPCHK(bsxk_sha512_challenge(st, d_val, v_max, dh.as<uint8_t>(), nullptr, v_max, &cwd));
-    RET(ctx_verify(ctx, st, d_val, dh.as<uint8_t>(), v_max, v_max, dok.as<uint8_t>(), nullptr, drd.p, 0));   // one commit: the table IS its keys
-    HIPCHK(bsxk_commit_tally(st, d_val, 1, v_max, dhash.as<uint8_t>() + 32, dok.as<uint8_t>(), dres.as<bsx_commit_result>(), &cwd));
+    HIPCHK(bsxk_sha512_challenge(sb, d_val, v_max, dh.as<uint8_t>(), nullptr, v_max, &cwd));
+    // validator leaves, the masked tree and the total power: nothing there depends on the signatures
+    HIPCHK(bsxk_commit_tally(s4, d_val, 1, v_max, nullptr, nullptr, dres.as<bsx_commit_result>(), &cwd));
+    HIPCHK(hipEventRecord(ctx->ev_f, s4));
     {
         bsxk_field_proofs_args fa{};
         fa.n_items = 1; fa.headers = d_hdr; fa.headers_per_item = 2; fa.flags = d_flags;
@@ -1386,16 +1400,39 @@ int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* p
         static const uint8_t fld[BSX_ST_N_PROOFS] = {1, BSX_BLOCK_HEIGHT_INDEX, 7, BSX_LAST_BLOCK_ID_INDEX, 8, BSX_DATA_HASH_INDEX};
         for (uint32_t k = 0; k < BSX_ST_N_PROOFS; k++)
             fa.proofs[k] = bsxk_proof_spec{hsel[k], fld[k], (uint16_t)bsx_st_proof_cap(k), bsx_st_off_proof(k), BSX_ST_W_LEAF_LEN + k, k == 5 ? 1u : 0u};
-        HIPCHK(bsxk_field_proofs(st, &fa));
+        HIPCHK(bsxk_field_proofs(s4, &fa));
     }
+    HIPCHK(hipEventRecord(ctx->ev_g, s4));
+    if (tab) {
+        // the table rows against this request's keys on the HOST (mirror of the keys the rows were built for), as in bsx_header_range
+        bool keys_same = ctx->keytab_rows == v_max && ctx->keytab_mirror_valid && ctx->keytab_mirror.size() == (size_t)v_max * 32;
+        for (uint32_t i = 0; keys_same && i < v_max; i++) keys_same = memcmp(ctx->keytab_mirror.data() + 32 * (size_t)i, next_validators[i].pubkey, 32) == 0;
+        if (!keys_same) {
+            HIPCHK(bsxk_ed25519_keytable(sb, d_val, v_max, tab));
+            ctx->keytab_mirror.resize((size_t)v_max * 32);
+            for (uint32_t i = 0; i < v_max; i++) memcpy(ctx->keytab_mirror.data() + 32 * (size_t)i, next_validators[i].pubkey, 32);
+            ctx->keytab_mirror_valid = true;
+        }
+        HIPCHK(hipStreamWaitEvent(sb, ctx->ev_d, 0));
+        HIPCHK(bsxk_ed25519_verify_keyed(sb, d_val, dh.as<uint8_t>(), v_max, v_max, tab, v_max, ctx->btab, dok.as<uint8_t>(), nullptr, drd.p, 0));   // one commit: the table IS its keys
+    } else {
+        HIPCHK(bsxk_ed25519_verify(sb, d_val, dh.as<uint8_t>(), v_max, dok.as<uint8_t>()));
+        HIPCHK(hipStreamWaitEvent(sb, ctx->ev_d, 0));
+    }
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_a, 0));                       // the next header's hash (the signed messages carry it)
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_f, 0));
+    HIPCHK(bsxk_commit_sums(sb, d_val, 1, v_max, dhash.as<uint8_t>() + 32, dok.as<uint8_t>(), dres.as<bsx_commit_result>(), &cwd));
+    HIPCHK(hipStreamWaitEvent(sb, ctx->ev_g, 0));
     {
         bsxk_step_args sa{};
         sa.headers = d_hdr; sa.hashes = dhash.as<uint8_t>(); sa.input40 = d_in40; sa.commit = dres.as<bsx_commit_result>();
         sa.step_status = d_st + 1; sa.dc_status = d_st + 2; sa.output64 = dout.as<uint8_t>(); sa.unit = swd;
         sa.chain_id_len = chain_id_len;
         if (chain_id_len) memcpy(sa.chain_id, chain_id, chain_id_len);
-        HIPCHK(bsxk_step_check(st, &sa));
+        HIPCHK(bsxk_step_check(sb, &sa));
     }
+    HIPCHK(hipEventRecord(ctx->ev_b, sb));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_b, 0));
     if (witness) {
         RET(dwit.alloc((CL.n_elements + TL.n_elements) * 8 + 32));
         RET(dscr.alloc(TL.n_elements * 8 + 16));
