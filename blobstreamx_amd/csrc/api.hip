@@ -49,6 +49,8 @@ int use(bsx_ctx* ctx) {
 }  // namespace bsxapi
 
 namespace {
+constexpr size_t BSX_VMM_RECYCLE_BLOCKS = 8;     // bsx_dev_free keeps at most this many blocks mapped for recycling ...
+constexpr size_t BSX_VMM_RECYCLE_BYTES = 96ull << 30;   // ... and at most this many bytes (a third of the 288 GB)
 using bsxapi::DBuf;
 using bsxapi::fail;
 using bsxapi::g_err;
@@ -230,7 +232,15 @@ int bsx_dev_alloc(bsx_ctx* ctx, uint64_t bytes, void** out_ptr) {
         }
     }
     bsx_vmm_block b{nullptr, size, {}};
-    HIPCHK(hipMemCreate(&b.handle, size, &prop, 0));
+    hipError_t ce = hipMemCreate(&b.handle, size, &prop, 0);
+    if (ce != hipSuccess && !ctx->vmm_free.empty()) {
+        // recycled blocks nobody holds (none of them fits this request) are what stands in the way: give them back and retry once
+        (void)hipGetLastError();
+        for (auto& f : ctx->vmm_free) { (void)hipMemUnmap(f.va, f.size); (void)hipMemRelease(f.handle); (void)hipMemAddressFree(f.va, f.size); }
+        ctx->vmm_free.clear();
+        ce = hipMemCreate(&b.handle, size, &prop, 0);
+    }
+    if (ce != hipSuccess) return fail(BSX_ERR_HIP, "bsx_dev_alloc(%llu): hipMemCreate: %s", (unsigned long long)bytes, hipGetErrorString(ce));
     hipError_t e = hipMemAddressReserve(&b.va, size, 1ull << 30, nullptr, 0);
     bool mapped = false;
     if (e == hipSuccess) { e = hipMemMap(b.va, size, 0, b.handle, 0); mapped = e == hipSuccess; }
@@ -261,6 +271,16 @@ int bsx_dev_free(bsx_ctx* ctx, void* ptr) {
             HIPCHK(hipDeviceSynchronize());                 // nothing in flight may still use it when the next owner clears it
             ctx->vmm.erase(ctx->vmm.begin() + (long)i);
             ctx->vmm_free.push_back(b);                     // stays mapped: recycled by bsx_dev_alloc, released by bsx_trim / bsx_shutdown
+            // the recycle list is bounded: at most BSX_VMM_RECYCLE_BLOCKS blocks / BSX_VMM_RECYCLE_BYTES bytes, the SMALLEST released first (the large images are the
+            // ones whose re-mapping faulted on ROCm 7.2; a caller cycling through many shapes must not pin one image per shape)
+            auto cached = [&] { size_t t = 0; for (auto& f : ctx->vmm_free) t += f.size; return t; };
+            while (ctx->vmm_free.size() > BSX_VMM_RECYCLE_BLOCKS || (ctx->vmm_free.size() > 1 && cached() > BSX_VMM_RECYCLE_BYTES)) {
+                size_t k = 0;
+                for (size_t q = 1; q < ctx->vmm_free.size(); q++) if (ctx->vmm_free[q].size < ctx->vmm_free[k].size) k = q;
+                const bsx_vmm_block f = ctx->vmm_free[k];
+                (void)hipMemUnmap(f.va, f.size); (void)hipMemRelease(f.handle); (void)hipMemAddressFree(f.va, f.size);
+                ctx->vmm_free.erase(ctx->vmm_free.begin() + (long)k);
+            }
             return BSX_OK;
         }
     return fail(BSX_ERR_BAD_ARG, "bsx_dev_free: pointer was not returned by bsx_dev_alloc on this context");
@@ -486,6 +506,7 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     if (!n_commits || n_commits > BSX_COMMIT_FOLD_MAX) return fail(BSX_ERR_UNSUPPORTED, "n_commits %u not in 1..%u", n_commits, BSX_COMMIT_FOLD_MAX);
     if (!d_validators || !d_header_hashes || !d_keytable || !d_scratch || !d_ok || !d_results || !d_fold) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (((uintptr_t)d_keytable & 127) || ((uintptr_t)d_scratch & 255)) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte, scratch 256-byte aligned");
+    if (flags & ~(BSX_COMMITS_KEYTABLE_READY | BSX_COMMITS_KEYS_UNIFORM)) return fail(BSX_ERR_BAD_ARG, "bsx_dev_verify_commits: unknown flags 0x%x", flags);
     hipStream_t st = S(ctx, stream);
     const uint64_t n = (uint64_t)n_commits * v_max;
     uint8_t* d_h = static_cast<uint8_t*>(d_scratch);
@@ -495,7 +516,6 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     const bsx_witness_layout CL = bsx_commit_layout(v_max);
     const bsxk_unit_dst cw = bsxk_unit(d_commit_compact, CL);
     HIPCHK(bsxk_sha512_challenge(st, d_validators, n, d_h, nullptr, v_max, d_commit_compact ? &cw : nullptr));
-    if (flags & ~(BSX_COMMITS_KEYTABLE_READY | BSX_COMMITS_KEYS_UNIFORM)) return fail(BSX_ERR_BAD_ARG, "bsx_dev_verify_commits: unknown flags 0x%x", flags);
     if (!(flags & BSX_COMMITS_KEYTABLE_READY)) HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable)));
     HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed, nullptr,
                                      (flags & BSX_COMMITS_KEYS_UNIFORM) ? 0 : -1));
@@ -592,6 +612,12 @@ struct StagedD2H {
 #define H2D(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, st))
 #define D2H(dst, src, n) HIPCHK(hipMemcpyAsync((dst), (src), (n), hipMemcpyDeviceToHost, st))
 #define SYNC() HIPCHK(hipStreamSynchronize(st))
+// Every stream a host-tier call launched on is drained before its ArenaScope rewinds the arena — also on the error paths: a
+// side-stream kernel still reading or writing arena buffers after the rewind would race with the next call's buffers and events.
+struct HostDrain {
+    hipStream_t s[4];
+    ~HostDrain() { for (int i = 3; i >= 0; i--) if (s[i]) (void)hipStreamSynchronize(s[i]); }
+};
 
 static int header_status_to_rc(uint32_t hs, uint32_t as) {
     if (hs & 1u) return fail(BSX_ERR_BAD_HEADER, "a packed header violates the field-size rules of bsx_header");
@@ -1112,12 +1138,9 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     // Three streams: the hashing chain (header hashes, hint, prove_subchain, reduce, finalize) on `st`; the commit check
     // (challenges, key table, signatures, tallies, skip conditions — latency bound at <= 100 signatures) beside it on `sb`; and
     // what the commit check needs but does not have to wait for in line (R decoded for the projective comparison, the trusted
-    // set's hash and power sum) on `s3`.  All are drained before the arena is rewound, also on the error paths (Drain).
+    // set's hash and power sum) on `s3`; both tallies on `s4`.  All four are drained before the arena is rewound, also on the error paths (HostDrain).
     hipStream_t sb = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
-    struct Drain {
-        hipStream_t a, b, c;
-        ~Drain() { (void)hipStreamSynchronize(c); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(a); }
-    } drain{st, sb, s3};
+    HostDrain drain{{st, sb, s3, s4}};
     bsx_shared_ctx range{};
     range.start_block = trusted_block;
     range.end_block = target_block;
@@ -1377,6 +1400,7 @@ int bsx_next_header(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* p
     // validator-set tally + the header-field proofs, and the two header hashes run side by side; the verification waits for the first
     // two, the sums for the tally and the header hash, the step conditions for everything (one stream: 0.36 ms per call; now 0.2x)
     hipStream_t sb = ctx->stream2, s3 = ctx->stream3, s4 = ctx->stream4;
+    HostDrain drain{{st, sb, s3, s4}};                                  // before the first side-stream launch (see bsx_header_range)
     HIPCHK(hipEventRecord(ctx->ev_c, st));                              // inputs uploaded, units cleared
     HIPCHK(hipStreamWaitEvent(s3, ctx->ev_c, 0));
     uint8_t* tab = nullptr;

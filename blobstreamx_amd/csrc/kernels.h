@@ -18,6 +18,24 @@ static inline long bsx_knob(const char* name, long dflt) {
 #define bsx_knob(name, dflt) (static_cast<long>(dflt))
 #endif
 
+// Experiments build only: the launchers note WHICH kernel form they launched, so that the tests that force a form through a knob
+// (tests/test_gpu_ed_variants.py, tests/test_gpu_engine.py::test_expansion_kernel_variants_agree) can assert that the forced form is
+// the one that ran — bsx_debug_last_launch_form(which) is exported by libbsx_exp.so and absent from the product library.
+//   which 0 (fixed-key Ed25519 signature kernel): 0x100 | lanes      k_ed25519_verify_keyed_proj<8 / 16>
+//                                                 0x200              k_ed25519_verify_keyed_mixed
+//                                                 0x300              k_ed25519_verify_keyed_small
+//                                                 0x400 | SPLIT | BYKEY << 4 | DEFER (scratch) << 5   k_ed25519_verify_keyed<DEFER, BYKEY, SPLIT>
+//   which 1 (witness expansion):                  staging chunk | non-temporal << 16 | capped grid << 17
+#define BSX_FORM_ED 0u
+#define BSX_FORM_EXPAND 1u
+#ifdef BSX_EXPERIMENTS
+extern "C" void bsxk_debug_note_form(uint32_t which, uint32_t form);
+extern "C" uint32_t bsx_debug_last_launch_form(uint32_t which);
+#define BSX_NOTE_FORM(which, form) bsxk_debug_note_form((which), (form))
+#else
+#define BSX_NOTE_FORM(which, form) ((void)0)
+#endif
+
 // Where a kernel of the commit chain leaves the witness variables it holds (include/bsx_layout.h): unit c at base + c * stride
 // (COMMIT units: c = commit; SKIP / STEP units: c = range); base == nullptr: no witness.  mode (k_commit_tally): 0 = the COMMIT
 // unit's own validator set, 1 = the trusted set inside a SKIP unit.

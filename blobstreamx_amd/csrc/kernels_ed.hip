@@ -1277,6 +1277,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
         static const long env_ps = bsx_knob("BSX_ED_PROJ_SPLIT", 0);
         const bool s16 = env_ps ? env_ps == 16 : n <= 8192;
         const int32_t* rd = static_cast<const int32_t*>(rdec);
+        BSX_NOTE_FORM(BSX_FORM_ED, 0x100u | (s16 ? 16u : 8u));
         if (s16) hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<16>, dim3((uint32_t)((n + 3) / 4)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
         else hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<8>, dim3((uint32_t)((n + 7) / 8)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
         BSX_LAUNCH_DEFERRED();
@@ -1319,6 +1320,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
                 const uint32_t blocks_a = (uint32_t)((wpk_a * v_max + 7) / 8 * 8);
                 const uint64_t wpk_b = (n_commits - commits_a + ED_THREADS / 4 - 1) / (ED_THREADS / 4);
                 const uint32_t blocks_b = (uint32_t)((wpk_b * v_max + 7) / 8 * 8);
+                BSX_NOTE_FORM(BSX_FORM_ED, 0x200u);
                 hipLaunchKernelGGL(k_ed25519_verify_keyed_mixed, dim3(blocks_a + blocks_b), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys,
                                    b_tab, ok, scr, blocks_a, commits_a);
                 const uint32_t K = ed_fin_k(n);
@@ -1329,15 +1331,21 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
             }
         }
     }
-#define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_) \
-    hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr)
+#define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_)                                                                        \
+    do {                                                                                                                \
+        BSX_NOTE_FORM(BSX_FORM_ED, 0x400u | (uint32_t)(SPLIT_) | ((BYKEY_) ? 0x10u : 0u) | ((DEFER_) ? 0x20u : 0u));    \
+        hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr); \
+    } while (0)
     // BSX_ED_SMALL=0 (experiments): no decode-R form for small batches
     static const bool small_form = bsx_knob("BSX_ED_SMALL", 1) != 0;
     if (split4 && !scr && !by_key && small_form) {
+        BSX_NOTE_FORM(BSX_FORM_ED, 0x300u);
         hipLaunchKernelGGL(k_ed25519_verify_keyed_small, dim3((uint32_t)((n + EL_SIGS - 1) / EL_SIGS)), dim3(128), 0, s, vals, h, n, v_max, table,
                            n_keys, b_tab, ok);
+#ifdef BSX_EXPERIMENTS
     } else if (split2) {
         if (by_key) BSX_LAUNCH_KEYED(true, true, 2); else BSX_LAUNCH_KEYED(true, false, 2);
+#endif
     } else if (split4) {
         if (scr) { if (by_key) BSX_LAUNCH_KEYED(true, true, 4); else BSX_LAUNCH_KEYED(true, false, 4); }
         else     { if (by_key) BSX_LAUNCH_KEYED(false, true, 4); else BSX_LAUNCH_KEYED(false, false, 4); }

@@ -399,3 +399,11 @@ hipError_t bsxk_fill_end_hash(hipStream_t s, uint32_t n_ranges, bsx_shared_ctx* 
     return hipGetLastError();
 }
 }
+
+#ifdef BSX_EXPERIMENTS
+// last launch form per kernel family (kernels.h BSX_NOTE_FORM): experiments build only, read by the variant tests
+#include <atomic>
+static std::atomic<uint32_t> g_last_form[4];
+extern "C" void bsxk_debug_note_form(uint32_t which, uint32_t form) { if (which < 4) g_last_form[which].store(form, std::memory_order_relaxed); }
+extern "C" uint32_t bsx_debug_last_launch_form(uint32_t which) { return which < 4 ? g_last_form[which].load(std::memory_order_relaxed) : 0u; }
+#endif

@@ -1188,12 +1188,22 @@ hipError_t bsxk_expand_witness(hipStream_t s, const bsx_witness_layout* lay, uin
     static const long cap = bsx_knob("BSX_EXPAND_BLOCKS", 0);
     uint64_t grid = (uint64_t)gx * n_jobs;
     if (cap > 0 && grid > (uint64_t)cap) grid = (uint64_t)cap;
-#define BSX_EX_LAUNCH(C, N) hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a)
+#define BSX_EX_LAUNCH(C, N)                                                                                              \
+    do {                                                                                                                 \
+        BSX_NOTE_FORM(BSX_FORM_EXPAND, (uint32_t)(C) | ((N) ? 1u << 16 : 0u) | (grid < (uint64_t)gx * n_jobs ? 1u << 17 : 0u)); \
+        hipLaunchKernelGGL((k_expand_witness<C, N>), dim3((uint32_t)grid), dim3(EX_THREADS), 0, s, a);                      \
+    } while (0)
+#ifdef BSX_EXPERIMENTS
+    // the sweep's other nine instantiations exist in the experiments build only: the product library launches (256, non-temporal)
     if (chunk == 256) { if (nt) BSX_EX_LAUNCH(256, true); else BSX_EX_LAUNCH(256, false); }
     else if (chunk == 512) { if (nt) BSX_EX_LAUNCH(512, true); else BSX_EX_LAUNCH(512, false); }
     else if (chunk == 2048) { if (nt) BSX_EX_LAUNCH(2048, true); else BSX_EX_LAUNCH(2048, false); }
     else if (chunk == 4096) { if (nt) BSX_EX_LAUNCH(4096, true); else BSX_EX_LAUNCH(4096, false); }
     else { if (nt) BSX_EX_LAUNCH(1024, true); else BSX_EX_LAUNCH(1024, false); }
+#else
+    (void)nt;
+    BSX_EX_LAUNCH(256, true);
+#endif
 #undef BSX_EX_LAUNCH
     return hipGetLastError();
 }

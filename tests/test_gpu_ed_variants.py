@@ -1,8 +1,14 @@
 """Every launch form of the fixed-key Ed25519 kernel (1 or 4 lanes per signature x signature-major or key-major lane order
-x with / without the batch-inversion scratch) against the oracle, on signatures FORGED for chosen (h, s): scalars whose
-radix-256 (h, per-key tables) and radix-65536 (s, table of B) recodings hit the extreme digits, plus random ones, valid and
-invalid.  The forms are chosen by the library from the batch size; BSX_ED_SPLIT / BSX_ED_BY_KEY force them, and are read
-once per process — hence one subprocess per form."""
+x with / without the batch-inversion scratch, and the small-batch decode-R form) against the oracle, on signatures FORGED for
+chosen (h, s): scalars whose radix-4096 (h, per-key tables) and radix-65536 (s, table of B) recodings hit the extreme digits, plus
+random ones, valid and invalid.  What the vectors protect: the per-validator Ed25519 check of builder.skip
+(/root/reference/circuits/header_range.rs:42-48).
+
+The product library chooses the form from the batch size and reads NO environment variable; the forms are forced through the
+BSX_ED_* knobs of the EXPERIMENTS build (blobstreamx_amd/lib/libbsx_exp.so, `make EXPERIMENTS=1`, built by
+__graft_entry__.build()), loaded through BSX_LIB_OVERRIDE in one subprocess per form (the knobs are read once per process).  The
+child reports bsx_debug_last_launch_form(0) after every call and the parent ASSERTS that the requested kernel is the one that ran
+(kernels.h BSX_NOTE_FORM): a parametrisation that silently runs the auto-chosen form fails."""
 import hashlib
 import os
 import subprocess
@@ -97,28 +103,55 @@ def _child():
     tab = torch.zeros(int(L.bsx_ed25519_keytable_bytes(C.c_uint32(n_keys))), dtype=torch.uint8, device="cuda")
     _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab)))
     scr = torch.zeros(int(L.bsx_ed25519_verify_scratch_bytes(C.c_uint64(n))), dtype=torch.uint8, device="cuda")
+    L.bsx_debug_last_launch_form.restype = C.c_uint32        # AttributeError here = the product library was loaded, not libbsx_exp.so
+    forms = []
     for scratch in (None, scr):
         ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
         _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v_max), dp(tab), C.c_uint32(n_keys),
                                                   dp(ok), dp(scratch) if scratch is not None else None))
+        forms.append(int(L.bsx_debug_last_launch_form(C.c_uint32(0))))
         torch.cuda.synchronize()
         got = ok.cpu().numpy()
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (os.environ.get("BSX_ED_SPLIT"), os.environ.get("BSX_ED_BY_KEY"), scratch is not None, bad[:8], got[bad[:8]])
-    print("ok", n, int(want.sum()))
+    print("ok", n, int(want.sum()), n_commits, "forms", *("0x%x" % f for f in forms))
+
+
+EXP_LIB = os.path.join(ROOT, "blobstreamx_amd", "lib", "libbsx_exp.so")
+
+
+def _expected_forms(split, by_key, small, n_commits):
+    """(form without scratch, form with scratch) the launcher must report — kernels.h BSX_NOTE_FORM, kernels_ed.hip
+    bsxk_ed25519_verify_keyed: 0x300 = k_ed25519_verify_keyed_small, 0x400 | SPLIT | BYKEY << 4 | DEFER << 5 = k_ed25519_verify_keyed."""
+    if split is None:                            # auto: a batch this small takes four lanes per signature; lanes by key from 32 commits on
+        split, by_key = 4, int(n_commits >= 32)
+    keyed = lambda scr: 0x400 | split | (0x10 if by_key else 0) | (0x20 if scr else 0)
+    no_scratch = 0x300 if (split == 4 and not by_key and small) else keyed(False)
+    return no_scratch, keyed(True)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("split,by_key,small", [(1, 0, 1), (1, 1, 1), (4, 0, 1), (4, 0, 0), (4, 1, 1), (None, None, 1)])
 def test_every_launch_form_on_forged_digit_edges(split, by_key, small):
     """(4, 0, 1) is the small-batch form that decodes R in a second wave and compares projectively instead of encoding."""
-    env = dict(os.environ)
+    assert os.path.exists(EXP_LIB), "libbsx_exp.so is not built: python -c 'import __graft_entry__ as g; g.build()'"
+    env = dict(os.environ, BSX_LIB_OVERRIDE=EXP_LIB)
     env.pop("BSX_ED_SPLIT", None); env.pop("BSX_ED_BY_KEY", None)
     env["BSX_ED_SMALL"] = str(small)
     if split is not None:
         env["BSX_ED_SPLIT"], env["BSX_ED_BY_KEY"] = str(split), str(by_key)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-1500:]
+    words = out.stdout.split()
+    n_commits = int(words[3])
+    got = tuple(int(x, 16) for x in words[words.index("forms") + 1:])
+    assert got == _expected_forms(split, by_key, small, n_commits), (got, _expected_forms(split, by_key, small, n_commits))
+
+
+def test_the_six_parametrisations_are_five_distinct_kernels_plus_the_auto_choice():
+    """The forced forms differ pairwise (per scratch flavour) — the round-4 regression was six runs of ONE kernel."""
+    rows = [_expected_forms(s, b, m, 70) for s, b, m in [(1, 0, 1), (1, 1, 1), (4, 0, 1), (4, 0, 0), (4, 1, 1)]]
+    assert len({r[0] for r in rows}) == 5 and len({r[1] for r in rows}) == 4       # with a scratch (4,0,1) and (4,0,0) coincide
 
 
 if __name__ == "__main__" and sys.argv[1:] == ["child"]:

@@ -288,9 +288,11 @@ def test_bench_two_ranks_share_one_gpu():
 
 
 def test_expansion_kernel_variants_agree():
-    """k_expand_witness has ten instantiations (staging chunk 256/512/1024/2048/4096 x plain / non-temporal stores, chosen
-    by BSX_EXPAND_CHUNK / BSX_EXPAND_NT when the library is loaded).  Every one of them, and a capped grid, must emit
-    the oracle's witness bit for bit; each runs in its own process because the choice is read once."""
+    """k_expand_witness has ten instantiations in the EXPERIMENTS build (staging chunk 256/512/1024/2048/4096 x plain /
+    non-temporal stores, chosen by BSX_EXPAND_CHUNK / BSX_EXPAND_NT when libbsx_exp.so is loaded; the product library holds only
+    the one it launches: 256, non-temporal).  Every one of them, and a capped grid, must emit the oracle's witness bit for bit; each
+    runs in its own process because the choice is read once — and reports bsx_debug_last_launch_form(1), which must be the
+    requested instantiation (a run that silently takes the default fails)."""
     import hashlib
     import os
     import subprocess
@@ -311,16 +313,25 @@ def test_expansion_kernel_variants_agree():
         "from blobstreamx_amd.engine import HeaderRangeEngine\n"
         "w = synth.Workload(9, %d, %d, %d, v=%d, n_blocks=200)\n"
         "e = HeaderRangeEngine(%d, %d, %d, %d); e.upload_workload(w); e.step()\n"
-        "m, _, _ = e.witness_numpy(); print('WITNESS', hashlib.sha256(m.tobytes()).hexdigest())\n" % (root, R, J, B, V, J, B, V, R))
+        "m, _, _ = e.witness_numpy(); print('WITNESS', hashlib.sha256(m.tobytes()).hexdigest())\n"
+        "import ctypes; from blobstreamx_amd import _lib; L = _lib.lib(); L.bsx_debug_last_launch_form.restype = ctypes.c_uint32\n"
+        "print('FORM', hex(L.bsx_debug_last_launch_form(ctypes.c_uint32(1))))\n" % (root, R, J, B, V, J, B, V, R))
+    exp_lib = os.path.join(root, "blobstreamx_amd", "lib", "libbsx_exp.so")
+    assert os.path.exists(exp_lib), "libbsx_exp.so is not built: python -c 'import __graft_entry__ as g; g.build()'"
     variants = [(c, nt, "") for c in (256, 512, 1024, 2048, 4096) for nt in (0, 1)] + [(256, 1, "7"), (2048, 0, "1")]
     for chunk, nt, cap in variants:
-        env = dict(os.environ, BSX_EXPAND_CHUNK=str(chunk), BSX_EXPAND_NT=str(nt))
+        env = dict(os.environ, BSX_EXPAND_CHUNK=str(chunk), BSX_EXPAND_NT=str(nt), BSX_LIB_OVERRIDE=exp_lib)
+        env.pop("BSX_EXPAND_BLOCKS", None)
         if cap:
             env["BSX_EXPAND_BLOCKS"] = cap
         out = subprocess.run([sys.executable, "-c", snippet], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, (chunk, nt, cap, out.stderr[-2000:])
         got = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("WITNESS")]
         assert got == [want.hexdigest()], (chunk, nt, cap)
+        # the last expansion the engine launched (the reduce nodes', same instantiation) ran the REQUESTED form; the capped grid
+        # bit is set for the map-job launch only, so it is not part of this check
+        form = [int(ln.split()[1], 16) for ln in out.stdout.splitlines() if ln.startswith("FORM")]
+        assert form and (form[0] & 0x1ffff) == (chunk | (nt << 16)), (chunk, nt, cap, form)
 
 
 def test_pipeline_driven_from_cpp_without_python(tmp_path):
