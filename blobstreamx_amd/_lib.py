@@ -40,6 +40,8 @@ SYMBOLS = [
     "bsx_witness_manifest_section", "bsx_commit_witness_layout", "bsx_skip_witness_layout", "bsx_step_witness_layout",
     "bsx_header_range_witness_elements", "bsx_next_header_witness_elements", "bsx_prepare_process",
     "bsx_pipeline_set_rccl", "bsx_rccl_get_unique_id", "bsx_rccl_comm_init_rank", "bsx_rccl_comm_destroy", "bsx_pipeline_check_allgather",
+    "bsx_batcher_create", "bsx_batcher_destroy", "bsx_submit_header_range", "bsx_submit_data_commitment_inputs", "bsx_submit_prove_subchain",
+    "bsx_wait", "bsx_poll", "bsx_enable_coalescing", "bsx_batcher_get_stats", "bsx_context_batcher", "bsx_batcher_cork",
 ]
 
 
@@ -87,6 +89,8 @@ def lib():
             L.bsx_status_str.restype = C.c_char_p
             L.bsx_ingest_last_error.restype = C.c_char_p
             L.bsx_pipeline_destroy.restype = None
+            L.bsx_batcher_destroy.restype = None
+            L.bsx_context_batcher.restype = C.c_void_p
             L.bsx_dev_verify_commits_scratch_bytes.restype = C.c_uint64
             L.bsx_ed25519_decoded_r_bytes.restype = C.c_uint64
             L.bsx_header_range_witness_elements.restype = C.c_uint64

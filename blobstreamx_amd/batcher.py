@@ -1,0 +1,158 @@
+"""Coalescing front end (include/bsx.h `bsx_batcher_*`, `bsx_submit_*`, `bsx_wait`; csrc/batcher.hip).
+
+The reference proves ONE range per call under a multi-thread runtime (circuits/header_range.rs:180-181) and calls the hint once per
+map job — 32 `async fn hint` calls per proof (circuits/builder.rs:325-332 -> circuits/data_commitment.rs:22-44).  A `Batcher` takes
+such requests from any number of threads, runs whatever arrived within a short window as ONE launch set and completes every ticket
+with its own status.  ctypes releases the GIL during submit / wait, so Python threads really overlap.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import types as T
+
+
+class BatcherConfig(C.Structure):
+    _fields_ = [("nb_map_jobs", C.c_uint32), ("batch_size", C.c_uint32), ("v_max", C.c_uint32), ("max_requests", C.c_uint32),
+                ("window_us", C.c_uint32), ("n_lanes", C.c_uint32), ("chain_id_len", C.c_uint32), ("chain_id", C.c_uint8 * 52),
+                ("flags", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
+
+
+class _KindStats(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("requests", C.c_uint64), ("max_batch", C.c_uint64), ("close_wait_ns", C.c_uint64)]
+
+
+class BatcherStats(C.Structure):
+    _fields_ = [("kind", _KindStats * 3)]
+
+
+assert C.sizeof(BatcherConfig) == 96 and C.sizeof(BatcherStats) == 96
+
+
+def make_config(nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0):
+    cfg = BatcherConfig()
+    cfg.nb_map_jobs, cfg.batch_size, cfg.v_max = nb_map_jobs, batch_size, v_max
+    cfg.max_requests, cfg.window_us, cfg.n_lanes = max_requests, window_us, n_lanes
+    cid = bytes(chain_id)
+    cfg.chain_id_len = len(cid)
+    for i, x in enumerate(cid):
+        cfg.chain_id[i] = x
+    return cfg
+
+
+class Ticket:
+    """A submitted request: the ticket number and the arrays its results land in (kept alive until `wait`)."""
+
+    def __init__(self, kind, ticket, outputs):
+        self.kind, self.ticket, self.outputs = kind, ticket, outputs
+
+
+class Batcher:
+    def __init__(self, nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0, device=0, handle=None):
+        self.J, self.B, self.V = nb_map_jobs, batch_size, v_max
+        self.L = _lib.lib()
+        self._owned = handle is None
+        if handle is None:
+            cfg = make_config(nb_map_jobs, batch_size, v_max, chain_id, max_requests, window_us, n_lanes)
+            h = C.c_void_p()
+            _lib.check(self.L.bsx_batcher_create(_lib.context(device), C.byref(cfg), C.byref(h)))
+            handle = h
+        self.h = handle
+
+    def close(self):
+        if self.h and self._owned:
+            self.L.bsx_batcher_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- CombinedSkipCircuit::define (header_range.rs:32-59)
+    def submit_header_range(self, input48, headers, first_height, latest_block, target_validators, trusted_validators):
+        inp = np.frombuffer(bytes(input48), np.uint8).copy()
+        hdr = np.ascontiguousarray(headers, T.HEADER).reshape(-1)
+        tv = np.ascontiguousarray(target_validators, T.VALIDATOR).reshape(-1)
+        rv = np.ascontiguousarray(trusted_validators, T.VALIDATOR).reshape(-1)
+        if tv.size != self.V or rv.size != self.V:
+            raise ValueError(f"validator arrays must have {self.V} slots")
+        out, res = np.zeros(64, np.uint8), np.zeros(1, T.COMMIT_RESULT)
+        t = C.c_uint64(0)
+        _lib.check(self.L.bsx_submit_header_range(self.h, _lib.p(inp), _lib.p(hdr), C.c_uint64(int(first_height)), C.c_uint64(hdr.size),
+                                                  C.c_uint64(int(latest_block)), _lib.p(tv), _lib.p(rv), _lib.p(out), _lib.p(res), C.byref(t)))
+        return Ticket("header_range", t.value, (out, res))
+
+    # ---- DataCommitmentOffchainInputs::hint (data_commitment.rs:18-45 -> input.rs:149-271), MAX_LEAVES = batch_size
+    def submit_data_commitment_inputs(self, headers, first_height, latest_block, start_block, end_block, want_expected=True):
+        hdr = np.ascontiguousarray(headers, T.HEADER).reshape(-1)
+        sh, eh = np.zeros(32, np.uint8), np.zeros(32, np.uint8)
+        exp = np.zeros(32, np.uint8) if want_expected else None
+        dh, lb = np.zeros(self.B, T.DH_PROOF), np.zeros(self.B, T.LB_PROOF)
+        t = C.c_uint64(0)
+        _lib.check(self.L.bsx_submit_data_commitment_inputs(self.h, _lib.p(hdr), C.c_uint64(int(first_height)), C.c_uint64(hdr.size),
+                                                            C.c_uint64(int(latest_block)), C.c_uint64(int(start_block)), C.c_uint64(int(end_block)),
+                                                            _lib.p(sh), _lib.p(eh), _lib.p(dh), _lib.p(lb), _lib.p(exp), C.byref(t)))
+        return Ticket("hint", t.value, (sh, eh, dh, lb, exp))
+
+    # ---- prove_subchain (builder.rs:150-271), BATCH_SIZE = batch_size
+    def submit_prove_subchain(self, start_header, end_header, dh, lb, batch_start_block, batch_end_block, global_end_block, global_end_header_hash):
+        dh = np.ascontiguousarray(dh, T.DH_PROOF)
+        lb = np.ascontiguousarray(lb, T.LB_PROOF)
+        if dh.size != self.B or lb.size != self.B:
+            raise ValueError(f"proof arrays must have BATCH_SIZE = {self.B} entries")
+        sh = np.frombuffer(bytes(start_header), np.uint8).copy()
+        eh = np.frombuffer(bytes(end_header), np.uint8).copy()
+        gh = np.frombuffer(bytes(global_end_header_hash), np.uint8).copy()
+        rec = np.zeros(1, T.SUBCHAIN)
+        t = C.c_uint64(0)
+        _lib.check(self.L.bsx_submit_prove_subchain(self.h, _lib.p(sh), _lib.p(eh), _lib.p(dh), _lib.p(lb), C.c_uint64(int(batch_start_block)),
+                                                    C.c_uint64(int(batch_end_block)), C.c_uint64(int(global_end_block)), _lib.p(gh), _lib.p(rec),
+                                                    C.byref(t)))
+        return Ticket("subchain", t.value, (rec,))
+
+    def wait(self, ticket, allow=()):
+        """-> (rc, results): header_range (output64 bytes, commit result); hint dict like InputDataFetcher.get_data_commitment_inputs;
+        subchain record.  Raises BsxError unless the status is OK or in `allow`."""
+        rc = _lib.check(self.L.bsx_wait(self.h, C.c_uint64(ticket.ticket)), allow=allow)
+        if ticket.kind == "header_range":
+            out, res = ticket.outputs
+            return rc, (out.tobytes(), res[0])
+        if ticket.kind == "hint":
+            sh, eh, dh, lb, exp = ticket.outputs
+            return rc, dict(start_header_hash=sh.tobytes(), end_header_hash=eh.tobytes(), data_hash_proofs=dh, last_block_id_proofs=lb,
+                            expected_data_commitment=exp.tobytes() if exp is not None else None)
+        return rc, ticket.outputs[0][0]
+
+    def done(self, ticket):
+        d = C.c_int(0)
+        _lib.check(self.L.bsx_poll(self.h, C.c_uint64(ticket.ticket), C.byref(d)))
+        return bool(d.value)
+
+    def cork(self, on=True):
+        """While corked, open batches close only when full (announce a burst, submit it, uncork)."""
+        _lib.check(self.L.bsx_batcher_cork(self.h, C.c_int(1 if on else 0)))
+
+    def stats(self):
+        s = BatcherStats()
+        _lib.check(self.L.bsx_batcher_get_stats(self.h, C.byref(s)))
+        names = ("header_range", "data_commitment_inputs", "prove_subchain")
+        return {n: {"batches": int(s.kind[i].batches), "requests": int(s.kind[i].requests), "max_batch": int(s.kind[i].max_batch),
+                    "close_wait_us": s.kind[i].close_wait_ns / 1e3 / max(1, int(s.kind[i].batches))} for i, n in enumerate(names)}
+
+
+def enable_coalescing(nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0, device=0):
+    """bsx_enable_coalescing on the process's context of `device`: the synchronous builder calls (CombinedSkipCircuit.prove without a
+    witness, InputDataFetcher.get_data_commitment_inputs with MAX_LEAVES = batch_size, DataCommitmentBuilder.prove_subchain without a
+    witness) made from any number of threads coalesce.  Returns a Batcher view of the attached batcher (stats)."""
+    cfg = make_config(nb_map_jobs, batch_size, v_max, chain_id, max_requests, window_us, n_lanes)
+    L = _lib.lib()
+    _lib.check(L.bsx_enable_coalescing(_lib.context(device), C.byref(cfg)))
+    L.bsx_context_batcher.restype = C.c_void_p
+    return Batcher(nb_map_jobs, batch_size, v_max, handle=C.c_void_p(L.bsx_context_batcher(_lib.context(device))))
+
+
+def disable_coalescing(device=0):
+    _lib.check(_lib.lib().bsx_enable_coalescing(_lib.context(device), None))

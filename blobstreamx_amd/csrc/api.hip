@@ -27,6 +27,7 @@ static_assert(sizeof(bsx_shared_ctx) == 80 && sizeof(bsx_subchain) == 128, "reco
 static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "commit");
 static_assert(sizeof(bsx_witness_layout) == 40, "layout");
 static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
+static_assert(sizeof(bsx_batcher_config) == 96 && sizeof(bsx_batcher_stats) == 96, "batcher");
 static_assert(sizeof(bsx_commit_fold) == 128 && sizeof(bsx_pipeline_config) == 112 && sizeof(bsx_calibration) == 80, "pipeline / fold / calibration");
 
 namespace bsxapi {
@@ -129,6 +130,7 @@ int bsx_init(int device, bsx_ctx** out) {
 void bsx_shutdown(bsx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (bsx_batcher* bt = ctx->batcher.exchange(nullptr)) bsx_batcher_destroy(bt);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->hr_exec) (void)hipGraphExecDestroy(ctx->hr_exec);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -626,6 +628,17 @@ static int header_status_to_rc(uint32_t hs, uint32_t as) {
     return BSX_OK;
 }
 
+// ---- coalescing (batcher.hip): a context with a batcher attached turns its synchronous calls of the batcher's shape into submit + wait
+int bsx_enable_coalescing(bsx_ctx* ctx, const bsx_batcher_config* cfg) {
+    if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");
+    bsx_batcher* nb = nullptr;
+    if (cfg) RET(bsx_batcher_create(ctx, cfg, &nb));
+    if (bsx_batcher* old = ctx->batcher.exchange(nb)) bsx_batcher_destroy(old);     // callers must not be inside a coalesced call while it is replaced
+    return BSX_OK;
+}
+bsx_batcher* bsx_context_batcher(bsx_ctx* ctx) { return ctx ? ctx->batcher.load() : nullptr; }
+const bsx_batcher_config* bsxb_config(const bsx_batcher* b);                          // batcher.hip
+
 int bsx_encode_data_root_tuple(bsx_ctx* ctx, const uint8_t data_hash[32], uint64_t height, uint8_t out[64]) {
     HOST_ENTER();
     if (!data_hash || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
@@ -779,6 +792,13 @@ int bsx_data_commitment_inputs(bsx_ctx* ctx, const bsx_header* headers, uint64_t
                                uint64_t start_block, uint64_t end_block, uint32_t max_leaves, uint8_t out_start_header[32],
                                uint8_t out_end_header[32], bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb,
                                uint8_t out_expected_data_commitment[32]) {
+    if (bsx_batcher* bt = ctx ? ctx->batcher.load() : nullptr)
+        if (bsxb_config(bt)->batch_size == max_leaves) {
+            bsx_ticket t = 0;
+            RET(bsx_submit_data_commitment_inputs(bt, headers, first_height, n_headers, latest_block, start_block, end_block, out_start_header, out_end_header,
+                                                  out_dh, out_lb, out_expected_data_commitment, &t));
+            return bsx_wait(bt, t);
+        }
     HOST_ENTER();
     if (!out_start_header || !out_end_header || !out_dh || !out_lb) return fail(BSX_ERR_BAD_ARG, "null output");
     if (!max_leaves || max_leaves > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "MAX_LEAVES must be in 1..%d", BSX_MAX_BATCH);
@@ -839,6 +859,13 @@ int bsx_prove_subchain(bsx_ctx* ctx, uint32_t batch_size, const uint8_t start_he
                        const bsx_data_hash_proof* dh, const bsx_last_block_id_proof* lb, uint64_t batch_start_block,
                        uint64_t batch_end_block, uint64_t global_end_block, const uint8_t global_end_header_hash[32],
                        bsx_subchain* out_record, uint64_t* witness) {
+    if (bsx_batcher* bt = (ctx && !witness) ? ctx->batcher.load() : nullptr)
+        if (bsxb_config(bt)->batch_size == batch_size) {
+            bsx_ticket t = 0;
+            RET(bsx_submit_prove_subchain(bt, start_header, end_header, dh, lb, batch_start_block, batch_end_block, global_end_block, global_end_header_hash,
+                                          out_record, &t));
+            return bsx_wait(bt, t);
+        }
     HOST_ENTER();
     if (!start_header || !end_header || !dh || !lb || !global_end_header_hash || !out_record) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
@@ -1119,6 +1146,16 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                      uint64_t first_height, uint64_t n_headers, uint64_t latest_block, const bsx_validator* target_validators,
                      const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness) {
+    if (bsx_batcher* bt = (ctx && !witness) ? ctx->batcher.load() : nullptr) {
+        const bsx_batcher_config* bc = bsxb_config(bt);
+        if (bc->nb_map_jobs == nb_map_jobs && bc->batch_size == batch_size && bc->v_max == v_max && bc->chain_id_len == chain_id_len &&
+            (chain_id_len == 0 || (chain_id && chain_id_len <= 50 && memcmp(bc->chain_id, chain_id, chain_id_len) == 0))) {
+            bsx_ticket t = 0;
+            RET(bsx_submit_header_range(bt, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64,
+                                        out_commit, &t));
+            return bsx_wait(bt, t);
+        }
+    }
     HOST_ENTER();
     const auto t_entry = std::chrono::steady_clock::now();
     if (!input48 || !headers || !target_validators || !trusted_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");

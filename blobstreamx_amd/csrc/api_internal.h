@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <atomic>
 #include <cstdio>
 #include <mutex>
 #include <string>
@@ -67,6 +68,8 @@ struct bsx_ctx {
     // recursive because host-tier entry points nest (bsx_next_header -> bsx_header_hashes).  The device tier holds no
     // per-call context state and does not take it.
     std::recursive_mutex host_mu;
+    // bsx_enable_coalescing: synchronous host-tier calls of the batcher's shape are submit + wait on it (batcher.hip)
+    std::atomic<bsx_batcher*> batcher{nullptr};
 };
 
 namespace bsxapi {

@@ -1,0 +1,815 @@
+// batcher.hip — the coalescing front end of the host tier (include/bsx.h, bsx_batcher_* / bsx_submit_* / bsx_wait).
+//
+// The reference's own call shape is ONE range per `prove` call under a multi-thread runtime (circuits/header_range.rs:180-181)
+// and ONE hint call per map job, 32 async hints per proof (circuits/builder.rs:325-332 -> circuits/data_commitment.rs:22-44,
+// `async fn hint`).  Served one by one, such a call is a string of ~10 dependent kernels of a single wave each: 0.26 ms for 2-3 % of
+// the GPU, and K concurrent callers on K contexts time-slice the same queues (round 4: 16 callers = 1.4x one caller).  The same
+// kernels take R ranges per launch at almost the same latency (bsx_pipeline_step: 1 range 0.15 ms, 16 ranges 0.22 ms).
+//
+// So concurrent requests are COALESCED: a submit claims a slot of the batch that is currently open, copies its inputs into the
+// batch's page-locked staging (on the caller's thread, callers in parallel) and returns a ticket; the worker thread of the lane that
+// owns the batch closes it after a short window (an idle GPU never waits longer than a debounce gap), uploads the staged inputs
+// with a handful of copies, runs ONE launch set over the R requests — the host tier's own kernels with n_ranges = R — downloads the
+// small results in one block and completes every ticket with ITS OWN status: statuses are per request on the device (header /
+// hint status words are indexed by request, assertion masks and skip statuses always were), so a malformed or tampered request
+// never fails its batch-mates.  n_lanes batches are in flight: the H2D copy of one runs beside the kernels of another.
+//
+// Three request kinds, each with its own lanes: header_range (CombinedSkipCircuit::define, header_range.rs:32-59),
+// data_commitment_inputs (the hint, data_commitment.rs:18-45 -> input.rs:149-271) and prove_subchain (builder.rs:150-271).
+//
+// Host code only: slots, staging, stream/event choreography, status decoding.  All arithmetic is in kernels_*.hip.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/bsx.h"
+#include "../../include/bsx_layout.h"
+#include "api_internal.h"
+#include "kernels.h"
+
+using bsxapi::fail;
+using bsxapi::pow2;
+
+namespace {
+
+inline uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
+constexpr uint32_t RING = 1u << 14;            // completion records kept: a ticket older than this many requests has expired
+constexpr uint32_t GAP_NS = 6000;              // debounce: a batch closes once no claim arrived for this long ...
+constexpr uint64_t CORK_MAX_NS = 20000000;     // a corked batch is released after 20 ms whatever happens
+struct DoneRec {
+    std::atomic<uint64_t> seq{0};
+    int rc = 0;
+    char msg[236] = {0};
+};
+
+// what a request leaves behind at submit: where its results go (the caller's pointers: they must stay valid until bsx_wait returns)
+struct Req {
+    uint64_t seq = 0;
+    uint8_t* output64 = nullptr;               // header_range
+    bsx_commit_result* out_commit = nullptr;
+    uint8_t *out_start = nullptr, *out_end = nullptr, *out_expected = nullptr;   // hint
+    bsx_data_hash_proof* out_dh = nullptr;
+    bsx_last_block_id_proof* out_lb = nullptr;
+    bsx_subchain* out_record = nullptr;        // prove_subchain
+    uint32_t n_headers = 0;                    // headers staged in the slot
+};
+
+struct Kind;
+struct Lane {
+    Kind* kind = nullptr;
+    uint32_t index = 0;
+    std::thread th;
+    enum State : int { FREE = 0, OPEN = 1, CLOSED = 2 };
+    std::atomic<int> state{FREE};
+    std::atomic<uint32_t> n_claimed{0}, n_ready{0};
+    std::atomic<uint64_t> t_first{0}, t_last{0};
+    std::vector<Req> reqs;
+    std::vector<uint32_t> slot_hwm;            // headers ever staged in a slot (tail beyond the current request is cleared when stale)
+    // resources (kind-specific use)
+    hipStream_t st = nullptr, sb = nullptr, s3 = nullptr, s4 = nullptr;
+    hipEvent_t ev[8] = {nullptr};
+    std::vector<void*> dallocs, hallocs;
+    uint8_t *h_headers = nullptr, *h_small = nullptr, *h_out = nullptr;          // page-locked
+    // device
+    uint8_t *d_headers = nullptr, *d_hashes = nullptr, *d_dh = nullptr, *d_lb = nullptr, *d_paths = nullptr;
+    uint8_t *d_ranges = nullptr, *d_latest = nullptr, *d_spans = nullptr, *d_compact = nullptr, *d_records = nullptr;
+    uint8_t *d_tv = nullptr, *d_rv = nullptr, *d_h = nullptr, *d_ok = nullptr, *d_tres = nullptr, *d_th = nullptr, *d_th2 = nullptr, *d_rdec = nullptr;
+    uint8_t *d_keytab = nullptr, *d_out = nullptr, *d_expected = nullptr;
+    std::vector<uint8_t> key_mirror;           // host copy of the keys this lane's table rows were built for
+    bool key_mirror_valid = false;
+    std::string err;                           // lane_init failure
+};
+
+}  // namespace
+
+struct bsx_batcher {
+    bsx_ctx* ctx = nullptr;
+    bsx_batcher_config cfg{};
+    uint32_t J = 0, B = 0, V = 0, M = 0, n_lanes = 0;
+    uint64_t window_ns = 0;
+    uint64_t hpr = 0;                          // headers per header_range slot: J * B + 1
+    std::atomic<uint64_t> next_seq{1};
+    std::vector<DoneRec> ring;
+    std::mutex mu_done;
+    std::condition_variable cv_done;
+    std::unique_ptr<Kind> range_kind, hint_kind, subchain_kind;
+    std::mutex mu_kinds;                       // lazy start of a kind's lanes
+    std::atomic<int> corked{0};                // bsx_batcher_cork: open batches close only when full
+    bsx_batcher() : ring(RING) {}
+};
+
+namespace {
+
+struct Kind {
+    bsx_batcher* b;
+    const char* name;
+    uint32_t M;                                // slots per batch
+    std::mutex mu;
+    std::condition_variable cv_open, cv_work;
+    std::vector<std::unique_ptr<Lane>> lanes;
+    Lane* open = nullptr;
+    std::deque<Lane*> free_;
+    std::atomic<uint32_t> in_flight{0};
+    bool stop = false, started = false;
+    int init_rc = BSX_OK;
+    std::string init_err;
+    // statistics
+    std::atomic<uint64_t> n_batches{0}, n_requests{0}, max_batch{0}, sum_close_wait_ns{0};
+
+    Kind(bsx_batcher* b_, const char* n, uint32_t m) : b(b_), name(n), M(m) {}
+    virtual ~Kind() {}
+    virtual int lane_init(Lane& l) = 0;
+    virtual int launch(Lane& l, uint32_t R) = 0;                      // enqueue everything and wait for it
+    virtual void complete(Lane& l, uint32_t R, int batch_rc, const std::string& batch_err) = 0;
+
+    void finish(Req& rq, int rc, const char* msg) {
+        DoneRec& d = b->ring[rq.seq % RING];
+        d.rc = rc;
+        if (msg) { strncpy(d.msg, msg, sizeof d.msg - 1); d.msg[sizeof d.msg - 1] = 0; } else d.msg[0] = 0;
+        d.seq.store(rq.seq, std::memory_order_release);
+    }
+
+    int dalloc(Lane& l, size_t bytes, uint8_t** out) {
+        if (bytes < 256) bytes = 256;
+        bytes = (bytes + 255) & ~(size_t)255;
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e == hipSuccess) e = hipMemset(q, 0, bytes);
+        if (e != hipSuccess) { if (q) (void)hipFree(q); return fail(BSX_ERR_HIP, "bsx_batcher(%s): hipMalloc(%zu): %s", name, bytes, hipGetErrorString(e)); }
+        l.dallocs.push_back(q);
+        *out = static_cast<uint8_t*>(q);
+        return BSX_OK;
+    }
+    int halloc(Lane& l, size_t bytes, uint8_t** out) {
+        if (bytes < 4096) bytes = 4096;
+        void* q = nullptr;
+        hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(BSX_ERR_HIP, "bsx_batcher(%s): hipHostMalloc(%zu): %s", name, bytes, hipGetErrorString(e));
+        memset(q, 0, bytes);
+        l.hallocs.push_back(q);
+        *out = static_cast<uint8_t*>(q);
+        return BSX_OK;
+    }
+    int lane_common(Lane& l) {
+        for (hipStream_t* s : {&l.st, &l.sb, &l.s3, &l.s4}) HIPCHK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+        for (auto& e : l.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        l.reqs.resize(M);
+        l.slot_hwm.assign(M, 0);
+        return BSX_OK;
+    }
+    void lane_free(Lane& l) {
+        for (hipStream_t s : {l.st, l.sb, l.s3, l.s4}) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        for (auto e : l.ev) if (e) (void)hipEventDestroy(e);
+        for (void* q : l.dallocs) (void)hipFree(q);
+        for (void* q : l.hallocs) (void)hipHostFree(q);
+    }
+
+    // the worker of one lane: waits until its batch is the open one and holds a request, closes it (window policy), runs it
+    void run(Lane* lp) {
+        Lane& l = *lp;
+        (void)hipSetDevice(b->ctx->device);
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || (l.state.load() == Lane::OPEN && l.n_claimed.load() > 0); });
+                if (stop) return;
+            }
+            // window: full, or no claim for GAP_NS while the GPU is idle, or the window has run out (earlier batches keep the GPU busy:
+            // waiting is free until then).  Spinning: the wait is tens of microseconds, below a timed condition wait's resolution
+            const uint64_t t_open = l.t_first.load();
+            for (;;) {
+                const uint32_t n = l.n_claimed.load(std::memory_order_acquire);
+                if (n >= M) break;
+                const uint64_t t = now_ns();
+                if (b->corked.load(std::memory_order_relaxed)) {                // the caller announced a burst: full batches only ...
+                    if (t - l.t_first.load() >= CORK_MAX_NS) break;             // ... but a forgotten cork must not hang a waiter
+                    cpu_relax();
+                    continue;
+                }
+                const bool quiet = t - l.t_last.load(std::memory_order_acquire) >= GAP_NS;
+                if (quiet && (in_flight.load() == 0 || t - t_open >= b->window_ns)) break;
+                if (t - l.t_first.load() >= 4 * b->window_ns + 1000000) break;   // never hold a request hostage to a stream of late claims
+                cpu_relax();
+            }
+            uint32_t R;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                R = l.n_claimed.load();
+                l.state.store(Lane::CLOSED);
+                in_flight.fetch_add(1);
+                open = nullptr;
+                if (!free_.empty()) { open = free_.front(); free_.pop_front(); open->state.store(Lane::OPEN); }
+            }
+            cv_open.notify_all();
+            sum_close_wait_ns.fetch_add(now_ns() - t_open);
+            while (l.n_ready.load(std::memory_order_acquire) < R) cpu_relax();   // submitters still copying into their slots
+            bsxapi::g_err.clear();
+            const int rc = launch(l, R);
+            const std::string err = bsxapi::g_err;
+            complete(l, R, rc, err);
+            n_batches.fetch_add(1);
+            n_requests.fetch_add(R);
+            uint64_t mb = max_batch.load();
+            while (R > mb && !max_batch.compare_exchange_weak(mb, R)) {}
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                l.n_claimed.store(0);
+                l.n_ready.store(0);
+                in_flight.fetch_sub(1);
+                if (!open) { open = &l; l.state.store(Lane::OPEN); } else { l.state.store(Lane::FREE); free_.push_back(&l); }
+            }
+            cv_open.notify_all();
+            { std::lock_guard<std::mutex> lk(b->mu_done); }
+            b->cv_done.notify_all();
+        }
+    }
+
+    int start() {
+        if (started) return init_rc;
+        started = true;
+        (void)hipSetDevice(b->ctx->device);
+        for (uint32_t i = 0; i < b->n_lanes; i++) {
+            lanes.emplace_back(new Lane());
+            Lane& l = *lanes.back();
+            l.kind = this;
+            l.index = i;
+            int rc = lane_common(l);
+            if (rc == BSX_OK) rc = lane_init(l);
+            if (rc != BSX_OK) { init_rc = rc; init_err = bsxapi::g_err; return rc; }
+        }
+        if (hipDeviceSynchronize() != hipSuccess) { init_rc = BSX_ERR_HIP; init_err = "bsx_batcher: device error while creating lanes"; return init_rc; }
+        open = lanes[0].get();
+        open->state.store(Lane::OPEN);
+        for (size_t i = 1; i < lanes.size(); i++) free_.push_back(lanes[i].get());
+        for (auto& l : lanes) l->th = std::thread(&Kind::run, this, l.get());
+        return BSX_OK;
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        cv_open.notify_all();
+        for (auto& l : lanes) if (l->th.joinable()) l->th.join();
+        (void)hipSetDevice(b->ctx->device);
+        for (auto& l : lanes) lane_free(*l);
+        lanes.clear();
+    }
+
+    // claim a slot of the open batch; the caller then stages its inputs into (lane, idx) and calls ready()
+    int claim(Lane** out_lane, uint32_t* out_idx, const Req& proto, bsx_ticket* ticket) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_open.wait(lk, [&] { return stop || (open && open->n_claimed.load() < M); });
+        if (stop) return fail(BSX_ERR_BAD_ARG, "bsx_batcher: destroyed while a submit was waiting");
+        Lane* l = open;
+        const uint32_t idx = l->n_claimed.load();
+        const uint64_t t = now_ns();
+        if (idx == 0) l->t_first.store(t);
+        l->t_last.store(t, std::memory_order_release);
+        Req& rq = l->reqs[idx];
+        rq = proto;
+        rq.seq = b->next_seq.fetch_add(1);
+        l->n_claimed.store(idx + 1, std::memory_order_release);
+        *ticket = rq.seq;
+        *out_lane = l;
+        *out_idx = idx;
+        lk.unlock();
+        if (idx == 0) cv_work.notify_all();
+        return BSX_OK;
+    }
+    static void ready(Lane* l) { l->n_ready.fetch_add(1, std::memory_order_release); }
+};
+
+#define LHIP(expr)                                                                                           \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(BSX_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ================================================================================================ header_range
+// out block (device and page-locked mirror), arrays of M entries each
+struct RangeOut {
+    size_t o64, res, hst, ast, fst, skip, commit, total;
+    explicit RangeOut(uint32_t M) {
+        o64 = 0; res = o64 + (size_t)M * 64; hst = res + (size_t)M * 128; ast = hst + (size_t)M * 4; fst = ast + (size_t)M * 4;
+        skip = fst + (size_t)M * 4; commit = skip + (size_t)M * 4; total = commit + (size_t)M * sizeof(bsx_commit_result);
+    }
+};
+struct RangeSmall {                            // page-locked staging of the small inputs, arrays of M entries each
+    size_t ranges, latest, tv, rv, total;
+    RangeSmall(uint32_t M, uint32_t V) {
+        ranges = 0; latest = ranges + (size_t)M * sizeof(bsx_shared_ctx); latest = (latest + 255) & ~(size_t)255;
+        tv = latest + (size_t)M * 8; tv = (tv + 255) & ~(size_t)255;
+        rv = tv + (size_t)M * V * sizeof(bsx_validator);
+        total = rv + (size_t)M * V * sizeof(bsx_validator);
+    }
+};
+
+struct RangeKind : Kind {
+    RangeKind(bsx_batcher* b_) : Kind(b_, "header_range", b_->M) {}
+    int lane_init(Lane& l) override {
+        const uint32_t J = b->J, B = b->B, V = b->V;
+        const uint64_t nh = (uint64_t)M * b->hpr;
+        const bsx_witness_layout L = bsx_map_layout(B);
+        const RangeOut O(M);
+        const RangeSmall S(M, V);
+        RET(halloc(l, nh * sizeof(bsx_header), &l.h_headers));
+        RET(halloc(l, S.total, &l.h_small));
+        RET(halloc(l, O.total, &l.h_out));
+        RET(dalloc(l, nh * sizeof(bsx_header), &l.d_headers));
+        RET(dalloc(l, nh * 32, &l.d_hashes));
+        RET(dalloc(l, nh * 128, &l.d_dh));
+        RET(dalloc(l, nh * 128, &l.d_lb));
+        RET(dalloc(l, nh * BSX_HEADER_PATH_BYTES, &l.d_paths));
+        RET(dalloc(l, (size_t)M * sizeof(bsx_shared_ctx), &l.d_ranges));
+        RET(dalloc(l, (size_t)M * 8, &l.d_latest));
+        RET(dalloc(l, (size_t)M * J * L.compact_stride, &l.d_compact));
+        RET(dalloc(l, (size_t)M * J * sizeof(bsx_subchain), &l.d_records));
+        RET(dalloc(l, (size_t)M * V * sizeof(bsx_validator), &l.d_tv));
+        RET(dalloc(l, (size_t)M * V * sizeof(bsx_validator), &l.d_rv));
+        RET(dalloc(l, (size_t)M * V * 32, &l.d_h));
+        RET(dalloc(l, (size_t)M * V, &l.d_ok));
+        RET(dalloc(l, (size_t)M * sizeof(bsx_commit_result), &l.d_tres));
+        RET(dalloc(l, (size_t)M * 32, &l.d_th));
+        RET(dalloc(l, (size_t)M * 32, &l.d_th2));
+        RET(dalloc(l, bsxk_ed25519_rdec_bytes((uint64_t)M * V), &l.d_rdec));
+        RET(dalloc(l, O.total, &l.d_out));
+        // every lane owns its fixed-key table (5.8 MB per validator slot): a lane that rebuilds rows for a new validator set must not
+        // do so under another lane's signature check.  No table (allocation failed): the generic per-signature kernel
+        {
+            void* q = nullptr;
+            if (hipMalloc(&q, bsxk_keytable_bytes(V)) == hipSuccess) {
+                if (hipMemset(q, 0, (size_t)V * 64) == hipSuccess) { l.dallocs.push_back(q); l.d_keytab = static_cast<uint8_t*>(q); }
+                else (void)hipFree(q);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        return BSX_OK;
+    }
+
+    int launch(Lane& l, uint32_t R) override {
+        const uint32_t J = b->J, B = b->B, V = b->V;
+        const uint64_t hpr = b->hpr, nh = (uint64_t)R * hpr, n = (uint64_t)R * V;
+        const RangeOut O(M);
+        const RangeSmall S(M, V);
+        bsx_ctx* ctx = b->ctx;
+        hipStream_t st = l.st, sb = l.sb, s3 = l.s3, s4 = l.s4;
+        hipEvent_t ev_c = l.ev[0], ev_d = l.ev[1], ev_a = l.ev[2], ev_f = l.ev[3], ev_g = l.ev[4], ev_b = l.ev[5];
+        struct Drain { Lane& l; ~Drain() { for (hipStream_t s : {l.s4, l.s3, l.sb, l.st}) (void)hipStreamSynchronize(s); } } drain{l};
+        auto* tv = reinterpret_cast<const bsx_validator*>(l.d_tv);
+        auto* rv = reinterpret_cast<const bsx_validator*>(l.d_rv);
+        auto* ranges = reinterpret_cast<bsx_shared_ctx*>(l.d_ranges);
+        auto* cres = reinterpret_cast<bsx_commit_result*>(l.d_out + O.commit);
+        auto* tres = reinterpret_cast<bsx_commit_result*>(l.d_tres);
+        // the fixed-key table against this batch's keys, on the host: rows follow the FIRST request's validator set; slots of the
+        // other requests whose key differs are counted (the signature check sizes — or skips — its generic-kernel pass from the count)
+        const bsx_validator* h_tv = reinterpret_cast<const bsx_validator*>(l.h_small + S.tv);
+        bool keys_same = l.d_keytab && l.key_mirror_valid;
+        for (uint32_t i = 0; keys_same && i < V; i++) keys_same = memcmp(l.key_mirror.data() + 32 * (size_t)i, h_tv[i].pubkey, 32) == 0;
+        const uint64_t n_mismatch = l.d_keytab ? bsxh_key_mismatches(h_tv, R, V) : 0;
+        // small inputs first (the commit chain starts from them), then the headers: the head of the hashing chain
+        LHIP(hipMemcpyAsync(l.d_ranges, l.h_small + S.ranges, (size_t)R * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
+        LHIP(hipMemcpyAsync(l.d_latest, l.h_small + S.latest, (size_t)R * 8, hipMemcpyHostToDevice, st));
+        LHIP(hipMemcpyAsync(l.d_tv, l.h_small + S.tv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+        LHIP(hipMemcpyAsync(l.d_rv, l.h_small + S.rv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+        LHIP(hipMemsetAsync(l.d_out + O.hst, 0, (size_t)M * 8, st));              // header + hint status words of every slot
+        LHIP(hipEventRecord(ev_c, st));
+        LHIP(hipMemcpyAsync(l.d_headers, l.h_headers, nh * sizeof(bsx_header), hipMemcpyHostToDevice, st));
+        // s3: R decoded strictly ahead of time (the longest kernel of the commit check; needs only the validator records)
+        LHIP(hipStreamWaitEvent(s3, ev_c, 0));
+        if (l.d_keytab) LHIP(bsxk_ed25519_decode_r(s3, tv, n, l.d_rdec));
+        LHIP(hipEventRecord(ev_d, s3));
+        // st: header hashes + both inclusion-proof paths of every header of every request; a malformed header marks ITS request
+        LHIP(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(l.d_headers), nh, l.d_hashes, l.d_dh, l.d_lb, l.d_paths,
+                                reinterpret_cast<uint32_t*>(l.d_out + O.hst), 0, 0, nullptr, hpr));
+        // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash, the first output half and what the
+        // signed messages must carry
+        LHIP(bsxk_fill_end_hash(st, R, ranges, l.d_hashes, hpr, nullptr, l.d_th, nullptr, 0));
+        LHIP(hipEventRecord(ev_a, st));
+        // sb: challenges; s4: validator-set hash + total power of the target sets, then of the trusted sets
+        LHIP(hipStreamWaitEvent(sb, ev_c, 0));
+        LHIP(hipStreamWaitEvent(s4, ev_c, 0));
+        LHIP(bsxk_sha512_challenge(sb, tv, n, l.d_h, nullptr, V, nullptr));
+        LHIP(bsxk_commit_tally(s4, tv, R, V, nullptr, nullptr, cres, nullptr));
+        LHIP(hipEventRecord(ev_f, s4));
+        LHIP(bsxk_commit_tally(s4, rv, R, V, nullptr, nullptr, tres, nullptr));
+        LHIP(hipEventRecord(ev_g, s4));
+        if (l.d_keytab) {
+            if (!keys_same) {
+                LHIP(bsxk_ed25519_keytable(sb, tv, V, l.d_keytab));
+                l.key_mirror.resize((size_t)V * 32);
+                for (uint32_t i = 0; i < V; i++) memcpy(l.key_mirror.data() + 32 * (size_t)i, h_tv[i].pubkey, 32);
+                l.key_mirror_valid = true;
+            }
+            LHIP(hipStreamWaitEvent(sb, ev_d, 0));
+            LHIP(bsxk_ed25519_verify_keyed(sb, tv, l.d_h, n, V, l.d_keytab, V, ctx->btab, l.d_ok, nullptr, l.d_rdec, (int64_t)n_mismatch));
+        } else {
+            LHIP(bsxk_ed25519_verify(sb, tv, l.d_h, n, l.d_ok));
+            LHIP(hipStreamWaitEvent(sb, ev_d, 0));
+        }
+        LHIP(hipStreamWaitEvent(sb, ev_a, 0));                              // target hashes (dense) and the ranges' header hashes
+        LHIP(hipStreamWaitEvent(sb, ev_f, 0));
+        LHIP(bsxk_commit_sums(sb, tv, R, V, l.d_th, l.d_ok, cres, nullptr));
+        LHIP(hipStreamWaitEvent(sb, ev_g, 0));
+        LHIP(bsxk_skip_check(sb, R, V, ranges, reinterpret_cast<const bsx_header*>(l.d_headers), hpr, l.d_hashes, tv, rv, l.d_ok, cres, tres,
+                             reinterpret_cast<uint32_t*>(l.d_out + O.skip), l.d_th2, nullptr, b->cfg.chain_id_len ? b->cfg.chain_id : nullptr,
+                             b->cfg.chain_id_len, nullptr));
+        LHIP(hipEventRecord(ev_b, sb));
+        // st: prove_data_commitment (header_range.rs:50-55): the hint of every map job, prove_subchain, reduce + final assertions
+        LHIP(bsxk_assemble_inputs(st, R, J, B, 0, J, B, ranges, reinterpret_cast<const uint64_t*>(l.d_latest), reinterpret_cast<const bsx_header*>(l.d_headers),
+                                  hpr, 0, l.d_hashes, l.d_dh, l.d_lb, l.d_compact, reinterpret_cast<uint32_t*>(l.d_out + O.ast), l.d_paths, ctx->zero_paths,
+                                  0, nullptr, 1));
+        LHIP(bsxk_prove_subchain(st, R, B, J, ranges, l.d_compact, reinterpret_cast<bsx_subchain*>(l.d_records), BSX_SUBCHAIN_PATHS_FROM_HINT));
+        LHIP(bsxk_reduce_finalize(st, R, J, reinterpret_cast<const bsx_subchain*>(l.d_records), reinterpret_cast<bsx_subchain*>(l.d_out + O.res), nullptr, J, B,
+                                  ranges, l.d_th, l.d_out + O.o64, reinterpret_cast<uint32_t*>(l.d_out + O.fst)));
+        LHIP(hipStreamWaitEvent(st, ev_b, 0));
+        LHIP(hipMemcpyAsync(l.h_out, l.d_out, O.total, hipMemcpyDeviceToHost, st));
+        LHIP(hipStreamSynchronize(st));
+        return BSX_OK;
+    }
+
+    void complete(Lane& l, uint32_t R, int batch_rc, const std::string& batch_err) override {
+        const RangeOut O(M);
+        char msg[236];
+        for (uint32_t r = 0; r < R; r++) {
+            Req& rq = l.reqs[r];
+            if (batch_rc != BSX_OK) { finish(rq, batch_rc, batch_err.c_str()); continue; }
+            uint32_t hs, as, fst, skip;
+            memcpy(&hs, l.h_out + O.hst + 4 * (size_t)r, 4);
+            memcpy(&as, l.h_out + O.ast + 4 * (size_t)r, 4);
+            memcpy(&fst, l.h_out + O.fst + 4 * (size_t)r, 4);
+            memcpy(&skip, l.h_out + O.skip + 4 * (size_t)r, 4);
+            bsx_commit_result cr;
+            memcpy(&cr, l.h_out + O.commit + sizeof cr * (size_t)r, sizeof cr);
+            // the order of bsx_header_range: malformed inputs first, then the skip verification, then the data commitment's assertions
+            if (hs & 1u) { finish(rq, BSX_ERR_BAD_HEADER, "a packed header violates the field-size rules of bsx_header"); continue; }
+            if (as & 2u) { finish(rq, BSX_ERR_BAD_HEADER, "an inclusion-proof leaf is not 34 / 72 bytes (circuits/input.rs:173,190)"); continue; }
+            if (as & 4u) { finish(rq, BSX_ERR_BAD_ARG, "the supplied headers do not cover [start, min(end, latest-2)] or latest < 2"); continue; }
+            memcpy(rq.output64, l.h_out + O.o64 + 64 * (size_t)r, 64);
+            if (rq.out_commit) *rq.out_commit = cr;
+            if (skip) {
+                snprintf(msg, sizeof msg, "skip verification failed: %s (bad signatures %u, first %u; bad messages %u; signed %llu of %llu; trusted overlap %llu)",
+                         bsx_status_str((int)skip), cr.n_bad_signature, cr.first_bad_signature, cr.n_bad_message, (unsigned long long)cr.signed_power,
+                         (unsigned long long)cr.total_power, (unsigned long long)cr.trusted_signed_power);
+                finish(rq, (int)skip, msg);
+                continue;
+            }
+            if (fst) {
+                snprintf(msg, sizeof msg, "prove_data_commitment: assertion mask 0x%x (A7 builder.rs:292-297, A8 :350-355, A9 :401-406; A1-A6 from the map jobs)", fst);
+                finish(rq, BSX_ERR_ASSERT, msg);
+                continue;
+            }
+            finish(rq, BSX_OK, nullptr);
+        }
+    }
+};
+
+// ================================================================================================ the hint (data_commitment_inputs)
+struct HintKind : Kind {
+    uint32_t hpr;                              // B + 1 headers per slot
+    size_t img_bytes;                          // what a request gets back of its compact image: ctx/start/end hashes + both proof arrays
+    HintKind(bsx_batcher* b_) : Kind(b_, "data_commitment_inputs", b_->M < 64 ? 64 : b_->M), hpr(b_->B + 1), img_bytes(bsx_off_slots(b_->B)) {}
+    struct Small { size_t ranges, latest, spans, total; explicit Small(uint32_t M) { ranges = 0; latest = (size_t)M * 80; spans = latest + (size_t)M * 8; total = spans + (size_t)M * 4; } };
+    struct Out { size_t img, expected, hst, ast, total; Out(uint32_t M, size_t ib) { img = 0; expected = (size_t)M * ib; expected = (expected + 255) & ~(size_t)255; hst = expected + (size_t)M * 32; ast = hst + (size_t)M * 4; total = ast + (size_t)M * 4; } };
+    int lane_init(Lane& l) override {
+        const uint64_t nh = (uint64_t)M * hpr;
+        const bsx_witness_layout L = bsx_map_layout(b->B);
+        const Small S(M);
+        const Out O(M, img_bytes);
+        RET(halloc(l, nh * sizeof(bsx_header), &l.h_headers));
+        RET(halloc(l, S.total, &l.h_small));
+        RET(halloc(l, O.total, &l.h_out));
+        RET(dalloc(l, nh * sizeof(bsx_header), &l.d_headers));
+        RET(dalloc(l, nh * 32, &l.d_hashes));
+        RET(dalloc(l, nh * 128, &l.d_dh));
+        RET(dalloc(l, nh * 128, &l.d_lb));
+        RET(dalloc(l, S.total, &l.d_ranges));                 // ranges, latest, spans in one block (same offsets as the staging)
+        RET(dalloc(l, (size_t)M * L.compact_stride, &l.d_compact));
+        RET(dalloc(l, O.total - O.expected, &l.d_out));       // expected, hst, ast
+        return BSX_OK;
+    }
+    int launch(Lane& l, uint32_t R) override {
+        const uint32_t B = b->B;
+        const bsx_witness_layout L = bsx_map_layout(B);
+        const Small S(M);
+        const Out O(M, img_bytes);
+        hipStream_t st = l.st;
+        struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+        const uint64_t nh = (uint64_t)R * hpr;
+        uint8_t* d_exp = l.d_out;
+        uint32_t* d_hst = reinterpret_cast<uint32_t*>(l.d_out + (O.hst - O.expected));
+        uint32_t* d_ast = reinterpret_cast<uint32_t*>(l.d_out + (O.ast - O.expected));
+        LHIP(hipMemcpyAsync(l.d_ranges, l.h_small, S.total, hipMemcpyHostToDevice, st));            // 92 bytes per slot: all M at once
+        LHIP(hipMemsetAsync(d_hst, 0, (size_t)M * 8, st));
+        LHIP(hipMemcpyAsync(l.d_headers, l.h_headers, nh * sizeof(bsx_header), hipMemcpyHostToDevice, st));
+        LHIP(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(l.d_headers), nh, l.d_hashes, l.d_dh, l.d_lb, nullptr, d_hst, 0, 0, nullptr, hpr));
+        // the hint's image is read back as it is: every byte of it is written (zero padding included), the bytes behind it are not ours
+        LHIP(bsxk_assemble_inputs(st, R, 1, B, 0, 1, B, reinterpret_cast<const bsx_shared_ctx*>(l.d_ranges + S.ranges),
+                                  reinterpret_cast<const uint64_t*>(l.d_ranges + S.latest), reinterpret_cast<const bsx_header*>(l.d_headers), hpr, 0, l.d_hashes,
+                                  l.d_dh, l.d_lb, l.d_compact, d_ast, nullptr, nullptr, 0, reinterpret_cast<const uint32_t*>(l.d_ranges + S.spans), 1));
+        bool want_expected = false;
+        for (uint32_t r = 0; r < R; r++) want_expected |= l.reqs[r].out_expected != nullptr;
+        if (want_expected)
+            LHIP(bsxk_expected_commitments(st, R, B, reinterpret_cast<const bsx_shared_ctx*>(l.d_ranges + S.ranges), reinterpret_cast<const uint32_t*>(l.d_ranges + S.spans),
+                                           reinterpret_cast<const uint64_t*>(l.d_ranges + S.latest), l.d_compact, d_exp));
+        LHIP(hipMemcpy2DAsync(l.h_out + O.img, img_bytes, l.d_compact, L.compact_stride, img_bytes, R, hipMemcpyDeviceToHost, st));
+        LHIP(hipMemcpyAsync(l.h_out + O.expected, l.d_out, O.total - O.expected, hipMemcpyDeviceToHost, st));
+        LHIP(hipStreamSynchronize(st));
+        return BSX_OK;
+    }
+    void complete(Lane& l, uint32_t R, int batch_rc, const std::string& batch_err) override {
+        const uint32_t B = b->B;
+        const Out O(M, img_bytes);
+        for (uint32_t r = 0; r < R; r++) {
+            Req& rq = l.reqs[r];
+            if (batch_rc != BSX_OK) { finish(rq, batch_rc, batch_err.c_str()); continue; }
+            uint32_t hs, as;
+            memcpy(&hs, l.h_out + O.hst + 4 * (size_t)r, 4);
+            memcpy(&as, l.h_out + O.ast + 4 * (size_t)r, 4);
+            if (hs & 1u) { finish(rq, BSX_ERR_BAD_HEADER, "a packed header violates the field-size rules of bsx_header"); continue; }
+            if (as & 2u) { finish(rq, BSX_ERR_BAD_HEADER, "an inclusion-proof leaf is not 34 / 72 bytes (circuits/input.rs:173,190)"); continue; }
+            if (as & 4u) { finish(rq, BSX_ERR_BAD_ARG, "the supplied headers do not cover [start, min(end, latest-2)] or latest < 2"); continue; }
+            const uint8_t* img = l.h_out + O.img + img_bytes * (size_t)r;
+            memcpy(rq.out_start, img + bsx_off_start_header(), 32);
+            memcpy(rq.out_end, img + bsx_off_end_header(), 32);
+            memcpy(rq.out_dh, img + bsx_off_dh_proofs(B), (size_t)B * sizeof(bsx_data_hash_proof));
+            memcpy(rq.out_lb, img + bsx_off_lb_proofs(B), (size_t)B * sizeof(bsx_last_block_id_proof));
+            if (rq.out_expected) memcpy(rq.out_expected, l.h_out + O.expected + 32 * (size_t)r, 32);
+            finish(rq, BSX_OK, nullptr);
+        }
+    }
+};
+
+// ================================================================================================ prove_subchain
+struct SubchainKind : Kind {
+    SubchainKind(bsx_batcher* b_) : Kind(b_, "prove_subchain", b_->M < 64 ? 64 : b_->M) {}
+    int lane_init(Lane& l) override {
+        const bsx_witness_layout L = bsx_map_layout(b->B);
+        RET(halloc(l, (size_t)M * L.compact_stride, &l.h_headers));       // the requests' compact images
+        RET(halloc(l, (size_t)M * sizeof(bsx_shared_ctx), &l.h_small));
+        RET(halloc(l, (size_t)M * sizeof(bsx_subchain), &l.h_out));
+        RET(dalloc(l, (size_t)M * L.compact_stride, &l.d_compact));
+        RET(dalloc(l, (size_t)M * sizeof(bsx_shared_ctx), &l.d_ranges));
+        RET(dalloc(l, (size_t)M * sizeof(bsx_subchain), &l.d_records));
+        return BSX_OK;
+    }
+    int launch(Lane& l, uint32_t R) override {
+        const bsx_witness_layout L = bsx_map_layout(b->B);
+        hipStream_t st = l.st;
+        struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+        // only the head of an image is the caller's (ctx / start / end hashes + proofs); the words section follows separately
+        LHIP(hipMemcpyAsync(l.d_compact, l.h_headers, (size_t)R * L.compact_stride, hipMemcpyHostToDevice, st));
+        LHIP(hipMemcpyAsync(l.d_ranges, l.h_small, (size_t)R * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
+        // the proofs are the CALLER's: both paths are re-derived per slot (builder.rs:189-199 literally)
+        LHIP(bsxk_prove_subchain(st, R, b->B, 1, reinterpret_cast<const bsx_shared_ctx*>(l.d_ranges), l.d_compact, reinterpret_cast<bsx_subchain*>(l.d_records), 0));
+        LHIP(hipMemcpyAsync(l.h_out, l.d_records, (size_t)R * sizeof(bsx_subchain), hipMemcpyDeviceToHost, st));
+        LHIP(hipStreamSynchronize(st));
+        return BSX_OK;
+    }
+    void complete(Lane& l, uint32_t R, int batch_rc, const std::string& batch_err) override {
+        char msg[236];
+        for (uint32_t r = 0; r < R; r++) {
+            Req& rq = l.reqs[r];
+            if (batch_rc != BSX_OK) { finish(rq, batch_rc, batch_err.c_str()); continue; }
+            memcpy(rq.out_record, l.h_out + sizeof(bsx_subchain) * (size_t)r, sizeof(bsx_subchain));
+            if (rq.out_record->assert_fail) {
+                snprintf(msg, sizeof msg, "prove_subchain: assertion mask 0x%x, first failing slot %u (A3 builder.rs:205-207, A4 :210-212, A5 :216-219, A6 :229-232)",
+                         rq.out_record->assert_fail, rq.out_record->first_bad_slot);
+                finish(rq, BSX_ERR_ASSERT, msg);
+            } else {
+                finish(rq, BSX_OK, nullptr);
+            }
+        }
+    }
+};
+
+template <typename K> int kind_of(bsx_batcher* b, std::unique_ptr<Kind>& slot, Kind** out) {
+    std::lock_guard<std::mutex> lk(b->mu_kinds);
+    if (!slot) slot.reset(new K(b));
+    const int rc = slot->start();
+    if (rc != BSX_OK) return fail(rc, "%s", slot->init_err.c_str());
+    *out = slot.get();
+    return BSX_OK;
+}
+
+// stage `n` headers into slot `idx` of the lane (stride `hpr` headers); a slot that held more headers before gets its tail cleared
+void stage_headers(Lane* l, uint32_t idx, uint64_t hpr, const bsx_header* src, uint64_t n) {
+    uint8_t* dst = l->h_headers + (size_t)idx * hpr * sizeof(bsx_header);
+    memcpy(dst, src, n * sizeof(bsx_header));
+    if (l->slot_hwm[idx] > n) memset(dst + n * sizeof(bsx_header), 0, (l->slot_hwm[idx] - n) * sizeof(bsx_header));
+    l->slot_hwm[idx] = (uint32_t)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+const bsx_batcher_config* bsxb_config(const bsx_batcher* b) { return &b->cfg; }
+
+int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher** out) {
+    RET(bsxapi::use(ctx));
+    if (!cfg || !out) return fail(BSX_ERR_BAD_ARG, "bsx_batcher_create: null pointer");
+    *out = nullptr;
+    if (!pow2(cfg->nb_map_jobs) || cfg->nb_map_jobs > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
+    if (!pow2(cfg->batch_size) || cfg->batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
+    if (cfg->v_max == 0 || (int)cfg->v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", cfg->v_max, bsxk_tally_vmax());
+    if (cfg->chain_id_len > 50) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
+    if (cfg->max_requests > 256 || cfg->n_lanes > 8 || cfg->window_us > 10000) return fail(BSX_ERR_BAD_ARG, "bsx_batcher_create: max_requests <= 256, n_lanes <= 8, window_us <= 10000");
+    if (cfg->flags) return fail(BSX_ERR_BAD_ARG, "bsx_batcher_create: unknown flags 0x%x", cfg->flags);
+    bsx_batcher* b = new bsx_batcher();
+    b->ctx = ctx;
+    b->cfg = *cfg;
+    b->J = cfg->nb_map_jobs; b->B = cfg->batch_size; b->V = cfg->v_max;
+    b->M = cfg->max_requests ? cfg->max_requests : 32;
+    b->n_lanes = cfg->n_lanes ? cfg->n_lanes : 3;
+    b->window_ns = (uint64_t)(cfg->window_us ? cfg->window_us : 50) * 1000;
+    b->hpr = (uint64_t)b->J * b->B + 1;
+    *out = b;
+    return BSX_OK;
+}
+
+void bsx_batcher_destroy(bsx_batcher* b) {
+    if (!b) return;
+    for (auto* k : {&b->range_kind, &b->hint_kind, &b->subchain_kind})
+        if (*k) (*k)->shutdown();
+    delete b;
+}
+
+int bsx_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
+                            uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                            uint8_t output64[64], bsx_commit_result* out_commit, bsx_ticket* out_ticket) {
+    if (!b || !out_ticket) return fail(BSX_ERR_BAD_ARG, "bsx_submit_header_range: null batcher / ticket");
+    if (!input48 || !headers || !target_validators || !trusted_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    // the checks bsx_header_range makes before it touches the device (header_range.rs:33-35: evm_read u64 big endian, bytes32, u64)
+    uint64_t trusted_block = 0, target_block = 0;
+    for (int i = 0; i < 8; i++) trusted_block = trusted_block << 8 | input48[i];
+    for (int i = 0; i < 8; i++) target_block = target_block << 8 | input48[40 + i];
+    const uint64_t span_max = (uint64_t)b->J * b->B;
+    if (!(target_block > trusted_block) || target_block - trusted_block > span_max)
+        return fail(BSX_ERR_RANGE_TOO_LONG, "skip: need trusted < target <= trusted + %llu", (unsigned long long)span_max);
+    if (trusted_block < first_height || target_block - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "trusted/target header not supplied");
+    if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
+    uint64_t avail = n_headers - (trusted_block - first_height);
+    if (avail > b->hpr) avail = b->hpr;
+    Kind* k = nullptr;
+    RET(kind_of<RangeKind>(b, b->range_kind, &k));
+    Req proto;
+    proto.output64 = output64;
+    proto.out_commit = out_commit;
+    proto.n_headers = (uint32_t)avail;
+    Lane* l = nullptr;
+    uint32_t idx = 0;
+    RET(k->claim(&l, &idx, proto, out_ticket));
+    const RangeSmall S(k->M, b->V);
+    bsx_shared_ctx range{};
+    range.start_block = trusted_block;
+    range.end_block = target_block;
+    memcpy(range.start_header_hash, input48 + 8, 32);
+    memcpy(l->h_small + S.ranges + sizeof range * (size_t)idx, &range, sizeof range);
+    memcpy(l->h_small + S.latest + 8 * (size_t)idx, &latest_block, 8);
+    const size_t vbytes = (size_t)b->V * sizeof(bsx_validator);
+    memcpy(l->h_small + S.tv + vbytes * idx, target_validators, vbytes);
+    memcpy(l->h_small + S.rv + vbytes * idx, trusted_validators, vbytes);
+    stage_headers(l, idx, b->hpr, headers + (trusted_block - first_height), avail);
+    Kind::ready(l);
+    return BSX_OK;
+}
+
+int bsx_submit_data_commitment_inputs(bsx_batcher* b, const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
+                                      uint64_t start_block, uint64_t end_block, uint8_t out_start_header[32], uint8_t out_end_header[32],
+                                      bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb, uint8_t out_expected_data_commitment[32],
+                                      bsx_ticket* out_ticket) {
+    if (!b || !out_ticket) return fail(BSX_ERR_BAD_ARG, "bsx_submit_data_commitment_inputs: null batcher / ticket");
+    if (!out_start_header || !out_end_header || !out_dh || !out_lb) return fail(BSX_ERR_BAD_ARG, "null output");
+    if (end_block - start_block > (uint64_t)b->B) return fail(BSX_ERR_RANGE_TOO_LONG, "end - start > MAX_LEAVES (circuits/input.rs:154)");
+    if (!headers || !n_headers) return fail(BSX_ERR_BAD_ARG, "no headers supplied");
+    if (start_block < first_height || start_block - first_height >= n_headers)
+        return fail(BSX_ERR_BAD_ARG, "header for start block %llu not supplied (first_height %llu, n %llu)", (unsigned long long)start_block, (unsigned long long)first_height, (unsigned long long)n_headers);
+    if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
+    uint64_t avail = n_headers - (start_block - first_height);
+    const uint64_t hpr = (uint64_t)b->B + 1;
+    if (avail > hpr) avail = hpr;
+    {   // the headers the hint reads: [start, req_end] (input.rs:160-198) — checked here, the slot's tail is zero headers
+        const uint64_t lim = latest_block - 2, req_end = end_block < lim ? end_block : lim;
+        if (start_block <= req_end && req_end - start_block >= avail)
+            return fail(BSX_ERR_BAD_ARG, "the supplied headers do not cover [start, min(end, latest-2)] or latest < 2");
+    }
+    Kind* k = nullptr;
+    RET(kind_of<HintKind>(b, b->hint_kind, &k));
+    Req proto;
+    proto.out_start = out_start_header; proto.out_end = out_end_header; proto.out_dh = out_dh; proto.out_lb = out_lb;
+    proto.out_expected = out_expected_data_commitment;
+    proto.n_headers = (uint32_t)avail;
+    Lane* l = nullptr;
+    uint32_t idx = 0;
+    RET(k->claim(&l, &idx, proto, out_ticket));
+    const HintKind::Small S(k->M);
+    bsx_shared_ctx range{};
+    range.start_block = start_block;
+    range.end_block = end_block;
+    const uint32_t span = (uint32_t)(end_block - start_block);
+    memcpy(l->h_small + S.ranges + sizeof range * (size_t)idx, &range, sizeof range);
+    memcpy(l->h_small + S.latest + 8 * (size_t)idx, &latest_block, 8);
+    memcpy(l->h_small + S.spans + 4 * (size_t)idx, &span, 4);
+    stage_headers(l, idx, hpr, headers + (start_block - first_height), avail);
+    Kind::ready(l);
+    return BSX_OK;
+}
+
+int bsx_submit_prove_subchain(bsx_batcher* b, const uint8_t start_header[32], const uint8_t end_header[32], const bsx_data_hash_proof* dh,
+                              const bsx_last_block_id_proof* lb, uint64_t batch_start_block, uint64_t batch_end_block, uint64_t global_end_block,
+                              const uint8_t global_end_header_hash[32], bsx_subchain* out_record, bsx_ticket* out_ticket) {
+    if (!b || !out_ticket) return fail(BSX_ERR_BAD_ARG, "bsx_submit_prove_subchain: null batcher / ticket");
+    if (!start_header || !end_header || !dh || !lb || !global_end_header_hash || !out_record) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    Kind* k = nullptr;
+    RET(kind_of<SubchainKind>(b, b->subchain_kind, &k));
+    Req proto;
+    proto.out_record = out_record;
+    Lane* l = nullptr;
+    uint32_t idx = 0;
+    RET(k->claim(&l, &idx, proto, out_ticket));
+    const uint32_t B = b->B;
+    const bsx_witness_layout L = bsx_map_layout(B);
+    // caller bytes -> compact witness image (no arithmetic: the kernel completes it), exactly as bsx_prove_subchain builds it
+    uint8_t* img = l->h_headers + (size_t)idx * L.compact_stride;
+    memset(img, 0, 128);
+    memcpy(img + bsx_off_ctx_end_header(), global_end_header_hash, 32);
+    memcpy(img + bsx_off_start_header(), start_header, 32);
+    memcpy(img + bsx_off_end_header(), end_header, 32);
+    memcpy(img + bsx_off_dh_proofs(B), dh, (size_t)B * sizeof *dh);
+    memcpy(img + bsx_off_lb_proofs(B), lb, (size_t)B * sizeof *lb);
+    memset(img + bsx_off_slots(B), 0, L.compact_stride - bsx_off_slots(B));
+    uint32_t* W = reinterpret_cast<uint32_t*>(img + L.off_words);
+    W[BSX_W_CTX_END] = (uint32_t)global_end_block; W[BSX_W_CTX_END + 1] = (uint32_t)(global_end_block >> 32);
+    W[BSX_W_BATCH_START] = (uint32_t)batch_start_block; W[BSX_W_BATCH_START + 1] = (uint32_t)(batch_start_block >> 32);
+    W[BSX_W_BATCH_END] = (uint32_t)batch_end_block; W[BSX_W_BATCH_END + 1] = (uint32_t)(batch_end_block >> 32);
+    bsx_shared_ctx range{};
+    range.end_block = global_end_block;
+    memcpy(range.end_header_hash, global_end_header_hash, 32);
+    memcpy(l->h_small + sizeof range * (size_t)idx, &range, sizeof range);
+    Kind::ready(l);
+    return BSX_OK;
+}
+
+int bsx_poll(bsx_batcher* b, bsx_ticket ticket, int* out_done) {
+    if (!b || !out_done || !ticket) return fail(BSX_ERR_BAD_ARG, "bsx_poll: null pointer / ticket 0");
+    const uint64_t s = b->ring[ticket % RING].seq.load(std::memory_order_acquire);
+    if (s > ticket) return fail(BSX_ERR_BAD_ARG, "ticket %llu has expired (more than %u requests ago)", (unsigned long long)ticket, RING);
+    *out_done = s == ticket;
+    return BSX_OK;
+}
+
+int bsx_wait(bsx_batcher* b, bsx_ticket ticket) {
+    if (!b || !ticket) return fail(BSX_ERR_BAD_ARG, "bsx_wait: null batcher / ticket 0");
+    if (ticket >= b->next_seq.load()) return fail(BSX_ERR_BAD_ARG, "bsx_wait: ticket %llu was never issued", (unsigned long long)ticket);
+    DoneRec& d = b->ring[ticket % RING];
+    if (d.seq.load(std::memory_order_acquire) < ticket) {
+        std::unique_lock<std::mutex> lk(b->mu_done);
+        b->cv_done.wait(lk, [&] { return d.seq.load(std::memory_order_acquire) >= ticket; });
+    }
+    if (d.seq.load(std::memory_order_acquire) != ticket)
+        return fail(BSX_ERR_BAD_ARG, "ticket %llu has expired (more than %u requests ago)", (unsigned long long)ticket, RING);
+    const int rc = d.rc;
+    if (rc != BSX_OK) bsxapi::g_err = d.msg;
+    return rc;
+}
+
+int bsx_batcher_cork(bsx_batcher* b, int on) {
+    if (!b) return fail(BSX_ERR_BAD_ARG, "null batcher");
+    b->corked.store(on ? 1 : 0);
+    return BSX_OK;
+}
+
+int bsx_batcher_get_stats(bsx_batcher* b, bsx_batcher_stats* out) {
+    if (!b || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    memset(out, 0, sizeof *out);
+    const std::unique_ptr<Kind>* ks[3] = {&b->range_kind, &b->hint_kind, &b->subchain_kind};
+    for (int i = 0; i < 3; i++) {
+        if (!*ks[i]) continue;
+        out->kind[i].batches = (*ks[i])->n_batches.load();
+        out->kind[i].requests = (*ks[i])->n_requests.load();
+        out->kind[i].max_batch = (*ks[i])->max_batch.load();
+        out->kind[i].close_wait_ns = (*ks[i])->sum_close_wait_ns.load();
+    }
+    return BSX_OK;
+}
+
+}  // extern "C"

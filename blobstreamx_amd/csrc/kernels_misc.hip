@@ -20,14 +20,10 @@ __global__ void k_encode_tuple(const uint8_t* data_hash, uint64_t height, uint8_
     out[t] = b;                                                       // :93-96 24 zero bytes first
 }
 
-// One workgroup, max_leaves (power of two <= 256) lanes.  out_flags: BSX_A1 / BSX_A2 bits.
-__global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_hashes, uint32_t max_leaves, uint64_t start_block,
-                                                         uint64_t end_block, uint8_t* out_root, uint32_t* out_flags) {
-    __shared__ uint32_t nodes[2][256 * 8];
-    const uint32_t tid = threadIdx.x, B = max_leaves;
-    const bool gte = end_block >= start_block;          // :113
-    const uint64_t nb = end_block - start_block;        // :119
-    const uint32_t nb_enabled = (uint32_t)nb;           // :124
+// get_data_commitment (builder.rs:105-148) by one workgroup: lane tid < B holds leaf tid's data hash at `dh` (32 bytes, any alignment);
+// returns through nodes[cur][0..8) — the caller reads the root after the call.  B = power of two <= 256.
+__device__ __forceinline__ int data_commitment_tree(uint32_t (*nodes)[256 * 8], const uint8_t* dh, uint32_t B, uint64_t start_block, uint32_t nb_enabled) {
+    const uint32_t tid = threadIdx.x;
     if (tid < B) {
         const uint64_t height = start_block + tid;      // :134
         uint32_t t[16];
@@ -37,7 +33,7 @@ __global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_has
         t[7] = (uint32_t)height;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const uint8_t* p = data_hashes + 32 * (uint64_t)tid + 4 * k;
+            const uint8_t* p = dh + 4 * k;
             t[8 + k] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
         }
         const Digest lh = leaf_hash_tuple(t);
@@ -60,12 +56,44 @@ __global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_has
         __syncthreads();
         cur ^= 1;
     }
+    return cur;
+}
+
+// One workgroup, max_leaves (power of two <= 256) lanes.  out_flags: BSX_A1 / BSX_A2 bits.
+__global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_hashes, uint32_t max_leaves, uint64_t start_block,
+                                                         uint64_t end_block, uint8_t* out_root, uint32_t* out_flags) {
+    __shared__ uint32_t nodes[2][256 * 8];
+    const uint32_t tid = threadIdx.x, B = max_leaves;
+    const bool gte = end_block >= start_block;          // :113
+    const uint64_t nb = end_block - start_block;        // :119
+    const uint32_t nb_enabled = (uint32_t)nb;           // :124
+    const int cur = data_commitment_tree(nodes, data_hashes + 32 * (uint64_t)(tid < B ? tid : 0), B, start_block, nb_enabled);
     if (tid < 8) {
         const uint32_t w = nodes[cur][tid];
         out_root[4 * tid] = (uint8_t)(w >> 24); out_root[4 * tid + 1] = (uint8_t)(w >> 16);
         out_root[4 * tid + 2] = (uint8_t)(w >> 8); out_root[4 * tid + 3] = (uint8_t)w;
     }
     if (tid == 0) *out_flags = (gte ? 0u : BSX_A1_END_GTE_START) | ((nb >> 32) ? BSX_A2_NB_BLOCKS_U32 : 0u);
+}
+
+// The hint's expected_data_commitment for n coalesced requests (input.rs:241-244; zero for an empty range, :70-72): one workgroup
+// per request, data hashes read from the request's assembled compact image (data_hash_proofs[i].leaf[2..34)).
+__global__ __launch_bounds__(256) void k_expected_commitments(uint32_t B, const bsx_shared_ctx* ranges, const uint32_t* spans, const uint64_t* latest,
+                                                              const uint8_t* compact, uint32_t compact_stride, uint8_t* out) {
+    __shared__ uint32_t nodes[2][256 * 8];
+    const uint32_t r = blockIdx.x, tid = threadIdx.x;
+    const uint64_t start = ranges[r].start_block, end = start + spans[r];
+    const uint64_t lim = latest[r] - 2;                                      // input.rs:160-162
+    const uint64_t req_end = end < lim ? end : lim;
+    const uint8_t* cw = compact + (uint64_t)r * compact_stride;
+    const bool empty = req_end <= start;                                     // block-uniform
+    const int cur = data_commitment_tree(nodes, cw + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * (tid < B ? tid : 0) + 128 + 2, B, start,
+                                         empty ? 0u : (uint32_t)(req_end - start));
+    if (tid < 8) {
+        const uint32_t w = empty ? 0u : nodes[cur][tid];
+        uint8_t* o = out + 32 * (uint64_t)r;
+        o[4 * tid] = (uint8_t)(w >> 24); o[4 * tid + 1] = (uint8_t)(w >> 16); o[4 * tid + 2] = (uint8_t)(w >> 8); o[4 * tid + 3] = (uint8_t)w;
+    }
 }
 
 __global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const uint8_t* hashes, uint64_t hpr,
@@ -385,6 +413,12 @@ hipError_t bsxk_commit_fold(hipStream_t s, const bsx_commit_result* res, uint32_
 }
 hipError_t bsxk_encode_tuple(hipStream_t s, const uint8_t* data_hash, uint64_t height, uint8_t* out) {
     hipLaunchKernelGGL(k_encode_tuple, dim3(1), dim3(64), 0, s, data_hash, height, out);
+    return hipGetLastError();
+}
+hipError_t bsxk_expected_commitments(hipStream_t s, uint32_t n, uint32_t B, const bsx_shared_ctx* ranges, const uint32_t* spans, const uint64_t* latest,
+                                     const uint8_t* compact, uint8_t* out) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_expected_commitments, dim3(n), dim3(256), 0, s, B, ranges, spans, latest, compact, bsx_map_layout(B).compact_stride, out);
     return hipGetLastError();
 }
 hipError_t bsxk_data_commitment(hipStream_t s, const uint8_t* data_hashes, uint32_t max_leaves, uint64_t start, uint64_t end,

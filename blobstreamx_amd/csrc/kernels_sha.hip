@@ -147,7 +147,8 @@ constexpr uint32_t HM_PATH_BYTES = 7 * 32;
 __global__ __launch_bounds__(HM_THREADS, 4) void k_header_merkle(const bsx_header* __restrict__ hdr, uint64_t n,
                                                               uint8_t* __restrict__ hashes, uint8_t* __restrict__ dh_aunts,
                                                               uint8_t* __restrict__ lb_aunts, uint8_t* __restrict__ paths,
-                                                              uint32_t* __restrict__ status, uint32_t low_prio, bsxk_merkle_tap tap) {
+                                                              uint32_t* __restrict__ status, uint32_t low_prio, bsxk_merkle_tap tap,
+                                                              uint64_t status_group) {
     // beside an expansion: above the commit check's waves (BSX_CHAIN_PRIO).  In the compact pipeline this kernel is the bulk
     // ALU work that the OTHER buffer set's short chain kernels (hint, prove_subchain, reduce, ...) must get through: it yields
     if (!low_prio) BSX_CHAIN_PRIO();
@@ -246,9 +247,13 @@ __global__ __launch_bounds__(HM_THREADS, 4) void k_header_merkle(const bsx_heade
                 }
             }
         }
-        // wave-ballot reduction of the "bad header" predicate: one atomic per wave
+        // wave-ballot reduction of the "bad header" predicate: one atomic per wave.  status_group != 0 (the coalescing front end:
+        // one status word per request, `status_group` headers each): a malformed header marks its own request only
         const unsigned long long m = __ballot(live && bad);
-        if (m && lane == 0 && status) atomicOr(status, 1u);
+        if (m && status) {
+            if (status_group) { if (live && bad) atomicOr(status + me / status_group, 1u); }
+            else if (lane == 0) atomicOr(status, 1u);
+        }
     }
 }
 
@@ -266,6 +271,8 @@ struct AssembleArgs {
     uint32_t* status;
     const uint8_t* paths;        // optional (k_header_merkle): the slots' path digests are gathered too
     const uint8_t* zero_paths;   // path digests of the all-zero proofs (padding slots): dh[5] then lb[5]
+    const uint32_t* spans;       // optional, per range: overrides `span` (coalesced hint requests of different lengths in one launch)
+    uint32_t status_per_range;   // 1: status word r belongs to range r (coalescing front end); 0: one shared word
 };
 
 // AS_IT = 16-byte pieces per lane = ceil(24 * B / 256): a template parameter so that the in-flight buffer (and with it
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     const bsx_shared_ctx rg = a.ranges[r];
     const uint64_t S = rg.start_block;
     const uint64_t batch_start = S + (uint64_t)j * B;          // builder.rs:315-316
-    const uint64_t batch_end = batch_start + a.span;           // builder.rs:317-322 (span == B for map jobs)
+    const uint64_t batch_end = batch_start + (a.spans ? a.spans[r] : a.span);   // builder.rs:317-322 (span == B for map jobs)
     const uint64_t latest = a.latest[r];
     const uint64_t latest_safe = latest - 2;                   // input.rs:160-161
     const uint64_t req_end = batch_end < latest_safe ? batch_end : latest_safe;  // input.rs:162
@@ -394,10 +401,10 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
         W[BSX_W_BATCH_START] = (uint32_t)batch_start; W[BSX_W_BATCH_START + 1] = (uint32_t)(batch_start >> 32);
         W[BSX_W_BATCH_END] = (uint32_t)batch_end; W[BSX_W_BATCH_END + 1] = (uint32_t)(batch_end >> 32);
         if (a.status) {
-            if (oob || latest < 2) atomicOr(a.status, 4u);
+            if (oob || latest < 2) atomicOr(a.status + (a.status_per_range ? r : 0u), 4u);
         }
     }
-    if (__ballot(bad_leaf) && (threadIdx.x & 63) == 0 && a.status) atomicOr(a.status, 2u);
+    if (__ballot(bad_leaf) && (threadIdx.x & 63) == 0 && a.status) atomicOr(a.status + (a.status_per_range ? r : 0u), 2u);
 }
 
 // ------------------------------------------------------------------------------------------------ prove_subchain
@@ -1052,7 +1059,7 @@ extern "C" {
 using namespace bsx;
 
 hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, uint8_t* hashes, uint8_t* dh, uint8_t* lb, uint8_t* paths,
-                              uint32_t* status, uint32_t max_wgs, uint32_t low_prio, const bsxk_merkle_tap* tap) {
+                              uint32_t* status, uint32_t max_wgs, uint32_t low_prio, const bsxk_merkle_tap* tap, uint64_t status_group) {
     if (!n) return hipSuccess;
     uint32_t grid = (uint32_t)((n + HM_GROUP - 1) / HM_GROUP);
     // cap on the grid (the workgroups then stride over the header groups): the context's BSX_TUNE_MERKLE_WORKGROUPS (an experiments
@@ -1062,7 +1069,7 @@ hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, 
     if (cap > 0 && grid > (uint32_t)cap) grid = (uint32_t)cap;
     static const long env_lp = bsx_knob("BSX_MERKLE_LOW_PRIO", -1);
     hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status, env_lp >= 0 ? (uint32_t)env_lp : low_prio,
-                       tap ? *tap : bsxk_merkle_tap{~0ull, nullptr, nullptr});
+                       tap ? *tap : bsxk_merkle_tap{~0ull, nullptr, nullptr}, status_group);
     return hipGetLastError();
 }
 hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {
@@ -1072,11 +1079,11 @@ hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {
 hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
                                 const bsx_shared_ctx* ranges, const uint64_t* latest, const bsx_header* headers, uint64_t hpr, uint64_t hfr,
                                 const uint8_t* hashes, const uint8_t* dh, const uint8_t* lb, uint8_t* compact, uint32_t* status,
-                                const uint8_t* paths, const uint8_t* zero_paths, uint32_t lds_pad) {
+                                const uint8_t* paths, const uint8_t* zero_paths, uint32_t lds_pad, const uint32_t* spans, uint32_t status_per_range) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hfr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status,
-                   paths, zero_paths};
+                   paths, zero_paths, spans, status_per_range};
     const uint32_t it = (24u * B + 255u) / 256u;
     // lds_pad: bytes of (unused) dynamic LDS per workgroup = a cap on the hint's workgroups resident per CU.  The hint is 0.7 GB of
     // 16-byte copies: at full occupancy it saturates HBM for 0.17 ms, and the header hashing it runs beside in the compact pipeline

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BSX_VERSION 0x00020000
+#define BSX_VERSION 0x00030000
 
 /* ------------------------------------------------------------------ constants (circuits/consts.rs) */
 #define BSX_HASH_SIZE 32                 /* consts.rs:1  HASH_SIZE */
@@ -844,6 +844,71 @@ typedef struct bsx_pipeline_timing_result {
     uint32_t _pad;
 } bsx_pipeline_timing_result;
 int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out);
+
+/* ------------------------------------------------------------------ coalescing front end (round 5)
+ * The reference's own call shape: ONE range per `prove` call under a multi-thread runtime (circuits/header_range.rs:180-181) and
+ * ONE hint call per map job — 32 `async fn hint` calls per proof (circuits/builder.rs:325-332 -> circuits/data_commitment.rs:22-44),
+ * each followed by prove_subchain (builder.rs:335).  One such call alone is a string of dependent single-wave kernels (0.26 ms for
+ * 2-3 % of the GPU), and K callers on K contexts time-slice the same queues.  A batcher COALESCES concurrent requests of one
+ * circuit shape: bsx_submit_* copies the request's inputs into the open batch's page-locked staging on the CALLER's thread and
+ * returns a ticket at once (the input buffers may be reused; the OUTPUT pointers must stay valid until bsx_wait returns); a worker
+ * closes the batch after a short window — an idle GPU waits for a 6 us lull only, never for the window — and runs ONE launch set
+ * over its R requests (the host tier's own kernels with n_ranges = R); every ticket completes with ITS OWN status: header / hint
+ * status words are per request on the device, so a malformed or tampered request never fails its batch-mates.  n_lanes batches are
+ * in flight (the H2D copy of one beside the kernels of another).  bsx_wait returns exactly what the synchronous call would have
+ * returned (code and bsx_last_error text).  Thread-safe: any number of threads may submit and wait on one batcher. */
+typedef struct bsx_batcher bsx_batcher;
+typedef uint64_t bsx_ticket;                /* never 0 */
+typedef struct bsx_batcher_config {
+    uint32_t nb_map_jobs, batch_size, v_max;   /* the circuit the requests belong to (bin/header_range_2048.rs:6-17: 32, 64, 100) */
+    uint32_t max_requests;                  /* most header_range requests one launch set takes; 0 = 32 (hint-level kinds: at least 64) */
+    uint32_t window_us;                     /* how long an open batch keeps collecting WHILE earlier batches occupy the GPU; 0 = 50 */
+    uint32_t n_lanes;                       /* batches in flight per request kind; 0 = 3 */
+    uint32_t chain_id_len;                  /* C::CHAIN_ID_BYTES (header_range.rs:42-43), at most 50 bytes */
+    uint8_t chain_id[52];
+    uint32_t flags;                         /* must be 0 */
+    uint32_t _reserved[3];
+} bsx_batcher_config;                       /* sizeof == 96 */
+int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher** out);
+void bsx_batcher_destroy(bsx_batcher* b);  /* waits for the batches in flight; tickets not yet waited for are lost */
+
+/* bsx_header_range (CombinedSkipCircuit::define, header_range.rs:32-59) without a witness.  Argument meaning as bsx_header_range;
+ * the circuit shape, v_max and chain id are the batcher's.  Errors detectable from the arguments alone are returned HERE (no
+ * ticket is issued); everything else through bsx_wait. */
+int bsx_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
+                            uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                            uint8_t output64[64], bsx_commit_result* out_commit /* optional */, bsx_ticket* out_ticket);
+/* bsx_data_commitment_inputs — the body of `DataCommitmentOffchainInputs<MAX_LEAVES>::hint` (data_commitment.rs:18-45 ->
+ * input.rs:149-271) with MAX_LEAVES = the batcher's batch_size. */
+int bsx_submit_data_commitment_inputs(bsx_batcher* b, const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
+                                      uint64_t start_block, uint64_t end_block, uint8_t out_start_header[32], uint8_t out_end_header[32],
+                                      bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb,
+                                      uint8_t out_expected_data_commitment[32] /* optional */, bsx_ticket* out_ticket);
+/* bsx_prove_subchain (builder.rs:45-52,150-271) with BATCH_SIZE = the batcher's batch_size, without a witness. */
+int bsx_submit_prove_subchain(bsx_batcher* b, const uint8_t start_header[32], const uint8_t end_header[32], const bsx_data_hash_proof* dh,
+                              const bsx_last_block_id_proof* lb, uint64_t batch_start_block, uint64_t batch_end_block, uint64_t global_end_block,
+                              const uint8_t global_end_header_hash[32], bsx_subchain* out_record, bsx_ticket* out_ticket);
+/* Blocks until the request has completed; returns ITS status.  A ticket may be waited for once or several times, from any thread,
+ * until 16,384 later requests have been issued on the batcher (then: BSX_ERR_BAD_ARG, "expired"). */
+int bsx_wait(bsx_batcher* b, bsx_ticket ticket);
+/* Non-blocking form for hosts with their own executor (a Rust future polls it): *out_done = 1 once bsx_wait would not block. */
+int bsx_poll(bsx_batcher* b, bsx_ticket ticket, int* out_done);
+/* Attach a batcher to the context: from then on the SYNCHRONOUS host-tier calls bsx_header_range (witness == NULL, same
+ * nb_map_jobs / batch_size / v_max / chain id), bsx_data_commitment_inputs (max_leaves == batch_size) and bsx_prove_subchain
+ * (batch_size equal, witness == NULL) made on this context by ANY number of threads are submit + wait on it — the reference's
+ * callers need no change beyond this one call.  Calls of another shape, or with a witness, take the serial path as before.
+ * cfg == NULL detaches (and destroys) it. */
+int bsx_enable_coalescing(bsx_ctx* ctx, const bsx_batcher_config* cfg);
+/* A caller that is about to submit a burst (the 32 hints of one proof from one thread) corks the batcher first: while corked, an
+ * open batch closes only when it is full (or after 20 ms); uncorking (on = 0) lets the open batches go at once.  Like TCP_CORK: purely
+ * a hint. */
+int bsx_batcher_cork(bsx_batcher* b, int on);
+typedef struct bsx_batcher_stats {
+    struct { uint64_t batches, requests, max_batch, close_wait_ns; } kind[3];   /* 0 header_range, 1 data_commitment_inputs, 2 prove_subchain */
+} bsx_batcher_stats;
+int bsx_batcher_get_stats(bsx_batcher* b, bsx_batcher_stats* out);
+/* the batcher bsx_enable_coalescing attached (NULL: none) — for bsx_batcher_get_stats / explicit submits beside the synchronous calls */
+bsx_batcher* bsx_context_batcher(bsx_ctx* ctx);
 
 #ifdef __cplusplus
 }
