@@ -97,6 +97,19 @@ class Batcher:
                                                             _lib.p(sh), _lib.p(eh), _lib.p(dh), _lib.p(lb), _lib.p(exp), C.byref(t)))
         return Ticket("hint", t.value, (sh, eh, dh, lb, exp))
 
+    # ---- the map closure (builder.rs:305-336): hint + prove_subchain of one map job as ONE request
+    def submit_map_job(self, range_ctx, job_index, headers, first_height, latest_block, want_proofs=True):
+        """range_ctx: 1-element T.SHARED_CTX array (DataCommitmentSharedCtx).  headers[i] = header at first_height + i."""
+        rg = np.ascontiguousarray(range_ctx, T.SHARED_CTX).reshape(1)
+        hdr = np.ascontiguousarray(headers, T.HEADER).reshape(-1)
+        sh, eh = (np.zeros(32, np.uint8), np.zeros(32, np.uint8)) if want_proofs else (None, None)
+        dh, lb = (np.zeros(self.B, T.DH_PROOF), np.zeros(self.B, T.LB_PROOF)) if want_proofs else (None, None)
+        rec = np.zeros(1, T.SUBCHAIN)
+        t = C.c_uint64(0)
+        _lib.check(self.L.bsx_submit_map_job(self.h, _lib.p(rg), C.c_uint32(int(job_index)), _lib.p(hdr), C.c_uint64(int(first_height)), C.c_uint64(hdr.size),
+                                             C.c_uint64(int(latest_block)), _lib.p(sh), _lib.p(eh), _lib.p(dh), _lib.p(lb), _lib.p(rec), C.byref(t)))
+        return Ticket("map_job", t.value, (sh, eh, dh, lb, rec))
+
     # ---- prove_subchain (builder.rs:150-271), BATCH_SIZE = batch_size
     def submit_prove_subchain(self, start_header, end_header, dh, lb, batch_start_block, batch_end_block, global_end_block, global_end_header_hash):
         dh = np.ascontiguousarray(dh, T.DH_PROOF)
@@ -124,6 +137,10 @@ class Batcher:
             sh, eh, dh, lb, exp = ticket.outputs
             return rc, dict(start_header_hash=sh.tobytes(), end_header_hash=eh.tobytes(), data_hash_proofs=dh, last_block_id_proofs=lb,
                             expected_data_commitment=exp.tobytes() if exp is not None else None)
+        if ticket.kind == "map_job":
+            sh, eh, dh, lb, rec = ticket.outputs
+            return rc, dict(start_header_hash=sh.tobytes() if sh is not None else None, end_header_hash=eh.tobytes() if eh is not None else None,
+                            data_hash_proofs=dh, last_block_id_proofs=lb, record=rec[0])
         return rc, ticket.outputs[0][0]
 
     def done(self, ticket):

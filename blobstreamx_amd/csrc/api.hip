@@ -638,6 +638,9 @@ int bsx_enable_coalescing(bsx_ctx* ctx, const bsx_batcher_config* cfg) {
 }
 bsx_batcher* bsx_context_batcher(bsx_ctx* ctx) { return ctx ? ctx->batcher.load() : nullptr; }
 const bsx_batcher_config* bsxb_config(const bsx_batcher* b);                          // batcher.hip
+int bsxb_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
+                             uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                             uint8_t output64[64], bsx_commit_result* out_commit, bsx_ticket* out_ticket, int inputs_stay);
 
 int bsx_encode_data_root_tuple(bsx_ctx* ctx, const uint8_t data_hash[32], uint64_t height, uint8_t out[64]) {
     HOST_ENTER();
@@ -903,6 +906,43 @@ int bsx_prove_subchain(bsx_ctx* ctx, uint32_t batch_size, const uint8_t start_he
     return subchain_rc(*out_record);
 }
 
+// the map closure of prove_data_commitment for one map job (builder.rs:305-336): coalesced on a context with a batcher, else the two
+// host-tier calls in turn
+int bsx_map_job(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const bsx_shared_ctx* range, uint32_t job_index, const bsx_header* headers,
+                uint64_t first_height, uint64_t n_headers, uint64_t latest_block, uint8_t out_start_header[32], uint8_t out_end_header[32],
+                bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb, bsx_subchain* out_record) {
+    if (!ctx) return fail(BSX_ERR_BAD_ARG, "null context");
+    if (!range || !out_record || !headers) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (!pow2(batch_size) || batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
+    if (job_index >= nb_map_jobs) return fail(BSX_ERR_BAD_ARG, "job_index %u is not below NB_MAP_JOBS = %u", job_index, nb_map_jobs);
+    if (bsx_batcher* bt = ctx->batcher.load())
+        if (bsxb_config(bt)->batch_size == batch_size && bsxb_config(bt)->nb_map_jobs >= nb_map_jobs) {
+            bsx_ticket t = 0;
+            RET(bsx_submit_map_job(bt, range, job_index, headers, first_height, n_headers, latest_block, out_start_header, out_end_header, out_dh, out_lb,
+                                   out_record, &t));
+            return bsx_wait(bt, t);
+        }
+    const uint64_t bs = range->start_block + (uint64_t)job_index * batch_size, be = bs + batch_size;
+    std::vector<bsx_data_hash_proof> dh(out_dh ? 0 : batch_size);
+    std::vector<bsx_last_block_id_proof> lb(out_lb ? 0 : batch_size);
+    uint8_t sh[32], eh[32];
+    bsx_data_hash_proof* pdh = out_dh ? out_dh : dh.data();
+    bsx_last_block_id_proof* plb = out_lb ? out_lb : lb.data();
+    // a batch the chain head cannot reach reads no header: the hint still wants a non-empty array
+    const uint64_t lim = latest_block >= 2 ? latest_block - 2 : 0, req_end = be < lim ? be : lim;
+    if (bs <= req_end) {
+        RET(bsx_data_commitment_inputs(ctx, headers, first_height, n_headers, latest_block, bs, be, batch_size, sh, eh, pdh, plb, nullptr));
+    } else {
+        // input.rs:220-262 with nothing to fetch: zero proofs, dummy (zero) start / end headers
+        if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
+        memset(sh, 0, 32); memset(eh, 0, 32);
+        memset(pdh, 0, (size_t)batch_size * sizeof *pdh); memset(plb, 0, (size_t)batch_size * sizeof *plb);
+    }
+    if (out_start_header) memcpy(out_start_header, sh, 32);
+    if (out_end_header) memcpy(out_end_header, eh, 32);
+    return bsx_prove_subchain(ctx, batch_size, sh, eh, pdh, plb, bs, be, range->end_block, range->end_header_hash, out_record, nullptr);
+}
+
 int bsx_reduce(bsx_ctx* ctx, const bsx_subchain* records, uint32_t n, bsx_subchain* out) {
     HOST_ENTER();
     if (!records || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
@@ -1151,8 +1191,8 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         if (bc->nb_map_jobs == nb_map_jobs && bc->batch_size == batch_size && bc->v_max == v_max && bc->chain_id_len == chain_id_len &&
             (chain_id_len == 0 || (chain_id && chain_id_len <= 50 && memcmp(bc->chain_id, chain_id, chain_id_len) == 0))) {
             bsx_ticket t = 0;
-            RET(bsx_submit_header_range(bt, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64,
-                                        out_commit, &t));
+            RET(bsxb_submit_header_range(bt, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64,
+                                         out_commit, &t, /*inputs_stay=*/1));
             return bsx_wait(bt, t);
         }
     }

@@ -68,6 +68,8 @@ struct Req {
     bsx_last_block_id_proof* out_lb = nullptr;
     bsx_subchain* out_record = nullptr;        // prove_subchain
     uint32_t n_headers = 0;                    // headers staged in the slot
+    const bsx_header* direct = nullptr;        // page-locked caller memory that stays valid until bsx_wait: uploaded from there, not staged
+    bool want_record = false;                  // hint kind: a map-job request (prove_subchain behind the hint)
 };
 
 struct Kind;
@@ -77,10 +79,12 @@ struct Lane {
     std::thread th;
     enum State : int { FREE = 0, OPEN = 1, CLOSED = 2 };
     std::atomic<int> state{FREE};
-    std::atomic<uint32_t> n_claimed{0}, n_ready{0};
+    std::atomic<uint32_t> n_claimed{0};
+    std::unique_ptr<std::atomic<uint8_t>[]> slot_ready;   // set by the submitter once its inputs are in the slot
     std::atomic<uint64_t> t_first{0}, t_last{0};
     std::vector<Req> reqs;
-    std::vector<uint32_t> slot_hwm;            // headers ever staged in a slot (tail beyond the current request is cleared when stale)
+    std::vector<uint32_t> slot_hwm;            // headers the slot's STAGING holds (stage_headers keeps everything behind them zero)
+    std::vector<uint32_t> dev_hwm;             // headers the slot's DEVICE block holds (the worker keeps everything behind them zero)
     // resources (kind-specific use)
     hipStream_t st = nullptr, sb = nullptr, s3 = nullptr, s4 = nullptr;
     hipEvent_t ev[8] = {nullptr};
@@ -171,6 +175,9 @@ struct Kind {
         for (auto& e : l.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         l.reqs.resize(M);
         l.slot_hwm.assign(M, 0);
+        l.dev_hwm.assign(M, 0);
+        l.slot_ready.reset(new std::atomic<uint8_t>[M]);
+        for (uint32_t i = 0; i < M; i++) l.slot_ready[i].store(0);
         return BSX_OK;
     }
     void lane_free(Lane& l) {
@@ -218,7 +225,6 @@ struct Kind {
             }
             cv_open.notify_all();
             sum_close_wait_ns.fetch_add(now_ns() - t_open);
-            while (l.n_ready.load(std::memory_order_acquire) < R) cpu_relax();   // submitters still copying into their slots
             bsxapi::g_err.clear();
             const int rc = launch(l, R);
             const std::string err = bsxapi::g_err;
@@ -230,7 +236,7 @@ struct Kind {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 l.n_claimed.store(0);
-                l.n_ready.store(0);
+                for (uint32_t i = 0; i < R; i++) l.slot_ready[i].store(0, std::memory_order_relaxed);
                 in_flight.fetch_sub(1);
                 if (!open) { open = &l; l.state.store(Lane::OPEN); } else { l.state.store(Lane::FREE); free_.push_back(&l); }
             }
@@ -294,7 +300,10 @@ struct Kind {
         if (idx == 0) cv_work.notify_all();
         return BSX_OK;
     }
-    static void ready(Lane* l) { l->n_ready.fetch_add(1, std::memory_order_release); }
+    static void ready(Lane* l, uint32_t idx) { l->slot_ready[idx].store(1, std::memory_order_release); }
+    // the worker's side: slot idx holds its request's inputs (submitters may still be copying when the batch closes)
+    static void await_slot(Lane& l, uint32_t idx) { while (!l.slot_ready[idx].load(std::memory_order_acquire)) cpu_relax(); }
+    static void await_slots(Lane& l, uint32_t R) { for (uint32_t i = 0; i < R; i++) await_slot(l, i); }
 };
 
 #define LHIP(expr)                                                                                           \
@@ -381,18 +390,34 @@ struct RangeKind : Kind {
         auto* tres = reinterpret_cast<bsx_commit_result*>(l.d_tres);
         // the fixed-key table against this batch's keys, on the host: rows follow the FIRST request's validator set; slots of the
         // other requests whose key differs are counted (the signature check sizes — or skips — its generic-kernel pass from the count)
+        // the headers of every request as soon as ITS slot is staged (1 MB each: the upload of the first runs beside the staging
+        // memcpy of the others); a request whose headers are page-locked caller memory is uploaded from there
+        for (uint32_t r = 0; r < R; r++) {
+            await_slot(l, r);
+            const Req& rq = l.reqs[r];
+            uint8_t* dst = l.d_headers + (size_t)r * hpr * sizeof(bsx_header);
+            const uint32_t had = l.dev_hwm[r];
+            if (rq.direct) {
+                LHIP(hipMemcpyAsync(dst, rq.direct, (size_t)rq.n_headers * sizeof(bsx_header), hipMemcpyHostToDevice, st));
+                if (had > rq.n_headers) LHIP(hipMemsetAsync(dst + (size_t)rq.n_headers * sizeof(bsx_header), 0, (size_t)(had - rq.n_headers) * sizeof(bsx_header), st));
+            } else {
+                // the staging is zero behind the request's headers: a longer copy also clears what a previous, longer request left
+                const uint32_t n = rq.n_headers > had ? rq.n_headers : had;
+                LHIP(hipMemcpyAsync(dst, l.h_headers + (size_t)r * hpr * sizeof(bsx_header), (size_t)n * sizeof(bsx_header), hipMemcpyHostToDevice, st));
+            }
+            l.dev_hwm[r] = rq.n_headers;
+        }
         const bsx_validator* h_tv = reinterpret_cast<const bsx_validator*>(l.h_small + S.tv);
         bool keys_same = l.d_keytab && l.key_mirror_valid;
         for (uint32_t i = 0; keys_same && i < V; i++) keys_same = memcmp(l.key_mirror.data() + 32 * (size_t)i, h_tv[i].pubkey, 32) == 0;
         const uint64_t n_mismatch = l.d_keytab ? bsxh_key_mismatches(h_tv, R, V) : 0;
-        // small inputs first (the commit chain starts from them), then the headers: the head of the hashing chain
+        // the small inputs go on the commit stream: the commit chain starts from them, the hashing chain waits for them at its hint
         LHIP(hipMemcpyAsync(l.d_ranges, l.h_small + S.ranges, (size_t)R * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
         LHIP(hipMemcpyAsync(l.d_latest, l.h_small + S.latest, (size_t)R * 8, hipMemcpyHostToDevice, st));
         LHIP(hipMemcpyAsync(l.d_tv, l.h_small + S.tv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
         LHIP(hipMemcpyAsync(l.d_rv, l.h_small + S.rv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
         LHIP(hipMemsetAsync(l.d_out + O.hst, 0, (size_t)M * 8, st));              // header + hint status words of every slot
         LHIP(hipEventRecord(ev_c, st));
-        LHIP(hipMemcpyAsync(l.d_headers, l.h_headers, nh * sizeof(bsx_header), hipMemcpyHostToDevice, st));
         // s3: R decoded strictly ahead of time (the longest kernel of the commit check; needs only the validator records)
         LHIP(hipStreamWaitEvent(s3, ev_c, 0));
         if (l.d_keytab) LHIP(bsxk_ed25519_decode_r(s3, tv, n, l.d_rdec));
@@ -482,13 +507,25 @@ struct RangeKind : Kind {
     }
 };
 
-// ================================================================================================ the hint (data_commitment_inputs)
+// ================================================================================================ the hint (data_commitment_inputs) / a map job
+// One request = the hint of one map job (data_commitment.rs:22-44 -> input.rs:149-271) and, for a map-job request, prove_subchain on
+// what the hint returned (the whole map closure, builder.rs:305-336).  Per request: ctx (bsx_shared_ctx), the job index inside it and
+// the span; a plain hint is "job 0 of a range that starts at start_block".
 struct HintKind : Kind {
     uint32_t hpr;                              // B + 1 headers per slot
     size_t img_bytes;                          // what a request gets back of its compact image: ctx/start/end hashes + both proof arrays
     HintKind(bsx_batcher* b_) : Kind(b_, "data_commitment_inputs", b_->M < 64 ? 64 : b_->M), hpr(b_->B + 1), img_bytes(bsx_off_slots(b_->B)) {}
-    struct Small { size_t ranges, latest, spans, total; explicit Small(uint32_t M) { ranges = 0; latest = (size_t)M * 80; spans = latest + (size_t)M * 8; total = spans + (size_t)M * 4; } };
-    struct Out { size_t img, expected, hst, ast, total; Out(uint32_t M, size_t ib) { img = 0; expected = (size_t)M * ib; expected = (expected + 255) & ~(size_t)255; hst = expected + (size_t)M * 32; ast = hst + (size_t)M * 4; total = ast + (size_t)M * 4; } };
+    struct Small {
+        size_t ranges, latest, spans, jobs, total;
+        explicit Small(uint32_t M) { ranges = 0; latest = (size_t)M * 80; spans = latest + (size_t)M * 8; jobs = spans + (size_t)M * 4; total = jobs + (size_t)M * 4; }
+    };
+    struct Out {                               // page-locked results; the device block holds everything but `img` at the same offsets - expected
+        size_t img, expected, hst, ast, records, total;
+        Out(uint32_t M, size_t ib) {
+            img = 0; expected = ((size_t)M * ib + 255) & ~(size_t)255; hst = expected + (size_t)M * 32; ast = hst + (size_t)M * 4;
+            records = (ast + (size_t)M * 4 + 255) & ~(size_t)255; total = records + (size_t)M * sizeof(bsx_subchain);
+        }
+    };
     int lane_init(Lane& l) override {
         const uint64_t nh = (uint64_t)M * hpr;
         const bsx_witness_layout L = bsx_map_layout(b->B);
@@ -501,9 +538,10 @@ struct HintKind : Kind {
         RET(dalloc(l, nh * 32, &l.d_hashes));
         RET(dalloc(l, nh * 128, &l.d_dh));
         RET(dalloc(l, nh * 128, &l.d_lb));
-        RET(dalloc(l, S.total, &l.d_ranges));                 // ranges, latest, spans in one block (same offsets as the staging)
+        RET(dalloc(l, nh * BSX_HEADER_PATH_BYTES, &l.d_paths));
+        RET(dalloc(l, S.total, &l.d_ranges));                 // ranges, latest, spans, jobs in one block (same offsets as the staging)
         RET(dalloc(l, (size_t)M * L.compact_stride, &l.d_compact));
-        RET(dalloc(l, O.total - O.expected, &l.d_out));       // expected, hst, ast
+        RET(dalloc(l, O.total - O.expected, &l.d_out));       // expected, hst, ast, records
         return BSX_OK;
     }
     int launch(Lane& l, uint32_t R) override {
@@ -517,19 +555,26 @@ struct HintKind : Kind {
         uint8_t* d_exp = l.d_out;
         uint32_t* d_hst = reinterpret_cast<uint32_t*>(l.d_out + (O.hst - O.expected));
         uint32_t* d_ast = reinterpret_cast<uint32_t*>(l.d_out + (O.ast - O.expected));
-        LHIP(hipMemcpyAsync(l.d_ranges, l.h_small, S.total, hipMemcpyHostToDevice, st));            // 92 bytes per slot: all M at once
+        bsx_subchain* d_rec = reinterpret_cast<bsx_subchain*>(l.d_out + (O.records - O.expected));
+        auto* ranges = reinterpret_cast<const bsx_shared_ctx*>(l.d_ranges + S.ranges);
+        auto* spans = reinterpret_cast<const uint32_t*>(l.d_ranges + S.spans);
+        auto* latest = reinterpret_cast<const uint64_t*>(l.d_ranges + S.latest);
+        await_slots(l, R);
+        bool want_expected = false, want_records = false;
+        for (uint32_t r = 0; r < R; r++) { want_expected |= l.reqs[r].out_expected != nullptr; want_records |= l.reqs[r].want_record; }
+        LHIP(hipMemcpyAsync(l.d_ranges, l.h_small, S.total, hipMemcpyHostToDevice, st));            // 96 bytes per slot: all M at once
         LHIP(hipMemsetAsync(d_hst, 0, (size_t)M * 8, st));
         LHIP(hipMemcpyAsync(l.d_headers, l.h_headers, nh * sizeof(bsx_header), hipMemcpyHostToDevice, st));
-        LHIP(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(l.d_headers), nh, l.d_hashes, l.d_dh, l.d_lb, nullptr, d_hst, 0, 0, nullptr, hpr));
+        // map-job requests take the slots' path digests from the header trees hashed here (the fused hint): prove_subchain then
+        // computes the tuple leaf hashes and the commitment tree only — the proofs ARE this library's own
+        LHIP(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(l.d_headers), nh, l.d_hashes, l.d_dh, l.d_lb, want_records ? l.d_paths : nullptr, d_hst, 0, 0,
+                                nullptr, hpr));
         // the hint's image is read back as it is: every byte of it is written (zero padding included), the bytes behind it are not ours
-        LHIP(bsxk_assemble_inputs(st, R, 1, B, 0, 1, B, reinterpret_cast<const bsx_shared_ctx*>(l.d_ranges + S.ranges),
-                                  reinterpret_cast<const uint64_t*>(l.d_ranges + S.latest), reinterpret_cast<const bsx_header*>(l.d_headers), hpr, 0, l.d_hashes,
-                                  l.d_dh, l.d_lb, l.d_compact, d_ast, nullptr, nullptr, 0, reinterpret_cast<const uint32_t*>(l.d_ranges + S.spans), 1));
-        bool want_expected = false;
-        for (uint32_t r = 0; r < R; r++) want_expected |= l.reqs[r].out_expected != nullptr;
-        if (want_expected)
-            LHIP(bsxk_expected_commitments(st, R, B, reinterpret_cast<const bsx_shared_ctx*>(l.d_ranges + S.ranges), reinterpret_cast<const uint32_t*>(l.d_ranges + S.spans),
-                                           reinterpret_cast<const uint64_t*>(l.d_ranges + S.latest), l.d_compact, d_exp));
+        LHIP(bsxk_assemble_inputs(st, R, 1, B, 0, 1, B, ranges, latest, reinterpret_cast<const bsx_header*>(l.d_headers), hpr, 0, l.d_hashes, l.d_dh, l.d_lb,
+                                  l.d_compact, d_ast, want_records ? l.d_paths : nullptr, b->ctx->zero_paths, 0, spans, 1,
+                                  reinterpret_cast<const uint32_t*>(l.d_ranges + S.jobs)));
+        if (want_expected) LHIP(bsxk_expected_commitments(st, R, B, ranges, spans, latest, reinterpret_cast<const uint32_t*>(l.d_ranges + S.jobs), l.d_compact, d_exp));
+        if (want_records) LHIP(bsxk_prove_subchain(st, R, B, 1, ranges, l.d_compact, d_rec, BSX_SUBCHAIN_PATHS_FROM_HINT));
         LHIP(hipMemcpy2DAsync(l.h_out + O.img, img_bytes, l.d_compact, L.compact_stride, img_bytes, R, hipMemcpyDeviceToHost, st));
         LHIP(hipMemcpyAsync(l.h_out + O.expected, l.d_out, O.total - O.expected, hipMemcpyDeviceToHost, st));
         LHIP(hipStreamSynchronize(st));
@@ -538,6 +583,7 @@ struct HintKind : Kind {
     void complete(Lane& l, uint32_t R, int batch_rc, const std::string& batch_err) override {
         const uint32_t B = b->B;
         const Out O(M, img_bytes);
+        char msg[236];
         for (uint32_t r = 0; r < R; r++) {
             Req& rq = l.reqs[r];
             if (batch_rc != BSX_OK) { finish(rq, batch_rc, batch_err.c_str()); continue; }
@@ -548,11 +594,20 @@ struct HintKind : Kind {
             if (as & 2u) { finish(rq, BSX_ERR_BAD_HEADER, "an inclusion-proof leaf is not 34 / 72 bytes (circuits/input.rs:173,190)"); continue; }
             if (as & 4u) { finish(rq, BSX_ERR_BAD_ARG, "the supplied headers do not cover [start, min(end, latest-2)] or latest < 2"); continue; }
             const uint8_t* img = l.h_out + O.img + img_bytes * (size_t)r;
-            memcpy(rq.out_start, img + bsx_off_start_header(), 32);
-            memcpy(rq.out_end, img + bsx_off_end_header(), 32);
-            memcpy(rq.out_dh, img + bsx_off_dh_proofs(B), (size_t)B * sizeof(bsx_data_hash_proof));
-            memcpy(rq.out_lb, img + bsx_off_lb_proofs(B), (size_t)B * sizeof(bsx_last_block_id_proof));
+            if (rq.out_start) memcpy(rq.out_start, img + bsx_off_start_header(), 32);
+            if (rq.out_end) memcpy(rq.out_end, img + bsx_off_end_header(), 32);
+            if (rq.out_dh) memcpy(rq.out_dh, img + bsx_off_dh_proofs(B), (size_t)B * sizeof(bsx_data_hash_proof));
+            if (rq.out_lb) memcpy(rq.out_lb, img + bsx_off_lb_proofs(B), (size_t)B * sizeof(bsx_last_block_id_proof));
             if (rq.out_expected) memcpy(rq.out_expected, l.h_out + O.expected + 32 * (size_t)r, 32);
+            if (rq.want_record) {
+                memcpy(rq.out_record, l.h_out + O.records + sizeof(bsx_subchain) * (size_t)r, sizeof(bsx_subchain));
+                if (rq.out_record->assert_fail) {
+                    snprintf(msg, sizeof msg, "prove_subchain: assertion mask 0x%x, first failing slot %u (A3 builder.rs:205-207, A4 :210-212, A5 :216-219, A6 :229-232)",
+                             rq.out_record->assert_fail, rq.out_record->first_bad_slot);
+                    finish(rq, BSX_ERR_ASSERT, msg);
+                    continue;
+                }
+            }
             finish(rq, BSX_OK, nullptr);
         }
     }
@@ -575,7 +630,7 @@ struct SubchainKind : Kind {
         const bsx_witness_layout L = bsx_map_layout(b->B);
         hipStream_t st = l.st;
         struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
-        // only the head of an image is the caller's (ctx / start / end hashes + proofs); the words section follows separately
+        await_slots(l, R);
         LHIP(hipMemcpyAsync(l.d_compact, l.h_headers, (size_t)R * L.compact_stride, hipMemcpyHostToDevice, st));
         LHIP(hipMemcpyAsync(l.d_ranges, l.h_small, (size_t)R * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
         // the proofs are the CALLER's: both paths are re-derived per slot (builder.rs:189-199 literally)
@@ -653,9 +708,20 @@ void bsx_batcher_destroy(bsx_batcher* b) {
     delete b;
 }
 
+// inputs_stay: the caller's input buffers stay valid until the ticket has been waited for (the synchronous calls of a context with
+// coalescing enabled): headers that lie in page-locked memory are then uploaded straight from there instead of through the staging
+int bsxb_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
+                             uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                             uint8_t output64[64], bsx_commit_result* out_commit, bsx_ticket* out_ticket, int inputs_stay);
 int bsx_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
                             uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
                             uint8_t output64[64], bsx_commit_result* out_commit, bsx_ticket* out_ticket) {
+    return bsxb_submit_header_range(b, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64, out_commit,
+                                    out_ticket, 0);
+}
+int bsxb_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
+                             uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                             uint8_t output64[64], bsx_commit_result* out_commit, bsx_ticket* out_ticket, int inputs_stay) {
     if (!b || !out_ticket) return fail(BSX_ERR_BAD_ARG, "bsx_submit_header_range: null batcher / ticket");
     if (!input48 || !headers || !target_validators || !trusted_validators || !output64) return fail(BSX_ERR_BAD_ARG, "null pointer");
     // the checks bsx_header_range makes before it touches the device (header_range.rs:33-35: evm_read u64 big endian, bytes32, u64)
@@ -675,6 +741,12 @@ int bsx_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx
     proto.output64 = output64;
     proto.out_commit = out_commit;
     proto.n_headers = (uint32_t)avail;
+    const bsx_header* h0 = headers + (trusted_block - first_height);
+    if (inputs_stay) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, h0) == hipSuccess && at.type == hipMemoryTypeHost) proto.direct = h0;
+        else (void)hipGetLastError();           // pageable memory is not an error: it is staged
+    }
     Lane* l = nullptr;
     uint32_t idx = 0;
     RET(k->claim(&l, &idx, proto, out_ticket));
@@ -688,8 +760,8 @@ int bsx_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx
     const size_t vbytes = (size_t)b->V * sizeof(bsx_validator);
     memcpy(l->h_small + S.tv + vbytes * idx, target_validators, vbytes);
     memcpy(l->h_small + S.rv + vbytes * idx, trusted_validators, vbytes);
-    stage_headers(l, idx, b->hpr, headers + (trusted_block - first_height), avail);
-    Kind::ready(l);
+    if (!proto.direct) stage_headers(l, idx, b->hpr, h0, avail);
+    Kind::ready(l, idx);
     return BSX_OK;
 }
 
@@ -729,8 +801,50 @@ int bsx_submit_data_commitment_inputs(bsx_batcher* b, const bsx_header* headers,
     memcpy(l->h_small + S.ranges + sizeof range * (size_t)idx, &range, sizeof range);
     memcpy(l->h_small + S.latest + 8 * (size_t)idx, &latest_block, 8);
     memcpy(l->h_small + S.spans + 4 * (size_t)idx, &span, 4);
+    memset(l->h_small + S.jobs + 4 * (size_t)idx, 0, 4);
     stage_headers(l, idx, hpr, headers + (start_block - first_height), avail);
-    Kind::ready(l);
+    Kind::ready(l, idx);
+    return BSX_OK;
+}
+
+int bsx_submit_map_job(bsx_batcher* b, const bsx_shared_ctx* range, uint32_t job_index, const bsx_header* headers, uint64_t first_height,
+                       uint64_t n_headers, uint64_t latest_block, uint8_t out_start_header[32], uint8_t out_end_header[32], bsx_data_hash_proof* out_dh,
+                       bsx_last_block_id_proof* out_lb, bsx_subchain* out_record, bsx_ticket* out_ticket) {
+    if (!b || !out_ticket) return fail(BSX_ERR_BAD_ARG, "bsx_submit_map_job: null batcher / ticket");
+    if (!range || !out_record) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (job_index >= b->J) return fail(BSX_ERR_BAD_ARG, "job_index %u is not below NB_MAP_JOBS = %u", job_index, b->J);
+    if (!headers || !n_headers) return fail(BSX_ERR_BAD_ARG, "no headers supplied");
+    if (latest_block < 2) return fail(BSX_ERR_BAD_ARG, "latest_block < 2");
+    const uint64_t bs = range->start_block + (uint64_t)job_index * b->B, be = bs + b->B;      // builder.rs:315-322
+    const uint64_t hpr = (uint64_t)b->B + 1;
+    uint64_t avail = 0;
+    {   // the headers the hint reads: [batch_start, req_end] (input.rs:160-198); a batch behind the chain head's reach reads none
+        const uint64_t lim = latest_block - 2, req_end = be < lim ? be : lim;
+        if (bs <= req_end) {
+            if (bs < first_height || bs - first_height >= n_headers) return fail(BSX_ERR_BAD_ARG, "header for batch start %llu not supplied", (unsigned long long)bs);
+            avail = n_headers - (bs - first_height);
+            if (avail > hpr) avail = hpr;
+            if (req_end - bs >= avail) return fail(BSX_ERR_BAD_ARG, "the supplied headers do not cover [start, min(end, latest-2)] or latest < 2");
+        }
+    }
+    Kind* k = nullptr;
+    RET(kind_of<HintKind>(b, b->hint_kind, &k));
+    Req proto;
+    proto.out_start = out_start_header; proto.out_end = out_end_header; proto.out_dh = out_dh; proto.out_lb = out_lb;
+    proto.out_record = out_record;
+    proto.want_record = true;
+    proto.n_headers = (uint32_t)avail;
+    Lane* l = nullptr;
+    uint32_t idx = 0;
+    RET(k->claim(&l, &idx, proto, out_ticket));
+    const HintKind::Small S(k->M);
+    const uint32_t span = b->B;
+    memcpy(l->h_small + S.ranges + sizeof *range * (size_t)idx, range, sizeof *range);
+    memcpy(l->h_small + S.latest + 8 * (size_t)idx, &latest_block, 8);
+    memcpy(l->h_small + S.spans + 4 * (size_t)idx, &span, 4);
+    memcpy(l->h_small + S.jobs + 4 * (size_t)idx, &job_index, 4);
+    stage_headers(l, idx, hpr, avail ? headers + (bs - first_height) : headers, avail);
+    Kind::ready(l, idx);
     return BSX_OK;
 }
 
@@ -765,7 +879,7 @@ int bsx_submit_prove_subchain(bsx_batcher* b, const uint8_t start_header[32], co
     range.end_block = global_end_block;
     memcpy(range.end_header_hash, global_end_header_hash, 32);
     memcpy(l->h_small + sizeof range * (size_t)idx, &range, sizeof range);
-    Kind::ready(l);
+    Kind::ready(l, idx);
     return BSX_OK;
 }
 

@@ -58,11 +58,12 @@ hipError_t bsxk_zero_paths(hipStream_t, uint8_t*);
 hipError_t bsxk_assemble_inputs(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*,
                                 const uint64_t*, const bsx_header*, uint64_t, uint64_t, const uint8_t*, const uint8_t*, const uint8_t*,
                                 uint8_t*, uint32_t*, const uint8_t*, const uint8_t*, uint32_t lds_pad = 0, const uint32_t* spans = nullptr,
-                                uint32_t status_per_range = 0);
+                                uint32_t status_per_range = 0, const uint32_t* jobs = nullptr);
 // the hint's expected_data_commitment (input.rs:241-244 with :70-72) of n coalesced requests, straight from their assembled compact
 // images: root over the data hashes of [start, min(end, latest - 2)), all-zero when that range is empty.  out: n x 32
 hipError_t bsxk_expected_commitments(hipStream_t, uint32_t n, uint32_t B, const bsx_shared_ctx* ranges, const uint32_t* spans, const uint64_t* latest,
-                                     const uint8_t* compact, uint8_t* out);
+                                     const uint32_t* jobs /* optional: request r starts at ranges[r].start_block + jobs[r] * B */, const uint8_t* compact,
+                                     uint8_t* out);
 hipError_t bsxk_prove_subchain(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_shared_ctx*, uint8_t*, bsx_subchain*, uint32_t);
 hipError_t bsxk_reduce(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, uint64_t, uint64_t, bsx_subchain*, uint8_t*);
 hipError_t bsxk_reduce_finalize(hipStream_t, uint32_t, uint32_t, const bsx_subchain*, bsx_subchain*, uint8_t*, uint32_t, uint32_t, const bsx_shared_ctx*,

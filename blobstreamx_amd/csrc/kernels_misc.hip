@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256) void k_data_commitment(const uint8_t* data_has
 // The hint's expected_data_commitment for n coalesced requests (input.rs:241-244; zero for an empty range, :70-72): one workgroup
 // per request, data hashes read from the request's assembled compact image (data_hash_proofs[i].leaf[2..34)).
 __global__ __launch_bounds__(256) void k_expected_commitments(uint32_t B, const bsx_shared_ctx* ranges, const uint32_t* spans, const uint64_t* latest,
-                                                              const uint8_t* compact, uint32_t compact_stride, uint8_t* out) {
+                                                              const uint32_t* jobs, const uint8_t* compact, uint32_t compact_stride, uint8_t* out) {
     __shared__ uint32_t nodes[2][256 * 8];
     const uint32_t r = blockIdx.x, tid = threadIdx.x;
-    const uint64_t start = ranges[r].start_block, end = start + spans[r];
+    const uint64_t start = ranges[r].start_block + (jobs ? (uint64_t)jobs[r] * B : 0), end = start + spans[r];
     const uint64_t lim = latest[r] - 2;                                      // input.rs:160-162
     const uint64_t req_end = end < lim ? end : lim;
     const uint8_t* cw = compact + (uint64_t)r * compact_stride;
@@ -416,9 +416,9 @@ hipError_t bsxk_encode_tuple(hipStream_t s, const uint8_t* data_hash, uint64_t h
     return hipGetLastError();
 }
 hipError_t bsxk_expected_commitments(hipStream_t s, uint32_t n, uint32_t B, const bsx_shared_ctx* ranges, const uint32_t* spans, const uint64_t* latest,
-                                     const uint8_t* compact, uint8_t* out) {
+                                     const uint32_t* jobs, const uint8_t* compact, uint8_t* out) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_expected_commitments, dim3(n), dim3(256), 0, s, B, ranges, spans, latest, compact, bsx_map_layout(B).compact_stride, out);
+    hipLaunchKernelGGL(k_expected_commitments, dim3(n), dim3(256), 0, s, B, ranges, spans, latest, jobs, compact, bsx_map_layout(B).compact_stride, out);
     return hipGetLastError();
 }
 hipError_t bsxk_data_commitment(hipStream_t s, const uint8_t* data_hashes, uint32_t max_leaves, uint64_t start, uint64_t end,

@@ -272,6 +272,8 @@ struct AssembleArgs {
     const uint8_t* paths;        // optional (k_header_merkle): the slots' path digests are gathered too
     const uint8_t* zero_paths;   // path digests of the all-zero proofs (padding slots): dh[5] then lb[5]
     const uint32_t* spans;       // optional, per range: overrides `span` (coalesced hint requests of different lengths in one launch)
+    const uint32_t* jobs;        // optional, per range (job_count must be 1): the map job this request is — overrides job_first, and the
+                                 // range's header block then starts at the JOB's first height (header_first_rel = job * batch)
     uint32_t status_per_range;   // 1: status word r belongs to range r (coalescing front end); 0: one shared word
 };
 
@@ -281,8 +283,9 @@ struct AssembleArgs {
 template <uint32_t AS_IT>
 __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     BSX_CHAIN_PRIO();
-    const uint32_t r = blockIdx.x / a.job_count, jl = blockIdx.x % a.job_count, j = a.job_first + jl;
+    const uint32_t r = blockIdx.x / a.job_count, jl = blockIdx.x % a.job_count, j = a.jobs ? a.jobs[r] : a.job_first + jl;
     const uint32_t B = a.batch;
+    const uint64_t header_first_rel = a.jobs ? (uint64_t)j * B : a.header_first_rel;
     const bsx_shared_ctx rg = a.ranges[r];
     const uint64_t S = rg.start_block;
     const uint64_t batch_start = S + (uint64_t)j * B;          // builder.rs:315-316
@@ -293,9 +296,9 @@ __global__ __launch_bounds__(256) void k_assemble_inputs(AssembleArgs a) {
     // number of real proofs: dh for [start, req_end), lb for (start, req_end]  (input.rs:167-198)
     const uint64_t n_real = (batch_start <= req_end) ? (req_end - batch_start) : 0;
     const bool have_hdrs = batch_start < req_end;              // input.rs:249
-    const uint64_t hbase = (uint64_t)r * a.headers_per_range - a.header_first_rel;  // virtual index of height S
+    const uint64_t hbase = (uint64_t)r * a.headers_per_range - header_first_rel;    // virtual index of height S
     bool oob = false;
-    if (batch_start <= req_end && ((batch_start - S) < a.header_first_rel || (req_end - S - a.header_first_rel) >= a.headers_per_range)) oob = true;
+    if (batch_start <= req_end && ((batch_start - S) < header_first_rel || (req_end - S - header_first_rel) >= a.headers_per_range)) oob = true;
     uint8_t* cw = a.compact + ((uint64_t)r * a.job_count + jl) * a.compact_stride;
     uint32_t* cw32 = reinterpret_cast<uint32_t*>(cw);
 
@@ -1079,11 +1082,12 @@ hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {
 hipError_t bsxk_assemble_inputs(hipStream_t s, uint32_t n_ranges, uint32_t J, uint32_t B, uint32_t job_first, uint32_t job_count, uint32_t span,
                                 const bsx_shared_ctx* ranges, const uint64_t* latest, const bsx_header* headers, uint64_t hpr, uint64_t hfr,
                                 const uint8_t* hashes, const uint8_t* dh, const uint8_t* lb, uint8_t* compact, uint32_t* status,
-                                const uint8_t* paths, const uint8_t* zero_paths, uint32_t lds_pad, const uint32_t* spans, uint32_t status_per_range) {
+                                const uint8_t* paths, const uint8_t* zero_paths, uint32_t lds_pad, const uint32_t* spans, uint32_t status_per_range,
+                                const uint32_t* jobs) {
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     AssembleArgs a{n_ranges, J, B, job_first, job_count, span, ranges, latest, headers, hpr, hfr, hashes, dh, lb, compact, L.compact_stride, L.off_words, status,
-                   paths, zero_paths, spans, status_per_range};
+                   paths, zero_paths, spans, jobs, status_per_range};
     const uint32_t it = (24u * B + 255u) / 256u;
     // lds_pad: bytes of (unused) dynamic LDS per workgroup = a cap on the hint's workgroups resident per CU.  The hint is 0.7 GB of
     // 16-byte copies: at full occupancy it saturates HBM for 0.17 ms, and the header hashing it runs beside in the compact pipeline

@@ -884,6 +884,15 @@ int bsx_submit_data_commitment_inputs(bsx_batcher* b, const bsx_header* headers,
                                       uint64_t start_block, uint64_t end_block, uint8_t out_start_header[32], uint8_t out_end_header[32],
                                       bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb,
                                       uint8_t out_expected_data_commitment[32] /* optional */, bsx_ticket* out_ticket);
+/* The whole map closure of prove_data_commitment (builder.rs:305-336) for ONE map job as one request: the hint for
+ * [S + job B, S + (job + 1) B) (builder.rs:315-332 -> data_commitment.rs:22-44) and prove_subchain on what it returned (builder.rs:335),
+ * with `range` = the map's shared ctx (DataCommitmentSharedCtx, builder.rs:12-18: global start / end block and header hashes).
+ * headers[i] is the header at height first_height + i and must cover [batch_start, min(batch_end, latest_block - 2)].  The proofs are
+ * the library's own, so their path digests come straight from the header trees (19 of prove_subchain's 21 compressions per slot are not
+ * repeated; the record is bit-identical).  out_record as bsx_prove_subchain; the four hint outputs are optional. */
+int bsx_submit_map_job(bsx_batcher* b, const bsx_shared_ctx* range, uint32_t job_index, const bsx_header* headers, uint64_t first_height,
+                       uint64_t n_headers, uint64_t latest_block, uint8_t out_start_header[32], uint8_t out_end_header[32], bsx_data_hash_proof* out_dh,
+                       bsx_last_block_id_proof* out_lb, bsx_subchain* out_record, bsx_ticket* out_ticket);
 /* bsx_prove_subchain (builder.rs:45-52,150-271) with BATCH_SIZE = the batcher's batch_size, without a witness. */
 int bsx_submit_prove_subchain(bsx_batcher* b, const uint8_t start_header[32], const uint8_t end_header[32], const bsx_data_hash_proof* dh,
                               const bsx_last_block_id_proof* lb, uint64_t batch_start_block, uint64_t batch_end_block, uint64_t global_end_block,
@@ -893,6 +902,12 @@ int bsx_submit_prove_subchain(bsx_batcher* b, const uint8_t start_header[32], co
 int bsx_wait(bsx_batcher* b, bsx_ticket ticket);
 /* Non-blocking form for hosts with their own executor (a Rust future polls it): *out_done = 1 once bsx_wait would not block. */
 int bsx_poll(bsx_batcher* b, bsx_ticket ticket, int* out_done);
+/* Synchronous form of bsx_submit_map_job on a context: submit + wait when the context has a batcher of this batch_size attached
+ * (bsx_enable_coalescing), otherwise bsx_data_commitment_inputs followed by bsx_prove_subchain on the serial path.  Returns
+ * BSX_ERR_ASSERT when an assertion of the map job fails (out_record->assert_fail says which). */
+int bsx_map_job(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const bsx_shared_ctx* range, uint32_t job_index, const bsx_header* headers,
+                uint64_t first_height, uint64_t n_headers, uint64_t latest_block, uint8_t out_start_header[32], uint8_t out_end_header[32],
+                bsx_data_hash_proof* out_dh, bsx_last_block_id_proof* out_lb, bsx_subchain* out_record);
 /* Attach a batcher to the context: from then on the SYNCHRONOUS host-tier calls bsx_header_range (witness == NULL, same
  * nb_map_jobs / batch_size / v_max / chain id), bsx_data_commitment_inputs (max_leaves == batch_size) and bsx_prove_subchain
  * (batch_size equal, witness == NULL) made on this context by ANY number of threads are submit + wait on it — the reference's

@@ -286,3 +286,66 @@ def test_validator_set_changes_between_and_inside_batches():
         assert (rc, out) == (wrc, wout) and res.tobytes() == wres.tobytes(), (r, rc, wrc)
     assert bt.stats()["header_range"]["max_batch"] == 8
     bt.close()
+
+
+@pytest.mark.parametrize("coalesce", [True, False])
+def test_map_job_one_call_vs_oracle(coalesce):
+    """bsx_map_job = the map closure of prove_data_commitment for one map job (builder.rs:305-336: hint, then prove_subchain) as ONE
+    call: through a batcher (threads, coalesced, path digests from the header trees) and on a plain context (the two host-tier calls in
+    turn) — proofs and record are the oracle's for every job of a short, tampered range, including the batches the chain head does not
+    reach."""
+    J, B, V = 16, 32, 4
+    n_blocks = J * B - 2 * B - 9
+    w = synth.Workload(89, 1, J, B, v=V, n_blocks=n_blocks)
+    w.latest[0] = int(w.first_height[0]) + n_blocks + 1
+    w.headers[0, 3 * B + 5]["hash"][1][9] ^= 4
+    S, latest, E = int(w.first_height[0]), int(w.latest[0]), int(w.first_height[0]) + n_blocks
+    hh = oracle.header_hash_only(w.headers[0])
+    rg = np.zeros(1, T.SHARED_CTX)
+    rg["start_block"], rg["end_block"] = S, E
+    rg["start_header_hash"][0] = hh[0]
+    rg["end_header_hash"][0] = hh[n_blocks]
+    L = _lib.lib()
+    got = [None] * J
+    if coalesce:
+        bt = BT.Batcher(J, B, V)
+        errors = []
+
+        def worker(j):
+            try:
+                rc, r = bt.wait(bt.submit_map_job(rg, j, w.headers[0][j * B:(j + 1) * B + 1], S + j * B, latest), allow=(T.ERR_ASSERT,))
+                got[j] = (rc, r["start_header_hash"], r["end_header_hash"], r["data_hash_proofs"], r["last_block_id_proofs"], r["record"].copy())
+            except Exception as e:      # noqa: BLE001
+                errors.append((j, repr(e)))
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(J)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors
+        assert bt.stats()["data_commitment_inputs"]["requests"] == J
+        bt.close()
+    else:
+        h = C.c_void_p()
+        assert L.bsx_init(C.c_int(0), C.byref(h)) == T.OK
+        for j in range(J):
+            hdrs = np.ascontiguousarray(w.headers[0][j * B:(j + 1) * B + 1])
+            sh, eh, dh, lb, rec = np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(B, T.DH_PROOF), np.zeros(B, T.LB_PROOF), np.zeros(1, T.SUBCHAIN)
+            rc = L.bsx_map_job(h, C.c_uint32(J), C.c_uint32(B), _lib.p(rg), C.c_uint32(j), _lib.p(hdrs), C.c_uint64(S + j * B), C.c_uint64(hdrs.size),
+                               C.c_uint64(latest), _lib.p(sh), _lib.p(eh), _lib.p(dh), _lib.p(lb), _lib.p(rec))
+            assert rc in (T.OK, T.ERR_ASSERT), (j, rc, _lib.last_error())
+            got[j] = (rc, sh.tobytes(), eh.tobytes(), dh, lb, rec[0].copy())
+        L.bsx_shutdown(h)
+    n_fail = 0
+    for j in range(J):
+        bs, be = S + j * B, S + (j + 1) * B
+        orc, oh = oracle.data_commitment_inputs(w.headers[0][j * B:(j + 1) * B + 1], bs, latest, bs, be, B)
+        assert orc == T.OK
+        wrc, wrec, _ = oracle.prove_subchain(B, oh["start_header"], oh["end_header"], oh["data_hash_proofs"], oh["last_block_id_proofs"], bs, be, E,
+                                             hh[n_blocks].tobytes())
+        rc, sh, eh, dh, lb, rec = got[j]
+        assert (sh, eh) == (oh["start_header"], oh["end_header"]), j
+        assert dh.tobytes() == oh["data_hash_proofs"].tobytes() and lb.tobytes() == oh["last_block_id_proofs"].tobytes(), j
+        assert rc == wrc and rec.tobytes() == wrec.tobytes(), (j, rc, wrc, rec, wrec)
+        n_fail += rc != T.OK
+    assert n_fail >= 1

@@ -1,0 +1,24 @@
+"""Run bench.py's coalescing legs alone (latency.concurrent, hint_concurrent) and print them: python tools/exp_batcher.py [sweep]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+J, B, V = 32, 64, 100
+dev = torch.device("cuda:0")
+out = {}
+if "sweep" in sys.argv:
+    for name, kw in (("w50_l3", {}), ("w20_l3", dict(window_us=20)), ("w10_l4", dict(window_us=10, n_lanes=4)), ("w20_l4", dict(window_us=20, n_lanes=4)),
+                     ("w20_l6", dict(window_us=20, n_lanes=6)), ("w20_l4_pinned", dict(window_us=20, n_lanes=4, pinned=True))):
+        r = bench.concurrent_leg(dev, J, B, V, ks=(1, 16, 64), seconds=0.4, serial=False, **kw)
+        out[name] = [(x["threads"], round(x["headers_per_s"] / 1e6, 1), round(x["p50_ms"], 3), round(x["p99_ms"], 3), round(x["requests_per_launch_set"], 1))
+                     for x in r["coalesced_shared_context"]]
+    print(json.dumps(out, indent=1))
+else:
+    out = {"concurrent": bench.concurrent_leg(dev, J, B, V), "hint_concurrent": bench.hint_concurrent_leg(dev, J, B, V)}
+    print(json.dumps(out, indent=1))
