@@ -567,6 +567,10 @@ def concurrent_leg(dev, J, B, V, ks=(1, 2, 4, 8, 16, 32, 64), seconds=0.5, windo
         s1 = view.stats()["header_range"]
         nb = max(1, s1["batches"] - s0["batches"])
         row["requests_per_launch_set"] = (s1["requests"] - s0["requests"]) / nb
+        # the worker's time per launch set by phase (us): collecting, staging (+ enqueuing the header uploads), enqueuing the kernels, waiting
+        # for the GPU, completing the tickets
+        row["worker_us_per_set"] = {k: round((s1[k] * s1["batches"] - s0[k] * s0["batches"]) / nb, 1)
+                                    for k in ("close_wait_us", "stage_wait_us", "enqueue_us", "gpu_wait_us", "complete_us")}
         rows.append(row)
     L.bsx_shutdown(shared_ctx)
     # serial: own contexts (round 4's shape)

@@ -20,14 +20,15 @@ class BatcherConfig(C.Structure):
 
 
 class _KindStats(C.Structure):
-    _fields_ = [("batches", C.c_uint64), ("requests", C.c_uint64), ("max_batch", C.c_uint64), ("close_wait_ns", C.c_uint64)]
+    _fields_ = [("batches", C.c_uint64), ("requests", C.c_uint64), ("max_batch", C.c_uint64), ("close_wait_ns", C.c_uint64),
+                ("stage_wait_ns", C.c_uint64), ("enqueue_ns", C.c_uint64), ("gpu_wait_ns", C.c_uint64), ("complete_ns", C.c_uint64)]
 
 
 class BatcherStats(C.Structure):
     _fields_ = [("kind", _KindStats * 3)]
 
 
-assert C.sizeof(BatcherConfig) == 96 and C.sizeof(BatcherStats) == 96
+assert C.sizeof(BatcherConfig) == 96 and C.sizeof(BatcherStats) == 192
 
 
 def make_config(nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0):
@@ -156,8 +157,12 @@ class Batcher:
         s = BatcherStats()
         _lib.check(self.L.bsx_batcher_get_stats(self.h, C.byref(s)))
         names = ("header_range", "data_commitment_inputs", "prove_subchain")
-        return {n: {"batches": int(s.kind[i].batches), "requests": int(s.kind[i].requests), "max_batch": int(s.kind[i].max_batch),
-                    "close_wait_us": s.kind[i].close_wait_ns / 1e3 / max(1, int(s.kind[i].batches))} for i, n in enumerate(names)}
+        def row(k):
+            nb = max(1, int(k.batches))
+            return {"batches": int(k.batches), "requests": int(k.requests), "max_batch": int(k.max_batch), "close_wait_us": k.close_wait_ns / 1e3 / nb,
+                    "stage_wait_us": k.stage_wait_ns / 1e3 / nb, "enqueue_us": k.enqueue_ns / 1e3 / nb, "gpu_wait_us": k.gpu_wait_ns / 1e3 / nb,
+                    "complete_us": k.complete_ns / 1e3 / nb}
+        return {n: row(s.kind[i]) for i, n in enumerate(names)}
 
 
 def enable_coalescing(nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0, device=0):

@@ -27,7 +27,7 @@ static_assert(sizeof(bsx_shared_ctx) == 80 && sizeof(bsx_subchain) == 128, "reco
 static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "commit");
 static_assert(sizeof(bsx_witness_layout) == 40, "layout");
 static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
-static_assert(sizeof(bsx_batcher_config) == 96 && sizeof(bsx_batcher_stats) == 96, "batcher");
+static_assert(sizeof(bsx_batcher_config) == 96 && sizeof(bsx_batcher_stats) == 192, "batcher");
 static_assert(sizeof(bsx_commit_fold) == 128 && sizeof(bsx_pipeline_config) == 112 && sizeof(bsx_calibration) == 80, "pipeline / fold / calibration");
 
 namespace bsxapi {
@@ -1298,7 +1298,7 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     // the headers: a pageable megabyte is staged by the runtime (25 us on this thread) and then copied (25 us of DMA) — the head of
     // the hashing chain, the longer one.  Enqueued FIRST; everything else that has to be enqueued before the header hashing can start
     // (the side streams' waits, the R decoding) is enqueued while the DMA runs
-    const bsxk_merkle_tap tap{target_block - trusted_block, io.d + offsetof(bsx_shared_ctx, end_header_hash), dth.as<uint8_t>()};
+    const bsxk_merkle_tap tap{target_block - trusted_block, io.d + offsetof(bsx_shared_ctx, end_header_hash), dth.as<uint8_t>(), nullptr, 0, nullptr};
     RET(upload_range(ctx, st, headers, first_height, n_headers, trusted_block, range, latest_block, rd, &io, capture, &tap, /*hash_later=*/true));
     HIPCHK(hipStreamWaitEvent(s3, ctx->ev_c, 0));                       // the commit check's inputs
     RET(drd.alloc(bsxk_ed25519_rdec_bytes(v_max)));

@@ -98,6 +98,7 @@ struct Lane {
     std::vector<uint8_t> key_mirror;           // host copy of the keys this lane's table rows were built for
     bool key_mirror_valid = false;
     std::string err;                           // lane_init failure
+    uint64_t t_staged = 0, t_enqueued = 0;     // phase marks of the batch in flight (statistics)
 };
 
 }  // namespace
@@ -134,7 +135,9 @@ struct Kind {
     int init_rc = BSX_OK;
     std::string init_err;
     // statistics
-    std::atomic<uint64_t> n_batches{0}, n_requests{0}, max_batch{0}, sum_close_wait_ns{0};
+    std::atomic<uint64_t> n_batches{0}, n_requests{0}, max_batch{0}, sum_close_wait_ns{0}, sum_stage_wait_ns{0}, sum_enqueue_ns{0}, sum_gpu_wait_ns{0},
+        sum_complete_ns{0};
+
 
     Kind(bsx_batcher* b_, const char* n, uint32_t m) : b(b_), name(n), M(m) {}
     virtual ~Kind() {}
@@ -226,9 +229,18 @@ struct Kind {
             cv_open.notify_all();
             sum_close_wait_ns.fetch_add(now_ns() - t_open);
             bsxapi::g_err.clear();
+            const uint64_t t_closed = now_ns();
+            l.t_staged = l.t_enqueued = 0;
             const int rc = launch(l, R);
+            const uint64_t t_done = now_ns();
             const std::string err = bsxapi::g_err;
             complete(l, R, rc, err);
+            if (l.t_staged && l.t_enqueued) {
+                sum_stage_wait_ns.fetch_add(l.t_staged - t_closed);
+                sum_enqueue_ns.fetch_add(l.t_enqueued - l.t_staged);
+                sum_gpu_wait_ns.fetch_add(t_done - l.t_enqueued);
+            }
+            sum_complete_ns.fetch_add(now_ns() - t_done);
             n_batches.fetch_add(1);
             n_requests.fetch_add(R);
             uint64_t mb = max_batch.load();
@@ -318,13 +330,13 @@ struct RangeOut {
     size_t o64, res, hst, ast, fst, skip, commit, total;
     explicit RangeOut(uint32_t M) {
         o64 = 0; res = o64 + (size_t)M * 64; hst = res + (size_t)M * 128; ast = hst + (size_t)M * 4; fst = ast + (size_t)M * 4;
-        skip = fst + (size_t)M * 4; commit = skip + (size_t)M * 4; total = commit + (size_t)M * sizeof(bsx_commit_result);
+        skip = fst + (size_t)M * 4; commit = skip + (size_t)M * 4; total = commit + 2 * (size_t)M * sizeof(bsx_commit_result);
     }
-};
+};                                             // commit: R target-set results, then R trusted-set results (one tally launch over both)
 struct RangeSmall {                            // page-locked staging of the small inputs, arrays of M entries each
     size_t ranges, latest, tv, rv, total;
     RangeSmall(uint32_t M, uint32_t V) {
-        ranges = 0; latest = ranges + (size_t)M * sizeof(bsx_shared_ctx); latest = (latest + 255) & ~(size_t)255;
+        ranges = 0; latest = ranges + (size_t)M * sizeof(bsx_shared_ctx);          // ranges + latest: ONE copy
         tv = latest + (size_t)M * 8; tv = (tv + 255) & ~(size_t)255;
         rv = tv + (size_t)M * V * sizeof(bsx_validator);
         total = rv + (size_t)M * V * sizeof(bsx_validator);
@@ -347,15 +359,13 @@ struct RangeKind : Kind {
         RET(dalloc(l, nh * 128, &l.d_dh));
         RET(dalloc(l, nh * 128, &l.d_lb));
         RET(dalloc(l, nh * BSX_HEADER_PATH_BYTES, &l.d_paths));
-        RET(dalloc(l, (size_t)M * sizeof(bsx_shared_ctx), &l.d_ranges));
-        RET(dalloc(l, (size_t)M * 8, &l.d_latest));
+        RET(dalloc(l, (size_t)M * (sizeof(bsx_shared_ctx) + 8), &l.d_ranges));        // ranges, then latest (as staged)
+        l.d_latest = l.d_ranges + (size_t)M * sizeof(bsx_shared_ctx);
         RET(dalloc(l, (size_t)M * J * L.compact_stride, &l.d_compact));
         RET(dalloc(l, (size_t)M * J * sizeof(bsx_subchain), &l.d_records));
-        RET(dalloc(l, (size_t)M * V * sizeof(bsx_validator), &l.d_tv));
-        RET(dalloc(l, (size_t)M * V * sizeof(bsx_validator), &l.d_rv));
+        RET(dalloc(l, 2 * (size_t)M * V * sizeof(bsx_validator), &l.d_tv));          // R target sets, then R trusted sets
         RET(dalloc(l, (size_t)M * V * 32, &l.d_h));
         RET(dalloc(l, (size_t)M * V, &l.d_ok));
-        RET(dalloc(l, (size_t)M * sizeof(bsx_commit_result), &l.d_tres));
         RET(dalloc(l, (size_t)M * 32, &l.d_th));
         RET(dalloc(l, (size_t)M * 32, &l.d_th2));
         RET(dalloc(l, bsxk_ed25519_rdec_bytes((uint64_t)M * V), &l.d_rdec));
@@ -381,62 +391,72 @@ struct RangeKind : Kind {
         const RangeSmall S(M, V);
         bsx_ctx* ctx = b->ctx;
         hipStream_t st = l.st, sb = l.sb, s3 = l.s3, s4 = l.s4;
-        hipEvent_t ev_c = l.ev[0], ev_d = l.ev[1], ev_a = l.ev[2], ev_f = l.ev[3], ev_g = l.ev[4], ev_b = l.ev[5];
+        hipEvent_t ev_c = l.ev[0], ev_d = l.ev[1], ev_a = l.ev[2], ev_f = l.ev[3], ev_b = l.ev[5];
         struct Drain { Lane& l; ~Drain() { for (hipStream_t s : {l.s4, l.s3, l.sb, l.st}) (void)hipStreamSynchronize(s); } } drain{l};
         auto* tv = reinterpret_cast<const bsx_validator*>(l.d_tv);
-        auto* rv = reinterpret_cast<const bsx_validator*>(l.d_rv);
+        auto* rv = tv + n;                                                  // right behind the R target sets: one tally launch takes both
         auto* ranges = reinterpret_cast<bsx_shared_ctx*>(l.d_ranges);
         auto* cres = reinterpret_cast<bsx_commit_result*>(l.d_out + O.commit);
-        auto* tres = reinterpret_cast<bsx_commit_result*>(l.d_tres);
+        auto* tres = cres + R;
+        await_slots(l, R);
+        l.t_staged = now_ns();
         // the fixed-key table against this batch's keys, on the host: rows follow the FIRST request's validator set; slots of the
         // other requests whose key differs are counted (the signature check sizes — or skips — its generic-kernel pass from the count)
-        // the headers of every request as soon as ITS slot is staged (1 MB each: the upload of the first runs beside the staging
-        // memcpy of the others); a request whose headers are page-locked caller memory is uploaded from there
-        for (uint32_t r = 0; r < R; r++) {
-            await_slot(l, r);
-            const Req& rq = l.reqs[r];
-            uint8_t* dst = l.d_headers + (size_t)r * hpr * sizeof(bsx_header);
-            const uint32_t had = l.dev_hwm[r];
-            if (rq.direct) {
-                LHIP(hipMemcpyAsync(dst, rq.direct, (size_t)rq.n_headers * sizeof(bsx_header), hipMemcpyHostToDevice, st));
-                if (had > rq.n_headers) LHIP(hipMemsetAsync(dst + (size_t)rq.n_headers * sizeof(bsx_header), 0, (size_t)(had - rq.n_headers) * sizeof(bsx_header), st));
-            } else {
-                // the staging is zero behind the request's headers: a longer copy also clears what a previous, longer request left
-                const uint32_t n = rq.n_headers > had ? rq.n_headers : had;
-                LHIP(hipMemcpyAsync(dst, l.h_headers + (size_t)r * hpr * sizeof(bsx_header), (size_t)n * sizeof(bsx_header), hipMemcpyHostToDevice, st));
-            }
-            l.dev_hwm[r] = rq.n_headers;
-        }
         const bsx_validator* h_tv = reinterpret_cast<const bsx_validator*>(l.h_small + S.tv);
         bool keys_same = l.d_keytab && l.key_mirror_valid;
         for (uint32_t i = 0; keys_same && i < V; i++) keys_same = memcmp(l.key_mirror.data() + 32 * (size_t)i, h_tv[i].pubkey, 32) == 0;
         const uint64_t n_mismatch = l.d_keytab ? bsxh_key_mismatches(h_tv, R, V) : 0;
-        // the small inputs go on the commit stream: the commit chain starts from them, the hashing chain waits for them at its hint
-        LHIP(hipMemcpyAsync(l.d_ranges, l.h_small + S.ranges, (size_t)R * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
-        LHIP(hipMemcpyAsync(l.d_latest, l.h_small + S.latest, (size_t)R * 8, hipMemcpyHostToDevice, st));
+        // A launch set of FEW requests is a latency problem: its commit check spreads over three streams (R decoding ‖ challenges ‖
+        // tallies), as in bsx_header_range.  From 4 requests on the headers' upload (>= 4 MB) is the longest piece of the hashing chain,
+        // the commit chain fits behind it on ONE stream, and every stream and event less is front-end time the other lanes' sets get
+        const bool wide = R < 4;
+        hipStream_t q3 = wide ? s3 : sb, q4 = wide ? s4 : sb;
+        // small inputs first: the commit chain starts from them
+        LHIP(hipMemcpyAsync(l.d_ranges, l.h_small + S.ranges, (size_t)M * (sizeof(bsx_shared_ctx) + 8), hipMemcpyHostToDevice, st));
         LHIP(hipMemcpyAsync(l.d_tv, l.h_small + S.tv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
-        LHIP(hipMemcpyAsync(l.d_rv, l.h_small + S.rv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+        LHIP(hipMemcpyAsync(l.d_tv + (size_t)n * sizeof(bsx_validator), l.h_small + S.rv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
         LHIP(hipMemsetAsync(l.d_out + O.hst, 0, (size_t)M * 8, st));              // header + hint status words of every slot
         LHIP(hipEventRecord(ev_c, st));
-        // s3: R decoded strictly ahead of time (the longest kernel of the commit check; needs only the validator records)
-        LHIP(hipStreamWaitEvent(s3, ev_c, 0));
-        if (l.d_keytab) LHIP(bsxk_ed25519_decode_r(s3, tv, n, l.d_rdec));
-        LHIP(hipEventRecord(ev_d, s3));
-        // st: header hashes + both inclusion-proof paths of every header of every request; a malformed header marks ITS request
+        // The headers: ONE copy per run of consecutive staged slots (normally one run = the whole batch).  Measured (tools/h2d_bench.hip):
+        // page-locked copies of 1 MB reach 37 GB/s, of 4 MB 50, of 16 MB 55 of the 57 GB/s this PCIe link gives — a copy per request as
+        // its slot arrives (tried) cost more in copy set-up than it won in overlap with the callers' staging memcpys (33 GB/s per thread).
+        // A request whose headers are page-locked caller memory is uploaded from there.
+        for (uint32_t r = 0; r < R;) {
+            const Req& rq = l.reqs[r];
+            uint8_t* dst = l.d_headers + (size_t)r * hpr * sizeof(bsx_header);
+            if (rq.direct) {
+                const uint32_t had = l.dev_hwm[r];
+                LHIP(hipMemcpyAsync(dst, rq.direct, (size_t)rq.n_headers * sizeof(bsx_header), hipMemcpyHostToDevice, st));
+                if (had > rq.n_headers) LHIP(hipMemsetAsync(dst + (size_t)rq.n_headers * sizeof(bsx_header), 0, (size_t)(had - rq.n_headers) * sizeof(bsx_header), st));
+                l.dev_hwm[r] = rq.n_headers;
+                r++;
+                continue;
+            }
+            // the staging is zero behind each request's headers: copying whole slots also clears what longer requests left on the device
+            // (the last slot of the run only as far as it — or its predecessor in that slot — reaches)
+            uint32_t e = r;
+            while (e + 1 < R && !l.reqs[e + 1].direct) e++;
+            const uint32_t last_n = l.reqs[e].n_headers > l.dev_hwm[e] ? l.reqs[e].n_headers : l.dev_hwm[e];
+            LHIP(hipMemcpyAsync(dst, l.h_headers + (size_t)r * hpr * sizeof(bsx_header), ((size_t)(e - r) * hpr + last_n) * sizeof(bsx_header), hipMemcpyHostToDevice, st));
+            for (uint32_t q = r; q <= e; q++) l.dev_hwm[q] = l.reqs[q].n_headers;
+            r = e + 1;
+        }
+        // st: header hashes + both inclusion-proof paths of every header of every request; a malformed header marks ITS request.  The
+        // hash of every request's target header becomes its ctx.end_header_hash, the first output half and what the signed messages must
+        // carry (builder.skip, header_range.rs:42-48): stored by the lane that joins that header's tree (per-range tap)
+        const bsxk_merkle_tap tap{~0ull, nullptr, nullptr, ranges, hpr, l.d_th};
         LHIP(bsxk_header_merkle(st, reinterpret_cast<const bsx_header*>(l.d_headers), nh, l.d_hashes, l.d_dh, l.d_lb, l.d_paths,
-                                reinterpret_cast<uint32_t*>(l.d_out + O.hst), 0, 0, nullptr, hpr));
-        // builder.skip (header_range.rs:42-48): the target header hash becomes ctx.end_header_hash, the first output half and what the
-        // signed messages must carry
-        LHIP(bsxk_fill_end_hash(st, R, ranges, l.d_hashes, hpr, nullptr, l.d_th, nullptr, 0));
+                                reinterpret_cast<uint32_t*>(l.d_out + O.hst), 0, 0, &tap, hpr));
         LHIP(hipEventRecord(ev_a, st));
-        // sb: challenges; s4: validator-set hash + total power of the target sets, then of the trusted sets
+        // commit chain: R decoded strictly ahead of time (needs only the validator records), the challenges, validator-set hash + total
+        // power of the target AND the trusted sets (one launch over 2 R sets)
         LHIP(hipStreamWaitEvent(sb, ev_c, 0));
-        LHIP(hipStreamWaitEvent(s4, ev_c, 0));
+        if (wide) { LHIP(hipStreamWaitEvent(s3, ev_c, 0)); LHIP(hipStreamWaitEvent(s4, ev_c, 0)); }
+        if (l.d_keytab) LHIP(bsxk_ed25519_decode_r(q3, tv, n, l.d_rdec));
+        if (wide) LHIP(hipEventRecord(ev_d, s3));
         LHIP(bsxk_sha512_challenge(sb, tv, n, l.d_h, nullptr, V, nullptr));
-        LHIP(bsxk_commit_tally(s4, tv, R, V, nullptr, nullptr, cres, nullptr));
-        LHIP(hipEventRecord(ev_f, s4));
-        LHIP(bsxk_commit_tally(s4, rv, R, V, nullptr, nullptr, tres, nullptr));
-        LHIP(hipEventRecord(ev_g, s4));
+        LHIP(bsxk_commit_tally(q4, tv, 2 * R, V, nullptr, nullptr, cres, nullptr));
+        if (wide) LHIP(hipEventRecord(ev_f, s4));
         if (l.d_keytab) {
             if (!keys_same) {
                 LHIP(bsxk_ed25519_keytable(sb, tv, V, l.d_keytab));
@@ -444,16 +464,14 @@ struct RangeKind : Kind {
                 for (uint32_t i = 0; i < V; i++) memcpy(l.key_mirror.data() + 32 * (size_t)i, h_tv[i].pubkey, 32);
                 l.key_mirror_valid = true;
             }
-            LHIP(hipStreamWaitEvent(sb, ev_d, 0));
+            if (wide) LHIP(hipStreamWaitEvent(sb, ev_d, 0));
             LHIP(bsxk_ed25519_verify_keyed(sb, tv, l.d_h, n, V, l.d_keytab, V, ctx->btab, l.d_ok, nullptr, l.d_rdec, (int64_t)n_mismatch));
         } else {
             LHIP(bsxk_ed25519_verify(sb, tv, l.d_h, n, l.d_ok));
-            LHIP(hipStreamWaitEvent(sb, ev_d, 0));
         }
         LHIP(hipStreamWaitEvent(sb, ev_a, 0));                              // target hashes (dense) and the ranges' header hashes
-        LHIP(hipStreamWaitEvent(sb, ev_f, 0));
+        if (wide) LHIP(hipStreamWaitEvent(sb, ev_f, 0));
         LHIP(bsxk_commit_sums(sb, tv, R, V, l.d_th, l.d_ok, cres, nullptr));
-        LHIP(hipStreamWaitEvent(sb, ev_g, 0));
         LHIP(bsxk_skip_check(sb, R, V, ranges, reinterpret_cast<const bsx_header*>(l.d_headers), hpr, l.d_hashes, tv, rv, l.d_ok, cres, tres,
                              reinterpret_cast<uint32_t*>(l.d_out + O.skip), l.d_th2, nullptr, b->cfg.chain_id_len ? b->cfg.chain_id : nullptr,
                              b->cfg.chain_id_len, nullptr));
@@ -467,6 +485,7 @@ struct RangeKind : Kind {
                                   ranges, l.d_th, l.d_out + O.o64, reinterpret_cast<uint32_t*>(l.d_out + O.fst)));
         LHIP(hipStreamWaitEvent(st, ev_b, 0));
         LHIP(hipMemcpyAsync(l.h_out, l.d_out, O.total, hipMemcpyDeviceToHost, st));
+        l.t_enqueued = now_ns();
         LHIP(hipStreamSynchronize(st));
         return BSX_OK;
     }
@@ -560,6 +579,7 @@ struct HintKind : Kind {
         auto* spans = reinterpret_cast<const uint32_t*>(l.d_ranges + S.spans);
         auto* latest = reinterpret_cast<const uint64_t*>(l.d_ranges + S.latest);
         await_slots(l, R);
+        l.t_staged = now_ns();
         bool want_expected = false, want_records = false;
         for (uint32_t r = 0; r < R; r++) { want_expected |= l.reqs[r].out_expected != nullptr; want_records |= l.reqs[r].want_record; }
         LHIP(hipMemcpyAsync(l.d_ranges, l.h_small, S.total, hipMemcpyHostToDevice, st));            // 96 bytes per slot: all M at once
@@ -577,6 +597,7 @@ struct HintKind : Kind {
         if (want_records) LHIP(bsxk_prove_subchain(st, R, B, 1, ranges, l.d_compact, d_rec, BSX_SUBCHAIN_PATHS_FROM_HINT));
         LHIP(hipMemcpy2DAsync(l.h_out + O.img, img_bytes, l.d_compact, L.compact_stride, img_bytes, R, hipMemcpyDeviceToHost, st));
         LHIP(hipMemcpyAsync(l.h_out + O.expected, l.d_out, O.total - O.expected, hipMemcpyDeviceToHost, st));
+        l.t_enqueued = now_ns();
         LHIP(hipStreamSynchronize(st));
         return BSX_OK;
     }
@@ -631,11 +652,13 @@ struct SubchainKind : Kind {
         hipStream_t st = l.st;
         struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
         await_slots(l, R);
+        l.t_staged = now_ns();
         LHIP(hipMemcpyAsync(l.d_compact, l.h_headers, (size_t)R * L.compact_stride, hipMemcpyHostToDevice, st));
         LHIP(hipMemcpyAsync(l.d_ranges, l.h_small, (size_t)R * sizeof(bsx_shared_ctx), hipMemcpyHostToDevice, st));
         // the proofs are the CALLER's: both paths are re-derived per slot (builder.rs:189-199 literally)
         LHIP(bsxk_prove_subchain(st, R, b->B, 1, reinterpret_cast<const bsx_shared_ctx*>(l.d_ranges), l.d_compact, reinterpret_cast<bsx_subchain*>(l.d_records), 0));
         LHIP(hipMemcpyAsync(l.h_out, l.d_records, (size_t)R * sizeof(bsx_subchain), hipMemcpyDeviceToHost, st));
+        l.t_enqueued = now_ns();
         LHIP(hipStreamSynchronize(st));
         return BSX_OK;
     }
@@ -922,6 +945,10 @@ int bsx_batcher_get_stats(bsx_batcher* b, bsx_batcher_stats* out) {
         out->kind[i].requests = (*ks[i])->n_requests.load();
         out->kind[i].max_batch = (*ks[i])->max_batch.load();
         out->kind[i].close_wait_ns = (*ks[i])->sum_close_wait_ns.load();
+        out->kind[i].stage_wait_ns = (*ks[i])->sum_stage_wait_ns.load();
+        out->kind[i].enqueue_ns = (*ks[i])->sum_enqueue_ns.load();
+        out->kind[i].gpu_wait_ns = (*ks[i])->sum_gpu_wait_ns.load();
+        out->kind[i].complete_ns = (*ks[i])->sum_complete_ns.load();
     }
     return BSX_OK;
 }

@@ -50,7 +50,9 @@ inline bsxk_unit_dst bsxk_unit(uint8_t* base, const bsx_witness_layout& L, uint3
 extern "C" {
 // tap (optional): the root of header `idx` of the launch is ALSO stored at dst_a / dst_b (32 bytes each, either may be null) — the
 // host tier's ctx.end_header_hash and dense target hash, which k_fill_end_hash would copy one kernel boundary later
-struct bsxk_merkle_tap { uint64_t idx; uint8_t* dst_a; uint8_t* dst_b; };
+// Per-range form (the coalescing front end: R requests of `hpr` headers each in one launch): ranges != nullptr -> the root of header
+// r * hpr + (ranges[r].end_block - ranges[r].start_block) is stored into ranges[r].end_header_hash and dense + 32 r (= k_fill_end_hash)
+struct bsxk_merkle_tap { uint64_t idx; uint8_t* dst_a; uint8_t* dst_b; bsx_shared_ctx* ranges; uint64_t hpr; uint8_t* dense; };
 // status_group (coalescing front end): != 0 -> one status word per `status_group` consecutive headers (status[me / status_group])
 hipError_t bsxk_header_merkle(hipStream_t, const bsx_header*, uint64_t, uint8_t*, uint8_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t, uint32_t,
                               const bsxk_merkle_tap* tap = nullptr, uint64_t status_group = 0);

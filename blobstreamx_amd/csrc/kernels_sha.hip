@@ -245,6 +245,13 @@ __global__ __launch_bounds__(HM_THREADS, 4) void k_header_merkle(const bsx_heade
                     if (tap.dst_a) store_digest_u(tap.dst_a, root);
                     if (tap.dst_b) store_digest_u(tap.dst_b, root);
                 }
+                if (tap.ranges) {                                    // the target header of its request (coalescing front end)
+                    const uint64_t r = me / tap.hpr, k = me - r * tap.hpr;
+                    if (tap.ranges[r].end_block - tap.ranges[r].start_block == k) {
+                        store_digest_u(tap.ranges[r].end_header_hash, root);
+                        if (tap.dense) store_digest_u(tap.dense + 32 * r, root);
+                    }
+                }
             }
         }
         // wave-ballot reduction of the "bad header" predicate: one atomic per wave.  status_group != 0 (the coalescing front end:
@@ -1072,7 +1079,7 @@ hipError_t bsxk_header_merkle(hipStream_t s, const bsx_header* hdr, uint64_t n, 
     if (cap > 0 && grid > (uint32_t)cap) grid = (uint32_t)cap;
     static const long env_lp = bsx_knob("BSX_MERKLE_LOW_PRIO", -1);
     hipLaunchKernelGGL(k_header_merkle, dim3(grid), dim3(HM_THREADS), 0, s, hdr, n, hashes, dh, lb, paths, status, env_lp >= 0 ? (uint32_t)env_lp : low_prio,
-                       tap ? *tap : bsxk_merkle_tap{~0ull, nullptr, nullptr}, status_group);
+                       tap ? *tap : bsxk_merkle_tap{~0ull, nullptr, nullptr, nullptr, 0, nullptr}, status_group);
     return hipGetLastError();
 }
 hipError_t bsxk_zero_paths(hipStream_t s, uint8_t* out) {

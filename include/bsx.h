@@ -919,8 +919,12 @@ int bsx_enable_coalescing(bsx_ctx* ctx, const bsx_batcher_config* cfg);
  * a hint. */
 int bsx_batcher_cork(bsx_batcher* b, int on);
 typedef struct bsx_batcher_stats {
-    struct { uint64_t batches, requests, max_batch, close_wait_ns; } kind[3];   /* 0 header_range, 1 data_commitment_inputs, 2 prove_subchain */
-} bsx_batcher_stats;
+    /* per request kind (0 header_range, 1 data_commitment_inputs / map jobs, 2 prove_subchain): launch sets run, requests served, the
+     * largest set, and where the worker's time went, summed over the sets: first claim -> closed, closed -> every slot staged (for
+     * header_range this includes enqueuing the header uploads as slots arrive), staged -> last enqueue returned, -> the GPU is done,
+     * -> every ticket completed */
+    struct { uint64_t batches, requests, max_batch, close_wait_ns, stage_wait_ns, enqueue_ns, gpu_wait_ns, complete_ns; } kind[3];
+} bsx_batcher_stats;                        /* sizeof == 192 */
 int bsx_batcher_get_stats(bsx_batcher* b, bsx_batcher_stats* out);
 /* the batcher bsx_enable_coalescing attached (NULL: none) — for bsx_batcher_get_stats / explicit submits beside the synchronous calls */
 bsx_batcher* bsx_context_batcher(bsx_ctx* ctx);

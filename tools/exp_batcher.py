@@ -13,10 +13,9 @@ J, B, V = 32, 64, 100
 dev = torch.device("cuda:0")
 out = {}
 if "sweep" in sys.argv:
-    for name, kw in (("w50_l3", {}), ("w20_l3", dict(window_us=20)), ("w10_l4", dict(window_us=10, n_lanes=4)), ("w20_l4", dict(window_us=20, n_lanes=4)),
-                     ("w20_l6", dict(window_us=20, n_lanes=6)), ("w20_l4_pinned", dict(window_us=20, n_lanes=4, pinned=True))):
+    for name, kw in (("w50_l3", {}), ("w100_l2", dict(window_us=100, n_lanes=2)), ("w50_l3_pinned", dict(pinned=True))):
         r = bench.concurrent_leg(dev, J, B, V, ks=(1, 16, 64), seconds=0.4, serial=False, **kw)
-        out[name] = [(x["threads"], round(x["headers_per_s"] / 1e6, 1), round(x["p50_ms"], 3), round(x["p99_ms"], 3), round(x["requests_per_launch_set"], 1))
+        out[name] = [(x["threads"], round(x["headers_per_s"] / 1e6, 1), round(x["p50_ms"], 3), round(x["p99_ms"], 3), round(x["requests_per_launch_set"], 1), x["worker_us_per_set"])
                      for x in r["coalesced_shared_context"]]
     print(json.dumps(out, indent=1))
 else:
