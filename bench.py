@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--merkle-wgs", type=int, default=0, help="bsx_pipeline_config.tune_merkle_workgroups (experiments; 0 = automatic)")
     ap.add_argument("--subchain-form", type=int, default=0, help="bsx_pipeline_config.tune_subchain (experiments; 0 = automatic)")
     ap.add_argument("--no-commit", action="store_true", help="experiments: no target-commit verification (not a valid headline)")
+    ap.add_argument("--no-units", action="store_true", help="A/B: do not materialise the COMMIT / SKIP units (BSX_PIPE_NO_UNITS: round 3's witness)")
+    ap.add_argument("--long-steps", type=int, default=200, help="steps of the second, longer timed loop reported as `long_run` (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only: none of the secondary objects")
@@ -412,13 +414,14 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
         want = oracle.expand_witness(lay, 1, cwc)
         assert got[i].shape == want.shape and (got[i] == want).all(), f"mode S: the COMMIT unit of commit {gc} differs from the oracle's"
     gpu_ok_w, gpu_res_w, gpu_fold_w = shw.download()
+    unit_traffic, unit_traffic_src = pmc_traffic(shw.n, {"layout": "commit", "v": V})
     out["witness"] = {"headers_per_s": nh / dtw, "ms": dtw * 1e3, "steps_in_flight": shw.K,
                       "one_step_in_flight": {"headers_per_s": nh / dtw1, "ms": dtw1 * 1e3}, "elements_per_commit": int(lay["n_elements"]),
                       "bytes_per_step_this_rank": int(shw.n * 8 * int(lay["n_elements"])),
                       "checked_against_oracle_commits": len(pick),
                       "roofline": {"kernel": "k_expand_witness (COMMIT units)", "bound": "hbm", "achieved": exp_bytes / t_x / 1e6, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": exp_bytes / t_x / 1e6 / HBM_PEAK_GBS, "avg_launch_ms": t_x,
-                                   "algorithmic_bytes_per_launch": exp_bytes, "traffic": None,
+                                   "algorithmic_bytes_per_launch": exp_bytes, "traffic": unit_traffic, "traffic_source": unit_traffic_src,
                                    "frac_of_measured_store_ceiling": min(1.0, exp_bytes / t_x * 1e3 / cal["hbm_store_bytes_per_s"])},
                       "note": "the whole mode-S step WITH the witness: verification + compact units + their 64x expansion into HBM; sampled commits' "
                               "units diffed element by element against the oracle"}
@@ -841,6 +844,20 @@ def subprocess_legs(args):
         "reference_equivalent_compressions_per_s_whole_step": d["value"] * (41 + 23),
         "note": "no Goldilocks expansion, one chunk per step, two buffer sets stepped in turn inside the pipeline (one header hashing at a time): header hashing (41 compressions/header) + prove_subchain + commit check "
                 "(Ed25519, SHA-512) on the side stream; fractions are of the SHA-256 ceiling measured in that process"}
+    if not args.no_witness:
+        # A/B on THIS box: the headline step with and without the COMMIT / SKIP units (two more expansion launches per chunk, the field
+        # proofs and the unit stores of the commit chain on the side stream) — VERDICT r4 weak #8 asked what they cost the big expansion
+        log("leg: units_ab (2 subprocesses)")
+        ab = {}
+        for key, extra in (("with_units", []), ("without_units", ["--no-units"])):
+            d, err = subprocess_leg(args, ["--long-steps", "0"] + extra)
+            ab[key] = {"error": err} if d is None else {
+                "value": d["value"], "ms_per_step": d["ms_per_step"], "expand_map_avg_launch_ms": d["roofline"]["avg_launch_ms"],
+                "frac_of_measured_store_ceiling": d["roofline"]["frac_of_measured_store_ceiling"],
+                "stored_bytes_per_step": d["roofline_whole_step"]["stored_bytes_per_step"], "whole_step_store_GBps": d["roofline_whole_step"]["achieved"]}
+        ab["note"] = ("same process shape, same box, back to back: `without_units` = BSX_PIPE_NO_UNITS (round 3's witness: map jobs + reduce nodes); the "
+                      "difference in expand_map_avg_launch_ms is what the units' side-stream work costs the large launch")
+        out["units_ab"] = ab
     if (J, B) == (32, 64):
         log("leg: header_range_1024 (subprocess)")
         a1024 = argparse.Namespace(**vars(args))
@@ -848,20 +865,28 @@ def subprocess_legs(args):
         d, err = subprocess_leg(a1024, [])
         out["header_range_1024"] = {"error": err} if d is None else {
             "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-            "steps": d["steps"], "roofline_frac": d["roofline"]["frac"], "witness_checked_ranges": d["config"]["witness_checked_ranges"]}
+            "steps": d["steps"], "roofline_frac": d["roofline"]["frac"], "witness_checked_ranges": d["config"]["witness_checked_ranges"],
+            # BASELINE config #3 ("header_range_1024 ... with rocprof HBM-GB/s counters"): the leg's own roofline object, `traffic` from the
+            # committed PMC passes of THIS shape (profiles/r5_1024_pmc_hbm_traffic.csv)
+            "roofline": d["roofline"]}
     return out
 
 
-def pmc_traffic(n_jobs, B):
-    """HBM bytes of one k_expand_witness launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.csv +
-    .meta.json written by the profiling command), scaled per map job.  None when no profile of this shape is committed."""
-    for tag in ("r4", "r3", "r2", "r1"):
-        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.csv")
-        meta = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.meta.json")
-        if not os.path.exists(path):
+def pmc_traffic(n_units, match):
+    """HBM bytes of one k_expand_witness launch of `n_units` units from the committed rocprofv3 PMC passes: the newest
+    profiles/*pmc_hbm_traffic*.csv whose .meta.json (written by the profiling script) matches `match` — {"batch": B} for the map-job
+    section of a header_range_{32 B}, {"layout": "commit", "v": V} for mode S's COMMIT units — scaled per unit.  (None, None) when no
+    profile of that shape is committed."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_hbm_traffic*.meta.json")), reverse=True)      # r5 before r4 ...
+    for meta in cands:
+        m = json.load(open(meta))
+        m.setdefault("layout", "map")
+        want = dict({"layout": "map"}, **match)
+        if any(m.get(k) != v for k, v in want.items()):
             continue
-        m = json.load(open(meta)) if os.path.exists(meta) else {"jobs_per_launch": 4096, "batch": 64}
-        if int(m.get("batch", 64)) != B:
+        path = meta[:-len(".meta.json")] + ".csv"
+        if not os.path.exists(path):
             continue
         kb = {}
         for r in csv.DictReader(open(path)):
@@ -869,7 +894,8 @@ def pmc_traffic(n_jobs, B):
                 kb[r["counter"]] = max(kb.get(r["counter"], 0), int(r["per_launch_max"]))
         if len(kb) == 2:
             # rocprofv3 units are KB; FETCH_SIZE not doubled: the kernel reads its source with dword loads (guide: HBM section)
-            return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024 / int(m["jobs_per_launch"]) * n_jobs, os.path.basename(path)
+            per_launch = int(m.get("jobs_per_launch") or m.get("units_per_launch"))
+            return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024 / per_launch * n_units, os.path.basename(path)
     return None, None
 
 
@@ -955,6 +981,7 @@ def main():
 
     import synth
     from blobstreamx_amd import engine as E
+    from blobstreamx_amd import types as T
 
     cal = calibrate(dev)
     J, B, V = args.jobs, args.batch, args.validators
@@ -980,7 +1007,7 @@ def main():
     t_gen = time.perf_counter() - t0
     Ech = args.engines
     kw = dict(n_engines=Ech, rank=rank, world=world, device=dev, with_witness=not args.no_witness, with_caps=args.caps, merkle_workgroups=args.merkle_wgs,
-              with_commit=not args.no_commit, subchain_form=args.subchain_form)
+              with_commit=not args.no_commit, subchain_form=args.subchain_form, units=not args.no_units)
     eng = E.AlternatingPipelines(args.alternate, J, B, V, R, **kw) if args.alternate > 1 else E.PipelinedEngines(J, B, V, R, **kw)
     eng.upload_workload(w)
     p0 = eng
@@ -1050,13 +1077,40 @@ def main():
     tm = eng.timing()
     eng.set_timing(False)
     t_sub, t_exp = tm["prove_subchain_ms"], tm["expand_map_ms"]
+    multi_gpu = None
     if world > 1:
+        # what the first hardware scaling run needs to be diagnosable: every rank's own step time and the all-gather as the library
+        # timed it on its exchange stream (HIP events), gathered to rank 0; `value` uses the MAX over ranks
+        mine = torch.tensor([elapsed / args.steps * 1e3, tm["allgather_us"]["avg"], tm["allgather_us"]["min"], tm["allgather_us"]["median"],
+                             tm["allgather_us"]["max"], float(tm["exchanges"])], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        rows = [[float(x) for x in t.tolist()] for t in allr]
+        multi_gpu = {"per_rank_ms_per_step": [r[0] for r in rows],
+                     "allgather_us_per_chunk": {"avg": [r[1] for r in rows], "min": [r[2] for r in rows], "median": [r[3] for r in rows],
+                                                "max": [r[4] for r in rows]},
+                     "allgathers_timed_per_rank": [int(r[5]) for r in rows],
+                     "note": "all-gather of one 128-byte record per (range, rank) per chunk, timed with HIP events on the library's exchange stream from "
+                             "'this rank's folded records are ready' to 'every rank's have arrived' (includes waiting for the slowest rank); it is "
+                             "issued behind the local fold and joined behind the chunk's expansion, so it is hidden unless it outlasts the expansion"}
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        assert torch.distributed.get_world_size() == world == args.gpus, (torch.distributed.get_world_size(), world, args.gpus)
     ms_per_step = elapsed / args.steps * 1e3
     headers_per_step = world * R * J * B
     value = headers_per_step / (elapsed / args.steps)
+    # a second, longer loop (20 steps are 0.12 s — SURVEY §8(d)'s 100 ms with no margin): same steps, `long_run`
+    long_run = None
+    if args.long_steps > 0 and world == 1:
+        torch.cuda.synchronize(dev)
+        t0l = time.perf_counter()
+        for i in range(args.long_steps):
+            eng.step()
+        eng.join()
+        el = time.perf_counter() - t0l
+        long_run = {"steps": args.long_steps, "seconds": el, "ms_per_step": el / args.long_steps * 1e3, "value": headers_per_step / (el / args.long_steps),
+                    "unit": "headers/s"}
     # the witness the TIMED loop left in HBM, against the oracle (every rank checks its own buffers)
     n_checked = cpu_baseline_witness_check(p0, w, J, B) if not args.no_witness else 0
     res2 = eng.download()
@@ -1069,10 +1123,20 @@ def main():
         exp_bytes = n_jobs * (int(ml["n_bytes"]) + 4 * int(ml["n_words"]) + int(ml["n_bools"]) + 8 * int(ml["n_elements"]))
         slots = n_jobs * B
         sub_bytes = slots * (362 + 352 + 64 + 32 + 64)      # per slot: proofs read; paths+curr, tuple, leaf hash, 2 tree nodes written
+        # every Goldilocks element the step stores (8 B each), by section: map jobs, reduce nodes (local + top levels), and — with the
+        # commit check on — the COMMIT + SKIP unit of every owned range (the units were missing from this figure)
+        rl_, cl_, sl_ = T.reduce_layout(), T.commit_layout(V), T.skip_layout(V)
+        units_on = bool(getattr(p0, "units", False))
+        step_sections = {"map_jobs": Ech * n_jobs * 8 * int(ml["n_elements"]),
+                         "reduce_nodes": Ech * (p0.RT * max(p0.jc - 1, 0) + p0.Rc * (world - 1)) * 8 * int(rl_["n_elements"]),
+                         "commit_units": (R * 8 * int(cl_["n_elements"])) if units_on else 0,
+                         "skip_units": (R * 8 * int(sl_["n_elements"])) if units_on else 0}
+        step_store_bytes = sum(step_sections.values())
         out = {
             "metric": f"headers/sec witness-gen, header_range_{J * B} (SHA HBM GB/s vs roofline in `roofline`/`kernels`)",
             "value": value, "unit": "headers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "long_run": long_run,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"header_range_{J * B} ({J} map jobs x {B} headers), {V} validators, mode F (one target commit per range), "
                                    f"{R} ranges per GPU per step, Goldilocks witness {'off' if args.no_witness else 'materialised'}"
@@ -1083,9 +1147,11 @@ def main():
                                        f"records per chunk; {'strong: ' + str(R * world) + ' ranges in total' if strong else 'weak: ' + str(R) + ' ranges per GPU'}")
                        if world > 1 else "1 GPU",
                        "nccl_ranks": torch.distributed.get_world_size() if world > 1 else 1, "dist_backend": backend, "collective": collective,
+                       "multi_gpu": multi_gpu,
                        "sharded_vs_unsharded_self_check_per_rank": self_check,
                        "witness_checked_ranges": n_checked,
-                       "witness_bytes_per_step_per_gpu": int(Ech * n_jobs * 8 * int(ml["n_elements"])) if not args.no_witness else 0,
+                       "witness_bytes_per_step_per_gpu": int(step_store_bytes) if not args.no_witness else 0,
+                       "witness_bytes_per_step_per_gpu_by_section": step_sections if not args.no_witness else None,
                        "input_generation_s": round(t_gen, 2), "stream_autotune": tune,
                        "ed25519_path": p0.ed_path, "commit_beside": p0.commit_with, "memory_partition": memory_partition_mode()},
             "calibration": cal,
@@ -1102,7 +1168,7 @@ def main():
                 iso[1].record()
                 torch.cuda.synchronize(dev)
                 t_iso += iso[0].elapsed_time(iso[1]) / 5
-            traffic, traffic_src = pmc_traffic(n_jobs, B)
+            traffic, traffic_src = pmc_traffic(n_jobs, {"batch": B})
             # SURVEY §8(d)'s LITERAL per-slot figure (362 B read + (362 + 384) x 64 B written = 48,106 B per header slot) beside the
             # layout's own count (every variable bsx_witness_manifest lists: 57,124 B per slot at B = 64) — VERDICT r3 weak #8
             survey_bytes = slots * 48106
@@ -1123,6 +1189,15 @@ def main():
                                        "`achieved` is measured with HIP events on the launch stream inside the timed region where the kernel "
                                        "co-runs with the other chunk's ALU-bound hashing; `isolated` is the same launch alone; `traffic` = PMC "
                                        "bytes per launch read from the committed profile at run time (null when no profile of this shape exists)"}
+            # the same bound priced over the WHOLE step: every byte stored (map jobs + reduce nodes + COMMIT / SKIP units) over the step's
+            # wall time — what `headers/s` does not credit (the units are 1.2 GB of the 30.7 GB per step)
+            out["roofline_whole_step"] = {"kernel": "every k_expand_witness launch of a step (map jobs, reduce nodes, COMMIT + SKIP units)", "bound": "hbm",
+                                          "achieved": step_store_bytes / ms_per_step / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": step_store_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, "stored_bytes_per_step": int(step_store_bytes),
+                                          "sections": step_sections, "ms_per_step": ms_per_step,
+                                          "frac_of_measured_store_ceiling": min(1.0, step_store_bytes / ms_per_step * 1e3 / cal["hbm_store_bytes_per_s"]),
+                                          "traffic": None, "note": "stores only (the compact reads are 1.6 % of the traffic); wall time of the step, so the "
+                                                                   "hashing / commit phases that run beside the expansions are inside it"}
         else:
             out["roofline"] = None
         fused = bool(p0.fused_hint)

@@ -30,8 +30,8 @@ namespace {
 constexpr size_t PIPE_POOL = 16;             // GPU_MAX_HW_QUEUES: more streams than that share queues anyway
 
 struct TimingSlot {
-    hipEvent_t ev[6];       // prove_subchain [0,1], map expansion [2,3], Poseidon commitment [4,5]
-    bool sub, exp, caps;
+    hipEvent_t ev[8];       // prove_subchain [0,1], map expansion [2,3], Poseidon commitment [4,5], the cross-GPU exchange [6,7] (its stream)
+    bool sub, exp, caps, xchg;
 };
 
 constexpr uint32_t PIPE_HINT_LDS_PAD_COMPACT = 65536;   // compact pipeline: two hint workgroups per CU (bsxk_assemble_inputs) ...
@@ -266,7 +266,7 @@ TimingSlot* timing_slot(Chunk& c) {
         c.timing.push_back(t);
     }
     TimingSlot* t = &c.timing[c.timing_used++];
-    t->sub = t->exp = t->caps = false;
+    t->sub = t->exp = t->caps = t->xchg = false;
     return t;
 }
 
@@ -430,11 +430,15 @@ int stream_inputs(bsx_pipeline* p, Chunk& c) {
     return BSX_OK;
 }
 
-int exchange_begin(bsx_pipeline* p, Chunk& c) {
+int exchange_begin(bsx_pipeline* p, Chunk& c, TimingSlot* ts) {
     if (!p->allgather) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline: world > 1 needs bsx_pipeline_set_allgather before the first step");
     RET(stream_wait_stream(c.xchg, c.main, c.ev_x_in));
+    // timed on the exchange stream itself, from "this rank's partial records are ready" to "every rank's have arrived": what the
+    // collective costs while the GPUs are busy — including the wait for the slowest rank
+    if (ts) HIPCHK(hipEventRecord(ts->ev[6], c.xchg));
     if (p->allgather(p->allgather_user, c.partial, c.gathered, (uint64_t)c.RT * 128, c.xchg) != 0)
         return fail(BSX_ERR_HIP, "bsx_pipeline: the caller's all-gather failed");
+    if (ts) { HIPCHK(hipEventRecord(ts->ev[7], c.xchg)); ts->xchg = true; }
     HIPCHK(hipEventRecord(c.ev_x_out, c.xchg));
     return BSX_OK;
 }
@@ -645,7 +649,7 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     const uint32_t J = cfg->nb_map_jobs, B = cfg->batch_size, V = cfg->v_max, world = cfg->world ? cfg->world : 1;
     if (!pow2(J) || J > 256) return fail(BSX_ERR_BAD_ARG, "NB_MAP_JOBS must be a power of two <= 256");
     if (!pow2(B) || B > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
-    if (cfg->flags & ~(BSX_PIPE_WITNESS | BSX_PIPE_COMMIT | BSX_PIPE_CAPS | BSX_PIPE_ED_GENERIC | BSX_PIPE_COMMIT_BESIDE_HASH | BSX_PIPE_RECOMPUTE_PATHS))
+    if (cfg->flags & ~(BSX_PIPE_WITNESS | BSX_PIPE_COMMIT | BSX_PIPE_CAPS | BSX_PIPE_ED_GENERIC | BSX_PIPE_COMMIT_BESIDE_HASH | BSX_PIPE_RECOMPUTE_PATHS | BSX_PIPE_NO_UNITS))
         return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_create: unknown flags 0x%x", cfg->flags);
     if ((cfg->flags & BSX_PIPE_COMMIT) && (V == 0 || (int)V > bsxk_tally_vmax())) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", V, bsxk_tally_vmax());
     if (!cfg->n_ranges || !cfg->n_chunks || cfg->n_ranges % cfg->n_chunks) return fail(BSX_ERR_BAD_ARG, "n_chunks must divide n_ranges (both > 0)");
@@ -676,7 +680,7 @@ int bsx_pipeline_create(bsx_ctx* ctx, const bsx_pipeline_config* cfg, bsx_pipeli
     p->rl = bsx_reduce_layout();
     p->cl = bsx_commit_layout(p->V);
     p->sl = bsx_skip_layout(p->V);
-    p->units = p->with_commit && (p->with_witness || p->with_caps);
+    p->units = p->with_commit && (p->with_witness || p->with_caps) && !(cfg->flags & BSX_PIPE_NO_UNITS);
     // Launch forms (measured): beside an expansion the header hashing is held to 2 workgroups per CU and
     // prove_subchain keeps its stages in separate launches, so that the expansion's waves keep half of the register file;
     // alone, both take the whole GPU.
@@ -902,7 +906,7 @@ int bsx_pipeline_step(bsx_pipeline* p) {
         }
         const uint8_t* res = c.partial;       // single GPU: the local fold already is the range result
         if (p->world > 1) {
-            RET(exchange_begin(p, c));        // collective in flight; finished behind this chunk's expansion
+            RET(exchange_begin(p, c, ts));    // collective in flight; finished behind this chunk's expansion
             res = nullptr;
         }
         if (multi) {
@@ -1103,6 +1107,7 @@ int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out) {
     RET(join_impl(p));
     double sub = 0, ex = 0, caps = 0;
     uint32_t n_sub = 0, n_ex = 0, n_caps = 0;
+    std::vector<float> xs;
     for (Chunk& c : p->chunks) {
         for (size_t i = 0; i < c.timing_used; i++) {
             TimingSlot& t = c.timing[i];
@@ -1110,6 +1115,7 @@ int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out) {
             if (t.sub) { HIPCHK(hipEventElapsedTime(&ms, t.ev[0], t.ev[1])); sub += ms; n_sub++; }
             if (t.exp) { HIPCHK(hipEventElapsedTime(&ms, t.ev[2], t.ev[3])); ex += ms; n_ex++; }
             if (t.caps) { HIPCHK(hipEventElapsedTime(&ms, t.ev[4], t.ev[5])); caps += ms; n_caps++; }
+            if (t.xchg) { HIPCHK(hipEventElapsedTime(&ms, t.ev[6], t.ev[7])); xs.push_back(ms); }
         }
         c.timing_used = 0;
     }
@@ -1117,7 +1123,17 @@ int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out) {
     out->expand_map_ms = n_ex ? ex / n_ex : 0;
     out->caps_ms = n_caps ? caps / n_caps : 0;
     out->launches = n_sub;
-    out->_pad = 0;
+    out->exchanges = (uint32_t)xs.size();
+    out->allgather_ms_avg = out->allgather_ms_min = out->allgather_ms_median = out->allgather_ms_max = 0;
+    if (!xs.empty()) {
+        std::sort(xs.begin(), xs.end());
+        double t = 0;
+        for (float v : xs) t += v;
+        out->allgather_ms_avg = t / xs.size();
+        out->allgather_ms_min = xs.front();
+        out->allgather_ms_median = xs[xs.size() / 2];
+        out->allgather_ms_max = xs.back();
+    }
     return BSX_OK;
 }
 

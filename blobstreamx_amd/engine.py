@@ -30,7 +30,7 @@ from . import _lib
 from . import types as T
 
 # bsx.h
-PIPE_WITNESS, PIPE_COMMIT, PIPE_CAPS, PIPE_ED_GENERIC, PIPE_COMMIT_BESIDE_HASH, PIPE_RECOMPUTE_PATHS = 1, 2, 4, 8, 16, 32
+PIPE_WITNESS, PIPE_COMMIT, PIPE_CAPS, PIPE_ED_GENERIC, PIPE_COMMIT_BESIDE_HASH, PIPE_RECOMPUTE_PATHS, PIPE_NO_UNITS = 1, 2, 4, 8, 16, 32, 64
 (BUF_WITNESS_MAP, BUF_WITNESS_REDUCE_LOCAL, BUF_WITNESS_REDUCE_TOP, BUF_COMPACT, BUF_TREES, BUF_PARTIAL, BUF_HEADERS, BUF_RECORDS,
  BUF_GATHERED, BUF_REDUCE_COMPACT_LOCAL, BUF_HASHES, BUF_DH_AUNTS, BUF_LB_AUNTS, BUF_PATHS, BUF_RANGES, BUF_WITNESS_COMMIT,
  BUF_WITNESS_SKIP, BUF_COMPACT_COMMIT, BUF_COMPACT_SKIP, BUF_TREES_COMMIT, BUF_TREES_SKIP) = range(21)
@@ -55,7 +55,8 @@ class _Results(C.Structure):
 
 class _Timing(C.Structure):
     _fields_ = [("prove_subchain_ms", C.c_double), ("expand_map_ms", C.c_double), ("caps_ms", C.c_double), ("launches", C.c_uint32),
-                ("_pad", C.c_uint32)]
+                ("exchanges", C.c_uint32), ("allgather_ms_avg", C.c_double), ("allgather_ms_min", C.c_double), ("allgather_ms_median", C.c_double),
+                ("allgather_ms_max", C.c_double)]
 
 
 class _Autotune(C.Structure):
@@ -169,7 +170,7 @@ class Pipeline:
 
     def __init__(self, nb_map_jobs, batch_size, v_max, n_ranges_local, n_chunks=1, rank=0, world=1, device=None, with_witness=True,
                  with_commit=True, with_caps=False, chain_id=b"celestia", ed_path=None, commit_with="expand", fused_hint=True,
-                 leaf_len=0, cap_height=0, merkle_workgroups=0, subchain_form=0, n_sets=1):
+                 leaf_len=0, cap_height=0, merkle_workgroups=0, subchain_form=0, n_sets=1, units=True):
         import torch
         self.J, self.B, self.V = nb_map_jobs, batch_size, v_max
         self.R, self.E, self.Rc = n_ranges_local, n_chunks, n_ranges_local // n_chunks
@@ -193,6 +194,8 @@ class Pipeline:
         flags |= PIPE_ED_GENERIC if ed_path == "generic" else 0
         flags |= PIPE_COMMIT_BESIDE_HASH if commit_with == "hash" else 0
         flags |= 0 if fused_hint else PIPE_RECOMPUTE_PATHS
+        flags |= 0 if units else PIPE_NO_UNITS
+        self.units = bool(units and with_commit and (with_witness or with_caps))
         self.fused_hint = fused_hint
         self._leaf_len = leaf_len or 135
         self.ed_path = "generic" if (ed_path == "generic" or self.Rc < 8) else "keyed"
@@ -289,7 +292,9 @@ class Pipeline:
     def timing(self):
         t = _Timing()
         _lib.check(self.L.bsx_pipeline_timing(self._h, C.byref(t)))
-        return {"prove_subchain_ms": t.prove_subchain_ms, "expand_map_ms": t.expand_map_ms, "caps_ms": t.caps_ms, "launches": t.launches}
+        return {"prove_subchain_ms": t.prove_subchain_ms, "expand_map_ms": t.expand_map_ms, "caps_ms": t.caps_ms, "launches": t.launches,
+                "exchanges": t.exchanges, "allgather_us": {"avg": t.allgather_ms_avg * 1e3, "min": t.allgather_ms_min * 1e3,
+                                                           "median": t.allgather_ms_median * 1e3, "max": t.allgather_ms_max * 1e3}}
 
     # ------------------------------------------------------------------ results
     def download(self):

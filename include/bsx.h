@@ -702,6 +702,8 @@ typedef struct bsx_pipeline bsx_pipeline;
 #define BSX_PIPE_COMMIT_BESIDE_HASH 16u /* run the whole commit check beside the hashing phase instead of beside the expansion */
 #define BSX_PIPE_RECOMPUTE_PATHS 32u    /* prove_subchain re-derives both proof paths per slot (builder.rs:189-199 literally)
                                            instead of taking the digests the header hashing already produced (same witness) */
+#define BSX_PIPE_NO_UNITS 64u           /* with BSX_PIPE_COMMIT + BSX_PIPE_WITNESS / _CAPS: do NOT materialise the COMMIT / SKIP units (the round-3
+                                           witness: map jobs + reduce nodes only) — the A/B that prices the units' side-stream work (bench.py units_ab) */
 typedef struct bsx_pipeline_config {
     uint32_t nb_map_jobs, batch_size, v_max;
     uint32_t n_ranges;                  /* header_range instances this rank OWNS per step */
@@ -835,14 +837,17 @@ int bsx_pipeline_get_results(bsx_pipeline* p, bsx_pipeline_results* out);
 int bsx_pipeline_buffer(bsx_pipeline* p, uint32_t chunk, uint32_t which, void** out_d_ptr, uint64_t* out_bytes);
 
 /* Kernel timing with HIP events on the launch streams: when on, every step brackets prove_subchain, the map-job witness
- * expansion and the Poseidon commitment of every chunk.  bsx_pipeline_timing joins, returns the average launch durations
+ * expansion, the Poseidon commitment and (world > 1) the all-gather of every chunk.  bsx_pipeline_timing joins, returns the average launch durations
  * (ms; 0 when not applicable) over the steps since the last call and resets. */
 int bsx_pipeline_set_timing(bsx_pipeline* p, int on);
 typedef struct bsx_pipeline_timing_result {
     double prove_subchain_ms, expand_map_ms, caps_ms;
     uint32_t launches;                  /* chunk-steps averaged */
-    uint32_t _pad;
-} bsx_pipeline_timing_result;
+    uint32_t exchanges;                 /* world > 1: all-gathers timed (one per chunk-step) */
+    /* world > 1: the one collective of the path (the map -> reduce hand-off across GPUs, builder.rs:337-395), HIP events on the
+     * exchange stream from "this rank's folded records are ready" to "every rank's have arrived" — includes waiting for the slowest rank */
+    double allgather_ms_avg, allgather_ms_min, allgather_ms_median, allgather_ms_max;
+} bsx_pipeline_timing_result;           /* sizeof == 64 */
 int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out);
 
 /* ------------------------------------------------------------------ coalescing front end (round 5)

@@ -285,6 +285,16 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["config"]["ranges_per_gpu"] == 8 and d["config"]["headers_per_step"] == 2 * 8 * 2048
     # bsx_pipeline_autotune ran as a collective: both ranks agreed on the steps per trial through the all-gather callback
     assert d["config"]["stream_autotune"]["n_trials"] == 26 and d["config"]["stream_autotune"]["steps_per_trial"] >= 3
+    # what makes the first hardware scaling run diagnosable: the world that ran, which collective, every rank's own step
+    # time, and the all-gather timed with HIP events on the library's exchange stream — one per chunk per timed step on every rank
+    mg = d["config"]["multi_gpu"]
+    assert d["config"]["nccl_ranks"] == d["n_gpus"] == 2 and d["config"]["collective"]
+    assert len(mg["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in mg["per_rank_ms_per_step"])
+    assert mg["allgathers_timed_per_rank"] == [3 * d["config"]["pipelined_chunks"]] * 2
+    for k in ("avg", "min", "median", "max"):
+        assert len(mg["allgather_us_per_chunk"][k]) == 2 and all(v > 0 for v in mg["allgather_us_per_chunk"][k]), (k, mg)
+    assert all(lo <= md <= hi for lo, md, hi in zip(mg["allgather_us_per_chunk"]["min"], mg["allgather_us_per_chunk"]["median"], mg["allgather_us_per_chunk"]["max"]))
+    assert d["ms_per_step"] >= max(mg["per_rank_ms_per_step"]) * 0.999
 
 
 def test_expansion_kernel_variants_agree():
