@@ -16,7 +16,7 @@ from . import types as T
 class BatcherConfig(C.Structure):
     _fields_ = [("nb_map_jobs", C.c_uint32), ("batch_size", C.c_uint32), ("v_max", C.c_uint32), ("max_requests", C.c_uint32),
                 ("window_us", C.c_uint32), ("n_lanes", C.c_uint32), ("chain_id_len", C.c_uint32), ("chain_id", C.c_uint8 * 52),
-                ("flags", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
+                ("flags", C.c_uint32), ("key_rows", C.c_uint32), ("_reserved", C.c_uint32 * 2)]
 
 
 class _KindStats(C.Structure):
@@ -31,8 +31,9 @@ class BatcherStats(C.Structure):
 assert C.sizeof(BatcherConfig) == 96 and C.sizeof(BatcherStats) == 192
 
 
-def make_config(nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0):
+def make_config(nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0, key_rows=0):
     cfg = BatcherConfig()
+    cfg.key_rows = key_rows
     cfg.nb_map_jobs, cfg.batch_size, cfg.v_max = nb_map_jobs, batch_size, v_max
     cfg.max_requests, cfg.window_us, cfg.n_lanes = max_requests, window_us, n_lanes
     cid = bytes(chain_id)
@@ -50,12 +51,12 @@ class Ticket:
 
 
 class Batcher:
-    def __init__(self, nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0, device=0, handle=None):
+    def __init__(self, nb_map_jobs, batch_size, v_max, chain_id=b"celestia", max_requests=0, window_us=0, n_lanes=0, device=0, handle=None, key_rows=0):
         self.J, self.B, self.V = nb_map_jobs, batch_size, v_max
         self.L = _lib.lib()
         self._owned = handle is None
         if handle is None:
-            cfg = make_config(nb_map_jobs, batch_size, v_max, chain_id, max_requests, window_us, n_lanes)
+            cfg = make_config(nb_map_jobs, batch_size, v_max, chain_id, max_requests, window_us, n_lanes, key_rows)
             h = C.c_void_p()
             _lib.check(self.L.bsx_batcher_create(_lib.context(device), C.byref(cfg), C.byref(h)))
             handle = h

@@ -34,6 +34,7 @@
 #include "../../include/bsx_layout.h"
 #include "api_internal.h"
 #include "kernels.h"
+#include "keycache.h"
 
 using bsxapi::fail;
 using bsxapi::pow2;
@@ -95,8 +96,10 @@ struct Lane {
     uint8_t *d_ranges = nullptr, *d_latest = nullptr, *d_spans = nullptr, *d_compact = nullptr, *d_records = nullptr;
     uint8_t *d_tv = nullptr, *d_rv = nullptr, *d_h = nullptr, *d_ok = nullptr, *d_tres = nullptr, *d_th = nullptr, *d_th2 = nullptr, *d_rdec = nullptr;
     uint8_t *d_keytab = nullptr, *d_out = nullptr, *d_expected = nullptr;
-    std::vector<uint8_t> key_mirror;           // host copy of the keys this lane's table rows were built for
-    bool key_mirror_valid = false;
+    // the lane's fixed-key table: rows keyed by public key (keycache.h); key records of the rows as the build kernel reads them
+    bsx_keycache kc;
+    uint8_t *h_rowkeys = nullptr, *d_rowkeys = nullptr, *h_rows = nullptr, *d_rows = nullptr;
+    std::vector<uint32_t> kc_dirty;
     std::string err;                           // lane_init failure
     uint64_t t_staged = 0, t_enqueued = 0;     // phase marks of the batch in flight (statistics)
 };
@@ -109,6 +112,7 @@ struct bsx_batcher {
     uint32_t J = 0, B = 0, V = 0, M = 0, n_lanes = 0;
     uint64_t window_ns = 0;
     uint64_t hpr = 0;                          // headers per header_range slot: J * B + 1
+    uint32_t key_rows = 0;                     // rows of a lane's fixed-key table
     std::atomic<uint64_t> next_seq{1};
     std::vector<DoneRec> ring;
     std::mutex mu_done;
@@ -370,16 +374,22 @@ struct RangeKind : Kind {
         RET(dalloc(l, (size_t)M * 32, &l.d_th2));
         RET(dalloc(l, bsxk_ed25519_rdec_bytes((uint64_t)M * V), &l.d_rdec));
         RET(dalloc(l, O.total, &l.d_out));
-        // every lane owns its fixed-key table (5.8 MB per validator slot): a lane that rebuilds rows for a new validator set must not
-        // do so under another lane's signature check.  No table (allocation failed): the generic per-signature kernel
-        {
+        // every lane owns its fixed-key table (5.8 MB per row): a lane that rebuilds rows for new keys must not do so under another
+        // lane's signature check.  Rows are keyed by public key (keycache.h): key_rows of them (default 2 V + 32), so that requests
+        // signed by DIFFERENT validator sets share the table; V rows if the larger table does not fit.  No table at all: the generic
+        // per-signature kernel
+        for (uint32_t rows : {b->key_rows, V}) {
             void* q = nullptr;
-            if (hipMalloc(&q, bsxk_keytable_bytes(V)) == hipSuccess) {
-                if (hipMemset(q, 0, (size_t)V * 64) == hipSuccess) { l.dallocs.push_back(q); l.d_keytab = static_cast<uint8_t*>(q); }
-                else (void)hipFree(q);
-            } else {
-                (void)hipGetLastError();
-            }
+            if (hipMalloc(&q, bsxk_keytable_bytes(rows)) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (hipMemset(q, 0, (size_t)rows * 64) != hipSuccess) { (void)hipFree(q); continue; }
+            l.dallocs.push_back(q);
+            l.d_keytab = static_cast<uint8_t*>(q);
+            l.kc.init(V, rows);
+            RET(halloc(l, (size_t)rows * sizeof(bsx_validator), &l.h_rowkeys));
+            RET(dalloc(l, (size_t)rows * sizeof(bsx_validator), &l.d_rowkeys));
+            RET(halloc(l, (size_t)M * V * 4, &l.h_rows));
+            RET(dalloc(l, (size_t)M * V * 4, &l.d_rows));
+            break;
         }
         return BSX_OK;
     }
@@ -403,9 +413,12 @@ struct RangeKind : Kind {
         // the fixed-key table against this batch's keys, on the host: rows follow the FIRST request's validator set; slots of the
         // other requests whose key differs are counted (the signature check sizes — or skips — its generic-kernel pass from the count)
         const bsx_validator* h_tv = reinterpret_cast<const bsx_validator*>(l.h_small + S.tv);
-        bool keys_same = l.d_keytab && l.key_mirror_valid;
-        for (uint32_t i = 0; keys_same && i < V; i++) keys_same = memcmp(l.key_mirror.data() + 32 * (size_t)i, h_tv[i].pubkey, 32) == 0;
-        const uint64_t n_mismatch = l.d_keytab ? bsxh_key_mismatches(h_tv, R, V) : 0;
+        uint64_t n_mismatch = 0;
+        bool rows_identity = true;
+        if (l.d_keytab) {
+            rows_identity = l.kc.assign(h_tv, R, reinterpret_cast<uint32_t*>(l.h_rows), l.kc_dirty, &n_mismatch);
+            for (uint32_t q : l.kc_dirty) memcpy(l.h_rowkeys + (size_t)q * sizeof(bsx_validator), &l.kc.keys[(size_t)q * 32], 32);
+        }
         // A launch set of FEW requests is a latency problem: its commit check spreads over three streams (R decoding ‖ challenges ‖
         // tallies), as in bsx_header_range.  From 4 requests on the headers' upload (>= 4 MB) is the longest piece of the hashing chain,
         // the commit chain fits behind it on ONE stream, and every stream and event less is front-end time the other lanes' sets get
@@ -416,6 +429,9 @@ struct RangeKind : Kind {
         LHIP(hipMemcpyAsync(l.d_tv, l.h_small + S.tv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
         LHIP(hipMemcpyAsync(l.d_tv + (size_t)n * sizeof(bsx_validator), l.h_small + S.rv, (size_t)n * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
         LHIP(hipMemsetAsync(l.d_out + O.hst, 0, (size_t)M * 8, st));              // header + hint status words of every slot
+        if (l.d_keytab && !l.kc_dirty.empty())                                    // new keys: their rows' key records (the build compares against them)
+            LHIP(hipMemcpyAsync(l.d_rowkeys, l.h_rowkeys, (size_t)l.kc.N * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+        if (l.d_keytab && !rows_identity) LHIP(hipMemcpyAsync(l.d_rows, l.h_rows, (size_t)n * 4, hipMemcpyHostToDevice, st));
         LHIP(hipEventRecord(ev_c, st));
         // The headers: ONE copy per run of consecutive staged slots (normally one run = the whole batch).  Measured (tools/h2d_bench.hip):
         // page-locked copies of 1 MB reach 37 GB/s, of 4 MB 50, of 16 MB 55 of the 57 GB/s this PCIe link gives — a copy per request as
@@ -458,14 +474,12 @@ struct RangeKind : Kind {
         LHIP(bsxk_commit_tally(q4, tv, 2 * R, V, nullptr, nullptr, cres, nullptr));
         if (wide) LHIP(hipEventRecord(ev_f, s4));
         if (l.d_keytab) {
-            if (!keys_same) {
-                LHIP(bsxk_ed25519_keytable(sb, tv, V, l.d_keytab));
-                l.key_mirror.resize((size_t)V * 32);
-                for (uint32_t i = 0; i < V; i++) memcpy(l.key_mirror.data() + 32 * (size_t)i, h_tv[i].pubkey, 32);
-                l.key_mirror_valid = true;
-            }
+            // rows whose key changed are rebuilt (k_keytable_check compares every row's record with the key it should hold and rebuilds
+            // the ones that differ; an unchanged table launches nothing)
+            if (!l.kc_dirty.empty()) LHIP(bsxk_ed25519_keytable(sb, reinterpret_cast<const bsx_validator*>(l.d_rowkeys), l.kc.N, l.d_keytab));
             if (wide) LHIP(hipStreamWaitEvent(sb, ev_d, 0));
-            LHIP(bsxk_ed25519_verify_keyed(sb, tv, l.d_h, n, V, l.d_keytab, V, ctx->btab, l.d_ok, nullptr, l.d_rdec, (int64_t)n_mismatch));
+            LHIP(bsxk_ed25519_verify_keyed(sb, tv, l.d_h, n, V, l.d_keytab, l.kc.N, ctx->btab, l.d_ok, nullptr, l.d_rdec, (int64_t)n_mismatch,
+                                           rows_identity ? nullptr : reinterpret_cast<const uint32_t*>(l.d_rows)));
         } else {
             LHIP(bsxk_ed25519_verify(sb, tv, l.d_h, n, l.d_ok));
         }
@@ -710,7 +724,8 @@ int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher*
     if (!pow2(cfg->batch_size) || cfg->batch_size > BSX_MAX_BATCH) return fail(BSX_ERR_BAD_ARG, "BATCH_SIZE must be a power of two <= %d", BSX_MAX_BATCH);
     if (cfg->v_max == 0 || (int)cfg->v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", cfg->v_max, bsxk_tally_vmax());
     if (cfg->chain_id_len > 50) return fail(BSX_ERR_BAD_ARG, "chain_id: at most 50 bytes");
-    if (cfg->max_requests > 256 || cfg->n_lanes > 8 || cfg->window_us > 10000) return fail(BSX_ERR_BAD_ARG, "bsx_batcher_create: max_requests <= 256, n_lanes <= 8, window_us <= 10000");
+    if (cfg->max_requests > 256 || cfg->n_lanes > 8 || cfg->window_us > 10000 || cfg->key_rows > 65536)
+        return fail(BSX_ERR_BAD_ARG, "bsx_batcher_create: max_requests <= 256, n_lanes <= 8, window_us <= 10000, key_rows <= 65536");
     if (cfg->flags) return fail(BSX_ERR_BAD_ARG, "bsx_batcher_create: unknown flags 0x%x", cfg->flags);
     bsx_batcher* b = new bsx_batcher();
     b->ctx = ctx;
@@ -720,6 +735,7 @@ int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher*
     b->n_lanes = cfg->n_lanes ? cfg->n_lanes : 3;
     b->window_ns = (uint64_t)(cfg->window_us ? cfg->window_us : 50) * 1000;
     b->hpr = (uint64_t)b->J * b->B + 1;
+    b->key_rows = cfg->key_rows ? (cfg->key_rows < b->V ? b->V : cfg->key_rows) : 2 * b->V + 32;
     *out = b;
     return BSX_OK;
 }

@@ -77,7 +77,11 @@ hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, ui
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
 uint64_t bsxk_keytable_bytes(uint32_t);
 hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
-hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*, const void*, int64_t);
+// rows (optional, n u32): signature i is checked against table row rows[i] instead of row i % v_max (0xffffffff = no row: deferred to
+// the generic kernel) — validator sets that differ between the commits of a batch share ONE table whose rows are keyed by public key
+// (bsx_keycache, api_internal.h).  Whatever the map says, a lane verifies against a row only when the row's key IS its public key.
+hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*, const void*, int64_t,
+                                     const uint32_t* rows = nullptr);
 // active (enabled and signed) slots of commits 1.. whose public key differs from the first commit's slot of the same index: what a
 // fixed-key table built from the first commit's keys cannot serve (host-side compare; api.hip)
 uint64_t bsxh_key_mismatches(const bsx_validator* validators, uint64_t n_commits, uint32_t v_max);

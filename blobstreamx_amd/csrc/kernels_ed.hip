@@ -337,7 +337,7 @@ template <bool DEFER, bool BY_KEY, int SPLIT>
 __device__ __forceinline__ void verify_keyed_body(uint32_t block, uint32_t n_blocks, const bsx_validator* __restrict__ vals,
                                                   const uint8_t* __restrict__ hs, uint64_t n, uint32_t v_max,
                                                   const uint8_t* __restrict__ table, uint32_t n_keys, const int32_t* __restrict__ b_tab,
-                                                  uint8_t* __restrict__ ok_out, int32_t* __restrict__ scratch) {
+                                                  uint8_t* __restrict__ ok_out, int32_t* __restrict__ scratch, const uint32_t* __restrict__ rows) {
     constexpr uint32_t SIGS = ED_THREADS / SPLIT;                              // signatures per workgroup
     const uint32_t sub = threadIdx.x / SPLIT, part0 = threadIdx.x % SPLIT;
     uint64_t me;
@@ -368,7 +368,7 @@ __device__ __forceinline__ void verify_keyed_body(uint32_t block, uint32_t n_blo
         const uint4 h0 = hp[0], h1 = hp[1];
         h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
 
-        const uint32_t slot = (uint32_t)(me % v_max);
+        const uint32_t slot = rows ? rows[me] : (uint32_t)(me % v_max);    // rows: the caller's key -> table row map
         bool keyed = slot < n_keys;
         bool decodes = false;
         if (keyed) {
@@ -434,8 +434,8 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
                                                                      uint32_t v_max, const uint8_t* __restrict__ table,
                                                                      uint32_t n_keys, const int32_t* __restrict__ b_tab,
                                                                      uint8_t* __restrict__ ok_out,
-                                                                     int32_t* __restrict__ scratch) {
-    verify_keyed_body<DEFER, BY_KEY, SPLIT>(blockIdx.x, gridDim.x, vals, hs, n, v_max, table, n_keys, b_tab, ok_out, scratch);
+                                                                     int32_t* __restrict__ scratch, const uint32_t* __restrict__ rows) {
+    verify_keyed_body<DEFER, BY_KEY, SPLIT>(blockIdx.x, gridDim.x, vals, hs, n, v_max, table, n_keys, b_tab, ok_out, scratch, rows);
 }
 // A batch whose one-lane-per-signature waves come to a little MORE than a whole number per SIMD (2048 commits x 100 slots: 3200
 // waves on 1024 SIMDs) takes as long as the SIMDs with the extra wave: 4 chains where the average is 3.125.  Here the first
@@ -446,13 +446,14 @@ __global__ __launch_bounds__(ED_THREADS, 4) void k_ed25519_verify_keyed_mixed(co
                                                                            const uint8_t* __restrict__ hs, uint64_t n, uint32_t v_max,
                                                                            const uint8_t* __restrict__ table, uint32_t n_keys,
                                                                            const int32_t* __restrict__ b_tab, uint8_t* __restrict__ ok_out,
-                                                                           int32_t* __restrict__ scratch, uint32_t blocks_a, uint64_t commits_a) {
+                                                                           int32_t* __restrict__ scratch, uint32_t blocks_a, uint64_t commits_a,
+                                                                           const uint32_t* __restrict__ rows) {
     const uint64_t na = commits_a * v_max;
     if (blockIdx.x < blocks_a)
-        verify_keyed_body<true, true, 1>(blockIdx.x, blocks_a, vals, hs, na, v_max, table, n_keys, b_tab, ok_out, scratch);
+        verify_keyed_body<true, true, 1>(blockIdx.x, blocks_a, vals, hs, na, v_max, table, n_keys, b_tab, ok_out, scratch, rows);
     else
         verify_keyed_body<true, true, 4>(blockIdx.x - blocks_a, gridDim.x - blocks_a, vals + na, hs + na * 32, n - na, v_max, table, n_keys, b_tab,
-                                         ok_out + na, scratch + na * ED_SLOT_I32);
+                                         ok_out + na, scratch + na * ED_SLOT_I32, rows ? rows + na : nullptr);
 }
 
 // The small-batch form (a single proof: 100 signatures): latency is everything, and a third of a signature's dependent
@@ -466,7 +467,7 @@ constexpr int EL_SIGS = 16;
 __global__ __launch_bounds__(128) void k_ed25519_verify_keyed_small(const bsx_validator* __restrict__ vals, const uint8_t* __restrict__ hs,
                                                                   uint64_t n, uint32_t v_max, const uint8_t* __restrict__ table,
                                                                   uint32_t n_keys, const int32_t* __restrict__ b_tab,
-                                                                  uint8_t* __restrict__ ok_out) {
+                                                                  uint8_t* __restrict__ ok_out, const uint32_t* __restrict__ rows) {
     __shared__ int32_t rdec[EL_SIGS][21];                 // -x_R (10 limbs), y_R (10), decodes
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t sub = wave == 0 ? lane / 4 : lane, part0 = lane % 4;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(128) void k_ed25519_verify_keyed_small(const bsx_va
         const uint4* hp = reinterpret_cast<const uint4*>(hs + me * 32);
         const uint4 h0 = hp[0], h1 = hp[1];
         h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
-        const uint32_t slot = (uint32_t)(me % v_max);
+        const uint32_t slot = rows ? rows[me] : (uint32_t)(me % v_max);    // rows: the caller's key -> table row map
         keyed = slot < n_keys;
         if (keyed) {
             const uint4* kr = reinterpret_cast<const uint4*>(table + (uint64_t)slot * KT_REC_BYTES);
@@ -572,7 +573,8 @@ template <int SPLIT>
 __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed_proj(const bsx_validator* __restrict__ vals, const uint8_t* __restrict__ hs,
                                                                           uint64_t n, uint32_t v_max, const uint8_t* __restrict__ table,
                                                                           uint32_t n_keys, const int32_t* __restrict__ b_tab,
-                                                                          const int32_t* __restrict__ rdec, uint8_t* __restrict__ ok_out) {
+                                                                          const int32_t* __restrict__ rdec, uint8_t* __restrict__ ok_out,
+                                                                          const uint32_t* __restrict__ rows) {
     constexpr uint32_t SIGS = ED_THREADS / SPLIT;
     const uint32_t sub = threadIdx.x / SPLIT, part0 = threadIdx.x % SPLIT;
     const uint64_t me = (uint64_t)blockIdx.x * SIGS + sub;
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed_proj(con
     const uint4* hp = reinterpret_cast<const uint4*>(hs + me * 32);
     const uint4 h0 = hp[0], h1 = hp[1];
     h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
-    const uint32_t slot = (uint32_t)(me % v_max);
+    const uint32_t slot = rows ? rows[me] : (uint32_t)(me % v_max);    // rows: the caller's key -> table row map
     bool keyed = slot < n_keys;
     bool decodes = false;
     if (keyed) {
@@ -1269,7 +1271,7 @@ hipError_t bsxk_ed25519_decode_r(hipStream_t s, const bsx_validator* vals, uint6
 // batch-inversion scratch take the latency form (k_ed25519_verify_keyed_proj)
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
                                      const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch, const void* rdec,
-                                     int64_t n_deferred) {
+                                     int64_t n_deferred, const uint32_t* rows) {
     if (n == 0) return hipSuccess;
     const int32_t* b_tab = reinterpret_cast<const int32_t*>(btable + bt_entries_off());
     if (rdec && rdec != BSXK_ED_THROUGHPUT && !scratch && n < ED_SPLIT_BELOW) {
@@ -1278,8 +1280,8 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
         const bool s16 = env_ps ? env_ps == 16 : n <= 8192;
         const int32_t* rd = static_cast<const int32_t*>(rdec);
         BSX_NOTE_FORM(BSX_FORM_ED, 0x100u | (s16 ? 16u : 8u));
-        if (s16) hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<16>, dim3((uint32_t)((n + 3) / 4)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
-        else hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<8>, dim3((uint32_t)((n + 7) / 8)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok);
+        if (s16) hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<16>, dim3((uint32_t)((n + 3) / 4)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok, rows);
+        else hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<8>, dim3((uint32_t)((n + 7) / 8)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok, rows);
         BSX_LAUNCH_DEFERRED();
         return hipGetLastError();
     }
@@ -1322,7 +1324,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
                 const uint32_t blocks_b = (uint32_t)((wpk_b * v_max + 7) / 8 * 8);
                 BSX_NOTE_FORM(BSX_FORM_ED, 0x200u);
                 hipLaunchKernelGGL(k_ed25519_verify_keyed_mixed, dim3(blocks_a + blocks_b), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys,
-                                   b_tab, ok, scr, blocks_a, commits_a);
+                                   b_tab, ok, scr, blocks_a, commits_a, rows);
                 const uint32_t K = ed_fin_k(n);
                 const uint64_t lanes = (n + K - 1) / K;
                 hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
@@ -1334,14 +1336,14 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
 #define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_)                                                                        \
     do {                                                                                                                \
         BSX_NOTE_FORM(BSX_FORM_ED, 0x400u | (uint32_t)(SPLIT_) | ((BYKEY_) ? 0x10u : 0u) | ((DEFER_) ? 0x20u : 0u));    \
-        hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr); \
+        hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr, rows); \
     } while (0)
     // BSX_ED_SMALL=0 (experiments): no decode-R form for small batches
     static const bool small_form = bsx_knob("BSX_ED_SMALL", 1) != 0;
     if (split4 && !scr && !by_key && small_form) {
         BSX_NOTE_FORM(BSX_FORM_ED, 0x300u);
         hipLaunchKernelGGL(k_ed25519_verify_keyed_small, dim3((uint32_t)((n + EL_SIGS - 1) / EL_SIGS)), dim3(128), 0, s, vals, h, n, v_max, table,
-                           n_keys, b_tab, ok);
+                           n_keys, b_tab, ok, rows);
 #ifdef BSX_EXPERIMENTS
     } else if (split2) {
         if (by_key) BSX_LAUNCH_KEYED(true, true, 2); else BSX_LAUNCH_KEYED(true, false, 2);

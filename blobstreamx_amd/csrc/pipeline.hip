@@ -20,6 +20,7 @@
 #include "../../include/bsx_layout.h"
 #include "api_internal.h"
 #include "kernels.h"
+#include "keycache.h"
 
 using bsxapi::fail;
 using bsxapi::pow2;
@@ -38,6 +39,7 @@ constexpr uint32_t PIPE_HINT_LDS_PAD_COMPACT = 65536;   // compact pipeline: two
 constexpr uint64_t PIPE_HINT_THROTTLE_FROM_JOBS = 6144; // ... for chunks whose header hashing is long enough to hide the stretched hint
                                                         // (256 ranges: 1.22 -> 1.16 ms per step; 64 / 128 ranges lose 3 % with it)
 constexpr uint64_t PIPE_LATENCY_FORM_BELOW = 16384;     // signatures per chunk: at or below, the commit check's latency form
+constexpr uint32_t PIPE_KEY_ROWS_MAX = 8192;            // most rows of a chunk's fixed-key table (5.8 MB each: 47 GB of the 288)
 struct Chunk {
     uint32_t R = 0, RT = 0;                  // owned ranges / ranges whose job slice this rank computes, in this chunk
     uint64_t nh_main = 0, nh_skip = 0, nh_all = 0;
@@ -66,7 +68,13 @@ struct Chunk {
     uint8_t *commit_compact = nullptr, *skip_compact = nullptr;
     uint64_t *witness_commit = nullptr, *witness_skip = nullptr, *trees_commit = nullptr, *trees_skip = nullptr;
     bool fin_recorded = false, wit_pending = false, units_done_valid = false;
-    uint64_t n_key_mismatch = 0;             // active slots whose key differs from the chunk's first range's (bsx_pipeline_upload)
+    uint64_t n_key_mismatch = 0;             // active slots the fixed-key table has no row for (bsx_pipeline_upload): the generic kernel's
+    // the chunk's fixed-key table: rows keyed by public key (keycache.h), sized at upload for the distinct keys of the chunk's ranges
+    bsx_keycache kc;
+    uint32_t keytable_rows = 0;
+    uint8_t* rowkeys = nullptr;              // device: the rows' key records as the build kernel reads them (bsx_validator each)
+    uint32_t* rows = nullptr;                // device: [R][V] table row of every slot; unused while the map is the identity
+    bool rows_identity = true;
     hipEvent_t ev_finalized = nullptr, ev_units_done = nullptr;
     size_t compact_bytes = 0, records_bytes = 0, headers_bytes = 0;
     // state
@@ -209,7 +217,8 @@ int create_chunk(bsx_pipeline* p, Chunk& c) {
         RET(dalloc_t(p, (size_t)R * 2 * sizeof(bsx_header), &c.skip_headers_pp[q]));
     }
     if (p->with_commit && p->keyed) {
-        RET(dalloc_t(p, bsxk_keytable_bytes(V), &c.keytable));   // zeroed: no row to reuse yet
+        // the table itself is allocated by bsx_pipeline_upload, which knows how many distinct keys the chunk's ranges hold
+        RET(dalloc_t(p, (size_t)R * V * 4, &c.rows));
         // beside an expansion (ALU to spare, one step to finish in) and for a FEW ranges (nothing to fill the GPU with anyway: the
         // commit chain's latency is the step) the latency form — R decoded beside the challenges, 8 / 16 lanes per signature, projective
         // compare: ~0.1 ms where the least-work form (one lane per signature, batch inversion) is a 0.7 ms chain whatever the batch
@@ -309,8 +318,8 @@ int commit_part(bsx_pipeline* p, Chunk& c, hipStream_t st, bool prep, bool verif
     }
     if (!verify) return BSX_OK;
     if (p->keyed)   // latency form beside an expansion (ALU to spare, one step to finish in); least-work form in the compact pipeline
-        HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, V, p->ctx->btab, c.ok, c.ed_scratch, c.rdec ? c.rdec : BSXK_ED_THROUGHPUT,
-                                         (int64_t)c.n_key_mismatch));
+        HIPCHK(bsxk_ed25519_verify_keyed(st, vals, c.h, n, V, c.keytable, c.keytable_rows, p->ctx->btab, c.ok, c.ed_scratch, c.rdec ? c.rdec : BSXK_ED_THROUGHPUT,
+                                         (int64_t)c.n_key_mismatch, c.rows_identity ? nullptr : c.rows));
     else
         HIPCHK(bsxk_ed25519_verify(st, vals, c.h, n, c.ok));
     HIPCHK(bsxk_commit_tally(st, vals, R, V, c.target_hashes_pp[c.parity], c.ok, cres, cwp));
@@ -840,10 +849,54 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
             if (p->keyed) {
                 // Fixed-key Ed25519 tables: validator sets change HERE and nowhere else, so this is where the rows are compared with
                 // the new keys and rebuilt where they differ (k_keytable_check + k_table_entries; rows persist) — not once per step.
-                // Slots of the chunk's other ranges whose key is not the first range's are counted on the host: the step's
-                // signature check sizes (or skips) its generic-kernel pass from this count.
-                c.n_key_mismatch = bsxh_key_mismatches(in->target_validators + r0 * V, Rc, V);
-                HIPCHK(bsxk_ed25519_keytable(st, reinterpret_cast<const bsx_validator*>(c.validators), V, c.keytable));
+                // Rows are keyed by PUBLIC KEY (keycache.h): the ranges of a chunk may be signed by different validator sets (sets
+                // change along the chain: header_range.rs:42-48, fetcher.rs:60-87) and still share the table; it is sized for the
+                // chunk's distinct keys.  Only keys beyond PIPE_KEY_ROWS_MAX go to the generic kernel (counted: the step sizes that pass).
+                const bsx_validator* sets = in->target_validators + r0 * V;
+                uint32_t want = V;
+                {
+                    bsx_keycache probe;                       // distinct active keys of the chunk (a dry run of the map)
+                    probe.init(V, PIPE_KEY_ROWS_MAX);
+                    std::vector<uint32_t> tmp((size_t)Rc * V), d;
+                    (void)probe.assign(sets, Rc, tmp.data(), d, nullptr);
+                    uint32_t hi = V;
+                    for (uint32_t q : d) if (q + 1 > hi) hi = q + 1;
+                    want = hi;
+                }
+                if (want > c.keytable_rows) {                // a larger table: the old rows are gone with it
+                    if (c.keytable) {
+                        for (auto it = p->allocs.begin(); it != p->allocs.end(); ++it)
+                            if (*it == c.keytable) { p->allocs.erase(it); break; }
+                        (void)hipFree(c.keytable);
+                        c.keytable = nullptr;
+                    }
+                    if (c.rowkeys) {
+                        for (auto it = p->allocs.begin(); it != p->allocs.end(); ++it)
+                            if (*it == c.rowkeys) { p->allocs.erase(it); break; }
+                        (void)hipFree(c.rowkeys);
+                        c.rowkeys = nullptr;
+                    }
+                    const uint32_t rows = want + want / 8;    // head room: the next upload's few new keys need no new table
+                    RET(dalloc_t(p, bsxk_keytable_bytes(rows), &c.keytable));
+                    RET(dalloc_t(p, (size_t)rows * sizeof(bsx_validator), &c.rowkeys));
+                    c.keytable_rows = rows;
+                    c.kc.init(V, rows);
+                }
+                std::vector<uint32_t> rows_h((size_t)Rc * V), dirty;
+                uint64_t deferred = 0;
+                c.rows_identity = c.kc.assign(sets, Rc, rows_h.data(), dirty, &deferred);
+                c.n_key_mismatch = deferred;
+                if (!c.rows_identity) HIPCHK(hipMemcpyAsync(c.rows, rows_h.data(), rows_h.size() * 4, hipMemcpyHostToDevice, st));
+                if (!dirty.empty()) {
+                    std::vector<bsx_validator> rk(c.keytable_rows);
+                    memset(rk.data(), 0, rk.size() * sizeof(bsx_validator));
+                    for (uint32_t q = 0; q < c.keytable_rows; q++) memcpy(rk[q].pubkey, &c.kc.keys[(size_t)q * 32], 32);
+                    HIPCHK(hipMemcpyAsync(c.rowkeys, rk.data(), rk.size() * sizeof(bsx_validator), hipMemcpyHostToDevice, st));
+                    HIPCHK(bsxk_ed25519_keytable(st, reinterpret_cast<const bsx_validator*>(c.rowkeys), c.keytable_rows, c.keytable));
+                    HIPCHK(hipStreamSynchronize(st));        // rows_h / rk are this scope's
+                } else {
+                    HIPCHK(hipStreamSynchronize(st));
+                }
             }
         }
         HIPCHK(hipStreamSynchronize(st));      // `sk` and the caller's buffers are free again

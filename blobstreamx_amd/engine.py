@@ -65,7 +65,7 @@ class _Autotune(C.Structure):
 
 
 assert C.sizeof(_Autotune) == 104
-assert C.sizeof(_Config) == 112 and C.sizeof(_Inputs) == 48 and C.sizeof(_Results) == 48 and C.sizeof(_Timing) == 32
+assert C.sizeof(_Config) == 112 and C.sizeof(_Inputs) == 48 and C.sizeof(_Results) == 48 and C.sizeof(_Timing) == 64
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 

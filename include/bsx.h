@@ -872,7 +872,10 @@ typedef struct bsx_batcher_config {
     uint32_t chain_id_len;                  /* C::CHAIN_ID_BYTES (header_range.rs:42-43), at most 50 bytes */
     uint8_t chain_id[52];
     uint32_t flags;                         /* must be 0 */
-    uint32_t _reserved[3];
+    uint32_t key_rows;                      /* rows of each lane's fixed-key Ed25519 table (5.8 MB per row), keyed by PUBLIC KEY: requests signed by
+                                               different validator sets share it (validator sets change along the chain: fetcher.rs:60-87);
+                                               0 = 2 * v_max + 32; keys beyond its capacity in one launch set go to the generic kernel */
+    uint32_t _reserved[2];
 } bsx_batcher_config;                       /* sizeof == 96 */
 int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher** out);
 void bsx_batcher_destroy(bsx_batcher* b);  /* waits for the batches in flight; tickets not yet waited for are lost */

@@ -53,6 +53,16 @@ class ValidatorSet:
                                        _p(self.powers), _p(self.hash))
         assert rc == 0
 
+    def rotated(self, seed, n_replace):
+        """A copy with `n_replace` slots (chosen by `seed`) re-keyed and re-powered: the next validator set along the chain."""
+        import copy
+        o = copy.copy(self)
+        o.sk_seeds, o.pubkeys, o.powers, o.hash = self.sk_seeds.copy(), self.pubkeys.copy(), self.powers.copy(), np.zeros(32, np.uint8)
+        rc = lib().synth_validator_set_rotate(C.c_uint64(seed), C.c_uint32(self.v), C.c_uint32(n_replace), _p(o.sk_seeds), _p(o.pubkeys),
+                                              _p(o.powers), _p(o.hash))
+        assert rc == 0
+        return o
+
     def as_validators(self, v_max):
         """The set as bsx_validator slots without signatures (the `trusted` argument of header_range)."""
         out = np.zeros(v_max, T.VALIDATOR)
@@ -130,7 +140,10 @@ class Workload:
     """
 
     def __init__(self, config_index, n_ranges, nb_map_jobs, batch_size, v, v_max=None, n_blocks=None, mode="F",
-                 absent_permille=0, chain_id=CHAIN_ID, round=0, nil_permille=0):
+                 absent_permille=0, chain_id=CHAIN_ID, round=0, nil_permille=0, rotate_permille=0):
+        """rotate_permille = p: range r + 1 is signed by range r's validator set with p / 1000 of its slots re-keyed (at least one when
+        p > 0) — validator sets change along a chain (circuits/fetcher.rs:60-87 exists because they do); 1000 = every range its own set.
+        The trusted set of a range is its target set (one validators_hash per range's headers)."""
         J, B = nb_map_jobs, batch_size
         self.J, self.B, self.R, self.v = J, B, n_ranges, v
         self.v_max = v_max or v
@@ -140,13 +153,18 @@ class Workload:
         self.seed = seed
         self.hpr = J * B + 1
         self.valset = ValidatorSet(seed, v)
+        self.rotate_permille = rotate_permille
+        self.valsets = [self.valset]
+        for r in range(1, n_ranges):
+            n_rep = 0 if not rotate_permille else max(1, (v * rotate_permille + 999) // 1000)
+            self.valsets.append(self.valsets[-1].rotated(seed * 7919 + r, n_rep) if n_rep else self.valset)
         self.headers = np.zeros((n_ranges, self.hpr), T.HEADER)
         self.hashes = np.zeros((n_ranges, self.hpr, 32), np.uint8)
         self.ranges = np.zeros(n_ranges, T.SHARED_CTX)
         self.latest = np.zeros(n_ranges, np.uint64)
         self.first_height = np.zeros(n_ranges, np.uint64)
         def gen(r):      # chains are independent: generate them on a thread pool (the C call releases the GIL)
-            return chain(seed * 1000003 + r, self.hpr, self.valset.hash, start_height=START_HEIGHT + r * 10_000, chain_id=chain_id)
+            return chain(seed * 1000003 + r, self.hpr, self.valsets[r].hash, start_height=START_HEIGHT + r * 10_000, chain_id=chain_id)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
             chains = list(pool.map(gen, range(n_ranges)))
@@ -170,9 +188,17 @@ class Workload:
         bh = np.stack([self.hashes[r, idx[r]] for r in range(n_ranges)]).reshape(-1, 32)
         ts = (TIME0 + 12 * idx).astype(np.uint64).reshape(-1)
         self.commit_hashes = bh.copy()
-        self.validators = commits(seed ^ 0xC0FFEE, self.valset, self.v_max, heights, bh, ts, chain_id=chain_id,
-                                  absent_permille=absent_permille, round=round, nil_permille=nil_permille)
-        self.trusted = np.tile(self.valset.as_validators(self.v_max), (n_ranges, 1))
+        if not rotate_permille:
+            self.validators = commits(seed ^ 0xC0FFEE, self.valset, self.v_max, heights, bh, ts, chain_id=chain_id,
+                                      absent_permille=absent_permille, round=round, nil_permille=nil_permille)
+            self.trusted = np.tile(self.valset.as_validators(self.v_max), (n_ranges, 1))
+        else:                       # every range signed by ITS set
+            per = idx.shape[1]
+            parts = [commits((seed ^ 0xC0FFEE) + 31 * r, self.valsets[r], self.v_max, heights[r * per:(r + 1) * per], bh[r * per:(r + 1) * per],
+                             ts[r * per:(r + 1) * per], chain_id=chain_id, absent_permille=absent_permille, round=round, nil_permille=nil_permille)
+                     for r in range(n_ranges)]
+            self.validators = np.concatenate(parts, axis=0)
+            self.trusted = np.stack([self.valsets[r].as_validators(self.v_max) for r in range(n_ranges)])
 
     def input48(self, r):
         rg = self.ranges[r]

