@@ -881,6 +881,9 @@ int bsx_pipeline_upload(bsx_pipeline* p, const bsx_pipeline_inputs* in) {
                     RET(dalloc_t(p, (size_t)rows * sizeof(bsx_validator), &c.rowkeys));
                     c.keytable_rows = rows;
                     c.kc.init(V, rows);
+                    // dalloc zeroes with a null-stream memset, which this chunk's non-blocking stream does not wait for: drained here, or
+                    // the build below could be overtaken and wiped by it (the same trap as in bsx_pipeline_create)
+                    HIPCHK(hipDeviceSynchronize());
                 }
                 std::vector<uint32_t> rows_h((size_t)Rc * V), dirty;
                 uint64_t deferred = 0;
