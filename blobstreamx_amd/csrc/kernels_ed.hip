@@ -724,34 +724,33 @@ __device__ __forceinline__ int validator_leaf(const uint32_t pk[8], uint64_t pow
 // bools, leaves, the masked tree, sums, verdicts); mode 1: the trusted set inside the SKIP unit of range c (pubkeys, leaves, tree,
 // enabled bools, total power; signed_target / overlap are k_skip_check's).  Every byte of the groups named here is written on
 // every launch, so a resident unit never needs clearing.
-__global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator* __restrict__ vals, uint32_t v_max,
+// G commits per workgroup (round 5).  One commit per workgroup left its second wave after the leaves and three quarters of the first
+// idle through the narrow levels: 16 wave-compressions per commit of P = 128 leaves where the hashing needs 4.7.  With G = 4 commits
+// side by side (256 threads) every level's G * width nodes are dealt densely to the lanes — 256 / 128 / 64 / 32 / 16 / 8 / 4 nodes on
+// 4 / 2 / 1 / 1 ... waves: 7.5 wave-compressions per commit, the same 15-compression dependent chain.  n_commits: commits beyond it
+// (the last workgroup's tail) are skipped.  G = 1 is the form for P > 128 and for single commits.
+template <int G>
+__global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator* __restrict__ vals, uint32_t v_max, uint32_t n_commits,
                                                              const uint8_t* __restrict__ header_hashes,
                                                              const uint8_t* __restrict__ ok_in,
                                                              bsx_commit_result* __restrict__ results, bsxk_unit_dst wit) {
-    // dynamic LDS sized by the padded validator count P (launcher): nodes[2][P * 8] u32, then en[2][P] u8 — 8.4 KB at
+    // dynamic LDS sized by the padded validator count P (launcher): nodes[2][G * P * 8] u32, then en[2][G * P] u8 — 8.4 KB per commit at
     // V = 100 instead of the 33 KB of the 512-slot maximum, so that 2048 commits are resident at once (mode S)
     extern __shared__ uint32_t tl_lds[];
-    __shared__ unsigned long long s_total, s_signed, s_trusted, s_total_hi, s_total_lo;
-    __shared__ uint32_t s_nen, s_nsig, s_nbad, s_firstbad, s_nbadmsg;
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    const bsx_validator* cv = vals + (uint64_t)c * v_max;
+    __shared__ unsigned long long s_total[G], s_signed[G], s_trusted[G], s_total_hi[G], s_total_lo[G];
+    __shared__ uint32_t s_nen[G], s_nsig[G], s_nbad[G], s_firstbad[G], s_nbadmsg[G];
+    const uint32_t c0 = blockIdx.x * G, tid = threadIdx.x;
     uint32_t P = 1;
     while (P < v_max) P *= 2;
     uint32_t* const nodes0 = tl_lds;
-    uint8_t* const en0 = reinterpret_cast<uint8_t*>(tl_lds + 2 * P * 8);
-#define nodes(b, idx) nodes0[(b) * P * 8 + (idx)]
-#define en(b, idx) en0[(b) * P + (idx)]
+    uint8_t* const en0 = reinterpret_cast<uint8_t*>(tl_lds + 2 * G * P * 8);
+#define nodes(b, idx) nodes0[(b) * G * P * 8 + (idx)]
+#define en(b, idx) en0[(b) * G * P + (idx)]
     const uint32_t nthreads = blockDim.x;
-    if (tid == 0) { s_total = 0; s_signed = 0; s_trusted = 0; s_total_hi = 0; s_total_lo = 0; s_nen = 0; s_nsig = 0; s_nbad = 0; s_firstbad = 0xffffffffu; s_nbadmsg = 0; }
+    if (tid < G) { s_total[tid] = 0; s_signed[tid] = 0; s_trusted[tid] = 0; s_total_hi[tid] = 0; s_total_lo[tid] = 0; s_nen[tid] = 0; s_nsig[tid] = 0; s_nbad[tid] = 0; s_firstbad[tid] = 0xffffffffu; s_nbadmsg[tid] = 0; }
     __syncthreads();
-    uint32_t hh[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) hh[k] = header_hashes ? reinterpret_cast<const uint32_t*>(header_hashes + 32 * (uint64_t)c)[k] : 0u;
-    // witness destinations of this unit
+    // witness destinations
     const bool w_on = wit.base != nullptr, w_commit = w_on && wit.mode == 0;
-    uint8_t* const cw = w_on ? wit.base + (uint64_t)c * wit.stride : nullptr;
-    uint32_t* const WW = w_on ? reinterpret_cast<uint32_t*>(cw + wit.off_words) : nullptr;
-    uint8_t* const WB = w_on ? cw + wit.off_bools : nullptr;
     const uint32_t o_leaf = w_commit ? bsx_cm_off_leaf(v_max) : bsx_sk_off_leaf(v_max);
     const uint32_t o_lh = w_commit ? bsx_cm_off_leaf_hash(v_max) : bsx_sk_off_leaf_hash(v_max);
     const uint32_t o_inner = w_commit ? bsx_cm_off_inner(v_max) : bsx_sk_off_inner(v_max);
@@ -759,16 +758,32 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     const uint32_t o_root = w_commit ? bsx_cm_off_root(v_max) : bsx_sk_off_root(v_max);
     const uint32_t b_leaf_en = w_commit ? bsx_cm_b_leaf_enabled(v_max) : bsx_sk_b_leaf_enabled(v_max);
     const uint32_t b_node_en = w_commit ? bsx_cm_b_node_enabled(v_max) : bsx_sk_b_node_enabled(v_max);
-    if (w_commit && tid < 8) reinterpret_cast<uint32_t*>(cw + bsx_cm_off_header_hash())[tid] = hh[tid];
 
-    uint64_t total = 0, signedp = 0, trusted = 0;
-    uint64_t total_hi = 0, total_lo = 0;     // exact sum in two halves: the u64 `total` may wrap
-    uint32_t nen = 0, nsig = 0, nbad = 0, nbadmsg = 0;
-    for (uint32_t v = tid; v < P; v += nthreads) {
+    // leaves: leaf index li = g * P + v over the workgroup's G commits.  P is a multiple of 64 or below it: with G > 1 (P <= 128, a
+    // power of two >= 64 is not required) the lanes of a wave may span commits, so the per-commit sums go through LDS atomics per lane
+    // group: every lane adds its own contribution only when it has one (enabled slots), wave-reduced when the wave is uniform in g
+    for (uint32_t li = tid; li < (uint32_t)G * P; li += nthreads) {
+        const uint32_t g = G == 1 ? 0u : li / P, v = G == 1 ? li : li % P;
+        const uint32_t c = c0 + g;
+        const bool live = c < n_commits;
+        const bsx_validator* cv = vals + (uint64_t)(live ? c : 0) * v_max;
+        uint8_t* const cw = (w_on && live) ? wit.base + (uint64_t)c * wit.stride : nullptr;
+        uint32_t* const WW = cw ? reinterpret_cast<uint32_t*>(cw + wit.off_words) : nullptr;
+        uint8_t* const WB = cw ? cw + wit.off_bools : nullptr;
+        uint32_t hh[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) hh[k] = (header_hashes && live) ? reinterpret_cast<const uint32_t*>(header_hashes + 32 * (uint64_t)c)[k] : 0u;
+        if (w_commit && cw && v == 0) {
+            uint4* hd = reinterpret_cast<uint4*>(cw + bsx_cm_off_header_hash());
+            hd[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]); hd[1] = make_uint4(hh[4], hh[5], hh[6], hh[7]);
+        }
+        uint64_t total = 0, signedp = 0, trusted = 0;
+        uint64_t total_hi = 0, total_lo = 0;     // exact sum in two halves: the u64 `total` may wrap
+        uint32_t nen = 0, nsig = 0, nbad = 0, nbadmsg = 0;
         uint32_t pk[8];
         uint64_t power = 0;
         bool enabled = false;
-        if (v < v_max) {
+        if (live && v < v_max) {
             const uint4* rec = reinterpret_cast<const uint4*>(cv + v);
             const uint4 p0 = rec[0], p1 = rec[1], fl = rec[14];
             pk[0] = p0.x; pk[1] = p0.y; pk[2] = p0.z; pk[3] = p0.w; pk[4] = p1.x; pk[5] = p1.y; pk[6] = p1.z; pk[7] = p1.w;
@@ -802,7 +817,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
                 if (is_signed) {
                     nsig++;
                     sig = ok_in ? (ok_in[(uint64_t)c * v_max + v] == 1) : false;     // a deferred / pending marker never counts as valid
-                    if (!sig) { nbad++; atomicMin(&s_firstbad, v); }
+                    if (!sig) { nbad++; atomicMin(&s_firstbad[g], v); }
                     if (!msg) nbadmsg++;
                     if (sig && msg) { signedp += power; if (present) trusted += power; }
                 }
@@ -829,9 +844,9 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
         {
             const Digest lh = leaf_hash_1block(d, len);
 #pragma unroll
-            for (int k = 0; k < 8; k++) nodes(0, v * 8 + k) = lh.w[k];
-            en(0, v) = enabled ? 1 : 0;
-            if (w_on) {
+            for (int k = 0; k < 8; k++) nodes(0, li * 8 + k) = lh.w[k];
+            en(0, li) = enabled ? 1 : 0;
+            if (cw) {
                 if (v < v_max) {
                     // the leaf's bytes beyond its length are zero by construction (validator_leaf fills static positions)
                     uint4* ld = reinterpret_cast<uint4*>(cw + o_leaf + 48 * v);
@@ -844,72 +859,93 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
                 WB[b_leaf_en + v] = enabled ? 1 : 0;
             }
         }
-    }
-    // wave-level reduction, then one LDS atomic per wave
-    total = wave_sum_u64(total); signedp = wave_sum_u64(signedp); trusted = wave_sum_u64(trusted);
-    total_hi = wave_sum_u64(total_hi); total_lo = wave_sum_u64(total_lo);
-    nen = wave_sum_u32(nen); nsig = wave_sum_u32(nsig); nbad = wave_sum_u32(nbad); nbadmsg = wave_sum_u32(nbadmsg);
-    if ((tid & 63) == 0) {
-        atomicAdd(&s_total, (unsigned long long)total); atomicAdd(&s_signed, (unsigned long long)signedp);
-        atomicAdd(&s_trusted, (unsigned long long)trusted);
-        atomicAdd(&s_total_hi, (unsigned long long)total_hi); atomicAdd(&s_total_lo, (unsigned long long)total_lo);
-        atomicAdd(&s_nen, nen); atomicAdd(&s_nsig, nsig); atomicAdd(&s_nbad, nbad); atomicAdd(&s_nbadmsg, nbadmsg);
+        // the commit's sums: a wave whose 64 leaves belong to ONE commit (P >= 64: always) reduces with shuffles and issues one LDS
+        // atomic per counter; smaller trees add per lane
+        if (P >= 64) {
+            total = wave_sum_u64(total); signedp = wave_sum_u64(signedp); trusted = wave_sum_u64(trusted);
+            total_hi = wave_sum_u64(total_hi); total_lo = wave_sum_u64(total_lo);
+            nen = wave_sum_u32(nen); nsig = wave_sum_u32(nsig); nbad = wave_sum_u32(nbad); nbadmsg = wave_sum_u32(nbadmsg);
+            if ((tid & 63) == 0) {
+                atomicAdd(&s_total[g], (unsigned long long)total); atomicAdd(&s_signed[g], (unsigned long long)signedp);
+                atomicAdd(&s_trusted[g], (unsigned long long)trusted);
+                atomicAdd(&s_total_hi[g], (unsigned long long)total_hi); atomicAdd(&s_total_lo[g], (unsigned long long)total_lo);
+                atomicAdd(&s_nen[g], nen); atomicAdd(&s_nsig[g], nsig); atomicAdd(&s_nbad[g], nbad); atomicAdd(&s_nbadmsg[g], nbadmsg);
+            }
+        } else if (nen) {
+            atomicAdd(&s_total[g], (unsigned long long)total); atomicAdd(&s_signed[g], (unsigned long long)signedp);
+            atomicAdd(&s_trusted[g], (unsigned long long)trusted);
+            atomicAdd(&s_total_hi[g], (unsigned long long)total_hi); atomicAdd(&s_total_lo[g], (unsigned long long)total_lo);
+            atomicAdd(&s_nen[g], nen); atomicAdd(&s_nsig[g], nsig); atomicAdd(&s_nbad[g], nbad); atomicAdd(&s_nbadmsg[g], nbadmsg);
+        }
     }
     __syncthreads();
     int cur = 0;
     uint32_t level_off = 0;
-    // a wave beyond the level's width has no node left on this or any later level: it ends (a barrier counts the surviving waves),
-    // and its slot goes to the next commit's workgroup instead of idling through the narrow levels
+    // a wave beyond the level's nodes has none left on this or any later level: it ends (a barrier counts the surviving waves), and its
+    // slot goes to the next workgroup instead of idling through the narrow levels.  Node ni of a level = commit ni / width, node ni % width
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u);
     for (uint32_t width = P / 2; width >= 1; width /= 2) {
-        if (wave_base && wave_base >= width) return;
-        for (uint32_t t = tid; t < width; t += nthreads) {
+        if (wave_base && wave_base >= (uint32_t)G * width) return;
+        for (uint32_t ni = tid; ni < (uint32_t)G * width; ni += nthreads) {
+            const uint32_t g = G == 1 ? 0u : ni / width, t = G == 1 ? ni : ni % width;
+            const uint32_t src = g * (2 * width) + 2 * t;          // this level's children live densely: commit g's 2 * width nodes first
             Digest l, r;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { l.w[k] = nodes(cur, (2 * t) * 8 + k); r.w[k] = nodes(cur, (2 * t + 1) * 8 + k); }
-            const bool el = en(cur, 2 * t) != 0, er = en(cur, 2 * t + 1) != 0;
+            for (int k = 0; k < 8; k++) { l.w[k] = nodes(cur, src * 8 + k); r.w[k] = nodes(cur, (src + 1) * 8 + k); }
+            const bool el = en(cur, src) != 0, er = en(cur, src + 1) != 0;
             const Digest in = inner_hash(l, r);
             const Digest node = (el && er) ? in : l;
 #pragma unroll
-            for (int k = 0; k < 8; k++) nodes(cur ^ 1, t * 8 + k) = node.w[k];
-            en(cur ^ 1, t) = (el || er) ? 1 : 0;
-            if (w_on) {
+            for (int k = 0; k < 8; k++) nodes(cur ^ 1, ni * 8 + k) = node.w[k];
+            en(cur ^ 1, ni) = (el || er) ? 1 : 0;
+            if (w_on && c0 + g < n_commits) {
+                uint8_t* const cw = wit.base + (uint64_t)(c0 + g) * wit.stride;
                 uint4* di = reinterpret_cast<uint4*>(cw + o_inner + 32 * (level_off + t));
                 di[0] = make_uint4(bswap32(in.w[0]), bswap32(in.w[1]), bswap32(in.w[2]), bswap32(in.w[3]));
                 di[1] = make_uint4(bswap32(in.w[4]), bswap32(in.w[5]), bswap32(in.w[6]), bswap32(in.w[7]));
                 uint4* dn = reinterpret_cast<uint4*>(cw + o_node + 32 * (level_off + t));
                 dn[0] = make_uint4(bswap32(node.w[0]), bswap32(node.w[1]), bswap32(node.w[2]), bswap32(node.w[3]));
                 dn[1] = make_uint4(bswap32(node.w[4]), bswap32(node.w[5]), bswap32(node.w[6]), bswap32(node.w[7]));
-                WB[b_node_en + level_off + t] = (el || er) ? 1 : 0;
+                (cw + wit.off_bools)[b_node_en + level_off + t] = (el || er) ? 1 : 0;
             }
         }
         __syncthreads();
         cur ^= 1;
         level_off += width;
     }
-    if (w_on && tid < 8) reinterpret_cast<uint32_t*>(cw + o_root)[tid] = bswap32(nodes(cur, tid));
-    if (tid == 0) {
-        bsx_commit_result* o = results + c;
+    // the roots: node g of the last level.  P == 1 (a single slot): the leaf itself
+    if (tid < 8 * G) {
+        const uint32_t g = tid >> 3, k = tid & 7;
+        if (w_on && c0 + g < n_commits) reinterpret_cast<uint32_t*>(wit.base + (uint64_t)(c0 + g) * wit.stride + o_root)[k] = bswap32(nodes(cur, g * 8 + k));
+    }
+    if (tid < G && c0 + tid < n_commits) {
+        const uint32_t g = tid;
+        bsx_commit_result* o = results + c0 + g;
 #pragma unroll
-        for (int k = 0; k < 8; k++) reinterpret_cast<uint32_t*>(o->validators_hash)[k] = bswap32(nodes(cur, k));
-        o->total_power = s_total; o->signed_power = s_signed; o->trusted_signed_power = s_trusted;
-        o->n_enabled = s_nen; o->n_signed = s_nsig; o->n_bad_signature = s_nbad; o->first_bad_signature = s_firstbad;
-        o->n_bad_message = s_nbadmsg;
-        const bool overflow = (((unsigned __int128)s_total_hi << 32) + s_total_lo) > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER;
-        const bool two_thirds = !overflow && (unsigned __int128)s_signed * 3 > (unsigned __int128)s_total * 2;
+        for (int k = 0; k < 8; k++) reinterpret_cast<uint32_t*>(o->validators_hash)[k] = bswap32(nodes(cur, g * 8 + k));
+        o->total_power = s_total[g]; o->signed_power = s_signed[g]; o->trusted_signed_power = s_trusted[g];
+        o->n_enabled = s_nen[g]; o->n_signed = s_nsig[g]; o->n_bad_signature = s_nbad[g]; o->first_bad_signature = s_firstbad[g];
+        o->n_bad_message = s_nbadmsg[g];
+        const bool overflow = (((unsigned __int128)s_total_hi[g] << 32) + s_total_lo[g]) > (unsigned __int128)BSX_MAX_TOTAL_VOTING_POWER;
+        const bool two_thirds = !overflow && (unsigned __int128)s_signed[g] * 3 > (unsigned __int128)s_total[g] * 2;
         o->two_thirds_ok = two_thirds ? 1u : 0u;
         o->power_overflow = overflow ? 1u : 0u;
         o->_pad[0] = o->_pad[1] = o->_pad[2] = 0;
-        if (w_commit) {
-            uint32_t* wt = WW + bsx_cm_w_total(v_max);
-            wt[0] = (uint32_t)s_total; wt[1] = (uint32_t)(s_total >> 32);
-            wt[2] = (uint32_t)s_signed; wt[3] = (uint32_t)(s_signed >> 32);
-            wt[4] = (uint32_t)s_trusted; wt[5] = (uint32_t)(s_trusted >> 32);
-            uint8_t* t = WB + bsx_cm_b_tail(v_max);
-            t[0] = two_thirds; t[1] = overflow; t[2] = (s_nbad == 0 && s_nbadmsg == 0);
-        } else if (w_on) {
-            uint32_t* wt = WW + bsx_sk_w_total(v_max);
-            wt[0] = (uint32_t)s_total; wt[1] = (uint32_t)(s_total >> 32);
+        if (w_on) {
+            uint8_t* const cw = wit.base + (uint64_t)(c0 + g) * wit.stride;
+            uint32_t* const WW = reinterpret_cast<uint32_t*>(cw + wit.off_words);
+            uint8_t* const WB = cw + wit.off_bools;
+            if (w_commit) {
+                uint32_t* wt = WW + bsx_cm_w_total(v_max);
+                wt[0] = (uint32_t)s_total[g]; wt[1] = (uint32_t)(s_total[g] >> 32);
+                wt[2] = (uint32_t)s_signed[g]; wt[3] = (uint32_t)(s_signed[g] >> 32);
+                wt[4] = (uint32_t)s_trusted[g]; wt[5] = (uint32_t)(s_trusted[g] >> 32);
+                uint8_t* t = WB + bsx_cm_b_tail(v_max);
+                t[0] = two_thirds; t[1] = overflow; t[2] = (s_nbad[g] == 0 && s_nbadmsg[g] == 0);
+            } else {
+                uint32_t* wt = WW + bsx_sk_w_total(v_max);
+                wt[0] = (uint32_t)s_total[g]; wt[1] = (uint32_t)(s_total[g] >> 32);
+            }
         }
     }
 #undef nodes
@@ -1370,11 +1406,18 @@ hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t 
     if (!n_commits) return hipSuccess;
     uint32_t P = 1;
     while (P < v_max) P *= 2;
-    // a commit of <= 128 validator slots is two waves' worth of leaves: a 128-thread workgroup (and 8.4 KB of LDS) lets twice
-    // as many commits be resident; the tree is a latency chain either way
-    const uint32_t threads = P <= 128 ? 128 : TL_THREADS;
     const bsxk_unit_dst w = wit ? *wit : bsxk_unit_dst{nullptr, 0, 0, 0, 0};
-    hipLaunchKernelGGL(k_commit_tally, dim3(n_commits), dim3(threads), 2 * P * 8 * 4 + 2 * P, s, vals, v_max, header_hashes, ok, results, w);
+    // up to 128 validator slots and at least four commits: four commits per 256-thread workgroup, the levels of their four trees dealt
+    // densely to the lanes (7.5 wave-compressions per commit instead of 16); a commit of <= 128 slots alone is two waves' worth of
+    // leaves: a 128-thread workgroup; larger sets: one commit per 256 threads.  The tree is a latency chain either way
+    if (P <= 128 && n_commits >= 4) {
+        constexpr int G = 4;
+        hipLaunchKernelGGL(k_commit_tally<G>, dim3((n_commits + G - 1) / G), dim3(TL_THREADS), G * (2 * P * 8 * 4 + 2 * P), s, vals, v_max, n_commits,
+                           header_hashes, ok, results, w);
+    } else {
+        const uint32_t threads = P <= 128 ? 128 : TL_THREADS;
+        hipLaunchKernelGGL(k_commit_tally<1>, dim3(n_commits), dim3(threads), 2 * P * 8 * 4 + 2 * P, s, vals, v_max, n_commits, header_hashes, ok, results, w);
+    }
     return hipGetLastError();
 }
 hipError_t bsxk_skip_check(hipStream_t s, uint32_t n_ranges, uint32_t v_max, const bsx_shared_ctx* ranges, const bsx_header* headers,

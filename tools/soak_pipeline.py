@@ -90,7 +90,7 @@ def main():
         R = E * int(rng.integers(1, 5)); witness = bool(rng.integers(0, 2)) and J * B <= 1024
         n_blocks = int(rng.integers(1, J * B + 1)) if rng.integers(0, 3) else J * B
         w = synth.Workload(int(rng.integers(1, 1 << 20)), R, J, B, v=V, n_blocks=n_blocks, absent_permille=int(rng.choice([0, 0, 100])),
-                           nil_permille=int(rng.choice([0, 0, 50])))
+                           nil_permille=int(rng.choice([0, 0, 50])), rotate_permille=int(rng.choice([0, 0, 50, 300, 1000])))   # round 5: drifting validator sets
         what = tamper(rng, w, R, V, J, B)
         p = Pipeline(J, B, V, R, n_chunks=E, n_sets=K, with_witness=witness)
         p.upload_workload(w)
