@@ -73,4 +73,90 @@ BSX_HDI uint64_t gl_pow7(uint64_t x) {
     return gl_mul(x3, x4);
 }
 
+// ---- hand-written gfx950 body (round 5): THREE independent multiplications per call, interleaved instruction by instruction.
+// What it buys over the compiler's gl_mul (tools/glmul_asm_bench.hip: 2.17 against 1.87 T multiplications/s, +16 %, same results):
+//   * the reduction's 64-bit adds / subs are v_add_co / v_addc pairs whose carry is USED — the compiler never keeps a carry-out: it
+//     re-derives every one with v_cmp_*_u64 + v_cndmask (4 half-rate compares and 8 instructions per multiplication);
+//   * hi_lo * (2^32 - 1) + t0 is ONE v_mad_u64_u32 with the 64-bit addend and its own carry-out (the compiler: a multiply-add
+//     with addend 0, a 64-bit add and a compare);
+//   * every VALU write of an SGPR carry sits two instructions in front of its reader (the gfx940 VALU-writes-SGPR -> VALU-reads
+//     hazard): no s_nop, where the compiler's schedule of ONE dependent chain pays 2-3 per multiplication.
+// Sub-registers of a 64-bit operand cannot be named in inline asm, so the blocks are split where a half is read on its own (the
+// compiler only renames registers there).  Device only; the host compiles the portable gl_mul (tests/hostcheck).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSX_GL_MUL3_ASM 1
+__device__ __forceinline__ void gl_mul3(uint64_t& x0, uint64_t& x1, uint64_t& x2, uint64_t y0, uint64_t y1, uint64_t y2) {
+    uint64_t P0, Q0, R0, H0, Z0, C0, P1, Q1, R1, H1, Z1, C1, P2, Q2, R2, H2, Z2, C2;
+    const uint32_t a00 = (uint32_t)x0, a01 = (uint32_t)(x0 >> 32), b00 = (uint32_t)y0, b01 = (uint32_t)(y0 >> 32);
+    const uint32_t a10 = (uint32_t)x1, a11 = (uint32_t)(x1 >> 32), b10 = (uint32_t)y1, b11 = (uint32_t)(y1 >> 32);
+    const uint32_t a20 = (uint32_t)x2, a21 = (uint32_t)(x2 >> 32), b20 = (uint32_t)y2, b21 = (uint32_t)(y2 >> 32);
+#define BSX_MAD0(P, C, a, b) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(P), "=s"(C) : "v"(a), "v"(b))
+#define BSX_MADZ(D, C, a, b, Z) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(D), "=s"(C) : "v"(a), "v"(b), "v"(Z))
+    BSX_MAD0(P0, C0, a00, b00); BSX_MAD0(P1, C1, a10, b10); BSX_MAD0(P2, C2, a20, b20);                     // a0 b0
+    Z0 = (uint32_t)(P0 >> 32); Z1 = (uint32_t)(P1 >> 32); Z2 = (uint32_t)(P2 >> 32);
+    BSX_MADZ(Q0, C0, a00, b01, Z0); BSX_MADZ(Q1, C1, a10, b11, Z1); BSX_MADZ(Q2, C2, a20, b21, Z2);         // a0 b1 + hi(a0 b0)
+    Z0 = (uint32_t)Q0; Z1 = (uint32_t)Q1; Z2 = (uint32_t)Q2;
+    BSX_MADZ(R0, C0, a01, b00, Z0); BSX_MADZ(R1, C1, a11, b10, Z1); BSX_MADZ(R2, C2, a21, b20, Z2);         // a1 b0 + lo(Q): word 1
+    Z0 = (uint32_t)(Q0 >> 32); Z1 = (uint32_t)(Q1 >> 32); Z2 = (uint32_t)(Q2 >> 32);
+    BSX_MADZ(H0, C0, a01, b01, Z0); BSX_MADZ(H1, C1, a11, b11, Z1); BSX_MADZ(H2, C2, a21, b21, Z2);         // a1 b1 + hi(Q)
+#undef BSX_MAD0
+#undef BSX_MADZ
+    H0 += (uint32_t)(R0 >> 32); H1 += (uint32_t)(R1 >> 32); H2 += (uint32_t)(R2 >> 32);                    // words 2, 3
+    uint32_t l00 = (uint32_t)P0, l01 = (uint32_t)R0, l10 = (uint32_t)P1, l11 = (uint32_t)R1, l20 = (uint32_t)P2, l21 = (uint32_t)R2;
+    const uint32_t h00 = (uint32_t)H0, h01 = (uint32_t)(H0 >> 32), h10 = (uint32_t)H1, h11 = (uint32_t)(H1 >> 32), h20 = (uint32_t)H2, h21 = (uint32_t)(H2 >> 32);
+    uint32_t m0, m1, m2;
+    // t0 = lo - hi_hi (2^96 = -1); a borrow wrapped by 2^64 = p + EPS: give EPS back
+    asm volatile(
+        "v_sub_co_u32 %0, %9, %0, %12\n\t"
+        "v_sub_co_u32 %2, %10, %2, %13\n\t"
+        "v_sub_co_u32 %4, %11, %4, %14\n\t"
+        "v_subbrev_co_u32 %1, %9, 0, %1, %9\n\t"
+        "v_subbrev_co_u32 %3, %10, 0, %3, %10\n\t"
+        "v_subbrev_co_u32 %5, %11, 0, %5, %11\n\t"
+        "v_cndmask_b32 %6, 0, -1, %9\n\t"
+        "v_cndmask_b32 %7, 0, -1, %10\n\t"
+        "v_cndmask_b32 %8, 0, -1, %11\n\t"
+        "v_sub_co_u32 %0, %9, %0, %6\n\t"
+        "v_sub_co_u32 %2, %10, %2, %7\n\t"
+        "v_sub_co_u32 %4, %11, %4, %8\n\t"
+        "v_subbrev_co_u32 %1, %9, 0, %1, %9\n\t"
+        "v_subbrev_co_u32 %3, %10, 0, %3, %10\n\t"
+        "v_subbrev_co_u32 %5, %11, 0, %5, %11\n\t"
+        : "+v"(l00), "+v"(l01), "+v"(l10), "+v"(l11), "+v"(l20), "+v"(l21), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&s"(C0), "=&s"(C1), "=&s"(C2)
+        : "v"(h01), "v"(h11), "v"(h21));
+    const uint64_t T0 = (uint64_t)l00 | ((uint64_t)l01 << 32), T1 = (uint64_t)l10 | ((uint64_t)l11 << 32), T2 = (uint64_t)l20 | ((uint64_t)l21 << 32);
+    // U = hi_lo * EPS + t0, carry out of the multiply-add itself (hi_lo * EPS <= 2^64 - 2^33 + 1: one wrap at most)
+    uint64_t U0, U1, U2;
+    asm volatile("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(U0), "=s"(C0) : "v"(h00), "v"(T0));
+    asm volatile("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(U1), "=s"(C1) : "v"(h10), "v"(T1));
+    asm volatile("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(U2), "=s"(C2) : "v"(h20), "v"(T2));
+    uint32_t u00 = (uint32_t)U0, u01 = (uint32_t)(U0 >> 32), u10 = (uint32_t)U1, u11 = (uint32_t)(U1 >> 32), u20 = (uint32_t)U2, u21 = (uint32_t)(U2 >> 32);
+    asm volatile(
+        "v_cndmask_b32 %6, 0, -1, %9\n\t"
+        "v_cndmask_b32 %7, 0, -1, %10\n\t"
+        "v_cndmask_b32 %8, 0, -1, %11\n\t"
+        "v_add_co_u32 %0, %9, %0, %6\n\t"
+        "v_add_co_u32 %2, %10, %2, %7\n\t"
+        "v_add_co_u32 %4, %11, %4, %8\n\t"
+        "v_addc_co_u32 %1, %9, 0, %1, %9\n\t"
+        "v_addc_co_u32 %3, %10, 0, %3, %10\n\t"
+        "v_addc_co_u32 %5, %11, 0, %5, %11\n\t"
+        : "+v"(u00), "+v"(u01), "+v"(u10), "+v"(u11), "+v"(u20), "+v"(u21), "=&v"(m0), "=&v"(m1), "=&v"(m2), "+s"(C0), "+s"(C1), "+s"(C2));
+    x0 = (uint64_t)u00 | ((uint64_t)u01 << 32);
+    x1 = (uint64_t)u10 | ((uint64_t)u11 << 32);
+    x2 = (uint64_t)u20 | ((uint64_t)u21 << 32);
+}
+// x^7 of three elements: x2 = x x, x3 = x2 x, x4 = x2 x2, x7 = x3 x4 (16 multiplications of a full round's 48 per call of four)
+__device__ __forceinline__ void gl_pow7_3(uint64_t& a, uint64_t& b, uint64_t& c) {
+    uint64_t a2 = a, b2 = b, c2 = c;
+    gl_mul3(a2, b2, c2, a, b, c);
+    uint64_t a3 = a2, b3 = b2, c3 = c2;
+    gl_mul3(a3, b3, c3, a, b, c);
+    uint64_t a4 = a2, b4 = b2, c4 = c2;
+    gl_mul3(a4, b4, c4, a2, b2, c2);
+    gl_mul3(a3, b3, c3, a4, b4, c4);
+    a = a3; b = b3; c = c3;
+}
+#endif
+
 }  // namespace bsx

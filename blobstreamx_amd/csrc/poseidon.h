@@ -133,19 +133,31 @@ BSX_HDI void poseidon_partial_rounds(uint64_t s[12], const uint64_t* rc) {
     for (int i = 1; i < 12; i++) s[i] = poseidon_recombine(a0[i], a1[i], a2[i]);
 }
 
+// add the round's constants, x^7 on all 12 lanes.  On the device the twelve S-boxes go through the hand-written triple multiplication
+// (goldilocks.h gl_mul3: three independent chains interleaved), four triples per round
+BSX_HDI void poseidon_full_sbox(uint64_t s[12], const uint64_t* rc) {
+#ifdef BSX_GL_MUL3_ASM
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_canon(s[i], rc[i]);
+#pragma unroll
+    for (int i = 0; i < 12; i += 3) gl_pow7_3(s[i], s[i + 1], s[i + 2]);
+#else
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_canon(s[i], rc[i]));
+#endif
+}
+
 // rc: the 360 round constants, round-major
 BSX_HDI void poseidon_permute(uint64_t s[12], const uint64_t* rc) {
     int r = 0;
     for (int k = 0; k < POSEIDON_FULL_HALF; k++, r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_canon(s[i], rc[12 * r + i]));
+        poseidon_full_sbox(s, rc + 12 * r);
         poseidon_mds(s);
     }
     poseidon_partial_rounds(s, rc);
     r += POSEIDON_PARTIAL;
     for (int k = 0; k < POSEIDON_FULL_HALF; k++, r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_canon(s[i], rc[12 * r + i]));
+        poseidon_full_sbox(s, rc + 12 * r);
         poseidon_mds(s);
     }
 }
