@@ -173,8 +173,8 @@ def verify_commits(validators, header_hashes, device=0, want_witness=False):
     res = np.zeros(n, T.COMMIT_RESULT)
     ok = np.zeros((n, vmax), np.uint8)
     wit = np.zeros((n, int(T.commit_layout(vmax)["n_elements"])), np.uint64) if want_witness else None
-    _lib.check(_lib.lib().bsx_verify_commits(_lib.context(device), _lib.p(v), C.c_uint32(n), C.c_uint32(vmax), _lib.p(hh),
-                                             _lib.p(res), _lib.p(ok), _lib.p(wit)))
+    _lib.check(_lib.lib().bsx_verify_commits_cap(_lib.context(device), _lib.p(v), C.c_uint32(n), C.c_uint32(vmax), _lib.p(hh),
+                                                 _lib.p(res), _lib.p(ok), _lib.p(wit), C.c_uint64(wit.size if wit is not None else 0)))
     return (res, ok, wit) if want_witness else (res, ok)
 
 
@@ -203,9 +203,9 @@ class CombinedStepCircuit:
         res = np.zeros(1, T.COMMIT_RESULT)
         cid = np.frombuffer(self.chain_id, np.uint8).copy() if self.chain_id else None
         wit = np.zeros(T.next_header_witness_elements(self.V), np.uint64) if want_witness else None
-        self.last_rc = _lib.check(_lib.lib().bsx_next_header(_lib.context(self.device), _lib.p(inp), _lib.p(ph), _lib.p(nh), C.c_uint64(latest_block),
-                                                             _lib.p(nv), C.c_uint32(self.V), _lib.p(cid), C.c_uint32(len(self.chain_id)), _lib.p(out),
-                                                             _lib.p(res), _lib.p(wit)), allow=allow)
+        self.last_rc = _lib.check(_lib.lib().bsx_next_header_cap(_lib.context(self.device), _lib.p(inp), _lib.p(ph), _lib.p(nh), C.c_uint64(latest_block),
+                                                                 _lib.p(nv), C.c_uint32(self.V), _lib.p(cid), C.c_uint32(len(self.chain_id)), _lib.p(out),
+                                                                 _lib.p(res), _lib.p(wit), C.c_uint64(wit.size if wit is not None else 0)), allow=allow)
         return (out.tobytes(), res[0], wit) if want_witness else (out.tobytes(), res[0])
 
 
@@ -278,13 +278,13 @@ class CombinedSkipCircuit:
             wit = self._witness_buffer(T.header_range_witness_elements(self.J, self.B, self.V))
         if getattr(self, "_cid", None) is None:         # per-object constants of the call, marshalled once
             self._cid = np.frombuffer(self.chain_id, np.uint8).copy() if self.chain_id else None
-            self._fixed = (_lib.lib().bsx_header_range, _lib.context(self.device), C.c_uint32(self.J), C.c_uint32(self.B), C.c_uint32(self.V),
+            self._fixed = (_lib.lib().bsx_header_range_cap, _lib.context(self.device), C.c_uint32(self.J), C.c_uint32(self.B), C.c_uint32(self.V),
                            _lib.p(self._cid), C.c_uint32(len(self.chain_id)))
         fn, ctx, cJ, cB, cV, cid, cidn = self._fixed
         self.last_rc = _lib.check(fn(
             ctx, cJ, cB, _lib.p(_b(input48, 48)), _lib.p(fetcher.headers),
             C.c_uint64(fetcher.first_height), C.c_uint64(fetcher.headers.size), C.c_uint64(fetcher.latest_block), _lib.p(tv),
-            _lib.p(rv), cV, cid, cidn, _lib.p(out), _lib.p(res), _lib.p(wit)), allow=allow)
+            _lib.p(rv), cV, cid, cidn, _lib.p(out), _lib.p(res), _lib.p(wit), C.c_uint64(wit.size if wit is not None else 0)), allow=allow)
         return out.tobytes(), res[0], wit
 
 

@@ -1422,6 +1422,45 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     return rc;
 }
 
+// capacity-checked forms: the witness buffer's size is part of the call (the round-4 witnesses are larger than round 3's)
+int bsx_header_range_cap(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const bsx_header* headers,
+                         uint64_t first_height, uint64_t n_headers, uint64_t latest_block, const bsx_validator* target_validators,
+                         const bsx_validator* trusted_validators, uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len,
+                         uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness, uint64_t witness_capacity_elements) {
+    if (witness) {
+        const uint64_t need = bsx_header_range_witness_elements(nb_map_jobs, batch_size, v_max);
+        if (!need) return fail(BSX_ERR_BAD_ARG, "bsx_header_range_cap: invalid circuit shape");
+        if (witness_capacity_elements < need)
+            return fail(BSX_ERR_BAD_ARG, "witness buffer holds %llu elements, the whole-circuit witness needs %llu (map jobs + reduce nodes + COMMIT + SKIP units)",
+                        (unsigned long long)witness_capacity_elements, (unsigned long long)need);
+    }
+    return bsx_header_range(ctx, nb_map_jobs, batch_size, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, v_max,
+                            chain_id, chain_id_len, output64, out_commit, witness);
+}
+int bsx_verify_commits_cap(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n_commits, uint32_t v_max, const uint8_t* header_hashes,
+                           bsx_commit_result* out_results, uint8_t* out_sig_ok, uint64_t* witness, uint64_t witness_capacity_elements) {
+    if (witness) {
+        if (v_max == 0 || (int)v_max > bsxk_tally_vmax()) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+        const uint64_t need = (uint64_t)n_commits * bsx_commit_layout(v_max).n_elements;
+        if (witness_capacity_elements < need)
+            return fail(BSX_ERR_BAD_ARG, "witness buffer holds %llu elements, %u COMMIT units need %llu", (unsigned long long)witness_capacity_elements, n_commits,
+                        (unsigned long long)need);
+    }
+    return bsx_verify_commits(ctx, validators, n_commits, v_max, header_hashes, out_results, out_sig_ok, witness);
+}
+int bsx_next_header_cap(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header, uint64_t latest_block,
+                        const bsx_validator* next_validators, uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64],
+                        bsx_commit_result* out_commit, uint64_t* witness, uint64_t witness_capacity_elements) {
+    if (witness) {
+        const uint64_t need = bsx_next_header_witness_elements(v_max);
+        if (!need) return fail(BSX_ERR_UNSUPPORTED, "v_max %u not in 1..%d", v_max, bsxk_tally_vmax());
+        if (witness_capacity_elements < need)
+            return fail(BSX_ERR_BAD_ARG, "witness buffer holds %llu elements, COMMIT unit + STEP unit need %llu", (unsigned long long)witness_capacity_elements,
+                        (unsigned long long)need);
+    }
+    return bsx_next_header(ctx, input40, prev_header, next_header, latest_block, next_validators, v_max, chain_id, chain_id_len, output64, out_commit, witness);
+}
+
 // CombinedStepCircuit::define (circuits/next_header.rs:25-46) as ONE enqueue: header hashes, the commit check of the next
 // header's validator set (challenges, fixed-key Ed25519, tally + validator-set hash), the header-field inclusion proofs, the step
 // conditions and prove_next_header_data_commitment (k_step_check) all run on the device; the host decodes two status words.

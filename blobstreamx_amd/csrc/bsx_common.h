@@ -13,6 +13,18 @@
 #define BSX_HD_NOINLINE static __attribute__((noinline))
 #endif
 
+// The device code is written for gfx950 (CDNA4) ONLY and relies on three of its properties:
+//   * s_barrier counts the waves of a workgroup that are still alive: k_batch_finish / k_commit_tally let whole waves RETURN before
+//     later __syncthreads() of their workgroup (divergent barrier participation is undefined in the portable HIP model);
+//   * global memory serves misaligned dword / dwordx4 accesses (unaligned-access mode; tools/unaligned_test.hip): the 2-byte aligned
+//     proof records of the packed witness image move as single 16-byte loads and stores;
+//   * wave64, v_bitop3 / v_alignbit / v_mad_u64_u32 rates as measured.
+// Every launch form that depends on them is pinned by tests over all shapes (tests/test_gpu_parity.py B = 1 .. 256,
+// tests/test_gpu_units.py V = 1 .. 512).  There is no portable fallback by design: another target must not compile this silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libbsx device code is gfx950-only (wave-exit before s_barrier, unaligned global access): build with --offload-arch=gfx950"
+#endif
+
 namespace bsx {
 
 // ({hi,lo} >> (8*bytes)) & 0xffffffff — compiles to one v_alignbit_b32 / v_alignbyte_b32

@@ -345,6 +345,24 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
                      const uint8_t* chain_id, uint32_t chain_id_len,
                      uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness);
 
+/* Capacity-checked forms.  Round 4 APPENDED the COMMIT and SKIP / STEP units to the witnesses of bsx_header_range,
+ * bsx_next_header and bsx_verify_commits: a host that still sizes its buffer the round-3 way (map jobs + reduce nodes) would be
+ * overrun by the trailing device-to-host copies.  These take the buffer's capacity in u64 elements and fail with BSX_ERR_BAD_ARG —
+ * before anything is enqueued — when it is smaller than bsx_header_range_witness_elements / bsx_next_header_witness_elements /
+ * n_commits * bsx_commit_witness_layout(v_max).n_elements.  New hosts should bind these. */
+int bsx_header_range_cap(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48],
+                         const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,
+                         const bsx_validator* target_validators, const bsx_validator* trusted_validators, uint32_t v_max,
+                         const uint8_t* chain_id, uint32_t chain_id_len,
+                         uint8_t output64[64], bsx_commit_result* out_commit, uint64_t* witness, uint64_t witness_capacity_elements);
+int bsx_next_header_cap(bsx_ctx* ctx, const uint8_t input40[40], const bsx_header* prev_header, const bsx_header* next_header,
+                        uint64_t latest_block, const bsx_validator* next_validators, uint32_t v_max,
+                        const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit,
+                        uint64_t* witness, uint64_t witness_capacity_elements);
+int bsx_verify_commits_cap(bsx_ctx* ctx, const bsx_validator* validators, uint32_t n_commits, uint32_t v_max,
+                           const uint8_t* header_hashes, bsx_commit_result* out_results, uint8_t* out_sig_ok,
+                           uint64_t* witness, uint64_t witness_capacity_elements);
+
 /* ------------------------------------------------------------------ wire-format ingest
  * Tendermint RPC JSON -> the packed layouts above; host-side byte formatting only (works without a GPU).
  * Replaces serde + tendermint-rs decoding at circuits/input.rs:19-27,67-110,120-145 and circuits/fetcher.rs:44-58,89-132;
@@ -491,7 +509,7 @@ int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
  * d_table persists between calls: its first n_keys * 64 bytes (the key records) must be ZERO before the first call;
  * afterwards bsx_dev_ed25519_keytable rebuilds only the rows whose public key (or n_keys) changed since the previous call
  * on the same buffer — a validator set is stable for hours, so steady-state calls cost one key compare per row.  Zero the
- * key records again (or set BSX_KEYTABLE_REUSE=0) to force a rebuild. */
+ * key records again to force a rebuild. */
 uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys);
 int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys,
                              void* d_table);

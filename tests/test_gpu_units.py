@@ -264,3 +264,35 @@ def test_mode_s_commit_units_vs_oracle(n_commits, v, v_max, world):
         assert fold["n_commits"] == sh.n
         del sh
         torch.cuda.empty_cache()
+
+
+def test_capacity_checked_entry_points_refuse_a_round_3_sized_buffer():
+    """the witnesses of bsx_header_range / bsx_next_header / bsx_verify_commits grew in round 4 (COMMIT + SKIP / STEP units
+    appended).  The *_cap forms take the buffer's capacity and fail with BSX_ERR_BAD_ARG before anything runs when it is the round-3
+    size (map jobs + reduce nodes only) — instead of overrunning the host buffer."""
+    import ctypes as C
+    from blobstreamx_amd import _lib
+    J, B, V = 2, 8, 5
+    w = synth.Workload(77, 1, J, B, v=V)
+    L, ctx = _lib.lib(), _lib.context(0)
+    ml, rl = T.map_layout(B), T.reduce_layout()
+    old = J * int(ml["n_elements"]) + (J - 1) * int(rl["n_elements"])          # what a round-3 host allocated
+    need = T.header_range_witness_elements(J, B, V)
+    assert old < need
+    wit = np.zeros(need, np.uint64)
+    out, res = np.zeros(64, np.uint8), np.zeros(1, T.COMMIT_RESULT)
+    inp = np.frombuffer(w.input48(0), np.uint8).copy()
+    hdr, tv, rv = np.ascontiguousarray(w.headers[0]), np.ascontiguousarray(w.validators[0]), np.ascontiguousarray(w.trusted[0])
+    cid = np.frombuffer(b"celestia", np.uint8).copy()
+
+    def call(cap):
+        return L.bsx_header_range_cap(ctx, C.c_uint32(J), C.c_uint32(B), _lib.p(inp), _lib.p(hdr), C.c_uint64(int(w.first_height[0])), C.c_uint64(hdr.size),
+                                      C.c_uint64(int(w.latest[0])), _lib.p(tv), _lib.p(rv), C.c_uint32(V), _lib.p(cid), C.c_uint32(8), _lib.p(out), _lib.p(res),
+                                      _lib.p(wit), C.c_uint64(cap))
+    assert call(old) == T.ERR_BAD_ARG and "needs" in _lib.last_error() and not wit.any()
+    assert call(need) == T.OK and wit.any()
+    hh = np.ascontiguousarray(w.hashes[0, w.n_blocks]).reshape(1, 32)
+    cw = np.zeros(int(T.commit_layout(V)["n_elements"]), np.uint64)
+    ok = np.zeros(V, np.uint8)
+    assert L.bsx_verify_commits_cap(ctx, _lib.p(tv), C.c_uint32(1), C.c_uint32(V), _lib.p(hh), _lib.p(res), _lib.p(ok), _lib.p(cw), C.c_uint64(cw.size - 1)) == T.ERR_BAD_ARG
+    assert L.bsx_verify_commits_cap(ctx, _lib.p(tv), C.c_uint32(1), C.c_uint32(V), _lib.p(hh), _lib.p(res), _lib.p(ok), _lib.p(cw), C.c_uint64(cw.size)) == T.OK
