@@ -74,11 +74,17 @@ BSX_HDI uint64_t gl_pow7(uint64_t x) {
 }
 
 // ---- hand-written gfx950 body (round 5): THREE independent multiplications per call, interleaved instruction by instruction.
-// What it buys over the compiler's gl_mul (tools/glmul_asm_bench.hip: 2.17 against 1.87 T multiplications/s, +16 %, same results):
+// What it buys over the compiler's gl_mul (tools/glmul_asm_bench.hip, same results):
 //   * the reduction's 64-bit adds / subs are v_add_co / v_addc pairs whose carry is USED — the compiler never keeps a carry-out: it
 //     re-derives every one with v_cmp_*_u64 + v_cndmask (4 half-rate compares and 8 instructions per multiplication);
 //   * hi_lo * (2^32 - 1) + t0 is ONE v_mad_u64_u32 with the 64-bit addend and its own carry-out (the compiler: a multiply-add
 //     with addend 0, a 64-bit add and a compare);
+//   * NO zero-extended addends (second pass): the schoolbook chain P = a0 b0, Q = a0 b1 + hi(P), R = a1 b0 + lo(Q), H = a1 b1 + hi(Q)
+//     feeds every multiply-add a 32-bit half widened to a register PAIR — two v_mov per addend (7.6 moves per multiplication in
+//     the compiled round).  Here the two middle products are summed as 64-bit values, Q = a1 b0 + (a0 b1) with the carry-out kept
+//     (bit 64 of Q), and the 128-bit product is put together by ONE carry chain over the halves:
+//         w1 = hi(P) + lo(Q);  w2 = lo(H) + hi(Q) + c;  w3 = hi(H) + c;  w3 += carry(Q)
+//     4 multiply-adds + 4 adds, no move;
 //   * every VALU write of an SGPR carry sits two instructions in front of its reader (the gfx940 VALU-writes-SGPR -> VALU-reads
 //     hazard): no s_nop, where the compiler's schedule of ONE dependent chain pays 2-3 per multiplication.
 // Sub-registers of a 64-bit operand cannot be named in inline asm, so the blocks are split where a half is read on its own (the
@@ -86,24 +92,51 @@ BSX_HDI uint64_t gl_pow7(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BSX_GL_MUL3_ASM 1
 __device__ __forceinline__ void gl_mul3(uint64_t& x0, uint64_t& x1, uint64_t& x2, uint64_t y0, uint64_t y1, uint64_t y2) {
-    uint64_t P0, Q0, R0, H0, Z0, C0, P1, Q1, R1, H1, Z1, C1, P2, Q2, R2, H2, Z2, C2;
+    uint64_t P0, R0, H0, K0, C0, P1, R1, H1, K1, C1, P2, R2, H2, K2, C2;
     const uint32_t a00 = (uint32_t)x0, a01 = (uint32_t)(x0 >> 32), b00 = (uint32_t)y0, b01 = (uint32_t)(y0 >> 32);
     const uint32_t a10 = (uint32_t)x1, a11 = (uint32_t)(x1 >> 32), b10 = (uint32_t)y1, b11 = (uint32_t)(y1 >> 32);
     const uint32_t a20 = (uint32_t)x2, a21 = (uint32_t)(x2 >> 32), b20 = (uint32_t)y2, b21 = (uint32_t)(y2 >> 32);
-#define BSX_MAD0(P, C, a, b) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(P), "=s"(C) : "v"(a), "v"(b))
-#define BSX_MADZ(D, C, a, b, Z) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(D), "=s"(C) : "v"(a), "v"(b), "v"(Z))
-    BSX_MAD0(P0, C0, a00, b00); BSX_MAD0(P1, C1, a10, b10); BSX_MAD0(P2, C2, a20, b20);                     // a0 b0
-    Z0 = (uint32_t)(P0 >> 32); Z1 = (uint32_t)(P1 >> 32); Z2 = (uint32_t)(P2 >> 32);
-    BSX_MADZ(Q0, C0, a00, b01, Z0); BSX_MADZ(Q1, C1, a10, b11, Z1); BSX_MADZ(Q2, C2, a20, b21, Z2);         // a0 b1 + hi(a0 b0)
-    Z0 = (uint32_t)Q0; Z1 = (uint32_t)Q1; Z2 = (uint32_t)Q2;
-    BSX_MADZ(R0, C0, a01, b00, Z0); BSX_MADZ(R1, C1, a11, b10, Z1); BSX_MADZ(R2, C2, a21, b20, Z2);         // a1 b0 + lo(Q): word 1
-    Z0 = (uint32_t)(Q0 >> 32); Z1 = (uint32_t)(Q1 >> 32); Z2 = (uint32_t)(Q2 >> 32);
-    BSX_MADZ(H0, C0, a01, b01, Z0); BSX_MADZ(H1, C1, a11, b11, Z1); BSX_MADZ(H2, C2, a21, b21, Z2);         // a1 b1 + hi(Q)
-#undef BSX_MAD0
-#undef BSX_MADZ
-    H0 += (uint32_t)(R0 >> 32); H1 += (uint32_t)(R1 >> 32); H2 += (uint32_t)(R2 >> 32);                    // words 2, 3
-    uint32_t l00 = (uint32_t)P0, l01 = (uint32_t)R0, l10 = (uint32_t)P1, l11 = (uint32_t)R1, l20 = (uint32_t)P2, l21 = (uint32_t)R2;
-    const uint32_t h00 = (uint32_t)H0, h01 = (uint32_t)(H0 >> 32), h10 = (uint32_t)H1, h11 = (uint32_t)(H1 >> 32), h20 = (uint32_t)H2, h21 = (uint32_t)(H2 >> 32);
+    // the four products of each multiplication in one block (a carry-out nobody reads goes to vcc): P = a0 b0, H = a1 b1,
+    // R = a1 b0 + a0 b1 with its carry K
+    asm volatile(
+        "v_mad_u64_u32 %0, vcc, %12, %14, 0\n\t"
+        "v_mad_u64_u32 %1, vcc, %16, %18, 0\n\t"
+        "v_mad_u64_u32 %2, vcc, %20, %22, 0\n\t"
+        "v_mad_u64_u32 %3, vcc, %12, %15, 0\n\t"
+        "v_mad_u64_u32 %4, vcc, %16, %19, 0\n\t"
+        "v_mad_u64_u32 %5, vcc, %20, %23, 0\n\t"
+        "v_mad_u64_u32 %6, vcc, %13, %15, 0\n\t"
+        "v_mad_u64_u32 %7, vcc, %17, %19, 0\n\t"
+        "v_mad_u64_u32 %8, vcc, %21, %23, 0\n\t"
+        "v_mad_u64_u32 %3, %9, %13, %14, %3\n\t"
+        "v_mad_u64_u32 %4, %10, %17, %18, %4\n\t"
+        "v_mad_u64_u32 %5, %11, %21, %22, %5\n\t"
+        : "=&v"(P0), "=&v"(P1), "=&v"(P2), "=&v"(R0), "=&v"(R1), "=&v"(R2), "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&s"(K0), "=&s"(K1), "=&s"(K2)
+        : "v"(a00), "v"(a01), "v"(b00), "v"(b01), "v"(a10), "v"(a11), "v"(b10), "v"(b11), "v"(a20), "v"(a21), "v"(b20), "v"(b21)
+        : "vcc");
+    uint32_t l00 = (uint32_t)P0, l10 = (uint32_t)P1, l20 = (uint32_t)P2, l01, l11, l21, h00, h01, h10, h11, h20, h21;
+    const uint32_t p01 = (uint32_t)(P0 >> 32), p11 = (uint32_t)(P1 >> 32), p21 = (uint32_t)(P2 >> 32);
+    const uint32_t g00 = (uint32_t)H0, g01 = (uint32_t)(H0 >> 32), g10 = (uint32_t)H1, g11 = (uint32_t)(H1 >> 32), g20 = (uint32_t)H2, g21 = (uint32_t)(H2 >> 32);
+    const uint32_t q00 = (uint32_t)R0, q01 = (uint32_t)(R0 >> 32), q10 = (uint32_t)R1, q11 = (uint32_t)(R1 >> 32), q20 = (uint32_t)R2, q21 = (uint32_t)(R2 >> 32);
+    // words 1-3 of the product: one carry chain per multiplication (l_1 = w1, h_0 = w2 = hi_lo, h_1 = w3 = hi_hi); the results go to
+    // fresh registers (an in-out operand on a half of a 64-bit asm result costs a copy)
+    asm volatile(
+        "v_add_co_u32 %0, %9, %12, %15\n\t"
+        "v_add_co_u32 %3, %10, %18, %21\n\t"
+        "v_add_co_u32 %6, %11, %24, %27\n\t"
+        "v_addc_co_u32 %1, %9, %13, %16, %9\n\t"
+        "v_addc_co_u32 %4, %10, %19, %22, %10\n\t"
+        "v_addc_co_u32 %7, %11, %25, %28, %11\n\t"
+        "v_addc_co_u32 %2, %9, 0, %14, %9\n\t"
+        "v_addc_co_u32 %5, %10, 0, %20, %10\n\t"
+        "v_addc_co_u32 %8, %11, 0, %26, %11\n\t"
+        "v_addc_co_u32 %2, %9, 0, %2, %17\n\t"
+        "v_addc_co_u32 %5, %10, 0, %5, %23\n\t"
+        "v_addc_co_u32 %8, %11, 0, %8, %29\n\t"
+        : "=&v"(l01), "=&v"(h00), "=&v"(h01), "=&v"(l11), "=&v"(h10), "=&v"(h11), "=&v"(l21), "=&v"(h20), "=&v"(h21), "=&s"(C0), "=&s"(C1), "=&s"(C2)
+        : "v"(p01), "v"(g00), "v"(g01), "v"(q00), "v"(q01), "s"(K0),
+          "v"(p11), "v"(g10), "v"(g11), "v"(q10), "v"(q11), "s"(K1),
+          "v"(p21), "v"(g20), "v"(g21), "v"(q20), "v"(q21), "s"(K2));
     uint32_t m0, m1, m2;
     // t0 = lo - hi_hi (2^96 = -1); a borrow wrapped by 2^64 = p + EPS: give EPS back
     asm volatile(

@@ -24,7 +24,7 @@
 
 namespace bsx {
 
-__constant__ uint64_t POSEIDON_RC[BSX_POSEIDON_N_CONSTANTS] = {BSX_POSEIDON_RC_TABLE};
+__constant__ uint64_t POSEIDON_RC[BSX_POSEIDON_TABLE_N] = {BSX_POSEIDON_TABLE};
 
 constexpr int PS_THREADS = 256;
 

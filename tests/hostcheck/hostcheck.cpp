@@ -146,7 +146,7 @@ uint64_t hc_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a, b); }
 uint64_t hc_gl_pow7(uint64_t a) { return gl_pow7(a); }
 uint64_t hc_gl_reduce128(uint64_t lo, uint64_t hi) { return gl_reduce128(lo, hi); }
 uint64_t hc_gl_canonical(uint64_t a) { return gl_canonical(a); }
-static const uint64_t HC_RC[BSX_POSEIDON_N_CONSTANTS] = {BSX_POSEIDON_RC_TABLE};
+static const uint64_t HC_RC[BSX_POSEIDON_TABLE_N] = {BSX_POSEIDON_TABLE};
 const uint64_t* hc_poseidon_rc(void) { return HC_RC; }
 void hc_poseidon_mds(uint64_t s[12]) { poseidon_mds(s); }
 void hc_poseidon_permute(uint64_t s[12]) { poseidon_permute(s, HC_RC); for (int i = 0; i < 12; i++) s[i] = gl_canonical(s[i]); }

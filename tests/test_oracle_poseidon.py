@@ -61,11 +61,34 @@ def test_round_constants_three_generators_and_public_head():
 
 
 def test_product_constant_table_is_the_generated_one(hc):
-    rc = np.ctypeslib.as_array(hc.hc_poseidon_rc(), shape=(360,))
-    assert list(map(int, rc)) == gen.round_constants()
+    rc = np.ctypeslib.as_array(hc.hc_poseidon_rc(), shape=(394,))
+    py = gen.round_constants()
+    assert list(map(int, rc[:360])) == py
     # the committed header is exactly what the generator writes (no hand edits)
     hdr = open(os.path.join(os.path.dirname(HERE), "blobstreamx_amd", "csrc", "poseidon_consts.h")).read()
-    assert all(f"0x{c:016x}ull" in hdr for c in gen.round_constants())
+    assert all(f"0x{c:016x}ull" in hdr for c in py)
+    # the folded partial-round constants (round 5): the table the device code indexes behind the 360, and the algebra behind it
+    f, g = gen.folded_partial_constants(py)
+    assert list(map(int, rc[360:])) == f + g and len(f) == 22 and len(g) == 12
+    rng = random.Random(5)
+    for st in [[0] * 12, [P - 1] * 12] + [[rng.getrandbits(64) % P for _ in range(12)] for _ in range(20)]:
+        assert gen.permute_folded(st, py, f, g) == gen.permute(st, py)
+
+
+def test_generated_sbox_asm_header_is_current(tmp_path):
+    """blobstreamx_amd/csrc/goldilocks_sbox_asm.h is what tools/gen_gl_sbox_asm.py writes (no hand edits)."""
+    import importlib.util
+    root = os.path.dirname(HERE)
+    spec = importlib.util.spec_from_file_location("gen_gl_sbox_asm", os.path.join(root, "tools", "gen_gl_sbox_asm.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    lines = []
+    chains = [m.chain(k) for k in range(3)]
+    for i in range(len(chains[0])):
+        for k in range(3):
+            lines.append(chains[k][i])
+    hdr = open(os.path.join(root, "blobstreamx_amd", "csrc", "goldilocks_sbox_asm.h")).read()
+    got = [l.strip()[1:].split("\\n")[0] for l in hdr.split("\n") if l.strip().startswith('"v_')]
+    assert got == lines and len(lines) == 222
 
 
 @pytest.mark.parametrize("inp,want", PUBLIC_KAT)

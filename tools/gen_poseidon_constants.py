@@ -104,10 +104,45 @@ def permute(state, rc=None):
     return s
 
 
+def mds(s):
+    return [(sum(s[(i + k) % 12] * MDS_CIRC[i] for i in range(12)) + s[k] * MDS_DIAG[k]) % ORDER for k in range(12)]
+
+
+def folded_partial_constants(rc):
+    """The partial rounds' constants pushed forward through the (linear) MDS layers: lanes 1..11 see nothing but "+ constant" and
+    the MDS between the first and the last partial round, so the constant of lane i > 0 in round r can be added AFTER that round's
+    MDS as M (0, c_r[1..11]) — i.e. merged into round r + 1's constants, whose lanes 1..11 move on in turn.  What is left: one
+    constant for lane 0 per partial round (f[0..22)) and one full vector g that replaces the constants of the first full round
+    behind the partial ones (round 26).  Same permutation, 11 x 22 additions fewer.  (plonky2 folds its partial rounds further,
+    into sparse matrices; that form multiplies by 64-bit constants and is no cheaper on this hardware.)"""
+    e = list(rc[12 * 4:12 * 5])
+    f = []
+    for r in range(4, 26):
+        f.append(e[0])
+        carry = mds([0] + e[1:])
+        e = [(rc[12 * (r + 1) + i] + carry[i]) % ORDER for i in range(12)]
+    return f, e
+
+
+def permute_folded(state, rc, f, g):
+    s = [x % ORDER for x in state]
+    for r in range(30):
+        if r < 4 or r >= 26:
+            c = g if r == 26 else rc[12 * r:12 * r + 12]
+            s = [pow((s[i] + c[i]) % ORDER, 7, ORDER) for i in range(12)]
+        else:
+            s[0] = pow((s[0] + f[r - 4]) % ORDER, 7, ORDER)
+        s = mds(s)
+    return s
+
+
 def main():
     rc = round_constants()
     assert rc[0] == 0xB585F766F2144405, hex(rc[0])
     assert permute([0] * 12, rc)[0] == 0x3C18A9786CB0B359
+    fc, gc = folded_partial_constants(rc)
+    for st in ([0] * 12, list(range(12)), [ORDER - 1 - 7 * i for i in range(12)], [(0x9E3779B97F4A7C15 * (i + 1)) % ORDER for i in range(12)]):
+        assert permute_folded(st, rc, fc, gc) == permute(st, rc)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "blobstreamx_amd", "csrc", "poseidon_consts.h")
     with open(out, "w") as f:
         f.write("// poseidon_consts.h — GENERATED by tools/gen_poseidon_constants.py (ChaCha8Rng::seed_from_u64(0) + gen_range(0..p),\n"
@@ -118,6 +153,16 @@ def main():
         for i in range(0, N_CONSTANTS, 4):
             f.write("    " + ", ".join(f"0x{c:016x}ull" for c in rc[i:i + 4]) + ("," if i + 4 < N_CONSTANTS else "") + " \\\n")
         f.write("\n")
+        f.write("// The partial rounds' constants folded forward through the MDS layers (folded_partial_constants in the generator):\n"
+                "// [0, 22) the constant of lane 0 in partial round k; [22, 34) the constants of round 26 (the first full round behind\n"
+                "// the partial ones) with what was left of lanes 1..11.  Same permutation as the 360-constant definition.\n"
+                "#define BSX_POSEIDON_FOLDED_N 34\n#define BSX_POSEIDON_FOLDED_TABLE \\\n")
+        fold = fc + gc
+        for i in range(0, len(fold), 4):
+            f.write("    " + ", ".join(f"0x{c:016x}ull" for c in fold[i:i + 4]) + ("," if i + 4 < len(fold) else "") + " \\\n")
+        f.write("\n// what poseidon_permute takes: the 360 constants followed by the folded ones\n"
+                "#define BSX_POSEIDON_TABLE_N (BSX_POSEIDON_N_CONSTANTS + BSX_POSEIDON_FOLDED_N)\n"
+                "#define BSX_POSEIDON_TABLE BSX_POSEIDON_RC_TABLE, BSX_POSEIDON_FOLDED_TABLE\n")
     print("wrote", os.path.normpath(out))
 
 

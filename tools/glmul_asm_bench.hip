@@ -84,7 +84,7 @@ __global__ void k(uint64_t* out, int iters) {
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 6; i++) v[i] = gl_mul(v[i], v[(i + 1) % 6] | 1);
-        } else {
+        } else if (MODE == 1) {
             // the same six products: v[i] * (v[i+1] | 1) with the OLD v[i+1] for i = 0..4 sequentially dependent in MODE 0; here both halves use
             // the values as MODE 0 does: (0,1,2) then (3,4,5) — v[2] needs the old v[3], v[5] the NEW v[0]
             uint64_t y0 = v[1] | 1, y1 = v[2] | 1, y2 = v[3] | 1;
@@ -92,6 +92,13 @@ __global__ void k(uint64_t* out, int iters) {
             gl_mul3_asm(v[0], v[1], v[2], y0, y1, y2);
             uint64_t z0 = v[4] | 1, z1 = v[5] | 1, z2 = v[0] | 1;
             gl_mul3_asm(v[3], v[4], v[5], z0, z1, z2);
+        } else if (MODE == 2) {      // the library's gl_mul3 (goldilocks.h: second pass, no zero-extended addends)
+#if defined(__HIP_DEVICE_COMPILE__)
+            uint64_t y0 = v[1] | 1, y1 = v[2] | 1, y2 = v[3] | 1;
+            gl_mul3(v[0], v[1], v[2], y0, y1, y2);
+            uint64_t z0 = v[4] | 1, z1 = v[5] | 1, z2 = v[0] | 1;
+            gl_mul3(v[3], v[4], v[5], z0, z1, z2);
+#endif
         }
     }
     uint64_t x = 0;
@@ -104,21 +111,27 @@ int main() {
     uint64_t *o0, *o1;
     hipMalloc(&o0, (size_t)blocks * threads * 8); hipMalloc(&o1, (size_t)blocks * threads * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    float ms[2];
-    for (int mode = 0; mode < 2; mode++) {
+    float ms[3];
+    std::vector<uint64_t> h0((size_t)blocks * threads), h1(h0.size());
+    int rc = 0;
+    for (int mode = 0; mode < 3; mode++) {
         for (int rep = 0; rep < 3; rep++) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(threads), 0, 0, o0, iters);
-            else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, o1, iters);
+            else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, o1, iters);
+            else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(threads), 0, 0, o1, iters);
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms[mode], e0, e1);
         }
-        printf("%s: %.3f ms  %.1f G gl_mul/s\n", mode ? "gl_mul3_asm (hand-written)" : "gl_mul (compiler)        ", ms[mode], (double)blocks * threads * iters * 6 / ms[mode] / 1e6);
+        printf("%s: %.3f ms  %.1f G gl_mul/s\n", mode == 2 ? "gl_mul3 (library, 2nd pass) " : mode ? "gl_mul3_asm (first pass)    " : "gl_mul (compiler)           ", ms[mode], (double)blocks * threads * iters * 6 / ms[mode] / 1e6);
+        if (mode == 0) hipMemcpy(h0.data(), o0, h0.size() * 8, hipMemcpyDeviceToHost);
+        else {
+            hipMemcpy(h1.data(), o1, h1.size() * 8, hipMemcpyDeviceToHost);
+            size_t bad = 0;
+            for (size_t i = 0; i < h0.size(); i++) bad += h0[i] != h1[i];
+            printf("  results %s (%zu of %zu differ)\n", bad ? "DIFFER" : "equal", bad, h0.size());
+            rc |= bad != 0;
+        }
     }
-    std::vector<uint64_t> h0((size_t)blocks * threads), h1(h0.size());
-    hipMemcpy(h0.data(), o0, h0.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), o1, h1.size() * 8, hipMemcpyDeviceToHost);
-    size_t bad = 0;
-    for (size_t i = 0; i < h0.size(); i++) bad += h0[i] != h1[i];
-    printf("results %s (%zu of %zu differ)\n", bad ? "DIFFER" : "equal", bad, h0.size());
-    return bad != 0;
+    return rc;
 }

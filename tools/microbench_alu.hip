@@ -13,7 +13,7 @@
 #include "../blobstreamx_amd/csrc/fe25519.h"
 using namespace bsx;
 
-__constant__ uint64_t RC[360] = {BSX_POSEIDON_RC_TABLE};
+__constant__ uint64_t RC[BSX_POSEIDON_TABLE_N] = {BSX_POSEIDON_TABLE};
 
 // MODE 0: v_add_u32   1: v_mad_u32_u24   2: v_mad_u64_u32   3: v_mul_lo_u32   4: v_xor3 (bitop3)   5: v_lshl_add_u64
 template <int MODE>
