@@ -56,7 +56,11 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s s
 # digits of h for the key, 16 radix-65536 digits of s for B): 38 mixed additions (3 + 4 mul each, the last one 3 + 3), no
 # doubling + encoding.  With the batch-inversion scratch (k_ed25519_finish) the encoding costs 5 multiplications per
 # signature plus one inversion (254 sq + 11 mul) per 8 / 16 / 32 signatures — counted at 16.
-FE_MUL_PER_VERIFY = 38 * 7 - 1 + 5 + 11 / 16
+# Round 5: a resident validator set's tables may hold 16-bit digits (BSX_COMMITS_KEYTABLE_WIDE): 16 + 16 = 32 additions.
+def fe_mul_per_verify(kt_bits=12):
+    adds = (253 + kt_bits) // kt_bits + 16
+    return adds * 7 - 1 + 5 + 11 / 16
+FE_MUL_PER_VERIFY = fe_mul_per_verify(12)
 FE_SQ_PER_VERIFY = 254 / 16
 # Goldilocks multiplications of one Poseidon permutation that NO formulation can avoid: the x^7 S-boxes (4 multiplications
 # each: x2, x3 = x2*x, x4 = x2*x2, x7 = x4*x3) of 8 full rounds x 12 lanes + 22 partial rounds x 1 lane.  The MDS layers are
@@ -188,9 +192,9 @@ def calibrate(dev):
     return d
 
 
-def keyed_verify_peak(cal):
+def keyed_verify_peak(cal, kt_bits=12):
     """Ed25519 verifications/s if only the kernel's field multiplications and squarings cost time, at the measured rates."""
-    return 1.0 / (FE_MUL_PER_VERIFY / cal["fe25519_mul_per_s"] + FE_SQ_PER_VERIFY / cal["fe25519_sq_per_s"])
+    return 1.0 / (fe_mul_per_verify(kt_bits) / cal["fe25519_mul_per_s"] + FE_SQ_PER_VERIFY / cal["fe25519_sq_per_s"])
 
 
 def valu_insts(kernel_substr):
@@ -316,10 +320,10 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
         ev[0].record()
         _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(sh.vals), C.c_uint64(n), dp(h_scratch), None))
         ev[1].record()
-        _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(sh.vals), C.c_uint32(V), dp(sh.keytable)))
+        _lib.check(L.bsx_dev_ed25519_keytable_w(ctx, st, dp(sh.vals), C.c_uint32(V), dp(sh.keytable), C.c_uint32(sh.kt_bits)))
         ev[2].record()
-        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(sh.vals), dp(h_scratch), C.c_uint64(n), C.c_uint32(V), dp(sh.keytable),
-                                                  C.c_uint32(V), dp(sh.ok), dp(ed_scr)))
+        _lib.check(L.bsx_dev_ed25519_verify_keyed_w(ctx, st, dp(sh.vals), dp(h_scratch), C.c_uint64(n), C.c_uint32(V), dp(sh.keytable),
+                                                    C.c_uint32(V), dp(sh.ok), dp(ed_scr), C.c_uint32(sh.kt_bits)))
         ev[3].record()
         _lib.check(L.bsx_dev_commit_tally(ctx, st, dp(sh.vals), C.c_uint32(sh.n), C.c_uint32(V), dp(sh.hh), dp(sh.ok), dp(sh.res)))
         ev[4].record()
@@ -363,16 +367,18 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
            "range_verdict": verdict,
            "stage_ms": {"sha512_challenge": t_sha, "keytable": t_tab, "ed25519_verify_keyed": t_ed, "tally_validator_hash": t_tally,
                         "keytable_cold_build": cold[1]},
-           "ed25519_path": "fixed-key affine tables: 22 radix-4096 digits of h for every validator key (5.8 MB per key), 16 radix-65536 digits of "
-                           "s for B (64 MB) = 38 mixed additions, no doubling; table rows reused while the validator set is unchanged; "
-                           "encodings through per-lane Montgomery batch inversion (8 / 16 / 32 signatures per inversion)"}
+           "keytable_digit_bits": sh.kt_bits, "keytable_MB": round(sh.keytable.numel() / 1e6, 1),
+           "ed25519_path": ("fixed-key affine tables: %s of h for every validator key, 16 radix-65536 digits of s for B (64 MB) = %d mixed additions, no "
+                            "doubling; table rows reused while the validator set is unchanged; encodings through per-lane Montgomery batch inversion "
+                            "(8 / 16 / 32 signatures per inversion)") % (("16 radix-65536 digits (64 MB per key: BSX_COMMITS_KEYTABLE_WIDE, the validator set "
+                            "is resident)", 32) if sh.kt_bits == 16 else ("22 radix-4096 digits (5.8 MB per key)", 38))}
     ver_per_s = n / (t_ed * 1e-3)
-    peak = keyed_verify_peak(cal)
+    peak = keyed_verify_peak(cal, sh.kt_bits)
     out["roofline"] = {"kernel": "k_ed25519_verify_keyed", "bound": "valu", "unit": "M Ed25519 verifications/s",
                        "achieved": ver_per_s / 1e6, "peak": peak / 1e6, "frac": min(1.0, ver_per_s / peak),
                        "avg_launch_ms": t_ed, "traffic": None,
-                       "field_ops_per_verification": {"mul": FE_MUL_PER_VERIFY, "sq": FE_SQ_PER_VERIFY},
-                       "achieved_G_field_ops_per_s": ver_per_s * (FE_MUL_PER_VERIFY + FE_SQ_PER_VERIFY) / 1e9,
+                       "field_ops_per_verification": {"mul": fe_mul_per_verify(sh.kt_bits), "sq": FE_SQ_PER_VERIFY},
+                       "achieved_G_field_ops_per_s": ver_per_s * (fe_mul_per_verify(sh.kt_bits) + FE_SQ_PER_VERIFY) / 1e9,
                        # 2048 x 100 runs k_ed25519_verify_keyed_mixed (kernels_ed.hip: whole waves per SIMD one lane per signature, the rest on four)
                        "valu_issue": valu_issue(cal, "k_ed25519_verify_keyed_mixed" if n < 300000 else "k_ed25519_verify_keyed<true, true, 1>", n, t_ed * 1e-3),
                        "note": "peak = the time the kernel's GF(2^255-19) multiplications and squarings would take at the fe_mul / fe_sq "

@@ -27,7 +27,8 @@ SYMBOLS = [
     "bsx_dev_alloc", "bsx_dev_free", "bsx_set_tuning", "bsx_trim", "bsx_dev_header_merkle", "bsx_dev_assemble_inputs", "bsx_dev_prove_subchain", "bsx_dev_reduce", "bsx_dev_reduce_strided", "bsx_dev_finalize",
     "bsx_dev_expand_witness", "bsx_dev_fill_end_hash", "bsx_dev_sha512_challenge", "bsx_dev_ed25519_verify",
     "bsx_dev_commit_tally", "bsx_dev_skip_check",
-    "bsx_ed25519_keytable_bytes", "bsx_dev_ed25519_keytable", "bsx_dev_ed25519_verify_keyed", "bsx_ed25519_verify_scratch_bytes",
+    "bsx_ed25519_keytable_bytes", "bsx_dev_ed25519_keytable", "bsx_dev_ed25519_verify_keyed", "bsx_ed25519_keytable_bytes_w", "bsx_dev_ed25519_keytable_w",
+    "bsx_dev_ed25519_verify_keyed_w", "bsx_ed25519_verify_scratch_bytes",
     "bsx_dev_skip_eval", "bsx_find_block_to_request",
     "bsx_poseidon_permute", "bsx_poseidon_hash_no_pad", "bsx_poseidon_two_to_one", "bsx_poseidon_tree_digests",
     "bsx_witness_leaf_count", "bsx_poseidon_merkle_tree", "bsx_witness_merkle_caps",
@@ -82,6 +83,7 @@ def lib():
                 L.bsx_prepare_process()
             L.bsx_version.restype = C.c_uint32
             L.bsx_ed25519_keytable_bytes.restype = C.c_uint64
+            L.bsx_ed25519_keytable_bytes_w.restype = C.c_uint64
             L.bsx_ed25519_verify_scratch_bytes.restype = C.c_uint64
             L.bsx_poseidon_tree_digests.restype = C.c_uint64
             L.bsx_witness_leaf_count.restype = C.c_uint32

@@ -419,25 +419,36 @@ int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
 }
 
 uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys) { return bsxk_keytable_bytes(n_keys); }
+uint64_t bsx_ed25519_keytable_bytes_w(uint32_t n_keys, uint32_t digit_bits) { return bsxk_keytable_bits_ok((int)digit_bits) ? bsxk_keytable_bytes(n_keys, (int)digit_bits) : 0; }
 uint64_t bsx_ed25519_verify_scratch_bytes(uint64_t n) { return bsxk_ed25519_scratch_bytes(n); }
 
-int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys, void* d_table) {
+int bsx_dev_ed25519_keytable_w(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys, void* d_table, uint32_t digit_bits) {
     DEV_ENTER();
     if (n_keys && (!d_validators || !d_table)) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (((uintptr_t)d_table & 127) != 0) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
-    HIPCHK(bsxk_ed25519_keytable(S(ctx, stream), d_validators, n_keys, static_cast<uint8_t*>(d_table)));
+    if (!bsxk_keytable_bits_ok((int)digit_bits)) return fail(BSX_ERR_BAD_ARG, "key-table digit width %u: %d or %d", digit_bits, BSXK_KT_BITS, BSXK_KT_BITS_WIDE);
+    HIPCHK(bsxk_ed25519_keytable(S(ctx, stream), d_validators, n_keys, static_cast<uint8_t*>(d_table), (int)digit_bits));
     return BSX_OK;
+}
+int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys, void* d_table) {
+    return bsx_dev_ed25519_keytable_w(ctx, stream, d_validators, n_keys, d_table, BSXK_KT_BITS);
 }
 
 int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n,
                                  uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok, void* d_scratch) {
+    return bsx_dev_ed25519_verify_keyed_w(ctx, stream, d_validators, d_h, n, v_max, d_table, n_keys, d_ok, d_scratch, BSXK_KT_BITS);
+}
+int bsx_dev_ed25519_verify_keyed_w(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n,
+                                   uint32_t v_max, const void* d_table, uint32_t n_keys, uint8_t* d_ok, void* d_scratch, uint32_t digit_bits) {
     DEV_ENTER();
+    if (!bsxk_keytable_bits_ok((int)digit_bits)) return fail(BSX_ERR_BAD_ARG, "key-table digit width %u: %d or %d", digit_bits, BSXK_KT_BITS, BSXK_KT_BITS_WIDE);
     if (n && (!d_validators || !d_h || !d_ok)) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (v_max == 0) return fail(BSX_ERR_BAD_ARG, "v_max is 0");
     if (n_keys && !d_table) return fail(BSX_ERR_BAD_ARG, "null key table");
     if ((uintptr_t)d_table & 127) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte aligned (one cache line per entry)");
     if ((uintptr_t)d_scratch & 15) return fail(BSX_ERR_BAD_ARG, "scratch must be 16-byte aligned");
-    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch, nullptr, -1));
+    HIPCHK(bsxk_ed25519_verify_keyed(S(ctx, stream), d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_table), n_keys, ctx->btab, d_ok, d_scratch, nullptr, -1,
+                                     nullptr, (int)digit_bits));
     return BSX_OK;
 }
 
@@ -508,7 +519,7 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     if (!n_commits || n_commits > BSX_COMMIT_FOLD_MAX) return fail(BSX_ERR_UNSUPPORTED, "n_commits %u not in 1..%u", n_commits, BSX_COMMIT_FOLD_MAX);
     if (!d_validators || !d_header_hashes || !d_keytable || !d_scratch || !d_ok || !d_results || !d_fold) return fail(BSX_ERR_BAD_ARG, "null pointer");
     if (((uintptr_t)d_keytable & 127) || ((uintptr_t)d_scratch & 255)) return fail(BSX_ERR_BAD_ARG, "key table must be 128-byte, scratch 256-byte aligned");
-    if (flags & ~(BSX_COMMITS_KEYTABLE_READY | BSX_COMMITS_KEYS_UNIFORM)) return fail(BSX_ERR_BAD_ARG, "bsx_dev_verify_commits: unknown flags 0x%x", flags);
+    if (flags & ~(BSX_COMMITS_KEYTABLE_READY | BSX_COMMITS_KEYS_UNIFORM | BSX_COMMITS_TALLY_BESIDE | BSX_COMMITS_KEYTABLE_WIDE)) return fail(BSX_ERR_BAD_ARG, "bsx_dev_verify_commits: unknown flags 0x%x", flags);
     hipStream_t st = S(ctx, stream);
     const uint64_t n = (uint64_t)n_commits * v_max;
     uint8_t* d_h = static_cast<uint8_t*>(d_scratch);
@@ -517,11 +528,27 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     if (d_commit_compact && ((uintptr_t)d_commit_compact & 15)) return fail(BSX_ERR_BAD_ARG, "d_commit_compact must be 16-byte aligned");
     const bsx_witness_layout CL = bsx_commit_layout(v_max);
     const bsxk_unit_dst cw = bsxk_unit(d_commit_compact, CL);
+    const bool beside = (flags & BSX_COMMITS_TALLY_BESIDE) != 0;
+    const int kt_bits = (flags & BSX_COMMITS_KEYTABLE_WIDE) ? BSXK_KT_BITS_WIDE : BSXK_KT_BITS;
+    if (beside) {
+        // the trees on the context's side stream, ordered behind whatever the caller's stream holds (the previous step's readers of
+        // d_results / the units) and joined in front of the sums
+        hipStream_t s4 = ctx->stream4;
+        HIPCHK(hipEventRecord(ctx->ev_f, st));
+        HIPCHK(hipStreamWaitEvent(s4, ctx->ev_f, 0));
+        HIPCHK(bsxk_commit_tally(s4, d_validators, n_commits, v_max, d_header_hashes, nullptr, d_results, d_commit_compact ? &cw : nullptr));
+        HIPCHK(hipEventRecord(ctx->ev_g, s4));
+    }
     HIPCHK(bsxk_sha512_challenge(st, d_validators, n, d_h, nullptr, v_max, d_commit_compact ? &cw : nullptr));
-    if (!(flags & BSX_COMMITS_KEYTABLE_READY)) HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable)));
+    if (!(flags & BSX_COMMITS_KEYTABLE_READY)) HIPCHK(bsxk_ed25519_keytable(st, d_validators, v_max, static_cast<uint8_t*>(d_keytable), kt_bits));
     HIPCHK(bsxk_ed25519_verify_keyed(st, d_validators, d_h, n, v_max, static_cast<const uint8_t*>(d_keytable), v_max, ctx->btab, d_ok, d_ed, nullptr,
-                                     (flags & BSX_COMMITS_KEYS_UNIFORM) ? 0 : -1));
-    HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results, d_commit_compact ? &cw : nullptr));
+                                     (flags & BSX_COMMITS_KEYS_UNIFORM) ? 0 : -1, nullptr, kt_bits));
+    if (beside) {
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_g, 0));
+        HIPCHK(bsxk_commit_sums(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results, d_commit_compact ? &cw : nullptr));
+    } else {
+        HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results, d_commit_compact ? &cw : nullptr));
+    }
     HIPCHK(bsxk_commit_fold(st, d_results, n_commits, first_index, d_fs, d_fold));
     return BSX_OK;
 }

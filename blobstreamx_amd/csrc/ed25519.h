@@ -193,6 +193,15 @@ constexpr int KT_KEY_I32 = KT_PARTS * KT_HALF_ENTRIES * KT_ENTRY_I32;
 constexpr int BT_I32 = BT_PARTS * BT_HALF_ENTRIES * KT_ENTRY_I32;
 static_assert(KT_W >= 8 && KT_W <= 16 && KT_W * KT_PARTS >= 254 && KT_W * KT_PARTS <= 288, "key-table digit width");
 static_assert(BT_W >= 8 && BT_W <= 16 && BT_W * BT_PARTS >= 254 && BT_W * BT_PARTS <= 288, "B-table digit width");
+// Round 5: the digit width of a KEY table is a property of the table (KT_W is the default: request-driven paths, where a validator
+// set may be new and its table is built on the spot).  A caller whose validator set is resident for many millions of signatures
+// (mode S) asks for KT_W_WIDE-bit digits: 16 parts of 32,768 entries = 64 MB per key, 16 + 16 instead of 22 + 16 additions per
+// signature (2048 x 100: verification 0.54 -> 0.49 ms; 6.4 GB of tables at V = 100).  Geometry of a w-bit table:
+constexpr int KT_W_WIDE = 16;
+BSX_HDI int kt_parts(int w) { return (253 + w) / w; }
+BSX_HDI int kt_half(int w) { return 1 << (w - 1); }
+BSX_HDI int64_t kt_key_i32(int w) { return (int64_t)kt_parts(w) * kt_half(w) * KT_ENTRY_I32; }
+BSX_HDI bool kt_w_ok(int w) { return w == KT_W || w == KT_W_WIDE; }
 // encoding of -B (B = (x, 4/5) with x even: the encoding of B is 0x58, 0x66 x 31; -B sets the sign bit of x)
 constexpr uint32_t GE_NEG_B_ENC[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0xe6666666u};
 
@@ -225,6 +234,17 @@ BSX_HDI int sc_digit_t(const uint32_t r[9], int i) {
     const int bit = W * i, wd = bit >> 5, sh = bit & 31;
     const uint64_t two = ((uint64_t)pick9(r, wd + 1 < 9 ? wd + 1 : 8) << 32) | pick9(r, wd);
     return (int)((uint32_t)(two >> sh) & ((1u << W) - 1)) - (1 << (W - 1));
+}
+
+// the same for a digit width known at run time (uniform over a launch): KT_W or KT_W_WIDE
+BSX_HDI void sc_recode_rt(const uint32_t x[8], uint32_t r[9], int w) {
+    if (w == KT_W_WIDE) sc_recode_t<KT_W_WIDE, (253 + KT_W_WIDE) / KT_W_WIDE>(x, r);
+    else sc_recode_t<KT_W, KT_PARTS>(x, r);
+}
+BSX_HDI int sc_digit_rt(const uint32_t r[9], int i, int w) {
+    const int bit = w * i, wd = bit >> 5, sh = bit & 31;
+    const uint64_t two = ((uint64_t)pick9(r, wd + 1 < 9 ? wd + 1 : 8) << 32) | pick9(r, wd);
+    return (int)((uint32_t)(two >> sh) & ((1u << w) - 1)) - (1 << (w - 1));
 }
 
 // base[k + 1] = 2^bits * base[k]
@@ -297,16 +317,18 @@ BSX_HDI ge_precomp keytable_pick(const int32_t* part_tab, int d) {
 // with ONE inversion (Montgomery's trick: 3 multiplications per extra element).
 template <bool DEFER>
 BSX_HDI bool ed25519_verify_keyed_core_t(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
-                                         const uint32_t h[8], ge_p2* out_q) {
+                                         const uint32_t h[8], ge_p2* out_q, int w = KT_W) {
     const bool ok = sc_is_canonical(sig_s);
     uint32_t hr[9], sr[9];
-    sc_recode_t<KT_W, KT_PARTS>(h, hr);
+    sc_recode_rt(h, hr, w);
     sc_recode_t<BT_W, BT_PARTS>(sig_s, sr);
     ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
+    const int parts = kt_parts(w);
+    const int64_t part_i32 = (int64_t)kt_half(w) * KT_ENTRY_I32;
     // not unrolled on the device: entries prefetched several at a time would spill
 #pragma unroll 1
-    for (int k = 0; k < KT_PARTS; k++)
-        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + (int64_t)k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<KT_W>(hr, k))));
+    for (int k = 0; k < parts; k++)
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + (int64_t)k * part_i32, sc_digit_rt(hr, k, w))));
 #pragma unroll 1
     for (int k = 0; k < BT_PARTS - 1; k++)
         p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<BT_W>(sr, k))));
@@ -323,21 +345,23 @@ BSX_HDI bool ed25519_verify_keyed_core_t(const int32_t* key_tab, const int32_t* 
     return ok && diff == 0;
 }
 BSX_HDI bool ed25519_verify_keyed_core(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_r[8], const uint32_t sig_s[8],
-                                       const uint32_t h[8]) {
-    return ed25519_verify_keyed_core_t<false>(key_tab, b_tab, sig_r, sig_s, h, nullptr);
+                                       const uint32_t h[8], int w = KT_W) {
+    return ed25519_verify_keyed_core_t<false>(key_tab, b_tab, sig_r, sig_s, h, nullptr, w);
 }
 // One of SPLIT partial sums of [s]B + [h](-A): the table parts k = part0 (mod SPLIT).  Without doublings the sum splits
 // freely — SPLIT lanes per signature shorten the dependent chain from 48 to 48 / SPLIT additions (+ log2 SPLIT full
 // additions to join, kernels_ed.hip) at 20 % more total work: the form for small batches, where latency is all there is.
 template <int SPLIT>
-BSX_HDI ge_p3 ed25519_keyed_partial(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_s[8], const uint32_t h[8], int part0) {
+BSX_HDI ge_p3 ed25519_keyed_partial(const int32_t* key_tab, const int32_t* b_tab, const uint32_t sig_s[8], const uint32_t h[8], int part0, int w = KT_W) {
     uint32_t hr[9], sr[9];
-    sc_recode_t<KT_W, KT_PARTS>(h, hr);
+    sc_recode_rt(h, hr, w);
     sc_recode_t<BT_W, BT_PARTS>(sig_s, sr);
     ge_p3 p{fe_zero(), fe_one(), fe_one(), fe_zero()};
+    const int parts = kt_parts(w);
+    const int64_t part_i32 = (int64_t)kt_half(w) * KT_ENTRY_I32;
 #pragma unroll 1
-    for (int k = part0; k < KT_PARTS; k += SPLIT)
-        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + (int64_t)k * KT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<KT_W>(hr, k))));
+    for (int k = part0; k < parts; k += SPLIT)
+        p = p1p1_to_p3(ge_madd(p, keytable_pick(key_tab + (int64_t)k * part_i32, sc_digit_rt(hr, k, w))));
 #pragma unroll 1
     for (int k = part0; k < BT_PARTS; k += SPLIT)
         p = p1p1_to_p3(ge_madd(p, keytable_pick(b_tab + (int64_t)k * BT_HALF_ENTRIES * KT_ENTRY_I32, sc_digit_t<BT_W>(sr, k))));

@@ -75,13 +75,20 @@ hipError_t bsxk_finalize(hipStream_t, uint32_t, uint32_t, uint32_t, const bsx_sh
 hipError_t bsxk_expand_witness(hipStream_t, const bsx_witness_layout*, uint32_t, const uint8_t*, uint64_t*);
 hipError_t bsxk_sha512_challenge(hipStream_t, const bsx_validator*, uint64_t, uint8_t*, uint8_t*, uint32_t, const bsxk_unit_dst*);
 hipError_t bsxk_ed25519_verify(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint8_t*);
-uint64_t bsxk_keytable_bytes(uint32_t);
-hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*);
+// digit width of a key table (round 5): BSXK_KT_BITS = the default (request-driven paths), BSXK_KT_BITS_WIDE for a resident validator set
+// verified millions of times (64 MB per key, 16 + 16 instead of 22 + 16 additions per signature); part of the rows' layout tag: a
+// kernel told the wrong width finds no usable row and defers every slot
+#define BSXK_KT_BITS 12
+#define BSXK_KT_BITS_WIDE 16
+int bsxk_keytable_default_bits(void);
+int bsxk_keytable_bits_ok(int);
+uint64_t bsxk_keytable_bytes(uint32_t, int w = BSXK_KT_BITS);
+hipError_t bsxk_ed25519_keytable(hipStream_t, const bsx_validator*, uint32_t, uint8_t*, int w = BSXK_KT_BITS);
 // rows (optional, n u32): signature i is checked against table row rows[i] instead of row i % v_max (0xffffffff = no row: deferred to
 // the generic kernel) — validator sets that differ between the commits of a batch share ONE table whose rows are keyed by public key
 // (bsx_keycache, api_internal.h).  Whatever the map says, a lane verifies against a row only when the row's key IS its public key.
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t, const bsx_validator*, const uint8_t*, uint64_t, uint32_t, const uint8_t*, uint32_t, const uint8_t*, uint8_t*, void*, const void*, int64_t,
-                                     const uint32_t* rows = nullptr);
+                                     const uint32_t* rows = nullptr, int w = BSXK_KT_BITS);
 // active (enabled and signed) slots of commits 1.. whose public key differs from the first commit's slot of the same index: what a
 // fixed-key table built from the first commit's keys cannot serve (host-side compare; api.hip)
 uint64_t bsxh_key_mismatches(const bsx_validator* validators, uint64_t n_commits, uint32_t v_max);

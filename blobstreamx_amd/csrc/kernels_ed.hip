@@ -151,12 +151,15 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed25519_verify(const bsx_validat
 //                                                [64 B table word: dword 0 = some row is dirty (k_keytable_check)]
 //                                                [n_keys x KT_PARTS x 40 i32 base points -2^(W k) A (X, Y, Z, T)]
 //                                                [n_keys x KT_PARTS x 2^(W-1) x 32 i32 affine multiples, one cache line each]
-constexpr uint64_t KT_REC_BYTES = 64, KT_BASE_I32 = 40 * KT_PARTS;
+// W = the table's digit width (ed25519.h: KT_W = 12 by default, KT_W_WIDE = 16 for resident validator sets): a property of the table,
+// uniform over a launch, part of the rows' layout tag.
+constexpr uint64_t KT_REC_BYTES = 64;
+__host__ __device__ inline uint64_t kt_base_i32(int w) { return 40ull * (uint64_t)kt_parts(w); }
 __host__ __device__ inline uint64_t kt_flag_off(uint64_t n_keys) { return n_keys * KT_REC_BYTES; }
 __host__ __device__ inline uint64_t kt_bases_off(uint64_t n_keys) { return (n_keys + 1) * KT_REC_BYTES; }
 // entries start on a cache line (the table itself must: hipMalloc / torch / arena allocations are 256-byte aligned)
-__host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys) { return (kt_bases_off(n_keys) + n_keys * KT_BASE_I32 * 4 + 127) & ~127ull; }
-__host__ __device__ inline uint64_t kt_bytes(uint64_t n_keys) { return kt_entries_off(n_keys) + n_keys * (uint64_t)KT_KEY_I32 * 4; }
+__host__ __device__ inline uint64_t kt_entries_off(uint64_t n_keys, int w) { return (kt_bases_off(n_keys) + n_keys * kt_base_i32(w) * 4 + 127) & ~127ull; }
+__host__ __device__ inline uint64_t kt_bytes(uint64_t n_keys, int w) { return kt_entries_off(n_keys, w) + n_keys * (uint64_t)kt_key_i32(w) * 4; }
 
 __device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) {
     const uint4* rec = reinterpret_cast<const uint4*>(v);
@@ -164,20 +167,21 @@ __device__ __forceinline__ void load_pk(const bsx_validator* v, uint32_t pk[8]) 
     pk[0] = p0.x; pk[1] = p0.y; pk[2] = p0.z; pk[3] = p0.w; pk[4] = p1.x; pk[5] = p1.y; pk[6] = p1.z; pk[7] = p1.w;
 }
 
-constexpr uint32_t KT_MAGIC = 0x4b54324bu;
+__host__ __device__ inline uint32_t kt_magic(int w) { return 0x4b540000u | (uint32_t)w; }     // layout tag: the digit width is part of it
 // decode, negate, and run the (KT_PARTS - 1) x KT_W doublings that give the base points of the upper digit positions; row k of `table`
-__device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint32_t k, uint32_t n_keys, uint8_t* __restrict__ table) {
+__device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint32_t k, uint32_t n_keys, uint8_t* __restrict__ table, int w) {
     ge_p3 b;
     const bool ok = ge_frombytes_negate(b, pk);
     uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
     rec[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     rec[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     rec[2] = make_uint4(ok ? 1u : 0u, 0u, 0u, 0u);
-    rec[3] = make_uint4(KT_MAGIC, n_keys, 1u, 0u);            // stays dirty for k_keytable_entries; the next check re-evaluates
-    int32_t* dst = reinterpret_cast<int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)k * KT_BASE_I32;
+    rec[3] = make_uint4(kt_magic(w), n_keys, 1u, 0u);         // stays dirty for k_keytable_entries; the next check re-evaluates
+    int32_t* dst = reinterpret_cast<int32_t*>(table + kt_bases_off(n_keys)) + (uint64_t)k * kt_base_i32(w);
+    const int parts = kt_parts(w);
 #pragma unroll 1
-    for (int half = 0; half < KT_PARTS; half++) {          // one base point live at a time (40 VGPRs), stored as it is produced
-        if (half) b = ge_keytable_next_base(b, KT_W);
+    for (int half = 0; half < parts; half++) {             // one base point live at a time (40 VGPRs), stored as it is produced
+        if (half) b = ge_keytable_next_base(b, w);
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             dst[half * 40 + i] = b.X.v[i];
@@ -197,14 +201,14 @@ __device__ __forceinline__ void keytable_build_bases(const uint32_t pk[8], uint3
 // V = 100), and a per-row flag load per wave cost 0.17 ms beside an expansion.
 constexpr int KC_THREADS = 256;
 __global__ __launch_bounds__(KC_THREADS) void k_keytable_check(const bsx_validator* __restrict__ vals, uint32_t n_keys,
-                                                               uint8_t* __restrict__ table, uint32_t force) {
+                                                               uint8_t* __restrict__ table, uint32_t force, int w) {
     int any = 0;
     for (uint32_t k = threadIdx.x; k < n_keys; k += KC_THREADS) {
         uint32_t pk[8];
         load_pk(vals + k, pk);
         uint4* rec = reinterpret_cast<uint4*>(table + k * KT_REC_BYTES);
         const uint4 k0 = rec[0], k1 = rec[1], tag = rec[3];
-        const bool same = tag.x == KT_MAGIC && tag.y == n_keys && k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] &&
+        const bool same = tag.x == kt_magic(w) && tag.y == n_keys && k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] &&
                           k1.x == pk[4] && k1.y == pk[5] && k1.z == pk[6] && k1.w == pk[7];
         const uint32_t dirty = (force || !same) ? 1u : 0u;
         reinterpret_cast<uint32_t*>(rec + 3)[2] = dirty;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(KC_THREADS) void k_keytable_check(const bsx_validat
         if (reinterpret_cast<const uint32_t*>(table + k * KT_REC_BYTES)[14] == 0) continue;
         uint32_t pk[8];
         load_pk(vals + k, pk);
-        keytable_build_bases(pk, k, n_keys, table);
+        keytable_build_bases(pk, k, n_keys, table, w);
     }
 }
 
@@ -337,7 +341,7 @@ template <bool DEFER, bool BY_KEY, int SPLIT>
 __device__ __forceinline__ void verify_keyed_body(uint32_t block, uint32_t n_blocks, const bsx_validator* __restrict__ vals,
                                                   const uint8_t* __restrict__ hs, uint64_t n, uint32_t v_max,
                                                   const uint8_t* __restrict__ table, uint32_t n_keys, const int32_t* __restrict__ b_tab,
-                                                  uint8_t* __restrict__ ok_out, int32_t* __restrict__ scratch, const uint32_t* __restrict__ rows) {
+                                                  uint8_t* __restrict__ ok_out, int32_t* __restrict__ scratch, const uint32_t* __restrict__ rows, int w) {
     constexpr uint32_t SIGS = ED_THREADS / SPLIT;                              // signatures per workgroup
     const uint32_t sub = threadIdx.x / SPLIT, part0 = threadIdx.x % SPLIT;
     uint64_t me;
@@ -375,27 +379,27 @@ __device__ __forceinline__ void verify_keyed_body(uint32_t block, uint32_t n_blo
             const uint4* kr = reinterpret_cast<const uint4*>(table + (uint64_t)slot * KT_REC_BYTES);
             const uint4 k0 = kr[0], k1 = kr[1];
             keyed = k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] && k1.x == pk[4] && k1.y == pk[5] &&
-                    k1.z == pk[6] && k1.w == pk[7];
+                    k1.z == pk[6] && k1.w == pk[7] && kr[3].x == kt_magic(w);      // the row holds THIS key in THIS digit width
             decodes = kr[2].x != 0;
         }
         if (!keyed) {
             if (part0 == 0) ok_out[me] = ED_DEFERRED;   // left to k_ed25519_verify<true>, launched right behind on the same stream
             return;
         }
-        const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
+        const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys, w)) + (uint64_t)slot * kt_key_i32(w);
         if (SPLIT == 1) {
             if (DEFER) {
                 ge_p2 q;
-                const bool pre = decodes && ed25519_verify_keyed_core_t<true>(kt, b_tab, sr, ss, h, &q);
+                const bool pre = decodes && ed25519_verify_keyed_core_t<true>(kt, b_tab, sr, ss, h, &q, w);
                 int32_t* d = scratch + me * ED_SLOT_I32;
 #pragma unroll
                 for (int i = 0; i < 10; i++) { d[i] = q.X.v[i]; d[10 + i] = q.Y.v[i]; d[20 + i] = q.Z.v[i]; }
                 ok_out[me] = pre ? ED_PENDING : 0;          // k_ed25519_finish turns ED_PENDING into the verdict
                 return;
             }
-            ok = decodes && ed25519_verify_keyed_core(kt, b_tab, sr, ss, h);
+            ok = decodes && ed25519_verify_keyed_core(kt, b_tab, sr, ss, h, w);
         } else {
-            ge_p3 p = ed25519_keyed_partial<SPLIT>(kt, b_tab, ss, h, (int)part0);
+            ge_p3 p = ed25519_keyed_partial<SPLIT>(kt, b_tab, ss, h, (int)part0, w);
             // butterfly over the SPLIT lanes of the signature (adjacent lanes of one wave): afterwards every lane holds the sum
 #pragma unroll
             for (int m = 1; m < SPLIT; m <<= 1) {
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed(const bs
                                                                      uint32_t v_max, const uint8_t* __restrict__ table,
                                                                      uint32_t n_keys, const int32_t* __restrict__ b_tab,
                                                                      uint8_t* __restrict__ ok_out,
-                                                                     int32_t* __restrict__ scratch, const uint32_t* __restrict__ rows) {
-    verify_keyed_body<DEFER, BY_KEY, SPLIT>(blockIdx.x, gridDim.x, vals, hs, n, v_max, table, n_keys, b_tab, ok_out, scratch, rows);
+                                                                     int32_t* __restrict__ scratch, const uint32_t* __restrict__ rows, int w) {
+    verify_keyed_body<DEFER, BY_KEY, SPLIT>(blockIdx.x, gridDim.x, vals, hs, n, v_max, table, n_keys, b_tab, ok_out, scratch, rows, w);
 }
 // A batch whose one-lane-per-signature waves come to a little MORE than a whole number per SIMD (2048 commits x 100 slots: 3200
 // waves on 1024 SIMDs) takes as long as the SIMDs with the extra wave: 4 chains where the average is 3.125.  Here the first
@@ -447,13 +451,13 @@ __global__ __launch_bounds__(ED_THREADS, 4) void k_ed25519_verify_keyed_mixed(co
                                                                            const uint8_t* __restrict__ table, uint32_t n_keys,
                                                                            const int32_t* __restrict__ b_tab, uint8_t* __restrict__ ok_out,
                                                                            int32_t* __restrict__ scratch, uint32_t blocks_a, uint64_t commits_a,
-                                                                           const uint32_t* __restrict__ rows) {
+                                                                           const uint32_t* __restrict__ rows, int w) {
     const uint64_t na = commits_a * v_max;
     if (blockIdx.x < blocks_a)
-        verify_keyed_body<true, true, 1>(blockIdx.x, blocks_a, vals, hs, na, v_max, table, n_keys, b_tab, ok_out, scratch, rows);
+        verify_keyed_body<true, true, 1>(blockIdx.x, blocks_a, vals, hs, na, v_max, table, n_keys, b_tab, ok_out, scratch, rows, w);
     else
         verify_keyed_body<true, true, 4>(blockIdx.x - blocks_a, gridDim.x - blocks_a, vals + na, hs + na * 32, n - na, v_max, table, n_keys, b_tab,
-                                         ok_out + na, scratch + na * ED_SLOT_I32, rows ? rows + na : nullptr);
+                                         ok_out + na, scratch + na * ED_SLOT_I32, rows ? rows + na : nullptr, w);
 }
 
 // The small-batch form (a single proof: 100 signatures): latency is everything, and a third of a signature's dependent
@@ -467,7 +471,7 @@ constexpr int EL_SIGS = 16;
 __global__ __launch_bounds__(128) void k_ed25519_verify_keyed_small(const bsx_validator* __restrict__ vals, const uint8_t* __restrict__ hs,
                                                                   uint64_t n, uint32_t v_max, const uint8_t* __restrict__ table,
                                                                   uint32_t n_keys, const int32_t* __restrict__ b_tab,
-                                                                  uint8_t* __restrict__ ok_out, const uint32_t* __restrict__ rows) {
+                                                                  uint8_t* __restrict__ ok_out, const uint32_t* __restrict__ rows, int w) {
     __shared__ int32_t rdec[EL_SIGS][21];                 // -x_R (10 limbs), y_R (10), decodes
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t sub = wave == 0 ? lane / 4 : lane, part0 = lane % 4;
@@ -505,12 +509,12 @@ __global__ __launch_bounds__(128) void k_ed25519_verify_keyed_small(const bsx_va
             const uint4* kr = reinterpret_cast<const uint4*>(table + (uint64_t)slot * KT_REC_BYTES);
             const uint4 k0 = kr[0], k1 = kr[1];
             keyed = k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] && k1.x == pk[4] && k1.y == pk[5] &&
-                    k1.z == pk[6] && k1.w == pk[7];
+                    k1.z == pk[6] && k1.w == pk[7] && kr[3].x == kt_magic(w);
             decodes = kr[2].x != 0;
         }
         if (keyed) {                                        // the 4 lanes of a signature agree on every test above
-            const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
-            p = ed25519_keyed_partial<4>(kt, b_tab, ss, h, (int)part0);
+            const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys, w)) + (uint64_t)slot * kt_key_i32(w);
+            p = ed25519_keyed_partial<4>(kt, b_tab, ss, h, (int)part0, w);
 #pragma unroll
             for (int m = 1; m < 4; m <<= 1) {
                 ge_p3 o;
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed_proj(con
                                                                           uint64_t n, uint32_t v_max, const uint8_t* __restrict__ table,
                                                                           uint32_t n_keys, const int32_t* __restrict__ b_tab,
                                                                           const int32_t* __restrict__ rdec, uint8_t* __restrict__ ok_out,
-                                                                          const uint32_t* __restrict__ rows) {
+                                                                          const uint32_t* __restrict__ rows, int w) {
     constexpr uint32_t SIGS = ED_THREADS / SPLIT;
     const uint32_t sub = threadIdx.x / SPLIT, part0 = threadIdx.x % SPLIT;
     const uint64_t me = (uint64_t)blockIdx.x * SIGS + sub;
@@ -600,15 +604,15 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_ed25519_verify_keyed_proj(con
         const uint4* kr = reinterpret_cast<const uint4*>(table + (uint64_t)slot * KT_REC_BYTES);
         const uint4 k0 = kr[0], k1 = kr[1];
         keyed = k0.x == pk[0] && k0.y == pk[1] && k0.z == pk[2] && k0.w == pk[3] && k1.x == pk[4] && k1.y == pk[5] &&
-                k1.z == pk[6] && k1.w == pk[7];
+                k1.z == pk[6] && k1.w == pk[7] && kr[3].x == kt_magic(w);
         decodes = kr[2].x != 0;
     }
     if (!keyed) {
         if (part0 == 0) ok_out[me] = ED_DEFERRED;   // left to k_ed25519_verify<true>, launched right behind on the same stream
         return;
     }
-    const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys)) + (uint64_t)slot * KT_KEY_I32;
-    ge_p3 p = ed25519_keyed_partial<SPLIT>(kt, b_tab, ss, h, (int)part0);
+    const int32_t* kt = reinterpret_cast<const int32_t*>(table + kt_entries_off(n_keys, w)) + (uint64_t)slot * kt_key_i32(w);
+    ge_p3 p = ed25519_keyed_partial<SPLIT>(kt, b_tab, ss, h, (int)part0, w);
 #pragma unroll
     for (int m = 1; m < SPLIT; m <<= 1) {
         ge_p3 o;
@@ -1258,15 +1262,18 @@ hipError_t bsxk_ed25519_verify(hipStream_t s, const bsx_validator* vals, const u
     hipLaunchKernelGGL(k_ed25519_verify<false>, dim3((uint32_t)((n + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, h, n, ok);
     return hipGetLastError();
 }
-uint64_t bsxk_keytable_bytes(uint32_t n_keys) { return kt_bytes(n_keys); }
-hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint32_t n_keys, uint8_t* table) {
+int bsxk_keytable_default_bits(void) { return KT_W; }
+int bsxk_keytable_bits_ok(int w) { return kt_w_ok(w) ? 1 : 0; }
+uint64_t bsxk_keytable_bytes(uint32_t n_keys, int w) { return kt_bytes(n_keys, w); }
+hipError_t bsxk_ed25519_keytable(hipStream_t s, const bsx_validator* vals, uint32_t n_keys, uint8_t* table, int w) {
     if (n_keys == 0) return hipSuccess;
+    if (!kt_w_ok(w)) return hipErrorInvalidValue;
     // experiments build only: BSX_KEYTABLE_REUSE=0 forces a full rebuild on every call (cold-build measurements)
     static const uint32_t force = bsx_knob("BSX_KEYTABLE_REUSE", 1) == 0 ? 1u : 0u;
-    hipLaunchKernelGGL(k_keytable_check, dim3(1), dim3(KC_THREADS), 0, s, vals, n_keys, table, force);
-    TableBuildArgs a{reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)), reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys)), table,
-                     reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)), n_keys * (uint32_t)KT_PARTS, (uint32_t)KT_PARTS, (uint32_t)KT_HALF_ENTRIES, (uint32_t)KT_W};
-    const uint64_t lanes = (uint64_t)a.n_rows * (KT_HALF_ENTRIES / KB_G);
+    hipLaunchKernelGGL(k_keytable_check, dim3(1), dim3(KC_THREADS), 0, s, vals, n_keys, table, force, w);
+    TableBuildArgs a{reinterpret_cast<const int32_t*>(table + kt_bases_off(n_keys)), reinterpret_cast<int32_t*>(table + kt_entries_off(n_keys, w)), table,
+                     reinterpret_cast<const uint32_t*>(table + kt_flag_off(n_keys)), n_keys * (uint32_t)kt_parts(w), (uint32_t)kt_parts(w), (uint32_t)kt_half(w), (uint32_t)w};
+    const uint64_t lanes = (uint64_t)a.n_rows * (kt_half(w) / KB_G);
     const uint64_t wgs = (lanes + ED_THREADS - 1) / ED_THREADS;
     hipLaunchKernelGGL(k_table_entries, dim3((uint32_t)(wgs < 1024 ? wgs : 1024)), dim3(ED_THREADS), 0, s, a);
     return hipGetLastError();
@@ -1307,8 +1314,9 @@ hipError_t bsxk_ed25519_decode_r(hipStream_t s, const bsx_validator* vals, uint6
 // batch-inversion scratch take the latency form (k_ed25519_verify_keyed_proj)
 hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, const uint8_t* h, uint64_t n, uint32_t v_max,
                                      const uint8_t* table, uint32_t n_keys, const uint8_t* btable, uint8_t* ok, void* scratch, const void* rdec,
-                                     int64_t n_deferred, const uint32_t* rows) {
+                                     int64_t n_deferred, const uint32_t* rows, int w) {
     if (n == 0) return hipSuccess;
+    if (!kt_w_ok(w)) return hipErrorInvalidValue;
     const int32_t* b_tab = reinterpret_cast<const int32_t*>(btable + bt_entries_off());
     if (rdec && rdec != BSXK_ED_THROUGHPUT && !scratch && n < ED_SPLIT_BELOW) {
         // BSX_ED_PROJ_SPLIT (experiments): 8 / 16 lanes per signature; default 16 while the launch is a single wave round anyway
@@ -1316,8 +1324,8 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
         const bool s16 = env_ps ? env_ps == 16 : n <= 8192;
         const int32_t* rd = static_cast<const int32_t*>(rdec);
         BSX_NOTE_FORM(BSX_FORM_ED, 0x100u | (s16 ? 16u : 8u));
-        if (s16) hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<16>, dim3((uint32_t)((n + 3) / 4)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok, rows);
-        else hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<8>, dim3((uint32_t)((n + 7) / 8)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok, rows);
+        if (s16) hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<16>, dim3((uint32_t)((n + 3) / 4)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok, rows, w);
+        else hipLaunchKernelGGL(k_ed25519_verify_keyed_proj<8>, dim3((uint32_t)((n + 7) / 8)), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, rd, ok, rows, w);
         BSX_LAUNCH_DEFERRED();
         return hipGetLastError();
     }
@@ -1360,7 +1368,7 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
                 const uint32_t blocks_b = (uint32_t)((wpk_b * v_max + 7) / 8 * 8);
                 BSX_NOTE_FORM(BSX_FORM_ED, 0x200u);
                 hipLaunchKernelGGL(k_ed25519_verify_keyed_mixed, dim3(blocks_a + blocks_b), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys,
-                                   b_tab, ok, scr, blocks_a, commits_a, rows);
+                                   b_tab, ok, scr, blocks_a, commits_a, rows, w);
                 const uint32_t K = ed_fin_k(n);
                 const uint64_t lanes = (n + K - 1) / K;
                 hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
@@ -1372,14 +1380,14 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
 #define BSX_LAUNCH_KEYED(DEFER_, BYKEY_, SPLIT_)                                                                        \
     do {                                                                                                                \
         BSX_NOTE_FORM(BSX_FORM_ED, 0x400u | (uint32_t)(SPLIT_) | ((BYKEY_) ? 0x10u : 0u) | ((DEFER_) ? 0x20u : 0u));    \
-        hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr, rows); \
+        hipLaunchKernelGGL((k_ed25519_verify_keyed<DEFER_, BYKEY_, SPLIT_>), grid, dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys, b_tab, ok, scr, rows, w); \
     } while (0)
     // BSX_ED_SMALL=0 (experiments): no decode-R form for small batches
     static const bool small_form = bsx_knob("BSX_ED_SMALL", 1) != 0;
     if (split4 && !scr && !by_key && small_form) {
         BSX_NOTE_FORM(BSX_FORM_ED, 0x300u);
         hipLaunchKernelGGL(k_ed25519_verify_keyed_small, dim3((uint32_t)((n + EL_SIGS - 1) / EL_SIGS)), dim3(128), 0, s, vals, h, n, v_max, table,
-                           n_keys, b_tab, ok, rows);
+                           n_keys, b_tab, ok, rows, w);
 #ifdef BSX_EXPERIMENTS
     } else if (split2) {
         if (by_key) BSX_LAUNCH_KEYED(true, true, 2); else BSX_LAUNCH_KEYED(true, false, 2);

@@ -117,17 +117,40 @@ __global__ void k_fill_end_hash(uint32_t n_ranges, bsx_shared_ctx* ranges, const
 // slice of per-header commit results folded into ONE 128-byte record — the unit of the mode-S all-gather.
 //   digest(c) = inner( leaf(result[c] bytes 0..64), leaf(result[c] bytes 64..84 ‖ u32 LE commit index ‖ 40 zero bytes) )
 //   root      = binary SHA-256 tree (RFC 6962 inner nodes) over digest(0..n) padded with all-zero digests to a power of two
-// leaf / inner are the Tendermint Merkle primitives (0x00 / 0x01 prefixes).  One workgroup; digests live in `scratch` (P x 32 B).
-__global__ __launch_bounds__(256) void k_commit_fold(const bsx_commit_result* __restrict__ res, uint32_t n, uint32_t first_index, uint32_t P,
-                                                     uint32_t* __restrict__ scratch, bsx_commit_fold* __restrict__ out) {
+// leaf / inner are the Tendermint Merkle primitives (0x00 / 0x01 prefixes).
+// Round 5: the per-commit digests (6 compressions each) and the tree are spread over one lane per commit — workgroups of 256 commits
+// fold their own sub-tree in LDS (k_commit_fold_parts: 6 + 16 dependent compressions), one wave joins the <= 8 sub-roots
+// (k_commit_fold_top: 6 more).  Round 3's single workgroup hashed 8 commits per lane and the wide levels in turns: 78 dependent
+// compressions = 0.26 ms of one-wave latency behind every mode-S step.
+struct FoldPart { uint32_t root[8]; unsigned long long ok, sigs; uint32_t first, pad[3]; };      // 64 bytes
+static_assert(sizeof(FoldPart) == 64, "FoldPart");
+
+__device__ __forceinline__ void fold_write(bsx_commit_fold* out, const uint32_t root[8], uint32_t n, uint32_t first_index, unsigned long long ok,
+                                           unsigned long long sigs, uint32_t first) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t w = root[k];
+        out->root[4 * k] = (uint8_t)(w >> 24); out->root[4 * k + 1] = (uint8_t)(w >> 16);
+        out->root[4 * k + 2] = (uint8_t)(w >> 8); out->root[4 * k + 3] = (uint8_t)w;
+    }
+    out->n_commits = n;
+    out->n_ok = ok;
+    out->n_signatures_ok = sigs;
+    out->first_index = first_index;
+    out->first_failing = first;
+    for (int k = 0; k < 16; k++) out->_pad[k] = 0;
+}
+
+// Pb = digests per workgroup (a power of two <= 256; P / gridDim.x).  gridDim.x == 1: writes the fold record itself.
+__global__ __launch_bounds__(256) void k_commit_fold_parts(const bsx_commit_result* __restrict__ res, uint32_t n, uint32_t first_index, uint32_t Pb,
+                                                           FoldPart* __restrict__ parts, bsx_commit_fold* __restrict__ out) {
+    __shared__ uint32_t nodes[2][256 * 8];
     __shared__ unsigned long long s_ok, s_sigs;
     __shared__ uint32_t s_first;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, c = blockIdx.x * Pb + tid;
     if (tid == 0) { s_ok = 0; s_sigs = 0; s_first = 0xffffffffu; }
     __syncthreads();
-    uint64_t ok = 0, sigs = 0;
-    uint32_t first = 0xffffffffu;
-    for (uint32_t c = tid; c < P; c += 256) {
+    if (tid < Pb) {
         Digest d;
 #pragma unroll
         for (int k = 0; k < 8; k++) d.w[k] = 0;
@@ -146,49 +169,70 @@ __global__ __launch_bounds__(256) void k_commit_fold(const bsx_commit_result* __
             d = inner_hash(a, b);
             const bsx_commit_result& r = res[c];
             const bool good = r.two_thirds_ok && !r.n_bad_signature && !r.n_bad_message && !r.power_overflow;
-            ok += good ? 1 : 0;
-            sigs += r.n_signed - r.n_bad_signature;
-            if (!good && first == 0xffffffffu) first = first_index + c;
+            atomicAdd(&s_ok, (unsigned long long)(good ? 1 : 0));
+            atomicAdd(&s_sigs, (unsigned long long)(r.n_signed - r.n_bad_signature));
+            if (!good) atomicMin(&s_first, first_index + c);
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) scratch[(uint64_t)c * 8 + k] = d.w[k];
+        for (int k = 0; k < 8; k++) nodes[0][tid * 8 + k] = d.w[k];
     }
-    atomicAdd(&s_ok, (unsigned long long)ok);
-    atomicAdd(&s_sigs, (unsigned long long)sigs);
-    atomicMin(&s_first, first);
     __syncthreads();
-    for (uint32_t width = P / 2; width >= 1; width /= 2) {
-        // parents are written over the left half of the level (node i <- children 2i, 2i+1): a lane reads both children before
-        // the barrier and writes after it, so no lane overwrites a digest another lane still has to read
-        Digest nd[8];
-        uint32_t cnt = 0;
-        for (uint32_t i = tid; i < width; i += 256, cnt++) {
+    int cur = 0;
+    for (uint32_t width = Pb / 2; width >= 1; width /= 2) {
+        if (tid < width) {
             Digest l, r;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { l.w[k] = scratch[(uint64_t)(2 * i) * 8 + k]; r.w[k] = scratch[(uint64_t)(2 * i + 1) * 8 + k]; }
-            if (cnt < 8) nd[cnt] = inner_hash(l, r);
+            for (int k = 0; k < 8; k++) { l.w[k] = nodes[cur][(2 * tid) * 8 + k]; r.w[k] = nodes[cur][(2 * tid + 1) * 8 + k]; }
+            const Digest nd = inner_hash(l, r);
+#pragma unroll
+            for (int k = 0; k < 8; k++) nodes[cur ^ 1][tid * 8 + k] = nd.w[k];
         }
         __syncthreads();
-        cnt = 0;
-        for (uint32_t i = tid; i < width; i += 256, cnt++)
-            if (cnt < 8) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) scratch[(uint64_t)i * 8 + k] = nd[cnt].w[k];
-            }
-        __syncthreads();
-    }
-    if (tid < 8) {
-        const uint32_t w = scratch[tid];
-        out->root[4 * tid] = (uint8_t)(w >> 24); out->root[4 * tid + 1] = (uint8_t)(w >> 16);
-        out->root[4 * tid + 2] = (uint8_t)(w >> 8); out->root[4 * tid + 3] = (uint8_t)w;
+        cur ^= 1;
     }
     if (tid == 0) {
-        out->n_commits = n;
-        out->n_ok = s_ok;
-        out->n_signatures_ok = s_sigs;
-        out->first_index = first_index;
-        out->first_failing = s_first;
-        for (int k = 0; k < 16; k++) out->_pad[k] = 0;
+        uint32_t root[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) root[k] = nodes[cur][k];
+        if (gridDim.x == 1) {
+            fold_write(out, root, n, first_index, s_ok, s_sigs, s_first);
+        } else {
+            FoldPart* o = parts + blockIdx.x;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o->root[k] = root[k];
+            o->ok = s_ok; o->sigs = s_sigs; o->first = s_first; o->pad[0] = o->pad[1] = o->pad[2] = 0;
+        }
+    }
+}
+
+// nb = 2, 4 or 8 sub-roots -> the record.  One wave.
+__global__ __launch_bounds__(64) void k_commit_fold_top(const FoldPart* __restrict__ parts, uint32_t nb, uint32_t n, uint32_t first_index,
+                                                        bsx_commit_fold* __restrict__ out) {
+    __shared__ uint32_t nodes[2][8 * 8];
+    const uint32_t tid = threadIdx.x;
+    if (tid < nb * 8) nodes[0][tid] = parts[tid >> 3].root[tid & 7];
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t width = nb / 2; width >= 1; width /= 2) {
+        if (tid < width) {
+            Digest l, r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { l.w[k] = nodes[cur][(2 * tid) * 8 + k]; r.w[k] = nodes[cur][(2 * tid + 1) * 8 + k]; }
+            const Digest nd = inner_hash(l, r);
+#pragma unroll
+            for (int k = 0; k < 8; k++) nodes[cur ^ 1][tid * 8 + k] = nd.w[k];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tid == 0) {
+        unsigned long long ok = 0, sigs = 0;
+        uint32_t first = 0xffffffffu;
+        for (uint32_t b = 0; b < nb; b++) { ok += parts[b].ok; sigs += parts[b].sigs; first = parts[b].first < first ? parts[b].first : first; }
+        uint32_t root[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) root[k] = nodes[cur][k];
+        fold_write(out, root, n, first_index, ok, sigs, first);
     }
 }
 
@@ -408,7 +452,10 @@ uint64_t bsxk_commit_fold_scratch_bytes(uint32_t n) {
 hipError_t bsxk_commit_fold(hipStream_t s, const bsx_commit_result* res, uint32_t n, uint32_t first_index, void* scratch, bsx_commit_fold* out) {
     uint32_t P = 1;
     while (P < n) P *= 2;
-    hipLaunchKernelGGL(k_commit_fold, dim3(1), dim3(256), 0, s, res, n, first_index, P, static_cast<uint32_t*>(scratch), out);
+    const uint32_t nb = P > 256 ? P / 256 : 1, Pb = P / nb;
+    FoldPart* parts = static_cast<FoldPart*>(scratch);
+    hipLaunchKernelGGL(k_commit_fold_parts, dim3(nb), dim3(256), 0, s, res, n, first_index, Pb, parts, out);
+    if (nb > 1) hipLaunchKernelGGL(k_commit_fold_top, dim3(1), dim3(64), 0, s, parts, nb, n, first_index, out);
     return hipGetLastError();
 }
 hipError_t bsxk_encode_tuple(hipStream_t s, const uint8_t* data_hash, uint64_t height, uint8_t* out) {

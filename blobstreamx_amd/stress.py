@@ -49,14 +49,18 @@ def range_verdict(folds):
 
 
 class CommitShard:
-    def __init__(self, n_commits_total, v_max, rank=0, world=1, device=None, with_witness=False, expand=False, n_sets=1):
+    def __init__(self, n_commits_total, v_max, rank=0, world=1, device=None, with_witness=False, expand=False, n_sets=1, tally_beside=True, wide_tables=None):
         """with_witness: every step also leaves the commits' COMMIT units (include/bsx_layout.h: the Goldilocks witness of the
         per-validator loop, BASELINE config #5) in compact form in `self.compact`; expand: and expands them into `self.witness`
         (u64 [n][commit_layout(V).n_elements]: 15 MB per commit at V = 512) on the same stream.
         n_sets = K > 1: K sets of output buffers (verdicts, results, fold, scratch, units) and K streams; step i runs on set i mod K,
         so that step i + 1 starts while step i's stages drain (a stage is a few resident rounds of long waves: alone, its ramp-up,
         its last partial round and the SIMDs with one wave less than their neighbours idle).  The inputs and the key tables are shared,
-        read only.  `ok` / `res` / `fold` / `compact` / `witness` name the set of the LAST step."""
+        read only.  `ok` / `res` / `fold` / `compact` / `witness` name the set of the LAST step.
+        wide_tables: BSX_COMMITS_KEYTABLE_WIDE — 16-bit digits in the key tables (64 MB per key; 16 + 16 instead of 22 + 16 additions per
+        signature).  Default: for validator sets of up to 128 slots (6.4 GB of tables at V = 100; a shard's set is resident).
+        tally_beside: BSX_COMMITS_TALLY_BESIDE — the validator-set trees run beside the signature check on the context's side stream
+        (one thread drives a shard, as the flag requires)."""
         import torch
         self.N, self.V, self.rank, self.world = n_commits_total, v_max, rank, world
         self.first, self.n = commit_slice(n_commits_total, rank, world)
@@ -66,10 +70,12 @@ class CommitShard:
         n, V, d = self.n, v_max, self.dev
         z = lambda nbytes: torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=d)
         self.K = int(n_sets)
+        self.tally_beside = bool(tally_beside)
         assert self.K >= 1
         self.vals = z(n * V * 256)
         self.hh = z(n * 32)
-        self.keytable = z(int(self.L.bsx_ed25519_keytable_bytes(C.c_uint32(V))))
+        self.kt_bits = 16 if (wide_tables if wide_tables is not None else v_max <= 128) else 12
+        self.keytable = z(int(self.L.bsx_ed25519_keytable_bytes_w(C.c_uint32(V), C.c_uint32(self.kt_bits))))
         self.lay = T.commit_layout(V)
         self._sets = []
         for _ in range(self.K):
@@ -101,11 +107,12 @@ class CommitShard:
         # the keys are compared on the host, so that a step launches neither the key compare nor — when every active slot carries
         # the first commit's key of its index — the generic-kernel pass (bsx.h BSX_COMMITS_*)
         st = torch.cuda.current_stream(self.dev)
-        _lib.check(self.L.bsx_dev_ed25519_keytable(self.ctx, C.c_void_p(st.cuda_stream), _lib.dp(self.vals), C.c_uint32(self.V), _lib.dp(self.keytable)))
+        _lib.check(self.L.bsx_dev_ed25519_keytable_w(self.ctx, C.c_void_p(st.cuda_stream), _lib.dp(self.vals), C.c_uint32(self.V), _lib.dp(self.keytable),
+                                                     C.c_uint32(self.kt_bits)))
         torch.cuda.synchronize(self.dev)
         active = (v["enabled"] != 0) & (v["is_signed"] != 0)
         uniform = bool((~active | (v["pubkey"] == v["pubkey"][0][None]).all(axis=2)).all())
-        self.flags = 1 | (2 if uniform else 0)
+        self.flags = 1 | (2 if uniform else 0) | (4 if self.tally_beside else 0) | (8 if self.kt_bits == 16 else 0)
 
     def step(self, stream=None):
         """One bsx_dev_verify_commits over this rank's slice [+ the units' expansion], on `stream` (default: the current stream; with

@@ -511,6 +511,15 @@ int bsx_dev_ed25519_verify(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
  * on the same buffer — a validator set is stable for hours, so steady-state calls cost one key compare per row.  Zero the
  * key records again to force a rebuild. */
 uint64_t bsx_ed25519_keytable_bytes(uint32_t n_keys);
+/* The digit width of a key table is a property of the table (round 5).  BSX_KEYTABLE_BITS (the plain entry points above and below;
+ * every request-driven path: a new validator set's table is built on the spot, 22 us per key) or BSX_KEYTABLE_BITS_WIDE (64 MB and
+ * 0.24 ms per key; mode S, BSX_COMMITS_KEYTABLE_WIDE).  Other widths: BSX_ERR_BAD_ARG / 0 bytes. */
+#define BSX_KEYTABLE_BITS 12u
+#define BSX_KEYTABLE_BITS_WIDE 16u
+uint64_t bsx_ed25519_keytable_bytes_w(uint32_t n_keys, uint32_t digit_bits);
+int bsx_dev_ed25519_keytable_w(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys, void* d_table, uint32_t digit_bits);
+int bsx_dev_ed25519_verify_keyed_w(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h, uint64_t n, uint32_t v_max,
+                                   const void* d_table, uint32_t n_keys, uint8_t* d_ok, void* d_scratch, uint32_t digit_bits);
 int bsx_dev_ed25519_keytable(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, uint32_t n_keys,
                              void* d_table);
 int bsx_dev_ed25519_verify_keyed(bsx_ctx* ctx, void* stream, const bsx_validator* d_validators, const uint8_t* d_h,
@@ -577,6 +586,18 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
  * when it uploaded the validators): no slot can be deferred to the generic per-signature kernel, whose scan launch is skipped.  A
  * false promise never turns into an accepted signature: a slot the fixed-key kernel had to defer then counts as a BAD signature. */
 #define BSX_COMMITS_KEYS_UNIFORM 2u
+/* The validator-set trees (SimpleValidator leaves, masked tree, total power: nothing there depends on the signatures) run BESIDE the
+ * signature check on a stream of the context instead of behind it, and only the signature-dependent sums follow the check (round 5:
+ * one step in flight loses the tally's 0.1 ms).  The call then uses the context's side stream and two of its events: calls that carry
+ * this flag on ONE context must be issued by one thread at a time (any number may be in flight), and not while a host-tier call of
+ * another thread runs on that context. */
+#define BSX_COMMITS_TALLY_BESIDE 4u
+/* d_keytable holds BSX_KEYTABLE_BITS_WIDE-bit digits (bsx_ed25519_keytable_bytes_w / bsx_dev_ed25519_keytable_w below): 16 + 16
+ * instead of 22 + 16 table additions per signature for 64 MB instead of 5.8 MB of table per key — the form for a validator set that
+ * stays resident over many millions of signatures (2048 x 100: verification 0.54 -> 0.49 ms).  The width is part of every row's
+ * layout tag: a table of the other width is never read as this one (its slots are deferred, and counted as bad under
+ * BSX_COMMITS_KEYS_UNIFORM). */
+#define BSX_COMMITS_KEYTABLE_WIDE 8u
 /* flags 0 = the call is self-contained (as in round 3). */
 
 /* ------------------------------------------------------------------ operator skip-target search

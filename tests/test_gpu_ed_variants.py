@@ -100,15 +100,16 @@ def _child():
     dh = torch.from_numpy(hs.reshape(-1).copy()).cuda()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     n_keys = 2                                   # slot 2 has no table row: generic fallback inside the same call
-    tab = torch.zeros(int(L.bsx_ed25519_keytable_bytes(C.c_uint32(n_keys))), dtype=torch.uint8, device="cuda")
-    _lib.check(L.bsx_dev_ed25519_keytable(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab)))
+    bits = int(os.environ.get("BSX_TEST_KT_BITS", "12"))      # 16: the wide key tables of round 5 (BSX_KEYTABLE_BITS_WIDE)
+    tab = torch.zeros(int(L.bsx_ed25519_keytable_bytes_w(C.c_uint32(n_keys), C.c_uint32(bits))), dtype=torch.uint8, device="cuda")
+    _lib.check(L.bsx_dev_ed25519_keytable_w(ctx, st, dp(dv), C.c_uint32(n_keys), dp(tab), C.c_uint32(bits)))
     scr = torch.zeros(int(L.bsx_ed25519_verify_scratch_bytes(C.c_uint64(n))), dtype=torch.uint8, device="cuda")
     L.bsx_debug_last_launch_form.restype = C.c_uint32        # AttributeError here = the product library was loaded, not libbsx_exp.so
     forms = []
     for scratch in (None, scr):
         ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
-        _lib.check(L.bsx_dev_ed25519_verify_keyed(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v_max), dp(tab), C.c_uint32(n_keys),
-                                                  dp(ok), dp(scratch) if scratch is not None else None))
+        _lib.check(L.bsx_dev_ed25519_verify_keyed_w(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(v_max), dp(tab), C.c_uint32(n_keys),
+                                                    dp(ok), dp(scratch) if scratch is not None else None, C.c_uint32(bits)))
         forms.append(int(L.bsx_debug_last_launch_form(C.c_uint32(0))))
         torch.cuda.synchronize()
         got = ok.cpu().numpy()
@@ -131,13 +132,16 @@ def _expected_forms(split, by_key, small, n_commits):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split,by_key,small", [(1, 0, 1), (1, 1, 1), (4, 0, 1), (4, 0, 0), (4, 1, 1), (None, None, 1)])
-def test_every_launch_form_on_forged_digit_edges(split, by_key, small):
-    """(4, 0, 1) is the small-batch form that decodes R in a second wave and compares projectively instead of encoding."""
+@pytest.mark.parametrize("split,by_key,small,bits", [(1, 0, 1, 12), (1, 1, 1, 12), (4, 0, 1, 12), (4, 0, 0, 12), (4, 1, 1, 12), (None, None, 1, 12),
+                                                     (1, 0, 1, 16), (1, 1, 1, 16), (4, 0, 1, 16), (4, 1, 1, 16)])
+def test_every_launch_form_on_forged_digit_edges(split, by_key, small, bits):
+    """(4, 0, 1) is the small-batch form that decodes R in a second wave and compares projectively instead of encoding.  bits = 16: the
+    same forms over key tables with 16-bit digits (the forged scalars hit the extreme radix-65536 digits as well: they are built for s)."""
     assert os.path.exists(EXP_LIB), "libbsx_exp.so is not built: python -c 'import __graft_entry__ as g; g.build()'"
     env = dict(os.environ, BSX_LIB_OVERRIDE=EXP_LIB)
     env.pop("BSX_ED_SPLIT", None); env.pop("BSX_ED_BY_KEY", None)
     env["BSX_ED_SMALL"] = str(small)
+    env["BSX_TEST_KT_BITS"] = str(bits)
     if split is not None:
         env["BSX_ED_SPLIT"], env["BSX_ED_BY_KEY"] = str(split), str(by_key)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)

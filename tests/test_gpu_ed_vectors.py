@@ -133,3 +133,41 @@ def test_latency_form_device_tier_parity_unpinned_by_reference():
         got = ok_new.cpu().numpy().reshape(n_commits, V)
         assert (got == want).all(), (n_commits, np.argwhere(got != want)[:5])
         assert torch.equal(ok_new, ok_old), n_commits
+
+
+def test_wide_key_tables_device_tier_parity_unpinned_by_reference():
+    """Round 5: key tables with 16-bit digits (bsx_ed25519_keytable_bytes_w / bsx_dev_ed25519_keytable_w / bsx_dev_ed25519_verify_keyed_w,
+    BSX_KEYTABLE_BITS_WIDE) judge every public vector as the 12-bit tables do — one lane per signature with and without the
+    batch-inversion scratch, four lanes, the small form — and a table is never read in the other width: the wrong promise defers
+    every slot to the generic kernel (same verdicts), it does not mis-verify."""
+    import torch
+    base = _slots(ALL)
+    V = base.size
+    L, ctx, dp = _lib.lib(), _lib.context(0), _lib.dp
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert int(L.bsx_ed25519_keytable_bytes_w(C.c_uint32(V), C.c_uint32(13))) == 0          # unsupported width
+    assert int(L.bsx_ed25519_keytable_bytes_w(C.c_uint32(V), C.c_uint32(12))) == int(L.bsx_ed25519_keytable_bytes(C.c_uint32(V)))
+    wide = torch.zeros(int(L.bsx_ed25519_keytable_bytes_w(C.c_uint32(V), C.c_uint32(16))), dtype=torch.uint8, device=dev)
+    assert wide.numel() > 10 * int(L.bsx_ed25519_keytable_bytes(C.c_uint32(V)))
+    for n_commits in (1, 3, 40, 5200):                       # small form; four lanes; lanes by key; one lane per signature (> 300,000)
+        vals = np.stack([base] * n_commits)
+        vals[n_commits // 2] = np.roll(base, 5)                      # one commit whose keys differ from the table rows
+        n = n_commits * V
+        dv = torch.from_numpy(vals.view(np.uint8).reshape(-1).copy()).to(dev)
+        dh = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+        scr = torch.zeros(int(L.bsx_ed25519_verify_scratch_bytes(C.c_uint64(n))), dtype=torch.uint8, device=dev)
+        _lib.check(L.bsx_dev_sha512_challenge(ctx, st, dp(dv), C.c_uint64(n), dp(dh), None))
+        _lib.check(L.bsx_dev_ed25519_keytable_w(ctx, st, dp(dv), C.c_uint32(V), dp(wide), C.c_uint32(16)))
+        want = np.stack([WANT] * n_commits)
+        want[n_commits // 2] = np.roll(WANT, 5)
+        for bits, scratch in ((16, None), (16, scr), (12, scr)):   # the last: a 12-bit kernel on the 16-bit table = every slot deferred
+            ok = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+            _lib.check(L.bsx_dev_ed25519_verify_keyed_w(ctx, st, dp(dv), dp(dh), C.c_uint64(n), C.c_uint32(V), dp(wide), C.c_uint32(V), dp(ok),
+                                                        dp(scratch) if scratch is not None else None, C.c_uint32(bits)))
+            torch.cuda.synchronize()
+            got = ok.cpu().numpy().reshape(n_commits, V)
+            assert (got == want).all(), (n_commits, bits, scratch is not None, np.argwhere(got != want)[:5])
+        if n_commits > 1000:
+            break
+    assert L.bsx_dev_ed25519_keytable_w(ctx, st, dp(dv), C.c_uint32(V), dp(wide), C.c_uint32(14)) == T.ERR_BAD_ARG

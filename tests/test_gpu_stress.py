@@ -26,7 +26,8 @@ def _clean(r):
 
 
 @pytest.mark.parametrize("world,J,B,V,tamper", [(1, 2, 16, 12, False), (2, 4, 16, 33, True), (4, 8, 8, 7, True), (8, 32, 64, 100, False), (1, 32, 64, 100, True),
-                                                 (8, 32, 64, 512, True)])      # the last one: BASELINE config #5 literally
+                                                 (8, 32, 64, 512, True),       # BASELINE config #5 literally
+                                                 (2, 32, 32, 5, True), (1, 16, 64, 3, True), (1, 5, 64, 9, False)])   # folds of 2 / 4 sub-trees, a ragged one (320 commits)
 def test_commit_shards_vs_oracle(world, J, B, V, tamper):
     """Every rank's CommitShard of an N-GPU mode-S run on ONE GPU: its slice's ok bits, commit results and fold equal the
     oracle's; the concatenation of the folds (= the all-gather's result) gives the range verdict, incl. the global index of a
@@ -91,12 +92,12 @@ def test_two_steps_in_flight_give_the_same_answers():
     vals = w.validators.reshape(nh, V).copy()
     k = int(np.nonzero(vals[11]["is_signed"])[0][0])
     vals[11, k]["signature"][3] ^= 2
-    one = CommitShard(nh, V, with_witness=True)
+    one = CommitShard(nh, V, with_witness=True, tally_beside=False)      # the self-contained call: everything on the one stream
     one.upload(vals, w.commit_hashes)
     one.step()
     ok1, res1, fold1 = one.download()
     cw1 = one.compact_of(range(nh))
-    two = CommitShard(nh, V, with_witness=True, n_sets=2)
+    two = CommitShard(nh, V, with_witness=True, n_sets=2)                 # BSX_COMMITS_TALLY_BESIDE (default): trees on the side stream
     two.upload(vals, w.commit_hashes)
     prev = None
     for i in range(5):
