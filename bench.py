@@ -82,6 +82,8 @@ def parse():
                     "ALU-bound hashing of one chunk beside the HBM-bound expansion of the other)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--mode", choices=["F", "S"], default="F", help="F: one commit per range (a reference proof); S: a commit on every header")
+    ap.add_argument("--wide-tables", choices=["auto", "0", "1"], default="auto", help="mode S: 16-bit digits in the key tables (BSX_COMMITS_KEYTABLE_WIDE; "
+                    "auto = on)")
     ap.add_argument("--no-witness", action="store_true", help="skip the Goldilocks expansion (reported as such)")
     ap.add_argument("--caps", action="store_true", help="Poseidon Merkle caps of the map-job witnesses from the compact bytes (with --no-witness: instead of the expansion)")
     ap.add_argument("--alternate", type=int, default=1, help="K buffer sets inside the pipeline, step i on set i mod K (pipelining across steps; the compact-only leg uses 2)")
@@ -301,7 +303,8 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     w = synth.Workload(5 if V > 100 else 4, 1, args.jobs, args.batch, v=V, mode="S")
     # three buffer sets on three streams: steps i + 1, i + 2 start while step i's stages drain (stress.py CommitShard; 2048 x 100:
     # 1.03 / 0.68 / 0.61 ms per step with 1 / 2 / 3 in flight); the fold all-gather of step i is taken while they run
-    sh = CommitShard(nh, V, rank=rank, world=world, device=dev, n_sets=3)
+    wide = None if getattr(args, "wide_tables", "auto") == "auto" else args.wide_tables == "1"
+    sh = CommitShard(nh, V, rank=rank, world=world, device=dev, n_sets=3, wide_tables=wide)
     sh.upload(w.validators.reshape(nh, V), w.commit_hashes)
     n = sh.n * V
     L, ctx, dp = sh.L, sh.ctx, _lib.dp
@@ -396,7 +399,7 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
     # expanded into Goldilocks elements by k_expand_witness on the same stream — HBM-write bound, its own roofline next to the VALU one.
     del sh
     torch.cuda.empty_cache()
-    shw = CommitShard(nh, V, rank=rank, world=world, device=dev, expand=True, n_sets=2)
+    shw = CommitShard(nh, V, rank=rank, world=world, device=dev, expand=True, n_sets=2, wide_tables=wide)
     shw.upload(w.validators.reshape(nh, V), w.commit_hashes)
     lay = shw.lay
     exp_bytes = shw.n * (int(lay["n_bytes"]) + 4 * int(lay["n_words"]) + int(lay["n_bools"]) + 8 * int(lay["n_elements"]))

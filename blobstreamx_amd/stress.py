@@ -58,7 +58,8 @@ class CommitShard:
         its last partial round and the SIMDs with one wave less than their neighbours idle).  The inputs and the key tables are shared,
         read only.  `ok` / `res` / `fold` / `compact` / `witness` name the set of the LAST step.
         wide_tables: BSX_COMMITS_KEYTABLE_WIDE — 16-bit digits in the key tables (64 MB per key; 16 + 16 instead of 22 + 16 additions per
-        signature).  Default: for validator sets of up to 128 slots (6.4 GB of tables at V = 100; a shard's set is resident).
+        signature).  Default: on (6.4 GB of tables at V = 100, 34 GB at V = 512 — of 288 GB; a shard's validator set is resident:
+        2048 x 512 verification 2.22 -> 1.94 ms).
         tally_beside: BSX_COMMITS_TALLY_BESIDE — the validator-set trees run beside the signature check on the context's side stream
         (one thread drives a shard, as the flag requires)."""
         import torch
@@ -74,7 +75,7 @@ class CommitShard:
         assert self.K >= 1
         self.vals = z(n * V * 256)
         self.hh = z(n * 32)
-        self.kt_bits = 16 if (wide_tables if wide_tables is not None else v_max <= 128) else 12
+        self.kt_bits = 16 if (wide_tables if wide_tables is not None else True) else 12
         self.keytable = z(int(self.L.bsx_ed25519_keytable_bytes_w(C.c_uint32(V), C.c_uint32(self.kt_bits))))
         self.lay = T.commit_layout(V)
         self._sets = []
