@@ -709,11 +709,24 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const uint8_t* slots = cw + bsx_off_slots(B);
     // curr_header entering slot i = start_header (i == 0 or m == 0) else lb_root of slot min(i, m) - 1
     const Digest start_header = load_digest_global(cw + bsx_off_start_header());
-    Digest curr_before = start_header, curr_after = start_header;
-    if (i > 0 && m > 0) curr_before = load_digest_global(slots + BSX_SLOT_BYTES * (min(i, m) - 1) + 160 + 128);
-    if (m > 0) curr_after = load_digest_global(slots + BSX_SLOT_BYTES * (min(i + 1, m) - 1) + 160 + 128);
     const Digest dh_root = load_digest_global(slots + BSX_SLOT_BYTES * i + 128);
     const Digest lb_root = load_digest_global(slots + BSX_SLOT_BYTES * i + 160 + 128);
+    Digest curr_before = start_header, curr_after = start_header;
+    if (B <= 64) {
+        // a job's slots are consecutive lanes of ONE wave (B divides the workgroup): the neighbouring slots' lb_root comes through the
+        // wave's crossbar instead of two more 32-byte loads at slot stride (round 5; 3 instead of 5 strided digest loads per slot)
+        const uint32_t base = (tid & 63u) & ~(B - 1u);
+        const uint32_t ib = min(i, m), ia = min(i + 1, m);
+        const int sb = (int)(base + (ib ? ib - 1 : 0)), sa = (int)(base + (ia ? ia - 1 : 0));
+        Digest nb, na;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { nb.w[k] = __shfl(lb_root.w[k], sb, 64); na.w[k] = __shfl(lb_root.w[k], sa, 64); }
+        if (i > 0 && m > 0) curr_before = nb;
+        if (m > 0) curr_after = na;
+    } else {
+        if (i > 0 && m > 0) curr_before = load_digest_global(slots + BSX_SLOT_BYTES * (min(i, m) - 1) + 160 + 128);
+        if (m > 0) curr_after = load_digest_global(slots + BSX_SLOT_BYTES * (min(i + 1, m) - 1) + 160 + 128);
+    }
     Digest claimed;                                                  // last_block_id_proofs[i].leaf[2..34] (:204)
     {
         // 2-byte aligned in the packed image: two misaligned 16-byte loads (gfx950 serves them) instead of nine dwords + funnels
