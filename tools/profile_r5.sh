@@ -55,6 +55,10 @@ python tools/timeline3.py $(kt $O/ktC) 6 2 > $O/r5_compact_timeline.txt
 # 7. one host-tier call (bsx_header_range)
 rocprofv3 --kernel-trace --output-format csv -d $O/ktL -o lat -- python tools/latency_probe.py 30 > $O/ktL.log 2>&1
 python tools/timeline3.py $(kt $O/ktL) 1.1 0 > $O/r5_latency_timeline.txt
+# 7b. mode S, one step in flight: the kernels of a joined step
+rocprofv3 --kernel-trace --output-format csv -d $O/ktJ -o ms -- python tools/modeS_joined_trace.py 100 12 > $O/ktJ.log 2>&1
+python tools/timeline3.py $(kt $O/ktJ) 2.0 0 > $O/r5_modeS_100_joined_timeline.txt
+rm -rf $O/ktJ
 # 8. commit-check stages alone
 python tools/commit_chain_time.py > $O/r5_commit_chain_stages.txt 2>&1
 # 9. VALU instructions per unit of work (for bench.py's valu_issue_frac): fused leaf hashing 256 jobs x 3332 rows x 17 permutations;
@@ -65,5 +69,8 @@ python tools/valu_insts.py $O/valu_insts.json "poseidon_leaf=$O/r5_poseidon_pmc_
 rm -rf $O/kt $O/kt1024 $O/pmc1024_FETCH_SIZE $O/pmc1024_WRITE_SIZE $O/pmcSU_FETCH_SIZE $O/pmcSU_WRITE_SIZE $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmcSQ $O/ktS $O/pmcS $O/pmcS1 $O/ktP $O/pmcP $O/ktC $O/ktL
 # 10. the bench line itself (all legs) — after valu_insts.json exists so that valu_issue_frac is filled in
 cp $O/valu_insts.json profiles/valu_insts.json
+# the traffic figures of this run's own counter passes (bench.py reads profiles/*pmc_hbm_traffic*.csv + .meta.json at run time)
+cp $O/r5_pmc_hbm_traffic.csv $O/r5_pmc_hbm_traffic.meta.json $O/r5_1024_pmc_hbm_traffic.csv $O/r5_1024_pmc_hbm_traffic.meta.json \
+   $O/r5_modeS_100_units_pmc_hbm_traffic.csv $O/r5_modeS_100_units_pmc_hbm_traffic.meta.json profiles/
 python bench.py > $O/r5_bench_n1.json 2> $O/bench.err
 ls -la $O
