@@ -12,7 +12,14 @@ import bench  # noqa: E402
 J, B, V = 32, 64, 100
 dev = torch.device("cuda:0")
 out = {}
-if "sweep" in sys.argv:
+if "sweep2" in sys.argv:          # lanes x window (round 5, second pass)
+    for lanes in (2, 3, 4, 6):
+        for win in (20, 50, 150):
+            r = bench.concurrent_leg(dev, J, B, V, ks=(16, 64), seconds=0.4, serial=False, window_us=win, n_lanes=lanes)
+            out["l%d_w%d" % (lanes, win)] = [(x["threads"], round(x["headers_per_s"] / 1e6, 1), round(x["p50_ms"], 3), round(x["p99_ms"], 3), round(x["requests_per_launch_set"], 1))
+                                            for x in r["coalesced_shared_context"]]
+            print("l%d_w%d" % (lanes, win), out["l%d_w%d" % (lanes, win)], flush=True)
+elif "sweep" in sys.argv:
     for name, kw in (("w50_l3", {}), ("w100_l2", dict(window_us=100, n_lanes=2)), ("w50_l3_pinned", dict(pinned=True))):
         r = bench.concurrent_leg(dev, J, B, V, ks=(1, 16, 64), seconds=0.4, serial=False, **kw)
         out[name] = [(x["threads"], round(x["headers_per_s"] / 1e6, 1), round(x["p50_ms"], 3), round(x["p99_ms"], 3), round(x["requests_per_launch_set"], 1), x["worker_us_per_set"])
