@@ -156,7 +156,8 @@ __device__ __forceinline__ void poseidon_recombine3(uint64_t& w0, uint64_t& w1, 
 }
 #endif
 // the same for limbs out of the partial rounds, whose lowest one may be slightly negative (see below): carry steps first
-// (two: a1 + carry is negative when a1 = 0 and a0 < 0 — every l1 of the state zero — and the value sits in a2)
+// (two: a1 + carry is negative when a1 = 0 and a0 < 0 — every l1 of the state zero — and the value sits in a2).  |a0|, a1 < 2^31 - 2^9:
+// the MDS outputs of the partial rounds (|a0| < 264 * 2^22, a1 < 264 * (2^22 + 2^18.1))
 BSX_HDI void poseidon_carry_signed(uint32_t& a0, uint32_t& a1, uint32_t& a2) {
     const uint32_t t1 = a1 + (uint32_t)((int32_t)a0 >> 22);
     a2 += (uint32_t)((int32_t)t1 >> 22);

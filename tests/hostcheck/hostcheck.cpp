@@ -149,6 +149,8 @@ uint64_t hc_gl_canonical(uint64_t a) { return gl_canonical(a); }
 static const uint64_t HC_RC[BSX_POSEIDON_TABLE_N] = {BSX_POSEIDON_TABLE};
 const uint64_t* hc_poseidon_rc(void) { return HC_RC; }
 void hc_poseidon_mds(uint64_t s[12]) { poseidon_mds(s); }
+// limbs a0 (signed) + 2^22 a1 + 2^44 a2 -> canonical word (the partial rounds' hand-over, poseidon.h poseidon_recombine_signed)
+uint64_t hc_poseidon_recombine_signed(int32_t a0, uint32_t a1, uint32_t a2) { return gl_canonical(poseidon_recombine_signed((uint32_t)a0, a1, a2)); }
 void hc_poseidon_permute(uint64_t s[12]) { poseidon_permute(s, HC_RC); for (int i = 0; i < 12; i++) s[i] = gl_canonical(s[i]); }
 void hc_poseidon_hash(const uint64_t* in, uint64_t n, int noop, uint64_t out[4]) {
     auto get = [&](uint64_t k) -> uint64_t { return in[k]; };

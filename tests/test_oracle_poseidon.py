@@ -125,6 +125,24 @@ def test_mds_layer_vs_definition(hc):
         assert [int(x) % P for x in s] == want
 
 
+def test_limb_recombination_with_a_signed_low_limb(hc):
+    """Round 5: between the partial rounds the lowest limb of a lane may be slightly negative (no borrow from the next limb).  The
+    hand-over back to words (poseidon_recombine_signed) against Python integers: bounds of the MDS outputs, the corner where the
+    middle limb is zero and the carry makes it negative, random values."""
+    hc.hc_poseidon_recombine_signed.restype = C.c_uint64
+    hc.hc_poseidon_recombine_signed.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
+    rng = random.Random(12)
+    A0MAX, A1MAX = 264 * (1 << 22), 264 * ((1 << 22) + (265 << 10))      # what an MDS layer can put out (poseidon.h invariants): < 2^31
+    cases = [(0, 0, 0), (-1, 1, 0), (-1, 0, 1), (-67840, 0, 1), (-67840, 1024 * 264, 0), (-(1 << 20), 0, (1 << 29) - 1), (A0MAX, A1MAX, (1 << 29) - 1),
+             (-1, (1 << 22), 0), (-(1 << 22), 1, 0), (-(1 << 22) - 1, 2, 0), (0x3fffff, 0x3fffff, 0xfffff), (-5, 0, 0xfffff + 1)]
+    cases += [(rng.randrange(-(1 << 20), A0MAX + 1), rng.randrange(0, A1MAX + 1), rng.randrange(0, 1 << 29)) for _ in range(3000)]
+    for a0, a1, a2 in cases:
+        v = a0 + (a1 << 22) + (a2 << 44)
+        if v < 0:
+            continue                                         # a lane's value is never negative (poseidon.h): not a reachable input
+        assert int(hc.hc_poseidon_recombine_signed(a0, a1, a2)) == v % P, (a0, a1, a2)
+
+
 def test_permutation_device_source_vs_oracle_random(hc):
     rng = np.random.default_rng(9)
     for t in range(4000):                 # enough to hit the rare borrow path of the limb-form partial rounds (~3 % of states)
