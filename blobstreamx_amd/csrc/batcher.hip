@@ -51,7 +51,8 @@ inline void cpu_relax() {
 }
 
 constexpr uint32_t RING = 1u << 14;            // completion records kept: a ticket older than this many requests has expired
-constexpr uint32_t GAP_NS = 6000;              // debounce: a batch closes once no claim arrived for this long ...
+constexpr uint32_t GAP_NS = 12000;             // debounce: a batch closes once no claim arrived for this long ... (BSX_BATCH_GAP_NS in the experiments build;
+                                               // 3 / 6 / 12 / 25 / 50 us measured, tools/exp_batch_gap.py: 12 us gathers 18 instead of 15 of a proof's 32 hints per set)
 constexpr uint64_t CORK_MAX_NS = 20000000;     // a corked batch is released after 20 ms whatever happens
 struct DoneRec {
     std::atomic<uint64_t> seq{0};
@@ -110,7 +111,7 @@ struct bsx_batcher {
     bsx_ctx* ctx = nullptr;
     bsx_batcher_config cfg{};
     uint32_t J = 0, B = 0, V = 0, M = 0, n_lanes = 0;
-    uint64_t window_ns = 0;
+    uint64_t window_ns = 0, gap_ns = GAP_NS;
     uint64_t hpr = 0;                          // headers per header_range slot: J * B + 1
     uint32_t key_rows = 0;                     // rows of a lane's fixed-key table
     std::atomic<uint64_t> next_seq{1};
@@ -216,7 +217,7 @@ struct Kind {
                     cpu_relax();
                     continue;
                 }
-                const bool quiet = t - l.t_last.load(std::memory_order_acquire) >= GAP_NS;
+                const bool quiet = t - l.t_last.load(std::memory_order_acquire) >= b->gap_ns;
                 if (quiet && (in_flight.load() == 0 || t - t_open >= b->window_ns)) break;
                 if (t - l.t_first.load() >= 4 * b->window_ns + 1000000) break;   // never hold a request hostage to a stream of late claims
                 cpu_relax();
@@ -734,6 +735,7 @@ int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher*
     b->M = cfg->max_requests ? cfg->max_requests : 32;
     b->n_lanes = cfg->n_lanes ? cfg->n_lanes : 3;
     b->window_ns = (uint64_t)(cfg->window_us ? cfg->window_us : 50) * 1000;
+    b->gap_ns = (uint64_t)bsx_knob("BSX_BATCH_GAP_NS", GAP_NS);
     b->hpr = (uint64_t)b->J * b->B + 1;
     b->key_rows = cfg->key_rows ? (cfg->key_rows < b->V ? b->V : cfg->key_rows) : 2 * b->V + 32;
     *out = b;
@@ -941,7 +943,14 @@ int bsx_wait(bsx_batcher* b, bsx_ticket ticket) {
     if (d.seq.load(std::memory_order_acquire) != ticket)
         return fail(BSX_ERR_BAD_ARG, "ticket %llu has expired (more than %u requests ago)", (unsigned long long)ticket, RING);
     const int rc = d.rc;
-    if (rc != BSX_OK) bsxapi::g_err = d.msg;
+    char msg[sizeof d.msg];
+    memcpy(msg, d.msg, sizeof msg);
+    msg[sizeof msg - 1] = 0;
+    // the record is reused RING requests later: what was read above is this ticket's only if the record still carries it
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (d.seq.load(std::memory_order_acquire) != ticket)
+        return fail(BSX_ERR_BAD_ARG, "ticket %llu has expired (more than %u requests ago)", (unsigned long long)ticket, RING);
+    if (rc != BSX_OK) bsxapi::g_err = msg;
     return rc;
 }
 
