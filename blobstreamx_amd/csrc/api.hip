@@ -530,7 +530,10 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
     const bsxk_unit_dst cw = bsxk_unit(d_commit_compact, CL);
     const bool beside = (flags & BSX_COMMITS_TALLY_BESIDE) != 0;
     const int kt_bits = (flags & BSX_COMMITS_KEYTABLE_WIDE) ? BSXK_KT_BITS_WIDE : BSXK_KT_BITS;
+    // an error return behind the side-stream launch must not leave the trees running on buffers the caller is about to reclaim
+    struct SideGuard { hipStream_t s; bool armed; ~SideGuard() { if (armed) (void)hipStreamSynchronize(s); } } side{ctx->stream4, false};
     if (beside) {
+        side.armed = true;
         // the trees on the context's side stream, ordered behind whatever the caller's stream holds (the previous step's readers of
         // d_results / the units) and joined in front of the sums
         hipStream_t s4 = ctx->stream4;
@@ -550,6 +553,7 @@ int bsx_dev_verify_commits(bsx_ctx* ctx, void* stream, const bsx_validator* d_va
         HIPCHK(bsxk_commit_tally(st, d_validators, n_commits, v_max, d_header_hashes, d_ok, d_results, d_commit_compact ? &cw : nullptr));
     }
     HIPCHK(bsxk_commit_fold(st, d_results, n_commits, first_index, d_fs, d_fold));
+    side.armed = false;                      // everything is enqueued and joined on the caller's stream
     return BSX_OK;
 }
 
