@@ -390,7 +390,13 @@ def stress(args, dev, V, cpu_seconds, cal, rank=0, world=1, check=True):
                                "not the limiter (96 B in per signature)",
                        "sha512_challenge": {"avg_launch_ms": t_sha, "compressions_per_s": 2 * n / t_sha * 1e3,
                                             "frac_of_measured_peak": min(1.0, 2 * n / t_sha * 1e3 / cal["sha512_compress_per_s"]),
-                                            "algorithmic_GBps": n * 237 / t_sha / 1e6}}
+                                            "algorithmic_GBps": n * 237 / t_sha / 1e6},
+                       # the validator-set trees: P = V rounded up to a power of two leaves (one compression each) + P - 1 inner nodes (two)
+                       "commit_tally": (lambda P: {"avg_launch_ms": t_tally, "sha256_compressions": sh.n * (3 * P - 2),
+                                                   "compressions_per_s": sh.n * (3 * P - 2) / t_tally * 1e3,
+                                                   "frac_of_measured_peak": min(1.0, sh.n * (3 * P - 2) / t_tally * 1e3 / cal["sha256_compress_per_s"]),
+                                                   "note": "a latency chain: 1 + 2 log2 P dependent compressions per commit (50 us at the one-wave rate); "
+                                                           "with BSX_COMMITS_TALLY_BESIDE (the timed steps) it runs beside the signature check"})(1 << max(0, (V - 1).bit_length()))}
     if not check:
         return out
     import oracle
