@@ -137,6 +137,22 @@ int hc_ed25519_verify_keyed(const uint8_t* pk, const uint8_t* sig, const uint8_t
     if (!b_ok || tab_state != 1) return 0;
     return ed25519_verify_keyed_core(tab, btab, r, s, hh) ? 1 : 0;
 }
+// the same over a key table with KT_W_WIDE-bit digits (round 5: the digit width is a run-time property of a table; 64 MB per key)
+int hc_ed25519_verify_keyed_wide(const uint8_t* pk, const uint8_t* sig, const uint8_t* h) {
+    uint32_t p[8], r[8], s[8], hh[8];
+    load_le(p, pk, 32, 8); load_le(r, sig, 32, 8); load_le(s, sig + 32, 32, 8); load_le(hh, h, 32, 8);
+    static int32_t* btab = static_cast<int32_t*>(aligned_alloc(128, (size_t)BT_I32 * 4));
+    static const bool b_ok = hc_build_table(GE_NEG_B_ENC, btab, BT_W, BT_PARTS, BT_HALF_ENTRIES);
+    static thread_local int32_t* tab = static_cast<int32_t*>(aligned_alloc(128, (size_t)kt_key_i32(KT_W_WIDE) * 4));
+    static thread_local uint32_t tab_pk[8];
+    static thread_local int tab_state = -1;
+    if (tab_state < 0 || memcmp(tab_pk, p, 32) != 0) {
+        tab_state = hc_build_table(p, tab, KT_W_WIDE, kt_parts(KT_W_WIDE), kt_half(KT_W_WIDE)) ? 1 : 0;
+        memcpy(tab_pk, p, 32);
+    }
+    if (!b_ok || tab_state != 1) return 0;
+    return ed25519_verify_keyed_core(tab, btab, r, s, hh, KT_W_WIDE) ? 1 : 0;
+}
 
 // ---- Goldilocks / Poseidon (goldilocks.h, poseidon.h): the device source on the host
 uint64_t hc_gl_add(uint64_t a, uint64_t b) { return gl_add(a, b); }

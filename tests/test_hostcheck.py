@@ -26,6 +26,7 @@ def hc():
     lib = C.CDLL(os.path.join(d, "libhostcheck.so"))
     lib.hc_ed25519_verify.restype = C.c_int
     lib.hc_ed25519_verify_keyed.restype = C.c_int
+    lib.hc_ed25519_verify_keyed_wide.restype = C.c_int
     lib.hc_sc_is_canonical.restype = C.c_int
     return lib
 
@@ -185,5 +186,7 @@ def test_fixed_key_path_digit_edges(hc):
         assert oracle.ed25519_verify_h(pk, sig, hb)
         assert hc.hc_ed25519_verify(pk, sig, hb) == 1, (hex(h), hex(s))
         assert hc.hc_ed25519_verify_keyed(pk, sig, hb) == 1, (hex(h), hex(s))
+        assert hc.hc_ed25519_verify_keyed_wide(pk, sig, hb) == 1, (hex(h), hex(s))      # key table with 16-bit digits (round 5)
         bad = ((h + 1) % L).to_bytes(32, "little")
         assert hc.hc_ed25519_verify_keyed(pk, sig, bad) == 0
+        assert hc.hc_ed25519_verify_keyed_wide(pk, sig, bad) == 0
