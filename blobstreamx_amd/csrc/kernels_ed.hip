@@ -1369,7 +1369,8 @@ hipError_t bsxk_ed25519_verify_keyed(hipStream_t s, const bsx_validator* vals, c
                 BSX_NOTE_FORM(BSX_FORM_ED, 0x200u);
                 hipLaunchKernelGGL(k_ed25519_verify_keyed_mixed, dim3(blocks_a + blocks_b), dim3(ED_THREADS), 0, s, vals, h, n, v_max, table, n_keys,
                                    b_tab, ok, scr, blocks_a, commits_a, rows, w);
-                const uint32_t K = ed_fin_k(n);
+                static const long env_kf = bsx_knob("BSX_ED_FIN_K", 0);        // experiments: signatures per batch inversion
+                const uint32_t K = env_kf > 0 ? (uint32_t)env_kf : ed_fin_k(n);
                 const uint64_t lanes = (n + K - 1) / K;
                 hipLaunchKernelGGL(k_ed25519_finish, dim3((uint32_t)((lanes + ED_THREADS - 1) / ED_THREADS)), dim3(ED_THREADS), 0, s, vals, n, ok, scr, K);
                 BSX_LAUNCH_DEFERRED();
