@@ -71,7 +71,7 @@ GL_MUL_PER_PERMUTATION = 4 * (8 * 12 + 22)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-autotune", action="store_true", help="keep the pipeline's default stream assignment")
     ap.add_argument("--ranges", type=int, default=256, help="header_range instances per GPU per step (R); with --scaling strong: in total")
