@@ -664,6 +664,8 @@ def hint_concurrent_leg(dev, J, B, V, reps=40):
             L.bsx_context_batcher.restype = C.c_void_p
             st = BT.Batcher(J, B, V, handle=C.c_void_p(L.bsx_context_batcher(ctx))).stats()
             res["requests_per_launch_set"] = {k: st[k]["requests"] / max(1, st[k]["batches"]) for k in ("data_commitment_inputs", "prove_subchain")}
+            res["worker_us_per_set"] = {k: {q: round(st[k][q], 1) for q in ("close_wait_us", "stage_wait_us", "enqueue_us", "gpu_wait_us", "complete_us")}
+                                        for k in ("data_commitment_inputs", "prove_subchain")}
             res["note"] = "map_job_one_call = bsx_map_job: the map closure (builder.rs:305-336: hint, then prove_subchain) as ONE coalesced request"
 
         out[mode] = res
