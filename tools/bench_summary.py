@@ -13,7 +13,7 @@ if "header_range_1024" in d: print("header_range_1024 %.1f M" % (d["header_range
 if "with_input_upload" in d: print("with_input_upload", {k: (round(v / 1e6, 1) if isinstance(v, float) and v > 1e5 else v) for k, v in d["with_input_upload"].items() if k in ("value", "headers_per_s", "ms_per_step")})
 if "latency" in d:
     l = d["latency"]; print("latency", {k: round(v, 4) for k, v in l["output_only_ms"].items()}, "witness dl %.2f ms" % l["with_witness_download_ms"]["median"])
-    if "concurrent" in l: print("concurrent", [(x["threads"], round(x["headers_per_s"] / 1e6, 1), round(x["p50_ms"], 2)) for x in l["concurrent"]["by_threads"]])
+    if "concurrent" in l: print("concurrent", [(x["threads"], round(x["headers_per_s"] / 1e6, 1), round(x["p50_ms"], 2)) for x in l["concurrent"].get("coalesced_shared_context", l["concurrent"].get("by_threads", []))])
 if "range_sweep" in d:
     for k in ("compact", "witness"):
         print("sweep", k, [(x["ranges"], round(x["headers_per_s"] / 1e6, 1), round(x["ms_per_step"], 3)) for x in d["range_sweep"][k]["by_ranges"]])
