@@ -10,6 +10,7 @@
 #include "../../blobstreamx_amd/csrc/sha512.h"
 #include "../../blobstreamx_amd/csrc/ed25519.h"
 #include "../../blobstreamx_amd/csrc/poseidon.h"
+#include "../../blobstreamx_amd/csrc/keycache.h"
 #include "../../blobstreamx_amd/csrc/poseidon_consts.h"
 
 using namespace bsx;
@@ -173,4 +174,19 @@ void hc_poseidon_hash(const uint64_t* in, uint64_t n, int noop, uint64_t out[4])
     if (noop) poseidon_hash_or_noop(get, n, HC_RC, out); else poseidon_hash_no_pad(get, n, HC_RC, out);
 }
 void hc_poseidon_two_to_one(const uint64_t* l, const uint64_t* r, uint64_t out[4]) { poseidon_two_to_one(l, r, HC_RC, out); }
+
+// ---- keycache.h (host-side bookkeeping of the fixed-key tables' rows; round 5): a cache object driven batch by batch
+void* hc_keycache_new(uint32_t V, uint32_t N) { auto* k = new bsx_keycache(); k->init(V, N); return k; }
+void hc_keycache_free(void* k) { delete static_cast<bsx_keycache*>(k); }
+// one batch: rows_out [R * V]; dirty_out [N] (first *n_dirty entries); returns 1 when the map is the identity
+int hc_keycache_assign(void* k_, const bsx_validator* sets, uint32_t R, uint32_t* rows_out, uint32_t* dirty_out, uint32_t* n_dirty, uint64_t* deferred) {
+    auto* k = static_cast<bsx_keycache*>(k_);
+    std::vector<uint32_t> d;
+    const bool id = k->assign(sets, R, rows_out, d, deferred);
+    *n_dirty = (uint32_t)d.size();
+    for (size_t i = 0; i < d.size(); i++) dirty_out[i] = d[i];
+    return id ? 1 : 0;
+}
+const uint8_t* hc_keycache_keys(void* k_) { return static_cast<bsx_keycache*>(k_)->keys.data(); }
+const uint8_t* hc_keycache_used(void* k_) { return static_cast<bsx_keycache*>(k_)->used.data(); }
 }

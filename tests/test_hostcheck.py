@@ -190,3 +190,76 @@ def test_fixed_key_path_digit_edges(hc):
         bad = ((h + 1) % L).to_bytes(32, "little")
         assert hc.hc_ed25519_verify_keyed(pk, sig, bad) == 0
         assert hc.hc_ed25519_verify_keyed_wide(pk, sig, bad) == 0
+
+
+def test_keycache_rows_keyed_by_public_key(hc):
+    """csrc/keycache.h (round 5; host-side bookkeeping of the fixed-key Ed25519 tables): random batches of validator sets that drift,
+    swap slots and come back — every active slot is mapped to a row that HOLDS its public key (or is deferred when the table is full of
+    rows the batch itself needs), rows are unique per key, `dirty` names exactly the rows whose key changed, a batch of one unchanged set is
+    the identity map, and rows persist across batches (a key seen in the previous batch costs no rebuild)."""
+    import random
+    import numpy as np
+    from blobstreamx_amd import types as T
+    hc.hc_keycache_new.restype = C.c_void_p
+    hc.hc_keycache_new.argtypes = [C.c_uint32, C.c_uint32]
+    hc.hc_keycache_free.argtypes = [C.c_void_p]
+    hc.hc_keycache_assign.restype = C.c_int
+    hc.hc_keycache_assign.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    hc.hc_keycache_keys.restype = C.POINTER(C.c_uint8)
+    hc.hc_keycache_keys.argtypes = [C.c_void_p]
+    hc.hc_keycache_used.restype = C.POINTER(C.c_uint8)
+    hc.hc_keycache_used.argtypes = [C.c_void_p]
+    rng = random.Random(31)
+    for V, N in ((5, 5), (8, 20), (20, 64), (100, 232)):
+        k = hc.hc_keycache_new(V, N)
+        pool = [bytes(rng.randrange(256) for _ in range(32)) for _ in range(3 * N)]
+        base = pool[:V]
+        prev_rows = {}
+        for batch in range(40):
+            R = rng.randrange(1, 7)
+            sets = np.zeros((R, V), T.VALIDATOR)
+            keys = list(base)
+            for r in range(R):
+                if batch and rng.random() < 0.5:                   # drift: a few slots re-keyed from the pool
+                    for _ in range(rng.randrange(0, 3)):
+                        keys[rng.randrange(V)] = rng.choice(pool[:N + V] if batch % 7 else pool)
+                if rng.random() < 0.2:                              # two slots swap
+                    a, b = rng.randrange(V), rng.randrange(V)
+                    keys[a], keys[b] = keys[b], keys[a]
+                for i in range(V):
+                    sets[r, i]["pubkey"] = np.frombuffer(keys[i], np.uint8)
+                    active = rng.random() < 0.9
+                    sets[r, i]["enabled"], sets[r, i]["is_signed"] = 1, int(active)
+            base = keys
+            rows = np.zeros(R * V, np.uint32)
+            dirty = np.zeros(N, np.uint32)
+            nd, deferred = C.c_uint32(0), C.c_uint64(0)
+            ident = hc.hc_keycache_assign(k, sets.ctypes.data_as(C.c_void_p), R, rows.ctypes.data_as(C.c_void_p), dirty.ctypes.data_as(C.c_void_p),
+                                          C.byref(nd), C.byref(deferred))
+            tab = np.ctypeslib.as_array(hc.hc_keycache_keys(k), shape=(N, 32)).copy()
+            used = np.ctypeslib.as_array(hc.hc_keycache_used(k), shape=(N,)).copy()
+            rows = rows.reshape(R, V)
+            n_def = 0
+            for r in range(R):
+                for i in range(V):
+                    if not sets[r, i]["is_signed"]:
+                        assert rows[r, i] == i                                          # inactive slots keep their own index
+                        continue
+                    q = int(rows[r, i])
+                    if q == 0xFFFFFFFF:
+                        n_def += 1
+                        continue
+                    assert q < N and used[q] and tab[q].tobytes() == sets[r, i]["pubkey"].tobytes(), (V, N, batch, r, i, q)
+            assert n_def == deferred.value
+            distinct_active = {sets[r, i]["pubkey"].tobytes() for r in range(R) for i in range(V) if sets[r, i]["is_signed"]}
+            if len(distinct_active) <= N:
+                assert n_def == 0, (V, N, batch, len(distinct_active))                # there is room: nothing goes to the generic kernel
+            held = [tab[q].tobytes() for q in range(N) if used[q]]
+            assert len(held) == len(set(held))                                          # one row per key
+            d = set(int(x) for x in dirty[:nd.value])
+            now_rows = {tab[q].tobytes(): q for q in range(N) if used[q]}
+            changed = {q for key, q in now_rows.items() if prev_rows.get(key) != q}
+            assert d == changed, (V, N, batch, sorted(d), sorted(changed))             # dirty = exactly the rows that hold a new key
+            assert bool(ident) == bool((rows == np.arange(V)[None, :]).all())
+            prev_rows = now_rows
+        hc.hc_keycache_free(k)
