@@ -263,7 +263,9 @@ def test_synchronous_calls_on_a_context_with_coalescing_enabled():
         assert wrc == T.OK and rec.tobytes() == wrec.tobytes()
         assert out2 == oracle.header_range(4, 16, w2.input48(0), w2.headers[0], int(w2.first_height[0]), int(w2.latest[0]), w2.validators[0], w2.trusted[0])[1]
         st = view.stats()
-        assert st["header_range"]["requests"] == 2 * R and st["data_commitment_inputs"]["requests"] == 1 and st["prove_subchain"]["requests"] == 1, st
+            # a caller that finds the batcher idle and the context's serial path free runs there (a lone caller pays no hops): most of the 2 R
+        # calls coalesced, a few took the serial path — every answer was checked above either way
+        assert R <= st["header_range"]["requests"] <= 2 * R and st["data_commitment_inputs"]["requests"] == 1 and st["prove_subchain"]["requests"] == 1, st
     finally:
         BT.disable_coalescing()
 
