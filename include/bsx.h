@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define BSX_VERSION 0x00030000
+/* 0x00030100 (round 5): additions only — the coalescing front end (bsx_batcher_*, bsx_submit_*, bsx_wait / bsx_poll, bsx_enable_coalescing,
+ * bsx_map_job), the *_cap witness entry points, key tables with a digit width (bsx_*_keytable*_w, BSX_COMMITS_KEYTABLE_WIDE),
+ * BSX_COMMITS_TALLY_BESIDE.  Every round-4 entry point keeps its signature and meaning. */
+#define BSX_VERSION 0x00030100
 
 /* ------------------------------------------------------------------ constants (circuits/consts.rs) */
 #define BSX_HASH_SIZE 32                 /* consts.rs:1  HASH_SIZE */
