@@ -322,8 +322,13 @@ def test_bench_two_ranks_share_one_gpu():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
-    d = json.loads(lines[0])
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE compact JSON line ...
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 6144      # ... the LAST line of stdout, < 6 KB
+    short = json.loads(lines[0])
+    from bench_legs.line import detail_of
+    d = detail_of(out.stdout)                           # the full object: the `DETAIL {...}` line before it
+    assert short["n_gpus"] == 2 and short["value"] == d["value"] and short["config"]["multi_gpu"]["per_rank_ms_per_step"]
+    assert short["roofline"]["frac"] > 0 and short["config"]["nccl_ranks"] == 2
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["ranges_per_gpu"] == 8 and d["config"]["headers_per_step"] == 2 * 8 * 2048
     # bsx_pipeline_autotune ran as a collective: both ranks agreed on the steps per trial through the all-gather callback

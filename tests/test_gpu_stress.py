@@ -127,8 +127,12 @@ def test_bench_mode_s_two_ranks_share_one_gpu():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 1 and out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 6144, out.stdout[-2000:]
+    short = json.loads(lines[0])                        # the compact line (last on stdout); the full object is the DETAIL line before it
+    assert short["n_gpus"] == 2 and short["value"] > 0 and short["roofline"]["frac"] <= 1.0 and short["cpu_baseline"]["value"] > 0
+    assert short["legs"]["stress"]["all_ok"] is True
+    from bench_legs.line import detail_of
+    d = detail_of(out.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] <= 1.0 and d["cpu_baseline"]["value"] > 0
     s = d["stress"]
     assert s["signatures"] == 8 * 32 * 40 and s["signatures_this_rank"] == 4 * 32 * 40

@@ -1,6 +1,9 @@
 """tools: one-screen summary of a bench.py JSON line (all legs).  usage: bench_summary.py file.json"""
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench_legs.line import detail_of
+d = detail_of(open(sys.argv[1]).read())
 r = d["roofline"]
 print("headline %.1f M headers/s  %.3f ms/step  expand avg %.3f ms  frac %.3f (store-ceiling %.3f, isolated %s)  traffic %s" % (
     d["value"] / 1e6, d["ms_per_step"], r.get("avg_launch_ms", 0), r["frac"], r.get("frac_of_measured_store_ceiling", 0), r.get("isolated", {}).get("frac") if isinstance(r.get("isolated"), dict) else r.get("isolated_frac"), r.get("traffic")))
