@@ -36,7 +36,7 @@ SYMBOLS = [
     "bsx_ingest_last_error", "bsx_ingest_header_json", "bsx_ingest_signed_block_json", "bsx_ingest_data_commitment_json",
     "bsx_pipeline_create", "bsx_pipeline_destroy", "bsx_pipeline_upload", "bsx_pipeline_enable_input_streaming", "bsx_pipeline_step",
     "bsx_pipeline_join", "bsx_pipeline_set_allgather", "bsx_pipeline_get_results", "bsx_pipeline_buffer", "bsx_pipeline_set_timing",
-    "bsx_pipeline_timing", "bsx_pipeline_autotune", "bsx_calibrate", "bsx_dev_verify_commits", "bsx_dev_verify_commits_scratch_bytes",
+    "bsx_pipeline_timing", "bsx_pipeline_timing2", "bsx_pipeline_autotune", "bsx_calibrate", "bsx_dev_verify_commits", "bsx_dev_verify_commits_scratch_bytes",
     "bsx_ed25519_decoded_r_bytes", "bsx_dev_ed25519_decode_r", "bsx_dev_ed25519_verify_keyed_r",
     "bsx_witness_manifest_section", "bsx_commit_witness_layout", "bsx_skip_witness_layout", "bsx_step_witness_layout",
     "bsx_header_range_witness_elements", "bsx_next_header_witness_elements", "bsx_prepare_process",

@@ -27,7 +27,7 @@ static_assert(sizeof(bsx_shared_ctx) == 80 && sizeof(bsx_subchain) == 128, "reco
 static_assert(sizeof(bsx_validator) == 256 && sizeof(bsx_commit_result) == 96, "commit");
 static_assert(sizeof(bsx_witness_layout) == 40, "layout");
 static_assert(sizeof(bsx_skip_eval) == 40, "skip eval");
-static_assert(sizeof(bsx_batcher_config) == 96 && sizeof(bsx_batcher_stats) == 192 && sizeof(bsx_pipeline_timing_result) == 64, "batcher / timing");
+static_assert(sizeof(bsx_batcher_config) == 96 && sizeof(bsx_batcher_stats) == 192 && sizeof(bsx_pipeline_timing_result) == 32 && sizeof(bsx_pipeline_timing_result2) == 64, "batcher / timing");
 static_assert(sizeof(bsx_commit_fold) == 128 && sizeof(bsx_pipeline_config) == 112 && sizeof(bsx_calibration) == 80, "pipeline / fold / calibration");
 
 namespace bsxapi {

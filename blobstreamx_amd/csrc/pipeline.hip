@@ -1157,8 +1157,9 @@ int bsx_pipeline_set_timing(bsx_pipeline* p, int on) {
     return BSX_OK;
 }
 
-int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out) {
+int bsx_pipeline_timing2(bsx_pipeline* p, bsx_pipeline_timing_result2* out, uint32_t out_bytes) {
     if (!p || !out) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (out_bytes < sizeof(bsx_pipeline_timing_result)) return fail(BSX_ERR_BAD_ARG, "bsx_pipeline_timing2: out_bytes %u < 32", out_bytes);
     RET(use(p->ctx));
     RET(join_impl(p));
     double sub = 0, ex = 0, caps = 0;
@@ -1175,21 +1176,33 @@ int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out) {
         }
         c.timing_used = 0;
     }
-    out->prove_subchain_ms = n_sub ? sub / n_sub : 0;
-    out->expand_map_ms = n_ex ? ex / n_ex : 0;
-    out->caps_ms = n_caps ? caps / n_caps : 0;
-    out->launches = n_sub;
-    out->exchanges = (uint32_t)xs.size();
-    out->allgather_ms_avg = out->allgather_ms_min = out->allgather_ms_median = out->allgather_ms_max = 0;
+    bsx_pipeline_timing_result2 r{};
+    r.prove_subchain_ms = n_sub ? sub / n_sub : 0;
+    r.expand_map_ms = n_ex ? ex / n_ex : 0;
+    r.caps_ms = n_caps ? caps / n_caps : 0;
+    r.launches = n_sub;
+    r.exchanges = (uint32_t)xs.size();
     if (!xs.empty()) {
         std::sort(xs.begin(), xs.end());
         double t = 0;
         for (float v : xs) t += v;
-        out->allgather_ms_avg = t / xs.size();
-        out->allgather_ms_min = xs.front();
-        out->allgather_ms_median = xs[xs.size() / 2];
-        out->allgather_ms_max = xs.back();
+        r.allgather_ms_avg = t / xs.size();
+        r.allgather_ms_min = xs.front();
+        r.allgather_ms_median = xs[xs.size() / 2];
+        r.allgather_ms_max = xs.back();
     }
+    memcpy(out, &r, out_bytes < sizeof r ? out_bytes : sizeof r);      // never more than the caller's struct holds
+    return BSX_OK;
+}
+
+int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out) {
+    bsx_pipeline_timing_result2 r{};
+    RET(bsx_pipeline_timing2(p, out ? &r : nullptr, sizeof r));
+    out->prove_subchain_ms = r.prove_subchain_ms;
+    out->expand_map_ms = r.expand_map_ms;
+    out->caps_ms = r.caps_ms;
+    out->launches = r.launches;
+    out->_pad = 0;
     return BSX_OK;
 }
 

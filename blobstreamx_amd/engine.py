@@ -291,7 +291,7 @@ class Pipeline:
 
     def timing(self):
         t = _Timing()
-        _lib.check(self.L.bsx_pipeline_timing(self._h, C.byref(t)))
+        _lib.check(self.L.bsx_pipeline_timing2(self._h, C.byref(t), C.c_uint32(C.sizeof(t))))
         return {"prove_subchain_ms": t.prove_subchain_ms, "expand_map_ms": t.expand_map_ms, "caps_ms": t.caps_ms, "launches": t.launches,
                 "exchanges": t.exchanges, "allgather_us": {"avg": t.allgather_ms_avg * 1e3, "min": t.allgather_ms_min * 1e3,
                                                            "median": t.allgather_ms_median * 1e3, "max": t.allgather_ms_max * 1e3}}

@@ -37,8 +37,11 @@ extern "C" {
 
 /* 0x00030100 (round 5): additions only — the coalescing front end (bsx_batcher_*, bsx_submit_*, bsx_wait / bsx_poll, bsx_enable_coalescing,
  * bsx_map_job), the *_cap witness entry points, key tables with a digit width (bsx_*_keytable*_w, BSX_COMMITS_KEYTABLE_WIDE),
- * BSX_COMMITS_TALLY_BESIDE.  Every round-4 entry point keeps its signature and meaning. */
-#define BSX_VERSION 0x00030100
+ * BSX_COMMITS_TALLY_BESIDE.  Every round-4 entry point keeps its signature and meaning.
+ * 0x00030200 (round 6): additions only — bsx_pipeline_timing2 (the all-gather statistics; bsx_pipeline_timing_result is the 32-byte
+ * round-4 struct again: round 5 had grown it in place, an overrun for hosts built against the round-4 header), page-locked / packed
+ * header uploads of the coalescing front end. */
+#define BSX_VERSION 0x00030200
 
 /* ------------------------------------------------------------------ constants (circuits/consts.rs) */
 #define BSX_HASH_SIZE 32                 /* consts.rs:1  HASH_SIZE */
@@ -885,12 +888,20 @@ int bsx_pipeline_set_timing(bsx_pipeline* p, int on);
 typedef struct bsx_pipeline_timing_result {
     double prove_subchain_ms, expand_map_ms, caps_ms;
     uint32_t launches;                  /* chunk-steps averaged */
+    uint32_t _pad;
+} bsx_pipeline_timing_result;           /* sizeof == 32: the round-4 struct, unchanged (round 5 had grown it in place) */
+int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out);
+/* The same averages plus the all-gather statistics (world > 1).  `out_bytes` = sizeof of the caller's struct: the library writes at most that
+ * many bytes, so the struct can grow again without overrunning a host built against an older header (BSX_ERR_BAD_ARG below 32). */
+typedef struct bsx_pipeline_timing_result2 {
+    double prove_subchain_ms, expand_map_ms, caps_ms;
+    uint32_t launches;                  /* chunk-steps averaged */
     uint32_t exchanges;                 /* world > 1: all-gathers timed (one per chunk-step) */
     /* world > 1: the one collective of the path (the map -> reduce hand-off across GPUs, builder.rs:337-395), HIP events on the
      * exchange stream from "this rank's folded records are ready" to "every rank's have arrived" — includes waiting for the slowest rank */
     double allgather_ms_avg, allgather_ms_min, allgather_ms_median, allgather_ms_max;
-} bsx_pipeline_timing_result;           /* sizeof == 64 */
-int bsx_pipeline_timing(bsx_pipeline* p, bsx_pipeline_timing_result* out);
+} bsx_pipeline_timing_result2;          /* sizeof == 64 */
+int bsx_pipeline_timing2(bsx_pipeline* p, bsx_pipeline_timing_result2* out, uint32_t out_bytes);
 
 /* ------------------------------------------------------------------ coalescing front end (round 5)
  * The reference's own call shape: ONE range per `prove` call under a multi-thread runtime (circuits/header_range.rs:180-181) and

@@ -22,7 +22,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/bsx.h but not exported by libbsx.so"
     assert set(_lib.SYMBOLS) == declared
-    assert L.bsx_version() == 0x00030100
+    assert L.bsx_version() == 0x00030200
     assert L.bsx_status_str(C.c_int(T.ERR_ASSERT)) == b"BSX_ERR_ASSERT"
 
 
