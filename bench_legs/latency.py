@@ -57,17 +57,21 @@ def _concdrive():
     call — at 50,000 calls/s that is the whole budget, and the library would not be what is measured).  Built by build()."""
     from blobstreamx_amd import _lib
     _lib.lib()                                                   # libbsx.so first: the driver binds to the same copy
-    D = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "hostcheck", "libconcdrive.so"))
+    D = C.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libconcdrive.so"))
     D.cd_header_range_loop.restype = C.c_double
     D.cd_hint_burst.restype = C.c_int
     return D
 
 
-def concurrent_leg(dev, J, B, V, ks=(1, 2, 4, 8, 16, 32, 64), seconds=0.5, window_us=0, n_lanes=0, max_requests=0, pinned=False, serial=True):
+def concurrent_leg(dev, J, B, V, ks=(1, 2, 4, 8, 16, 32, 64), seconds=0.5, window_us=0, n_lanes=0, max_requests=0, pinned=False, serial=True,
+                   forms=("pageable", "page_locked", "registered", "packed"), form_ks=(1, 16, 64)):
     """The reference's shape of use: ONE range per `prove` call, several calls in flight under a multi-thread runtime
     (circuits/header_range.rs:180-181, bin/header_range_2048.rs:6-17).  K native threads call the UNCHANGED bsx_header_range back to
-    back, each on its own range (pageable host memory in, 64 B out), for `seconds`:
-      coalesced   all threads share ONE context with bsx_enable_coalescing (round 5): calls arriving together run as one launch set
+    back, each on its own range (host pointers in, 64 B out), for `seconds`:
+      coalesced   all threads share ONE context with bsx_enable_coalescing: calls arriving together run as one launch set.  Four upload
+                  forms (round 6): `pageable` host memory (staged into the batcher's page-locked block by the caller's thread), `page_locked`
+                  (hipHostMalloc'ed: uploaded from where it lies), `registered` (the same pageable buffers after ONE bsx_host_register each:
+                  what a host that reuses its buffer does), `packed` (bsx_header_range_packed: ~408 instead of 512 bytes per header)
       serial      every thread has its OWN context and the calls run one by one per context (round 4's shape), K = 1 and 16
     headers/s, p50 / p99 per call, requests per launch set; every output checked against the chain's own target hash."""
     import synth
@@ -75,40 +79,44 @@ def concurrent_leg(dev, J, B, V, ks=(1, 2, 4, 8, 16, 32, 64), seconds=0.5, windo
     from blobstreamx_amd import batcher as BT
     L = _lib.lib()
     D = _concdrive()
+    D.cd_header_range_loop2.restype = C.c_double
     kmax = max(ks)
     n_w = min(kmax, 32)                                          # distinct ranges (threads beyond take them again)
     w = synth.Workload(4, n_w, J, B, v=V)
     cid = np.frombuffer(b"celestia", np.uint8).copy()
     inp = np.stack([np.frombuffer(w.input48(k % n_w), np.uint8) for k in range(kmax)]).copy()
-    hdrs = [np.ascontiguousarray(w.headers[k % n_w]) for k in range(kmax)]
-    if pinned:                                                   # page-locked caller memory: uploaded from where it lies (no staging copy)
-        keep = [torch.empty(h.nbytes, dtype=torch.uint8, pin_memory=True) for h in hdrs]
-        for t_, h in zip(keep, hdrs):
-            t_.numpy()[:] = h.view(np.uint8).reshape(-1)
-        hdrs = [t_.numpy().view(hdrs[0].dtype) for t_ in keep]
+    hdrs = [np.ascontiguousarray(w.headers[k % n_w]).copy() for k in range(kmax)]
+    keep = [torch.empty(h.nbytes, dtype=torch.uint8, pin_memory=True) for h in hdrs] if (pinned or "page_locked" in forms) else []
+    for t_, h in zip(keep, hdrs):
+        t_.numpy()[:] = h.view(np.uint8).reshape(-1)
+    hdrs_pinned = [t_.numpy().view(hdrs[0].dtype) for t_ in keep]
+    packed = [BT.pack_headers(h) for h in hdrs] if "packed" in forms else []
     tv = [np.ascontiguousarray(w.validators[k % n_w]) for k in range(kmax)]
     rv = [np.ascontiguousarray(w.trusted[k % n_w]) for k in range(kmax)]
     fh = np.array([int(w.first_height[k % n_w]) for k in range(kmax)], np.uint64)
-    nh = np.array([hdrs[k].size for k in range(kmax)], np.uint64)
     lt = np.array([int(w.latest[k % n_w]) for k in range(kmax)], np.uint64)
     PP = C.c_void_p * kmax
-    p_h, p_tv, p_rv = PP(*[h.ctypes.data for h in hdrs]), PP(*[x.ctypes.data for x in tv]), PP(*[x.ctypes.data for x in rv])
+    p_tv, p_rv = PP(*[x.ctypes.data for x in tv]), PP(*[x.ctypes.data for x in rv])
     cap = 1 << 16
 
-    def run(ctx_handles, shared, K):
+    def run(ctx_handles, shared, K, bufs=None, form=0):
+        bufs = hdrs if bufs is None else bufs
+        p_h = PP(*[h.ctypes.data for h in bufs])
+        nh = np.array([bufs[k].size for k in range(kmax)], np.uint64)      # headers, or BYTES of a packed block
         lat = np.zeros((K, cap), np.float32)
         counts, rcs, o64 = np.zeros(K, np.int32), np.zeros(K, np.int32), np.zeros((K, 64), np.uint8)
         CT = C.c_void_p * len(ctx_handles)
-        dt = D.cd_header_range_loop(CT(*[h.value for h in ctx_handles]), C.c_int(shared), C.c_int(K), C.c_double(seconds), C.c_uint32(J), C.c_uint32(B),
-                                    C.c_uint32(V), _lib.p(inp), p_h, _lib.p(fh), _lib.p(nh), _lib.p(lt), p_tv, p_rv, _lib.p(cid), C.c_uint32(8), _lib.p(lat),
-                                    C.c_int(cap), _lib.p(counts), _lib.p(o64), _lib.p(rcs))
+        dt = D.cd_header_range_loop2(CT(*[h.value for h in ctx_handles]), C.c_int(shared), C.c_int(K), C.c_double(seconds), C.c_uint32(J), C.c_uint32(B),
+                                     C.c_uint32(V), _lib.p(inp), p_h, _lib.p(fh), _lib.p(nh), _lib.p(lt), p_tv, p_rv, _lib.p(cid), C.c_uint32(8), _lib.p(lat),
+                                     C.c_int(cap), _lib.p(counts), _lib.p(o64), _lib.p(rcs), C.c_int(form))
         assert dt > 0 and not rcs.any(), (dt, rcs)
         for k in range(K):
             assert o64[k, :32].tobytes() == w.hashes[k % n_w, w.n_blocks].tobytes()
         allv = np.sort(np.concatenate([lat[k, :min(cap, counts[k])] for k in range(K)]))
         n = int(counts.sum())
+        per_call = sum(int(bufs[k].nbytes) for k in range(K)) / K
         return {"threads": K, "calls": n, "headers_per_s": n * J * B / dt, "calls_per_s": n / dt, "p50_ms": float(allv[len(allv) // 2]),
-                "p99_ms": float(allv[min(len(allv) - 1, int(len(allv) * 0.99))]), "h2d_GBps_implied": n * (J * B + 1) * 512 / dt / 1e9}
+                "p99_ms": float(allv[min(len(allv) - 1, int(len(allv) * 0.99))]), "h2d_GBps_implied": n * per_call / dt / 1e9}
 
     # coalesced: one shared context
     shared_ctx = C.c_void_p()
@@ -118,18 +126,37 @@ def concurrent_leg(dev, J, B, V, ks=(1, 2, 4, 8, 16, 32, 64), seconds=0.5, windo
     L.bsx_context_batcher.restype = C.c_void_p
     view = BT.Batcher(J, B, V, handle=C.c_void_p(L.bsx_context_batcher(shared_ctx)))
     run([shared_ctx], 1, min(8, kmax))                           # warm: lanes, key tables
-    rows = []
-    for K in ks:
-        s0 = view.stats()["header_range"]
-        row = run([shared_ctx], 1, K)
-        s1 = view.stats()["header_range"]
-        nb = max(1, s1["batches"] - s0["batches"])
-        row["requests_per_launch_set"] = (s1["requests"] - s0["requests"]) / nb
-        # the worker's time per launch set by phase (us): collecting, staging (+ enqueuing the header uploads), enqueuing the kernels, waiting
-        # for the GPU, completing the tickets
-        row["worker_us_per_set"] = {k: round((s1[k] * s1["batches"] - s0[k] * s0["batches"]) / nb, 1)
-                                    for k in ("close_wait_us", "stage_wait_us", "enqueue_us", "gpu_wait_us", "complete_us")}
-        rows.append(row)
+
+    def sweep(Ks, bufs=None, form=0):
+        rows = []
+        for K in Ks:
+            s0 = view.stats()["header_range"]
+            row = run([shared_ctx], 1, K, bufs, form)
+            s1 = view.stats()["header_range"]
+            nb = max(1, s1["batches"] - s0["batches"])
+            row["requests_per_launch_set"] = (s1["requests"] - s0["requests"]) / nb
+            # the worker's time per launch set by phase (us): collecting, staging (+ enqueuing the header uploads), enqueuing the kernels, waiting
+            # for the GPU, publishing + taking out the results nobody has taken yet
+            row["worker_us_per_set"] = {k: round((s1[k] * s1["batches"] - s0[k] * s0["batches"]) / nb, 1)
+                                        for k in ("close_wait_us", "stage_wait_us", "enqueue_us", "gpu_wait_us", "complete_us")}
+            rows.append(row)
+        return rows
+    out_forms = {}
+    rows = sweep(ks, hdrs_pinned if pinned else None)
+    fks = [k for k in form_ks if k <= kmax]
+    if "page_locked" in forms and not pinned:
+        out_forms["coalesced_page_locked"] = sweep(fks, hdrs_pinned)
+    if "packed" in forms:
+        out_forms["coalesced_packed_headers"] = sweep(fks, packed, form=1)
+    if "registered" in forms and not pinned:
+        for h in hdrs:                                           # ONE registration per buffer, reused by every call from it
+            _lib.check(L.bsx_host_register(shared_ctx, C.c_void_p(h.ctypes.data), C.c_uint64(h.nbytes)))
+        try:
+            out_forms["coalesced_registered_once"] = sweep(fks)
+        finally:
+            for h in hdrs:
+                L.bsx_host_unregister(shared_ctx, C.c_void_p(h.ctypes.data))
+    view.h = None
     L.bsx_shutdown(shared_ctx)
     # serial: own contexts (round 4's shape)
     serial_rows = []
@@ -144,12 +171,13 @@ def concurrent_leg(dev, J, B, V, ks=(1, 2, 4, 8, 16, 32, 64), seconds=0.5, windo
             serial_rows.append(run(ctxs[:K], 0, K))
     for h in ctxs:
         L.bsx_shutdown(h)
-    return {"workload": f"K native threads x bsx_header_range (one header_range_{J * B}, {V} validators per call, pageable host pointers in, 64 B out)",
-            "coalesced_shared_context": rows, "serial_own_contexts": serial_rows, "headers_page_locked": bool(pinned),
-            "pcie_note": f"every call uploads {(J * B + 1) * 512 / 1e6:.2f} MB of headers: 100 M headers/s = 51 GB/s of H2D, the PCIe Gen5 x16 practical "
-                         "ceiling (with_input_upload measures ~46 GB/s on these boxes) — h2d_GBps_implied says how close a row is",
-            "note": "the reference proves ONE range per call under a multi-thread runtime (header_range.rs:180-181): this is that shape.  Round 4 "
-                    "(serial, own contexts): 16 callers = 1.4x one caller; coalesced: concurrent calls share launch sets"}
+    return {"workload": f"K native threads x bsx_header_range (one header_range_{J * B}, {V} validators per call, host pointers in, 64 B out)",
+            "coalesced_shared_context": rows, **out_forms, "serial_own_contexts": serial_rows, "headers_page_locked": bool(pinned),
+            "bytes_per_call": {"records": int(hdrs[0].nbytes), "packed": int(packed[0].nbytes) if packed else None},
+            "pcie_note": f"every call uploads {(J * B + 1) * 512 / 1e6:.2f} MB of header records ({(packed[0].nbytes if packed else 0) / 1e6:.2f} MB packed): 100 M headers/s = "
+                         "51 GB/s of H2D, the PCIe Gen5 x16 practical ceiling (with_input_upload measures ~46 GB/s on these boxes) — h2d_GBps_implied says how close a row is",
+            "note": "the reference proves ONE range per call under a multi-thread runtime (header_range.rs:180-181): this is that shape.  coalesced_shared_context "
+                    "= pageable caller memory (the default row); the other coalesced_* rows change only how the headers reach the GPU"}
 
 
 def hint_concurrent_leg(dev, J, B, V, reps=40):

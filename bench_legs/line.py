@@ -132,16 +132,20 @@ def _legs(full):
     if isinstance(lat, dict):
         L = {"single_range_ms": _get(lat, "output_only_ms", "median"), "next_header_ms": _get(lat, "next_header_ms", "median")}
         conc = lat.get("concurrent")
+        if isinstance(conc, dict) and "error" in conc:
+            L["concurrent_error"] = str(conc["error"])[-110:]       # a leg that failed must be visible in the record
         if isinstance(conc, dict):
-            for name, rows_key in (("coalesced", "coalesced_shared_context"), ("coalesced_page_locked", "coalesced_page_locked"),
-                                   ("coalesced_packed", "coalesced_packed_headers")):
+            for name, rows_key in (("coalesced", "coalesced_shared_context"), ("page_locked", "coalesced_page_locked"),
+                                   ("registered", "coalesced_registered_once"), ("packed", "coalesced_packed_headers")):
                 for k in (1, 16, 64):
                     r = _row(conc.get(rows_key), "threads", k)
                     if r:
                         L[f"{name}_k{k}"] = {"headers_per_s": r.get("headers_per_s"), "p99_ms": r.get("p99_ms")}
         legs["latency"] = L
     hc = full.get("hint_concurrent")
-    if isinstance(hc, dict):
+    if isinstance(hc, dict) and "error" in hc:
+        legs["hint_burst_32"] = {"error": str(hc["error"])[-110:]}
+    elif isinstance(hc, dict):
         legs["hint_burst_32"] = {"median_ms": _get(hc, "coalesced", "hint_only", "median_ms"),
                                  "map_job_one_call_median_ms": _get(hc, "coalesced", "map_job_one_call", "median_ms"),
                                  "serial_median_ms": _get(hc, "serial", "hint_only", "median_ms")}

@@ -43,6 +43,7 @@ SYMBOLS = [
     "bsx_pipeline_set_rccl", "bsx_rccl_get_unique_id", "bsx_rccl_comm_init_rank", "bsx_rccl_comm_destroy", "bsx_pipeline_check_allgather",
     "bsx_batcher_create", "bsx_batcher_destroy", "bsx_submit_header_range", "bsx_submit_data_commitment_inputs", "bsx_submit_prove_subchain",
     "bsx_wait", "bsx_poll", "bsx_enable_coalescing", "bsx_batcher_get_stats", "bsx_context_batcher", "bsx_batcher_cork", "bsx_submit_map_job", "bsx_map_job", "bsx_header_range_cap", "bsx_next_header_cap", "bsx_verify_commits_cap",
+    "bsx_submit_header_range_ex", "bsx_header_range_packed", "bsx_packed_headers_bound", "bsx_pack_headers", "bsx_unpack_headers", "bsx_host_register", "bsx_host_unregister",
 ]
 
 

@@ -670,9 +670,21 @@ int bsx_enable_coalescing(bsx_ctx* ctx, const bsx_batcher_config* cfg) {
 bsx_batcher* bsx_context_batcher(bsx_ctx* ctx) { return ctx ? ctx->batcher.load() : nullptr; }
 const bsx_batcher_config* bsxb_config(const bsx_batcher* b);                          // batcher.hip
 bool bsxb_range_idle(bsx_batcher* b);
-int bsxb_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
-                             uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
-                             uint8_t output64[64], bsx_commit_result* out_commit, bsx_ticket* out_ticket, int inputs_stay);
+
+// page-lock caller memory for hosts that do not link HIP themselves (a Rust shim registers its header buffer ONCE and reuses it:
+// every bsx_header_range / BSX_SUBMIT_INPUTS_STAY submit from it is then uploaded from where it lies, no staging copy)
+int bsx_host_register(bsx_ctx* ctx, void* p, uint64_t bytes) {
+    RET(use(ctx));
+    if (!p || !bytes) return fail(BSX_ERR_BAD_ARG, "bsx_host_register: null pointer / zero size");
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return BSX_OK;
+}
+int bsx_host_unregister(bsx_ctx* ctx, void* p) {
+    RET(use(ctx));
+    if (!p) return fail(BSX_ERR_BAD_ARG, "bsx_host_unregister: null pointer");
+    HIPCHK(hipHostUnregister(p));
+    return BSX_OK;
+}
 
 int bsx_encode_data_root_tuple(bsx_ctx* ctx, const uint8_t data_hash[32], uint64_t height, uint8_t out[64]) {
     HOST_ENTER();
@@ -1244,8 +1256,8 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
             const bool crowd = t_now - ctx->sync_range_crowd_ns.load(std::memory_order_relaxed) < 2000000ull;
             if (!(fast_alone && inside.others == 0 && !crowd && bsxb_range_idle(bt) && alone.try_lock())) {
                 bsx_ticket t = 0;
-                RET(bsxb_submit_header_range(bt, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64,
-                                             out_commit, &t, /*inputs_stay=*/1));
+                RET(bsx_submit_header_range_ex(bt, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64,
+                                               out_commit, &t, BSX_SUBMIT_INPUTS_STAY));
                 return bsx_wait(bt, t);
             }
             return bsx_header_range_serial(ctx, nb_map_jobs, batch_size, input48, headers, first_height, n_headers, latest_block, target_validators,
@@ -1254,6 +1266,31 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
     }
     return bsx_header_range_serial(ctx, nb_map_jobs, batch_size, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators,
                                    v_max, chain_id, chain_id_len, output64, out_commit, witness);
+}
+
+// bsx_header_range with the headers PACKED (wire.cpp: ~408 instead of 512 bytes per header over PCIe).  On a context whose batcher has this
+// shape the block is staged and uploaded packed and laid out as records in HBM (k_unpack_headers); any other context unpacks on the
+// host and takes the ordinary path, so the call is always valid.
+int bsx_header_range_packed(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const void* packed, uint64_t packed_bytes,
+                            uint64_t first_height, uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                            uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit) {
+    if (!ctx || !packed) return fail(BSX_ERR_BAD_ARG, "null pointer");
+    if (bsx_batcher* bt = ctx->batcher.load()) {
+        const bsx_batcher_config* bc = bsxb_config(bt);
+        if (bc->nb_map_jobs == nb_map_jobs && bc->batch_size == batch_size && bc->v_max == v_max && bc->chain_id_len == chain_id_len &&
+            (chain_id_len == 0 || (chain_id && chain_id_len <= 50 && memcmp(bc->chain_id, chain_id, chain_id_len) == 0))) {
+            bsx_ticket t = 0;
+            RET(bsx_submit_header_range_ex(bt, input48, packed, first_height, packed_bytes, latest_block, target_validators, trusted_validators, output64,
+                                           out_commit, &t, BSX_SUBMIT_PACKED_HEADERS));
+            return bsx_wait(bt, t);
+        }
+    }
+    uint64_t n = 0;
+    if (bsx_unpack_headers(packed, packed_bytes, nullptr, 0, &n) != BSX_OK) return fail(BSX_ERR_BAD_HEADER, "bsx_header_range_packed: the packed header block is inconsistent");
+    std::vector<bsx_header> recs(n);
+    if (bsx_unpack_headers(packed, packed_bytes, recs.data(), n, &n) != BSX_OK) return fail(BSX_ERR_BAD_HEADER, "bsx_header_range_packed: the packed header block is inconsistent");
+    return bsx_header_range(ctx, nb_map_jobs, batch_size, input48, recs.data(), first_height, n, latest_block, target_validators, trusted_validators, v_max, chain_id,
+                            chain_id_len, output64, out_commit, nullptr);
 }
 
 // the serial host-tier path of bsx_header_range (one request, the context's own streams and arena)

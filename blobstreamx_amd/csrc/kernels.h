@@ -144,6 +144,8 @@ struct bsxk_step_args {
 };
 hipError_t bsxk_step_check(hipStream_t, const bsxk_step_args*);
 hipError_t bsxk_encode_tuple(hipStream_t, const uint8_t*, uint64_t, uint8_t*);
+// packed wire headers -> bsx_header records (kernels_misc.hip k_unpack_headers): desc = (block offset | 0xffffffff, n headers) per slot
+hipError_t bsxk_unpack_headers(hipStream_t, const uint8_t* packed, const uint32_t* desc, uint32_t n_slots, uint32_t hpr, const uint32_t* wipe_to, bsx_header* out);
 hipError_t bsxk_data_commitment(hipStream_t, const uint8_t*, uint32_t, uint64_t, uint64_t, uint8_t*, uint32_t*);
 hipError_t bsxk_fill_end_hash(hipStream_t, uint32_t, bsx_shared_ctx*, const uint8_t*, uint64_t, const uint32_t*, uint8_t*, uint8_t*, uint64_t);
 int bsxk_tally_vmax(void);

@@ -430,6 +430,54 @@ __global__ __launch_bounds__(64) void k_step_check(bsxk_step_args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- packed wire headers
+// A header on the wire is ~394 bytes of protobuf fields; the 512-byte bsx_header record pads every field to a fixed,
+// 4-byte aligned capacity so that the hashing kernels stage records with 16-byte loads — 23 % of an upload is padding.  Hosts may hand
+// the coalescing front end PACKED headers instead (include/bsx.h: bsx_pack_headers: len[14] then the fields back to back); the bytes
+// cross PCIe packed and this kernel lays them out as records in HBM, where the padding is free.  One wave per header, 8 output bytes
+// per lane; slots that did not come packed are left alone.  desc[2 r] = byte offset of slot r's block in `packed` (0xffffffff: the slot
+// was uploaded as records), desc[2 r + 1] = headers in it; a block = u32 off[n + 1] (relative to its 16-aligned data), then the data.
+static constexpr uint32_t kFieldAt[BSX_HEADER_FIELDS + 1] = {16, 40, 92, 104, 124, 200, 236, 272, 308, 344, 380, 416, 452, 488, 512};   // offsetof each field of bsx_header
+__global__ __launch_bounds__(256) void k_unpack_headers(const uint8_t* __restrict__ packed, const uint32_t* __restrict__ desc, uint32_t n_slots, uint32_t hpr,
+                                                        const uint32_t* __restrict__ wipe_to, bsx_header* __restrict__ out) {
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slot = wave / hpr, h = wave % hpr;
+    if (slot >= n_slots) return;
+    const uint32_t boff = desc[2 * slot], n = desc[2 * slot + 1];
+    if (boff == 0xffffffffu) return;
+    uint2* dst = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out + (size_t)slot * hpr + h)) + lane;
+    if (h >= n) {                                            // behind the request's headers: zero records, as far as an earlier request reached
+        if (h < wipe_to[slot]) *dst = make_uint2(0u, 0u);
+        return;
+    }
+    const uint32_t* off = reinterpret_cast<const uint32_t*>(packed + boff);
+    const uint8_t* data = packed + boff + ((4u * (n + 1u) + 15u) & ~15u);
+    const uint32_t b0 = off[h], b1 = off[h + 1];             // validated on the host at submit: monotone, inside the block, >= 14 apart
+    const uint8_t* src = data + b0;
+    uint32_t len[BSX_HEADER_FIELDS], pre[BSX_HEADER_FIELDS];
+    uint32_t acc = BSX_HEADER_FIELDS;
+#pragma unroll
+    for (int f = 0; f < BSX_HEADER_FIELDS; f++) { len[f] = src[f]; pre[f] = acc; acc += len[f]; }
+    const uint32_t avail = b1 - b0;
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t p = lane * 8u + k;
+        uint32_t byte = 0;
+        if (p < BSX_HEADER_FIELDS) byte = src[p];            // the length bytes as they came: a length over its field's capacity is the
+        else if (p >= 16) {                                  // hashing kernel's to flag (BSX_ERR_BAD_HEADER), not ours to hide
+            uint32_t lf = len[0], pf = pre[0], at0 = kFieldAt[0];
+#pragma unroll
+            for (int q = 1; q < BSX_HEADER_FIELDS; q++)
+                if (p >= kFieldAt[q]) { lf = len[q]; pf = pre[q]; at0 = kFieldAt[q]; }
+            const uint32_t i = p - at0, at = pf + i;         // i < the field's capacity by construction: an over-long field cannot spill
+            if (i < lf && at < avail) byte = src[at];
+        }
+        w[k >> 2] |= byte << (8 * (k & 3));
+    }
+    *dst = make_uint2(w[0], w[1]);
+}
+
 }  // namespace bsx
 
 extern "C" {
@@ -448,6 +496,13 @@ uint64_t bsxk_commit_fold_scratch_bytes(uint32_t n) {
     uint32_t P = 1;
     while (P < n) P *= 2;
     return (uint64_t)P * 32;
+}
+hipError_t bsxk_unpack_headers(hipStream_t s, const uint8_t* packed, const uint32_t* desc, uint32_t n_slots, uint32_t hpr, const uint32_t* wipe_to,
+                               bsx_header* out) {
+    if (!n_slots) return hipSuccess;
+    const uint64_t waves = (uint64_t)n_slots * hpr;
+    hipLaunchKernelGGL(k_unpack_headers, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, packed, desc, n_slots, hpr, wipe_to, out);
+    return hipGetLastError();
 }
 hipError_t bsxk_commit_fold(hipStream_t s, const bsx_commit_result* res, uint32_t n, uint32_t first_index, void* scratch, bsx_commit_fold* out) {
     uint32_t P = 1;

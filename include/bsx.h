@@ -910,7 +910,7 @@ int bsx_pipeline_timing2(bsx_pipeline* p, bsx_pipeline_timing_result2* out, uint
  * 2-3 % of the GPU), and K callers on K contexts time-slice the same queues.  A batcher COALESCES concurrent requests of one
  * circuit shape: bsx_submit_* copies the request's inputs into the open batch's page-locked staging on the CALLER's thread and
  * returns a ticket at once (the input buffers may be reused; the OUTPUT pointers must stay valid until bsx_wait returns); a worker
- * closes the batch after a short window — an idle GPU waits for a 6 us lull only, never for the window — and runs ONE launch set
+ * closes the batch after a short window — an idle GPU waits for a 12 us lull only, never for the window — and runs ONE launch set
  * over its R requests (the host tier's own kernels with n_ranges = R); every ticket completes with ITS OWN status: header / hint
  * status words are per request on the device, so a malformed or tampered request never fails its batch-mates.  n_lanes batches are
  * in flight (the H2D copy of one beside the kernels of another).  bsx_wait returns exactly what the synchronous call would have
@@ -931,7 +931,10 @@ typedef struct bsx_batcher_config {
     uint32_t _reserved[2];
 } bsx_batcher_config;                       /* sizeof == 96 */
 int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher** out);
-void bsx_batcher_destroy(bsx_batcher* b);  /* waits for the batches in flight; tickets not yet waited for are lost */
+/* Finishes the batches in flight, fails requests that were only collected (BSX_ERR_BAD_ARG "destroyed before the request ran"), wakes
+ * every waiter and lets threads inside bsx_wait / bsx_poll / a submit leave before anything is freed.  Tickets cannot be waited for
+ * afterwards. */
+void bsx_batcher_destroy(bsx_batcher* b);
 
 /* bsx_header_range (CombinedSkipCircuit::define, header_range.rs:32-59) without a witness.  Argument meaning as bsx_header_range;
  * the circuit shape, v_max and chain id are the batcher's.  Errors detectable from the arguments alone are returned HERE (no
@@ -939,6 +942,38 @@ void bsx_batcher_destroy(bsx_batcher* b);  /* waits for the batches in flight; t
 int bsx_submit_header_range(bsx_batcher* b, const uint8_t input48[48], const bsx_header* headers, uint64_t first_height, uint64_t n_headers,
                             uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
                             uint8_t output64[64], bsx_commit_result* out_commit /* optional */, bsx_ticket* out_ticket);
+/* Round 6 — the upload of a one-range-per-call host: 1.05 MB of 512-byte header records per call, 23 % of it padding,
+ * copied once into the batcher's staging.
+ *   BSX_SUBMIT_INPUTS_STAY     the input buffers stay valid and unchanged until bsx_wait has returned: headers that lie in page-locked
+ *                              memory (hipHostMalloc / bsx_host_register) are uploaded from where they lie — no staging copy
+ *   BSX_SUBMIT_PACKED_HEADERS  `headers` points at a PACKED block (below) and `n_headers` is its size in BYTES; the block crosses PCIe
+ *                              packed (~408 B per header) and is laid out as bsx_header records in HBM.  first_height = height of the
+ *                              block's first header
+ * flags == 0 is bsx_submit_header_range. */
+#define BSX_SUBMIT_INPUTS_STAY 1u
+#define BSX_SUBMIT_PACKED_HEADERS 2u
+int bsx_submit_header_range_ex(bsx_batcher* b, const uint8_t input48[48], const void* headers, uint64_t first_height, uint64_t n_headers,
+                               uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                               uint8_t output64[64], bsx_commit_result* out_commit /* optional */, bsx_ticket* out_ticket, uint32_t flags);
+/* Synchronous form with packed headers: submit + wait on a context whose batcher has this shape; any other context unpacks on the host
+ * and calls bsx_header_range. */
+int bsx_header_range_packed(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, const uint8_t input48[48], const void* packed, uint64_t packed_bytes,
+                            uint64_t first_height, uint64_t latest_block, const bsx_validator* target_validators, const bsx_validator* trusted_validators,
+                            uint32_t v_max, const uint8_t* chain_id, uint32_t chain_id_len, uint8_t output64[64], bsx_commit_result* out_commit /* optional */);
+/* Packed wire headers: the 14 protobuf-encoded fields of each header (what get_signed_header_range fetches per block, input.rs:120-145;
+ * ~394 B) back to back instead of padded to bsx_header's fixed capacities:
+ *   u32 n_headers, u32 n_bytes (the whole block) | u32 off[n_headers + 1] (byte offsets into the data section; off[n] = its size) |
+ *   padding to a multiple of 16 | data: per header u8 len[14], then field 0 .. 13, len[f] bytes each
+ * bsx_pack_headers writes a block from records (out_cap >= bsx_packed_headers_bound(n) always suffices), bsx_unpack_headers is its inverse
+ * (host code, no GPU; out == NULL with out_cap_headers == 0 only validates).  A field length over its capacity travels as it is and is
+ * reported as BSX_ERR_BAD_HEADER by the request, exactly as for a 512-byte record; a block whose own offsets are inconsistent is
+ * BSX_ERR_BAD_HEADER at submit. */
+uint64_t bsx_packed_headers_bound(uint64_t n_headers);
+int bsx_pack_headers(const bsx_header* headers, uint64_t n_headers, void* out, uint64_t out_cap, uint64_t* out_bytes);
+int bsx_unpack_headers(const void* packed, uint64_t packed_bytes, bsx_header* out, uint64_t out_cap_headers, uint64_t* out_n);
+/* hipHostRegister / hipHostUnregister for hosts that do not link HIP: page-lock a header buffer ONCE, reuse it for every call. */
+int bsx_host_register(bsx_ctx* ctx, void* p, uint64_t bytes);
+int bsx_host_unregister(bsx_ctx* ctx, void* p);
 /* bsx_data_commitment_inputs — the body of `DataCommitmentOffchainInputs<MAX_LEAVES>::hint` (data_commitment.rs:18-45 ->
  * input.rs:149-271) with MAX_LEAVES = the batcher's batch_size. */
 int bsx_submit_data_commitment_inputs(bsx_batcher* b, const bsx_header* headers, uint64_t first_height, uint64_t n_headers, uint64_t latest_block,

@@ -39,10 +39,12 @@ extern "C" {
 // K threads; thread k calls bsx_header_range on ctxs[shared ? 0 : k] with ITS inputs back to back for `seconds`.
 // out_lat: K x cap per-call latencies in ms; out_counts: K; out64: K x 64 (last output); out_rc: K (first non-zero status, or 0).
 // Returns the wall time of the measured interval in seconds (< 0: bad arguments).
-double cd_header_range_loop(void** ctxs, int shared, int K, double seconds, uint32_t J, uint32_t B, uint32_t V, const uint8_t* input48 /* K x 48 */,
-                            const bsx_header* const* headers, const uint64_t* first_height, const uint64_t* n_headers, const uint64_t* latest,
-                            const bsx_validator* const* tv, const bsx_validator* const* rv, const uint8_t* chain_id, uint32_t chain_id_len, float* out_lat,
-                            int cap, int* out_counts, uint8_t* out64, int* out_rc) {
+// form 0: headers[k] = bsx_header records, n_headers[k] of them (bsx_header_range); form 1: headers[k] = a packed block of n_headers[k]
+// BYTES (bsx_header_range_packed)
+double cd_header_range_loop2(void** ctxs, int shared, int K, double seconds, uint32_t J, uint32_t B, uint32_t V, const uint8_t* input48 /* K x 48 */,
+                             const void* const* headers, const uint64_t* first_height, const uint64_t* n_headers, const uint64_t* latest,
+                             const bsx_validator* const* tv, const bsx_validator* const* rv, const uint8_t* chain_id, uint32_t chain_id_len, float* out_lat,
+                             int cap, int* out_counts, uint8_t* out64, int* out_rc, int form) {
     if (K <= 0 || !ctxs || cap <= 0) return -1;
     SpinBarrier go(K + 1);
     std::atomic<bool> stop{false};
@@ -58,8 +60,11 @@ double cd_header_range_loop(void** ctxs, int shared, int K, double seconds, uint
             go.wait();
             while (!stop.load(std::memory_order_relaxed)) {
                 const double t0 = now_ms();
-                const int rc = bsx_header_range(ctx, J, B, input48 + 48 * (size_t)k, headers[k], first_height[k], n_headers[k], latest[k], tv[k], rv[k], V, chain_id,
-                                                chain_id_len, o, &cr, nullptr);
+                const int rc = form == 1
+                    ? bsx_header_range_packed(ctx, J, B, input48 + 48 * (size_t)k, headers[k], n_headers[k], first_height[k], latest[k], tv[k], rv[k], V, chain_id,
+                                              chain_id_len, o, &cr)
+                    : bsx_header_range(ctx, J, B, input48 + 48 * (size_t)k, static_cast<const bsx_header*>(headers[k]), first_height[k], n_headers[k], latest[k], tv[k],
+                                       rv[k], V, chain_id, chain_id_len, o, &cr, nullptr);
                 const double t1 = now_ms();
                 if (rc != BSX_OK && !out_rc[k]) out_rc[k] = rc;
                 if (n < cap) out_lat[(size_t)k * cap + n] = (float)(t1 - t0);
@@ -75,6 +80,14 @@ double cd_header_range_loop(void** ctxs, int shared, int K, double seconds, uint
     stop.store(true);
     for (auto& t : th) t.join();
     return (now_ms() - t0) / 1e3;
+}
+
+double cd_header_range_loop(void** ctxs, int shared, int K, double seconds, uint32_t J, uint32_t B, uint32_t V, const uint8_t* input48,
+                            const bsx_header* const* headers, const uint64_t* first_height, const uint64_t* n_headers, const uint64_t* latest,
+                            const bsx_validator* const* tv, const bsx_validator* const* rv, const uint8_t* chain_id, uint32_t chain_id_len, float* out_lat,
+                            int cap, int* out_counts, uint8_t* out64, int* out_rc) {
+    return cd_header_range_loop2(ctxs, shared, K, seconds, J, B, V, input48, reinterpret_cast<const void* const*>(headers), first_height, n_headers, latest, tv, rv,
+                                 chain_id, chain_id_len, out_lat, cap, out_counts, out64, out_rc, 0);
 }
 
 // The map-job hints of ONE proof, one thread each (builder.rs:325-332: `async_hint` per map job under the runtime): thread j calls

@@ -22,7 +22,7 @@ usage: python tools/gen_gl_sbox_asm.py   (writes the header; tests/test_oracle_p
 import os
 import sys
 
-BASE = 98          # fixed VGPRs v[BASE .. BASE + 29]; kernels that use the block stay at <= 128 VGPRs (4 waves per SIMD)
+BASE = int(os.environ.get("BSX_SBOX_BASE", "98"))          # fixed VGPRs (BSX_SBOX_BASE: occupancy experiments, tools/exp_poseidon_occ.sh) v[BASE .. BASE + 29]; kernels that use the block stay at <= 128 VGPRs (4 waves per SIMD)
 
 
 def chain_regs(k):
@@ -100,14 +100,14 @@ def main():
         for k in range(3):
             lines.append(chains[k][i])
     clob = ", ".join('"v%d"' % r for r in range(BASE, BASE + 30))
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "blobstreamx_amd", "csrc", "goldilocks_sbox_asm.h")
+    out = os.environ.get("BSX_SBOX_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "blobstreamx_amd", "csrc", "goldilocks_sbox_asm.h")
     with open(out, "w") as f:
         f.write("// goldilocks_sbox_asm.h — GENERATED by tools/gen_gl_sbox_asm.py; do not edit.\n"
                 "// s_k <- (s_k + c_k)^7 mod p for three state words as one hand-scheduled gfx950 asm block: three independent chains\n"
                 "// interleaved instruction by instruction (%d instructions, %d issue slots per word: 6 for the constant, 4 x 22 for the\n"
                 "// multiplications; no s_nop, no v_mov besides the constant's upper half).  64-bit temporaries in the fixed registers\n"
                 "// v[%d:%d] (clobbers).  See the generator for the derivation; device only.\n"
-                "#pragma once\n#include <stdint.h>\n\n#if defined(__HIP_DEVICE_COMPILE__)\n#define BSX_GL_SBOX3_ASM 1\nnamespace bsx {\n\n"
+                "#pragma once\n#ifndef BSX_GL_SBOX_ASM_H   // (a variant header given with -include wins: tools/exp_poseidon_occ.sh)\n#define BSX_GL_SBOX_ASM_H\n#include <stdint.h>\n\n#if defined(__HIP_DEVICE_COMPILE__)\n#define BSX_GL_SBOX3_ASM 1\nnamespace bsx {\n\n"
                 % (3 * n, 6 + 4 * 22, BASE, BASE + 29))
         f.write("__device__ __forceinline__ void gl_sbox3(uint64_t& s0, uint64_t& s1, uint64_t& s2, uint64_t c0, uint64_t c1, uint64_t c2) {\n"
                 "    uint32_t o00, o01, o10, o11, o20, o21;\n"
@@ -121,7 +121,7 @@ def main():
                 '          "s"((uint32_t)c0), "s"((uint32_t)(c0 >> 32)), "s"((uint32_t)c1), "s"((uint32_t)(c1 >> 32)), "s"((uint32_t)c2), "s"((uint32_t)(c2 >> 32))\n'
                 '        : "vcc", %s);\n' % clob)
         f.write("    s0 = (uint64_t)o00 | ((uint64_t)o01 << 32);\n    s1 = (uint64_t)o10 | ((uint64_t)o11 << 32);\n    s2 = (uint64_t)o20 | ((uint64_t)o21 << 32);\n}\n\n"
-                "}  // namespace bsx\n#endif\n")
+                "}  // namespace bsx\n#endif\n#endif  // BSX_GL_SBOX_ASM_H\n")
     print("wrote", os.path.normpath(out), "-", 3 * n, "instructions")
 
 
