@@ -743,13 +743,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     extern __shared__ uint32_t tl_lds[];
     __shared__ unsigned long long s_total[G], s_signed[G], s_trusted[G], s_total_hi[G], s_total_lo[G];
     __shared__ uint32_t s_nen[G], s_nsig[G], s_nbad[G], s_firstbad[G], s_nbadmsg[G];
-    // Which wave carries the tree's narrow levels?  The dealt levels leave ONE wave with 15 of a workgroup's 26 wave-compressions (the
-    // serial tail of the tree); two workgroups share a compute unit at 2048 x 100, and with the tail always on wave 0 both tails queued
-    // on the same SIMD (30 wave-compressions there, 6-10 on the other three: 0.107 ms per 2048 x 100, round 5).  The logical thread
-    // index is rotated by the workgroup index so that neighbouring workgroups — whether the dispatcher pairs i with i + 1 or with
-    // i + 256 on a compute unit — put their tails on different SIMDs (18 wave-compressions on the busiest).
-    const uint32_t rot = (G > 1 && blockDim.x == TL_THREADS) ? ((blockIdx.x + (blockIdx.x >> 8)) & 3u) : 0u;
-    const uint32_t c0 = blockIdx.x * G, tid = (threadIdx.x + 64u * rot) & (TL_THREADS - 1);
+    const uint32_t c0 = blockIdx.x * G, tid = threadIdx.x;
     uint32_t P = 1;
     while (P < v_max) P *= 2;
     uint32_t* const nodes0 = tl_lds;
