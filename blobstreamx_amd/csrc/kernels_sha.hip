@@ -428,7 +428,15 @@ struct SubchainArgs {
     uint32_t level, width, level_off;        // k_tree_level: nodes per job at this level, offset of the level in inner[]/node[]
     uint32_t top_inputs;                     // k_batch_finish: 0 = every remaining level + the batch tail; else it stops below the level
                                              // of width top_inputs / 2 and k_batch_top finishes (level / width / level_off = its first)
+    uint32_t exp_skip;                       // experiments build only (BSX_BF_SKIP): bit 0 = k_batch_finish drops its per-slot scattered stores,
+                                             // bit 1 = and takes its strided predicate inputs from one broadcast line — WRONG results, timing only:
+                                             // the upper bound of what ANY re-layout of the compact witness could win
 };
+#ifdef BSX_EXPERIMENTS
+#define BF_SKIP(a, bit) (((a).exp_skip >> (bit)) & 1u)
+#else
+#define BF_SKIP(a, bit) 0u
+#endif
 
 // dword k of a byte region starting at global byte address p (2-byte aligned): funnel of two aligned dwords
 __device__ __forceinline__ uint32_t gdword_at(const uint8_t* p, int k) {
@@ -521,10 +529,12 @@ __global__ __launch_bounds__(SH_THREADS) void k_slot_hashes(SubchainArgs a) {
         for (int k = 0; k < 8; k++) t[8 + k] = bswap32(data_hash_le[k]);
         const Digest tleaf = leaf_hash_tuple(t);
         uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
+        if (!BF_SKIP(a, 0)) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            stu4(tp + 16 * k, make_uint4(bswap32(t[4 * k]), bswap32(t[4 * k + 1]), bswap32(t[4 * k + 2]), bswap32(t[4 * k + 3])));
-        store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
+            for (int k = 0; k < 4; k++)
+                stu4(tp + 16 * k, make_uint4(bswap32(t[4 * k]), bswap32(t[4 * k + 1]), bswap32(t[4 * k + 2]), bswap32(t[4 * k + 3])));
+            store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
+        }
     }
 }
 
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     Digest tleaf = Digest{};
     if (FUSED && live) {
         // data-root tuple (builder.rs:82-103,134-137) and its leaf hash (:144-147): data_hash = data_hash_proofs[i].leaf[2..34]
-        const uint8_t* pr = cw + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * i;
+        const uint8_t* pr = cw + bsx_off_dh_proofs(B) + BSX_DH_PROOF_SIZE * (BF_SKIP(a, 1) ? 0u : i);
         const uint4 l0 = ldu4(pr + 128), l1 = ldu4(pr + 144);
         const uint32_t l2 = (uint32_t)reinterpret_cast<const uint16_t*>(pr + 160)[0];
         const uint32_t lf[9] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2};
@@ -691,10 +701,12 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
         for (int k = 0; k < 8; k++) t[8 + k] = bswap32(funnel_r(lf[k + 1], lf[k], 16));
         tleaf = leaf_hash_tuple(t);
         uint8_t* tp = cw + bsx_off_tuples(B) + 64 * i;
+        if (!BF_SKIP(a, 0)) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            stu4(tp + 16 * k, make_uint4(bswap32(t[4 * k]), bswap32(t[4 * k + 1]), bswap32(t[4 * k + 2]), bswap32(t[4 * k + 3])));
-        store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
+            for (int k = 0; k < 4; k++)
+                stu4(tp + 16 * k, make_uint4(bswap32(t[4 * k]), bswap32(t[4 * k + 1]), bswap32(t[4 * k + 2]), bswap32(t[4 * k + 3])));
+            store_digest_u(cw + bsx_off_leaf_hashes(B) + 32 * i, tleaf);
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) leaf_lds[tid * 8 + k] = tleaf.w[k];
     }
@@ -709,8 +721,9 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const uint8_t* slots = cw + bsx_off_slots(B);
     // curr_header entering slot i = start_header (i == 0 or m == 0) else lb_root of slot min(i, m) - 1
     const Digest start_header = load_digest_global(cw + bsx_off_start_header());
-    const Digest dh_root = load_digest_global(slots + BSX_SLOT_BYTES * i + 128);
-    const Digest lb_root = load_digest_global(slots + BSX_SLOT_BYTES * i + 160 + 128);
+    const uint32_t i_ld = BF_SKIP(a, 1) ? 0u : i;                   // (experiments: every lane reads slot 0's lines)
+    const Digest dh_root = load_digest_global(slots + BSX_SLOT_BYTES * i_ld + 128);
+    const Digest lb_root = load_digest_global(slots + BSX_SLOT_BYTES * i_ld + 160 + 128);
     Digest curr_before = start_header, curr_after = start_header;
     if (B <= 64) {
         // a job's slots are consecutive lanes of ONE wave (B divides the workgroup): the neighbouring slots' lb_root comes through the
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     Digest claimed;                                                  // last_block_id_proofs[i].leaf[2..34] (:204)
     {
         // 2-byte aligned in the packed image: two misaligned 16-byte loads (gfx950 serves them) instead of nine dwords + funnels
-        const uint8_t* lf = cw + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * i + 128 + 2;
+        const uint8_t* lf = cw + bsx_off_lb_proofs(B) + BSX_LB_PROOF_SIZE * i_ld + 128 + 2;
         const uint4 c0 = ldu4(lf), c1 = ldu4(lf + 16);
         const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         claimed = digest_from_le(c);
@@ -744,7 +757,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void k_batch_finish(SubchainArgs a) 
     const bool end_check = !is_last || root_matches_end;             // :218
     const bool en_after = en_before && !is_last;                     // :225
     const uint32_t nb_enabled = (uint32_t)(end_block_num - batch_start);   // :119,124
-    if (live) {
+    if (live && !BF_SKIP(a, 0)) {
         store_digest_global(cw + bsx_off_slots(B) + BSX_SLOT_BYTES * i + 320, curr_after);   // :223
         const uint2 idx2 = make_uint2((uint32_t)curr_idx, (uint32_t)(curr_idx >> 32));
         *reinterpret_cast<uint2*>(W + BSX_W_CURR_IDX + 2 * i) = idx2;
@@ -1131,7 +1144,8 @@ hipError_t bsxk_prove_subchain(hipStream_t s, uint32_t n_ranges, uint32_t B, uin
     if (!n_ranges || !job_count) return hipSuccess;
     const bsx_witness_layout L = bsx_map_layout(B);
     const uint32_t n_jobs = n_ranges * job_count;
-    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0};
+    SubchainArgs a{n_jobs, B, job_count, ranges, compact, L.compact_stride, L.off_words, L.off_bools, records, 0, 0, 0, 0, 0};
+    a.exp_skip = (uint32_t)bsx_knob("BSX_BF_SKIP", 0);
     const uint64_t slots = (uint64_t)n_jobs * B;
     // BSX_SUBCHAIN_FUSED=0 / 1 (experiments) overrides BSX_SUBCHAIN_SEPARATE_LAUNCHES
     static const long env_fuse = bsx_knob("BSX_SUBCHAIN_FUSED", -1);
