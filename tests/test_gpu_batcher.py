@@ -539,3 +539,30 @@ def test_tickets_nobody_waits_for_polling_and_destroy_with_requests_pending():
     assert time.time() - t0 < 10 and got == [T.OK, T.OK], got
     for r, tk in enumerate(pend):
         assert tk.outputs[0].tobytes() == want[r][1] and tk.outputs[1][0].tobytes() == want[r][2].tobytes(), r
+
+
+def test_sixteen_native_callers_on_two_cpus():
+    """the batcher's workers spin while a batch collects (tens of microseconds) — what if the box grants fewer CPUs
+    than there are callers + workers?  16 native caller threads (tests/hostcheck/concurrent_driver.cpp) + the lanes' workers pinned to TWO
+    CPUs: every call still returns the chain's own target hash, the run ends on time, and calls keep completing (no starvation of the
+    threads the spinning workers wait for)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpus = sorted(os.sched_getaffinity(0))[:2]
+    code = (
+        "import os, sys, json\n"
+        f"os.sched_setaffinity(0, {set(cpus)!r})\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch\n"
+        "from bench_legs.latency import concurrent_leg\n"
+        "r = concurrent_leg(torch.device('cuda:0'), 8, 32, 20, ks=(16,), seconds=0.5, serial=False, forms=('packed',), form_ks=(16,))\n"
+        "print('ROWS ' + json.dumps({'rec': r['coalesced_shared_context'][0], 'packed': r['coalesced_packed_headers'][0]}))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]          # concurrent_leg asserts every call's status and output itself
+    import json
+    rows = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("ROWS ")][-1][5:])
+    for name, row in rows.items():
+        assert row["threads"] == 16 and row["calls"] >= 16 * 20, (name, row)     # >= 20 calls per thread in 0.5 s on two CPUs
+        assert row["p99_ms"] < 250, (name, row)
