@@ -18,7 +18,13 @@ sharded with their headers, one all-gather of 128-byte folds.
 Every `peak` of an ALU-bound roofline is measured in THIS process on THIS device (`bsx_calibrate`, ~50 ms at start-up):
 no constants carried over from another box.
 
-Objects on the JSON line beside the contract's keys (N = 1 unless noted):
+stdout carries TWO lines (bench_legs/line.py; VERDICT r5 #1: round 5's single ~28 KB line could not be parsed by the driver):
+    DETAIL {...}      the full object: every leg below with its notes (profiles/r6_bench_n1.json is this object)
+    {...}             the LAST line, < 6 KB: the contract's keys, `config`, `roofline`, `cpu_baseline`, `long_run` and one or two numbers
+                      per leg under `legs` (tests/test_bench_line.py holds its size and schema)
+Progress goes to stderr.  The legs live in bench_legs/*.py (latency, stress, sweeps, commitment, cpu); this file keeps the headline path.
+
+Objects of the full object beside the contract's keys (N = 1 unless noted):
   roofline            dominant kernel of the headline (witness expansion, HBM-write bound); also at N > 1
   calibration         the device ceilings measured at start-up
   kernels             the SHA kernels' compact-byte rates (never mixed with the expanded figure)

@@ -29,7 +29,7 @@ FE_SQ_PER_VERIFY = 254 / 16
 GL_MUL_PER_PERMUTATION = 4 * (8 * 12 + 22)
 
 def log(msg):
-    """progress on stderr (stdout carries the ONE JSON line)"""
+    """progress on stderr (stdout carries the DETAIL line and the compact line)"""
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
