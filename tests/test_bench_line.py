@@ -120,3 +120,20 @@ def test_bench_py_prints_through_emit_only():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "emit(out)" in src and "print(json.dumps(out))" not in src
     assert "detail_of(out.stdout)" in src              # the sub-process legs read the DETAIL line
+
+
+def test_design_numbers_are_the_profile_s():
+    """every number of DESIGN.md §5 comes from profiles/r6_bench_n1.json — the table is generated
+    (tools/design_numbers.py) and the committed block must be what the generator produces from the committed profile."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("design_numbers", os.path.join(ROOT, "tools", "design_numbers.py"))
+    dn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dn)
+    full = json.load(open(dn.SRC))
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    i, j = text.index(dn.BEGIN), text.index(dn.END)
+    assert text[i + len(dn.BEGIN):j].strip() == dn.block(full).strip(), "run `python tools/design_numbers.py` after replacing profiles/r6_bench_n1.json"
+    assert len(text.splitlines()) <= 300, "DESIGN.md is the current state only (<= 300 lines); history goes to HISTORY.md"
+    # no live citation of an older round's profile in the current-state document
+    import re
+    assert not re.findall(r"profiles/r[1-5]_", text), re.findall(r"profiles/r[1-5]_\w+", text)
