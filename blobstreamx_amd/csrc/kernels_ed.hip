@@ -734,7 +734,7 @@ __device__ __forceinline__ int validator_leaf(const uint32_t pk[8], uint64_t pow
 // 4 / 2 / 1 / 1 ... waves: 7.5 wave-compressions per commit, the same 15-compression dependent chain.  n_commits: commits beyond it
 // (the last workgroup's tail) are skipped.  G = 1 is the form for P > 128 and for single commits.
 template <int G>
-__global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator* __restrict__ vals, uint32_t v_max, uint32_t n_commits,
+__global__ __launch_bounds__(G == 8 ? 2 * TL_THREADS : TL_THREADS) void k_commit_tally(const bsx_validator* __restrict__ vals, uint32_t v_max, uint32_t n_commits,
                                                              const uint8_t* __restrict__ header_hashes,
                                                              const uint8_t* __restrict__ ok_in,
                                                              bsx_commit_result* __restrict__ results, bsxk_unit_dst wit) {
@@ -746,8 +746,10 @@ __global__ __launch_bounds__(TL_THREADS) void k_commit_tally(const bsx_validator
     const uint32_t c0 = blockIdx.x * G, tid = threadIdx.x;
     uint32_t P = 1;
     while (P < v_max) P *= 2;
+    // two node buffers: [0] holds a level of up to G * P nodes (the leaves), [1] the level above (G * P / 2) — every later level fits the
+    // buffer it lands in, so 1.5 x the leaves' size is enough (G = 8, P = 128: 48 KB + 1.5 KB of flags)
     uint32_t* const nodes0 = tl_lds;
-    uint8_t* const en0 = reinterpret_cast<uint8_t*>(tl_lds + 2 * G * P * 8);
+    uint8_t* const en0 = reinterpret_cast<uint8_t*>(tl_lds + (G * P * 8 + G * (P / 2 ? P / 2 : 1) * 8));
 #define nodes(b, idx) nodes0[(b) * G * P * 8 + (idx)]
 #define en(b, idx) en0[(b) * G * P + (idx)]
     const uint32_t nthreads = blockDim.x;
@@ -1419,13 +1421,23 @@ hipError_t bsxk_commit_tally(hipStream_t s, const bsx_validator* vals, uint32_t 
     // up to 128 validator slots and at least four commits: four commits per 256-thread workgroup, the levels of their four trees dealt
     // densely to the lanes (7.5 wave-compressions per commit instead of 16); a commit of <= 128 slots alone is two waves' worth of
     // leaves: a 128-thread workgroup; larger sets: one commit per 256 threads.  The tree is a latency chain either way
-    if (P <= 128 && n_commits >= 4) {
+    // dynamic LDS: the leaves' buffer + the half-size buffer of the level above, node flags likewise (k_commit_tally)
+    auto lds_bytes = [P](uint32_t G) { const uint32_t h = P / 2 ? P / 2 : 1; return (size_t)G * (P * 32 + h * 32 + P + h); };
+    static const long env_g = bsx_knob("BSX_TALLY_G", 0);                 // experiments: 4 / 8 forces the form
+    // Round 6: from two 4-commit workgroups per compute unit on (2048 x 100: 512 workgroups on 256 CUs) EIGHT commits share a 512-thread
+    // workgroup — one per CU, so a CU carries ONE serial tail of narrow levels instead of two that may land on the same SIMD
+    const bool g8 = env_g ? env_g == 8 : (P <= 128 && n_commits >= 8u * (uint32_t)bsxk_compute_units());
+    if (P <= 128 && n_commits >= 8 && g8) {
+        constexpr int G = 8;
+        hipLaunchKernelGGL(k_commit_tally<G>, dim3((n_commits + G - 1) / G), dim3(2 * TL_THREADS), lds_bytes(G), s, vals, v_max, n_commits,
+                           header_hashes, ok, results, w);
+    } else if (P <= 128 && n_commits >= 4) {
         constexpr int G = 4;
-        hipLaunchKernelGGL(k_commit_tally<G>, dim3((n_commits + G - 1) / G), dim3(TL_THREADS), G * (2 * P * 8 * 4 + 2 * P), s, vals, v_max, n_commits,
+        hipLaunchKernelGGL(k_commit_tally<G>, dim3((n_commits + G - 1) / G), dim3(TL_THREADS), lds_bytes(G), s, vals, v_max, n_commits,
                            header_hashes, ok, results, w);
     } else {
         const uint32_t threads = P <= 128 ? 128 : TL_THREADS;
-        hipLaunchKernelGGL(k_commit_tally<1>, dim3(n_commits), dim3(threads), 2 * P * 8 * 4 + 2 * P, s, vals, v_max, n_commits, header_hashes, ok, results, w);
+        hipLaunchKernelGGL(k_commit_tally<1>, dim3(n_commits), dim3(threads), lds_bytes(1), s, vals, v_max, n_commits, header_hashes, ok, results, w);
     }
     return hipGetLastError();
 }
