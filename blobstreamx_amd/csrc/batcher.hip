@@ -10,9 +10,11 @@
 // batch's page-locked staging (on the caller's thread, callers in parallel) and returns a ticket; the worker thread of the lane that
 // owns the batch closes it after a short window (an idle GPU never waits longer than a debounce gap), uploads the staged inputs
 // with a handful of copies, runs ONE launch set over the R requests — the host tier's own kernels with n_ranges = R — downloads the
-// small results in one block and completes every ticket with ITS OWN status: statuses are per request on the device (header /
-// hint status words are indexed by request, assertion masks and skip statuses always were), so a malformed or tampered request
-// never fails its batch-mates.  n_lanes batches are in flight: the H2D copy of one runs beside the kernels of another.
+// small results in one block and publishes the batch: its waiters (and nobody else) are woken through the lane's futex word, each copies
+// ITS OWN results and decodes ITS OWN status out of that block, and the worker takes out what nobody has (round 6).  Statuses are per
+// request on the device (header / hint status words are indexed by request, assertion masks and skip statuses always were), so a
+// malformed or tampered request never fails its batch-mates.  n_lanes batches are in flight: the H2D copy of one runs beside the
+// kernels of another.
 //
 // Three request kinds, each with its own lanes: header_range (CombinedSkipCircuit::define, header_range.rs:32-59),
 // data_commitment_inputs (the hint, data_commitment.rs:18-45 -> input.rs:149-271) and prove_subchain (builder.rs:150-271).

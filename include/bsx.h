@@ -903,7 +903,7 @@ typedef struct bsx_pipeline_timing_result2 {
 } bsx_pipeline_timing_result2;          /* sizeof == 64 */
 int bsx_pipeline_timing2(bsx_pipeline* p, bsx_pipeline_timing_result2* out, uint32_t out_bytes);
 
-/* ------------------------------------------------------------------ coalescing front end (round 5)
+/* ------------------------------------------------------------------ coalescing front end (round 5; completion and uploads: round 6)
  * The reference's own call shape: ONE range per `prove` call under a multi-thread runtime (circuits/header_range.rs:180-181) and
  * ONE hint call per map job — 32 `async fn hint` calls per proof (circuits/builder.rs:325-332 -> circuits/data_commitment.rs:22-44),
  * each followed by prove_subchain (builder.rs:335).  One such call alone is a string of dependent single-wave kernels (0.26 ms for
@@ -912,8 +912,9 @@ int bsx_pipeline_timing2(bsx_pipeline* p, bsx_pipeline_timing_result2* out, uint
  * returns a ticket at once (the input buffers may be reused; the OUTPUT pointers must stay valid until bsx_wait returns); a worker
  * closes the batch after a short window — an idle GPU waits for a 12 us lull only, never for the window — and runs ONE launch set
  * over its R requests (the host tier's own kernels with n_ranges = R); every ticket completes with ITS OWN status: header / hint
- * status words are per request on the device, so a malformed or tampered request never fails its batch-mates.  n_lanes batches are
- * in flight (the H2D copy of one beside the kernels of another).  bsx_wait returns exactly what the synchronous call would have
+ * status words are per request on the device, so a malformed or tampered request never fails its batch-mates.  A completed batch
+ * wakes only its own waiters (a futex word per lane); each waiter copies its own results out, the worker takes out the rest.  n_lanes
+ * batches are in flight (the H2D copy of one beside the kernels of another).  bsx_wait returns exactly what the synchronous call would have
  * returned (code and bsx_last_error text).  Thread-safe: any number of threads may submit and wait on one batcher. */
 typedef struct bsx_batcher bsx_batcher;
 typedef uint64_t bsx_ticket;                /* never 0 */
