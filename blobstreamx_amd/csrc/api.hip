@@ -669,6 +669,7 @@ int bsx_enable_coalescing(bsx_ctx* ctx, const bsx_batcher_config* cfg) {
 }
 bsx_batcher* bsx_context_batcher(bsx_ctx* ctx) { return ctx ? ctx->batcher.load() : nullptr; }
 const bsx_batcher_config* bsxb_config(const bsx_batcher* b);                          // batcher.hip
+bool bsxb_range_idle(bsx_batcher* b);
 
 // page-lock caller memory for hosts that do not link HIP themselves (a Rust shim registers its header buffer ONCE and reuses it:
 // every bsx_header_range / BSX_SUBMIT_INPUTS_STAY submit from it is then uploaded from where it lies, no staging copy)
@@ -1237,13 +1238,30 @@ int bsx_header_range(bsx_ctx* ctx, uint32_t nb_map_jobs, uint32_t batch_size, co
         const bsx_batcher_config* bc = bsxb_config(bt);
         if (bc->nb_map_jobs == nb_map_jobs && bc->batch_size == batch_size && bc->v_max == v_max && bc->chain_id_len == chain_id_len &&
             (chain_id_len == 0 || (chain_id && chain_id_len <= 50 && memcmp(bc->chain_id, chain_id, chain_id_len) == 0))) {
-            // Every call of the batcher's shape is submit + wait — a lone caller too: with round 6's completion (the waiter copies its own
-            // results, no shared condition variable) the batcher costs a lone caller nothing (0.254 ms through it, 0.254 on the serial
-            // path; profiles/r6_lone_caller_ab.txt), so round 5's serial short-cut for lone callers and its crowd heuristics are gone.
-            bsx_ticket t = 0;
-            RET(bsx_submit_header_range_ex(bt, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64,
-                                           out_commit, &t, BSX_SUBMIT_INPUTS_STAY));
-            return bsx_wait(bt, t);
+            // A LONE caller gains nothing from the batcher's hops (staging copy, debounce, the worker's wake-up and the completion's: 0.32
+            // against 0.26 ms): a call that finds NO other thread inside this wrapper, nothing of the kind collecting or in flight and the
+            // context's serial path free runs on that path directly.  Two or more steady callers are (almost) always inside at the same
+            // time — whoever finds another one inside stamps the context, and nobody takes the serial path within 2 ms of such a stamp:
+            // they coalesce as before (taking every momentary gap of the batcher instead cost them 7-12 %: one request less per set).
+            struct Inside { std::atomic<uint32_t>& n; uint32_t others; explicit Inside(std::atomic<uint32_t>& c) : n(c), others(c.fetch_add(1)) {} ~Inside() { n.fetch_sub(1); } }
+                inside(ctx->sync_range_callers);
+            std::unique_lock<std::recursive_mutex> alone(ctx->host_mu, std::defer_lock);
+#ifdef BSX_NO_SYNC_FAST_PATH                          // A/B builds: always through the batcher
+            const bool fast_alone = false;
+#else
+            const bool fast_alone = true;
+#endif
+            const uint64_t t_now = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            if (inside.others) ctx->sync_range_crowd_ns.store(t_now, std::memory_order_relaxed);
+            const bool crowd = t_now - ctx->sync_range_crowd_ns.load(std::memory_order_relaxed) < 2000000ull;
+            if (!(fast_alone && inside.others == 0 && !crowd && bsxb_range_idle(bt) && alone.try_lock())) {
+                bsx_ticket t = 0;
+                RET(bsx_submit_header_range_ex(bt, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators, output64,
+                                               out_commit, &t, BSX_SUBMIT_INPUTS_STAY));
+                return bsx_wait(bt, t);
+            }
+            return bsx_header_range_serial(ctx, nb_map_jobs, batch_size, input48, headers, first_height, n_headers, latest_block, target_validators,
+                                           trusted_validators, v_max, chain_id, chain_id_len, output64, out_commit, witness);
         }
     }
     return bsx_header_range_serial(ctx, nb_map_jobs, batch_size, input48, headers, first_height, n_headers, latest_block, target_validators, trusted_validators,

@@ -70,6 +70,8 @@ struct bsx_ctx {
     std::recursive_mutex host_mu;
     // bsx_enable_coalescing: synchronous host-tier calls of the batcher's shape are submit + wait on it (batcher.hip)
     std::atomic<bsx_batcher*> batcher{nullptr};
+    std::atomic<uint32_t> sync_range_callers{0};   // threads inside a synchronous bsx_header_range on a coalescing context (lone-caller test)
+    std::atomic<uint64_t> sync_range_crowd_ns{0};  // steady-clock time a thread last found another one inside that wrapper
 };
 
 namespace bsxapi {

@@ -164,7 +164,7 @@ struct Kind {
     std::mutex mu;
     std::condition_variable cv_open, cv_work;
     std::vector<std::unique_ptr<Lane>> lanes;
-    std::atomic<Lane*> open{nullptr};          // written under `mu`
+    std::atomic<Lane*> open{nullptr};          // written under `mu`; bsxb_range_idle peeks at it without
     std::deque<Lane*> free_;
     std::atomic<uint32_t> in_flight{0};
     std::atomic<bool> stop{false};             // written under `mu`; the closing spin peeks at it
@@ -849,6 +849,15 @@ void stage_headers(Lane* l, uint32_t idx, uint64_t hpr, const bsx_header* src, u
 extern "C" {
 
 const bsx_batcher_config* bsxb_config(const bsx_batcher* b) { return &b->cfg; }
+// nothing of the header_range kind is collecting or in flight (a hint to the synchronous wrapper; racy by nature, harmless either way)
+bool bsxb_range_idle(bsx_batcher* b) {
+    Kind* k = b->range_kind.get();
+    if (!k || !k->started.load(std::memory_order_acquire)) return true;
+    if (k->in_flight.load(std::memory_order_relaxed) != 0) return false;
+    Lane* o = k->open.load(std::memory_order_acquire);   // without the kind's lock: only its claim counter is looked at
+    return !o || o->n_claimed.load(std::memory_order_relaxed) == 0;
+}
+
 int bsx_batcher_create(bsx_ctx* ctx, const bsx_batcher_config* cfg, bsx_batcher** out) {
     RET(bsxapi::use(ctx));
     if (!cfg || !out) return fail(BSX_ERR_BAD_ARG, "bsx_batcher_create: null pointer");

@@ -91,7 +91,7 @@ open("gpurun_out/r6prof/r6_bench_n1_compact_line.json", "w").write(txt.rstrip().
 PY
 # 11. the driver's own form of the command (its record is BENCH_r06.json): 20 timed steps, 5 warm-up
 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench_driver_form.err | tail -n 1 > $O/r6_bench_n1_driver_form_compact_line.json
-# 12. K = 1, 2 coalesced callers alone (the A/B against round 5's lone-caller serial short-cut is profiles/r6_lone_caller_ab.txt, recorded
-#     with the two builds before the short-cut was removed)
-python tools/lone_caller_ab.py > $O/r6_lone_caller_now.txt 2>> $O/bench.err
+# 12. the lone-caller serial path of the coalescing front end, A/B (the round-5 claim had no profile)
+python tools/lone_caller_ab.py > $O/r6_lone_caller_ab.txt 2>> $O/bench.err
+[ -f blobstreamx_amd/lib/libbsx_nofast.so ] && BSX_LIB_OVERRIDE=$PWD/blobstreamx_amd/lib/libbsx_nofast.so python tools/lone_caller_ab.py >> $O/r6_lone_caller_ab.txt 2>> $O/bench.err
 ls -la $O
