@@ -76,7 +76,10 @@ def lib():
                     import torch  # noqa: F401
                 except Exception:  # torch is plumbing, not a requirement of the C ABI
                     pass
-            L = C.CDLL(_SO)
+            # An override (kernel A/B builds) is loaded RTLD_GLOBAL: the native caller harness (tests/hostcheck/libconcdrive.so, NEEDED
+            # libbsx.so) then binds ITS calls to the override too — loaded locally, the harness pulled in the product library beside it and
+            # the A/B compared the product with itself (round 6: the lone-caller A/B was void for that reason, profiles/r6_lone_caller_ab.txt)
+            L = C.CDLL(_SO, mode=C.RTLD_GLOBAL) if os.environ.get("BSX_LIB_OVERRIDE") else C.CDLL(_SO)
             # the pipeline's 16 streams need their own hardware queues: asked for BEFORE the HIP runtime initialises (it usually has
             # not: importing torch does not initialise HIP).  An explicit, documented call — the library itself never touches the
             # environment (bsx.h bsx_prepare_process); BSX_KEEP_ENV=1 skips it
