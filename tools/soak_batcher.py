@@ -78,6 +78,8 @@ def main():
         errors = []
         go = threading.Barrier(NT)
         pauses = rng.random(len(reqs)) * 2e-4
+        forms, hows = rng.integers(0, 3, len(reqs)), rng.integers(0, 3, len(reqs))
+        packed = [BT.pack_headers(w.headers[r]) if kinds[r] != "bad_header" else None for r in range(R)]
 
         def check_range(r, rc, out, res, msg):
             wrc, wout, wres = want_range[r]
@@ -94,8 +96,22 @@ def main():
                     kind, r, j = reqs[int(i)]
                     time.sleep(float(pauses[int(i)]))
                     if kind == "range":
-                        tk = bt.submit_header_range(w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r])
+                        # round 6: a random upload form (512-byte records / packed wire headers / records that "stay" — pageable here, so
+                        # staged all the same) and a random way to collect the result (wait / poll until done, then wait / wait twice)
+                        form = int(forms[int(i)])
+                        if form == 1 and kinds[r] != "bad_header":
+                            tk = bt.submit_header_range(w.input48(r), packed[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r], packed=True)
+                        else:
+                            tk = bt.submit_header_range(w.input48(r), w.headers[r], int(w.first_height[r]), int(w.latest[r]), w.validators[r], w.trusted[r],
+                                                        inputs_stay=(form == 2))
+                        how = int(hows[int(i)])
+                        if how == 1:
+                            while not bt.done(tk):
+                                time.sleep(2e-5)
                         rc, (out, res) = bt.wait(tk, allow=tuple(range(1, 10)))
+                        if how == 2:
+                            rc_again, (out2, _) = bt.wait(tk, allow=tuple(range(1, 10)))
+                            assert rc_again == rc and out2 == out, ("second wait", r)
                         check_range(r, rc, out, res.copy(), _lib.last_error() if rc else "")
                         continue
                     S, latest = int(w.first_height[r]), int(w.latest[r])
